@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Extracts the reference's own test fixtures for the hot path into small JSON files.
+
+Run in the build container (where /root/reference is mounted):
+    python tests/golden/make_golden.py
+The GPU box has no /root/reference, so tests read only the committed JSON.
+Sources (data files, not code): /root/reference/test/vectors/...
+  secp256k1/privates-2.txt     k:x:y  (test/secp256k1.test.ts:59-71)
+  secp256k1/points.json        bitcoinjs tiny-secp256k1 vectors (test/secp256k1.test.ts:79-131)
+  secp256k1/endomorphism.json  GLV multiplyUnsafe KATs (test/nist.test.ts:550-559)
+  bls12-381/zkcrypto/converted.json  i*G for G1/G2 (test/bls12-381.test.ts:1463-1535)
+  ed25519/vectors.txt          cr.yp.to sign.input (test/ed25519.test.ts:50-66)
+  ed25519/zip215.json          ZIP-215 verdicts (test/ed25519.test.ts:393-418)
+  ed25519/edge-cases.json      (test/ed25519.test.ts:189)
+"""
+import json
+import os
+
+REF = "/root/reference/test/vectors"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def dump(name, obj):
+    with open(os.path.join(OUT, name), "w") as f:
+        json.dump(obj, f, separators=(",", ":"))
+    print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")
+
+
+def main():
+    # secp256k1
+    rows = []
+    for line in open(f"{REF}/secp256k1/privates-2.txt"):
+        line = line.strip()
+        if line:
+            k, x, y = line.split(":")
+            rows.append([k, x, y])
+    dump("secp256k1_privates2.json", rows)
+    pts = json.load(open(f"{REF}/secp256k1/points.json"))
+    dump("secp256k1_points.json", {
+        "valid": {k: pts["valid"][k] for k in ("pointMultiply", "pointAdd", "pointFromScalar")},
+        "invalid": {k: pts["invalid"][k] for k in ("pointMultiply",)},
+    })
+    dump("secp256k1_endomorphism.json", json.load(open(f"{REF}/secp256k1/endomorphism.json")))
+    # bls12-381: uncompressed i*G, first 256 of each
+    conv = json.load(open(f"{REF}/bls12-381/zkcrypto/converted.json"))
+    dump("bls12_381_multiples.json", {
+        "G1_Uncompressed": conv["G1_Uncompressed"][:256],
+        "G2_Uncompressed": conv["G2_Uncompressed"][:256],
+    })
+    # ed25519: first 160 sign.input lines (messages of 0..159 bytes)
+    rows = []
+    for i, line in enumerate(open(f"{REF}/ed25519/vectors.txt")):
+        if i >= 160:
+            break
+        parts = line.strip().split(":")
+        sk_pk, pk, msg, sig_msg = parts[0], parts[1], parts[2], parts[3]
+        rows.append({"sk": sk_pk[:64], "pk": pk, "msg": msg, "sig": sig_msg[:128]})
+    dump("ed25519_vectors.json", rows)
+    dump("ed25519_zip215.json", json.load(open(f"{REF}/ed25519/zip215.json")))
+    dump("ed25519_edge_cases.json", json.load(open(f"{REF}/ed25519/edge-cases.json")))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,243 @@
+"""Pins the CPU oracle against the reference's own fixtures.
+
+Fixtures under tests/golden/ were extracted from /root/reference/test/vectors by
+tests/golden/make_golden.py; each test names the reference test it mirrors.
+"""
+import json
+import os
+
+import pytest
+
+from oracle import curve as C
+from oracle.curves import (BLS_R, BlsG1, BlsG2, ED25519_L, Ed25519, SECP256K1_N, Secp256k1,
+                           makeRng, secp256k1_ENDO)
+from oracle.edwards import eddsa_verify
+from oracle.field import Field, FpInvertBatch, invert
+from oracle.weierstrass import (_splitEndoScalar, bls_g1_decode_uncompressed,
+                                bls_g2_decode_uncompressed, sec1_decode, sec1_encode)
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+# ---------------------------------------------------------------- secp256k1
+def test_secp256k1_privates2_fixed_base():
+    """test/secp256k1.test.ts:59-71 - k*G for 45 scalars, via multiply and multiplyUnsafe."""
+    for k, x, y in load("secp256k1_privates2.json"):
+        k = int(k)
+        exp = (int(x, 16), int(y, 16))
+        assert Secp256k1.BASE.multiply(k).toAffine() == exp
+        assert Secp256k1.BASE.multiplyUnsafe(k).toAffine() == exp
+        assert C.wnafCachedMul(Secp256k1, Secp256k1.BASE, k, 8, 256).toAffine() == exp
+
+
+def test_secp256k1_points_json():
+    """test/secp256k1.test.ts:79-131 - pointAdd / pointMultiply / invalid pointMultiply."""
+    v = load("secp256k1_points.json")
+    for t in v["valid"]["pointAdd"]:
+        p = sec1_decode(Secp256k1, bytes.fromhex(t["P"]))
+        q = sec1_decode(Secp256k1, bytes.fromhex(t["Q"]))
+        if t["expected"]:
+            assert sec1_encode(p.add(q)).hex() == t["expected"]
+        else:
+            assert p.add(q).is0()
+    for t in v["valid"]["pointMultiply"]:
+        p = sec1_decode(Secp256k1, bytes.fromhex(t["P"]))
+        d = int(t["d"], 16)
+        if t["expected"]:
+            assert sec1_encode(p.multiply(d)).hex() == t["expected"]
+            assert sec1_encode(p.multiplyUnsafe(d)).hex() == t["expected"]
+    for t in v["valid"]["pointFromScalar"]:
+        d = int(t["d"], 16)
+        assert sec1_encode(Secp256k1.BASE.multiply(d)).hex() == t["expected"]
+    for t in v["invalid"]["pointMultiply"]:
+        with pytest.raises((ValueError, TypeError)):
+            p = sec1_decode(Secp256k1, bytes.fromhex(t["P"]))
+            sec1_encode(p.multiply(int(t["d"], 16)))
+
+
+def test_secp256k1_endomorphism_vectors():
+    """test/nist.test.ts:550-559 - GLV multiplyUnsafe, all sign combinations."""
+    for t in load("secp256k1_endomorphism.json"):
+        a = Secp256k1.fromAffine((int(t["ax"]), int(t["ay"])))
+        c = a.multiplyUnsafe(int(t["scalar"]))
+        assert c.toAffine() == (int(t["cx"]), int(t["cy"]))
+
+
+def test_split_endo_scalar_identity():
+    """test/endomorphism.test.ts:85-176 - k == k1 + lambda*k2 (mod n), halves < 2^128."""
+    n = SECP256K1_N
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    rng = makeRng(0xE0D0)
+    ks = [0, 1, 2, n - 1, n - 2, n // 2, (n // 2) + 1] + [rng.rndBelow(n) for _ in range(2000)]
+    for k in ks:
+        k1neg, k1, k2neg, k2 = _splitEndoScalar(k, secp256k1_ENDO["basises"], n)
+        assert k1 < (1 << 128) and k2 < (1 << 128)
+        s1 = -k1 if k1neg else k1
+        s2 = -k2 if k2neg else k2
+        assert (s1 + lam * s2 - k) % n == 0
+
+
+# ---------------------------------------------------------------- bls12-381
+def test_bls12_381_g1_multiples():
+    """test/bls12-381.test.ts:1478-1494 - G1 uncompressed i*G, i = 0..255."""
+    rows = load("bls12_381_multiples.json")["G1_Uncompressed"]
+    p1 = BlsG1.ZERO
+    for i, t in enumerate(rows):
+        P = bls_g1_decode_uncompressed(BlsG1, bytes.fromhex(t))
+        assert P.equals(p1)
+        assert P.toAffine() == p1.toAffine()
+        if i:
+            assert BlsG1.BASE.multiplyUnsafe(i).toAffine() == P.toAffine()
+            if i % 16 == 1:
+                assert BlsG1.BASE.multiply(i).toAffine() == P.toAffine()
+        p1 = p1.add(BlsG1.BASE)
+
+
+def test_bls12_381_g2_multiples():
+    """test/bls12-381.test.ts:1496-1535 - G2 (Fp2) uncompressed i*G, i = 0..255."""
+    rows = load("bls12_381_multiples.json")["G2_Uncompressed"]
+    p1 = BlsG2.ZERO
+    for i, t in enumerate(rows):
+        P = bls_g2_decode_uncompressed(BlsG2, bytes.fromhex(t))
+        assert P.equals(p1)
+        if i and i % 8 == 0:
+            assert BlsG2.BASE.multiplyUnsafe(i).toAffine() == P.toAffine()
+        p1 = p1.add(BlsG2.BASE)
+
+
+@pytest.mark.parametrize("Pt,order", [(Secp256k1, SECP256K1_N), (BlsG1, BLS_R), (BlsG2, BLS_R),
+                                      (Ed25519, ED25519_L)])
+def test_pippenger_matches_naive_and_progression(Pt, order):
+    """test/point.test.ts:264-305 and test/slow-curves.test.ts:185-252: MSM == sum of
+    multiplies == (sum (a+i*b)*s_i mod n)*G, incl. zero scalars and ZERO / P / -P inputs."""
+    rng = makeRng(0x6D736D)
+    a, b = rng.rndBelow(order - 1) + 1, rng.rndBelow(order - 1) + 1
+    n = 24
+    ks = [(a + i * b) % order for i in range(n)]
+    pts = [Pt.BASE.multiplyUnsafe(k) for k in ks]
+    sc = [0 if i % 17 == 0 else rng.rndBelow(order) for i in range(n)]
+    exp = Pt.BASE.multiplyUnsafe(sum(k * s for k, s in zip(ks, sc)) % order)
+    assert C.pippenger(Pt, pts, sc).equals(exp)
+    acc = Pt.ZERO
+    for p, s in zip(pts, sc):
+        acc = acc.add(p.multiplyUnsafe(s))
+    assert acc.equals(exp)
+    # degenerate inputs
+    Gp = Pt.BASE
+    assert C.pippenger(Pt, [Gp, Gp.negate(), Pt.ZERO], [5, 5, 7]).is0()
+    assert C.pippenger(Pt, [], []).is0()
+    assert C.pippenger(Pt, [Gp, Gp], [0, 0]).is0()
+    assert C.pippenger(Pt, [Gp] * 5, [3] * 5).equals(Gp.multiplyUnsafe(15))
+    with pytest.raises(ValueError, match="invalid scalar at index 1"):
+        C.pippenger(Pt, [Gp, Gp], [1, order])
+    with pytest.raises(ValueError, match="equal length"):
+        C.pippenger(Pt, [Gp, Gp], [1])
+
+
+def test_toy_curve_exhaustive():
+    """test/point.test.ts:572-741 - y^2 = x^3 + x + 6 over F_1039 (order 1009): every ladder
+    x every scalar against the full multiple table."""
+    from oracle.weierstrass import weierstrass
+    Fp, Fn = Field(1039), Field(1009)
+    # find a generator point
+    pt = None
+    for x in range(1, 1039):
+        y2 = (x * x * x + x + 6) % 1039
+        for y in range(1, 1039):
+            if y * y % 1039 == y2:
+                pt = (x, y)
+                break
+        if pt:
+            break
+    Toy = weierstrass(dict(a=1, b=6, Gx=pt[0], Gy=pt[1], h=1), Fp, Fn, name="toy")
+    table = [Toy.ZERO]
+    for _ in range(1009):
+        table.append(table[-1].add(Toy.BASE))
+    assert table[1009].is0()
+    for k in range(0, 1009):
+        exp = table[k].toAffine()
+        assert Toy.BASE.multiplyUnsafe(k).toAffine() == exp
+        assert C.naiveMul(Toy, Toy.BASE, k).toAffine() == exp
+        if k:
+            assert Toy.BASE.multiply(k).toAffine() == exp
+            assert C.wnafCachedMul(Toy, Toy.BASE, k, 4, Fn.BITS).toAffine() == exp
+    rng = makeRng(77)
+    for _ in range(20):
+        ks = [rng.rndBelow(1009) for _ in range(9)]
+        ss = [rng.rndBelow(1009) for _ in range(9)]
+        exp = table[sum(k * s for k, s in zip(ks, ss)) % 1009].toAffine()
+        assert C.pippenger(Toy, [table[k] for k in ks], ss).toAffine() == exp
+        assert C.mulAddUnsafe(Toy, [table[k] for k in ks], ss).toAffine() == exp
+
+
+def test_field_invert_and_batch():
+    """test/modular.test.ts:615-770,1243-1266 - invert / invertBatch properties."""
+    Fp = Secp256k1.Fp
+    rng = makeRng(0xF1E1D)
+    nums = [rng.rndBelow(Fp.ORDER) for _ in range(50)] + [0, 1, Fp.ORDER - 1]
+    inv = FpInvertBatch(Fp, nums)
+    for n, i in zip(nums, inv):
+        if n == 0:
+            assert i is None
+        else:
+            assert n * i % Fp.ORDER == 1 and i == invert(n, Fp.ORDER)
+    assert FpInvertBatch(Fp, [0, 2], True)[0] == 0
+    with pytest.raises(ValueError):
+        invert(0, Fp.ORDER)
+
+
+# ---------------------------------------------------------------- ed25519
+def test_ed25519_sign_input_vectors_verify():
+    """test/ed25519.test.ts:50-66 - cr.yp.to sign.input: pk = [a]B, and (pk,msg,sig) verifies."""
+    import hashlib
+    for row in load("ed25519_vectors.json"):
+        sk, pk, msg, sig = (bytes.fromhex(row[k]) for k in ("sk", "pk", "msg", "sig"))
+        h = bytearray(hashlib.sha512(sk).digest()[:32])
+        h[0] &= 248
+        h[31] &= 127
+        h[31] |= 64
+        a = int.from_bytes(h, "little") % ED25519_L
+        assert Ed25519.BASE.multiply(a).toBytes() == pk
+        assert eddsa_verify(Ed25519, sig, msg, pk, zip215=True)
+        assert eddsa_verify(Ed25519, sig, msg, pk, zip215=False)
+        bad = bytearray(sig)
+        bad[3] ^= 1
+        assert not eddsa_verify(Ed25519, bytes(bad), msg, pk)
+        assert not eddsa_verify(Ed25519, sig, msg + b"x", pk)
+
+
+def test_ed25519_zip215_verdicts():
+    """test/ed25519.test.ts:393-418 - 196 ZIP-215 cases, both modes (valid_legacy is the
+    libsodium-style verdict and is not what zip215=false implements, so only zip215 mode
+    plus the strict-mode invariants are pinned)."""
+    msg = b"Zcash"
+    for v in load("ed25519_zip215.json"):
+        got = eddsa_verify(Ed25519, bytes.fromhex(v["sig_bytes"]), msg, bytes.fromhex(v["vk_bytes"]),
+                           zip215=True)
+        assert got == v["valid_zip215"], v
+
+
+def test_ed25519_edge_cases_strict():
+    """test/ed25519.test.ts:189-197 - eprint 2020/1244 cases that strict mode must reject."""
+    ec = load("ed25519_edge_cases.json")
+    for i in (0, 1, 6, 7, 8, 9, 10, 11):
+        v = ec[i]
+        assert not eddsa_verify(Ed25519, bytes.fromhex(v["signature"]), bytes.fromhex(v["message"]),
+                                bytes.fromhex(v["pub_key"]), zip215=False)
+
+
+def test_ed25519_torsion_exact():
+    """test/ed25519.test.ts:355-390 - multiply on points with a torsion component is exact
+    integer scalar multiplication (no reduction mod L)."""
+    # an order-8 point: decode y with x from small-order list (y = 0x7a03ac92... is order 8)
+    t8 = Ed25519.fromBytes(bytes.fromhex("c7176a703d4dd84fba3c0b760d10670f2a2053fa2c39ccc64ec7fd7792ac03fa"), True)
+    assert t8.isSmallOrder()
+    P = Ed25519.BASE.add(t8)
+    for k in (1, 2, 7, 8, 9, 12345, ED25519_L - 1):
+        assert P.multiplyUnsafe(k).equals(C.naiveMul(Ed25519, P, k))
+        assert P.multiply(k).equals(C.naiveMul(Ed25519, P, k))
