@@ -1,0 +1,82 @@
+/* ncg.h - C ABI of the MI355X batch elliptic-curve engine ("noble-curves GPU").
+ *
+ * This is the drop-in boundary for the hot path of paulmillr/noble-curves.  The reference
+ * has no FFI seam - the seam is its public TypeScript surface - so each entry point below
+ * names the reference function whose *result* it reproduces for a whole batch.  A thin
+ * N-API addon or the Python host mirror (noble-curves_amd/) binds these.
+ *
+ * Wire format:
+ *   - field elements: canonical residues (NOT Montgomery), little-endian bytes, fixed width:
+ *       secp256k1 / ed25519 Fp: 32 bytes;  bls12-381 Fp: 48 bytes;  Fp2 = c0 || c1 (96 bytes)
+ *   - affine points: x || y.  Infinity is (0,0) on Weierstrass curves
+ *       (reference src/abstract/weierstrass.ts:716 fromAffine, :966 toAffine) and (0,1) on
+ *       Edwards (src/abstract/edwards.ts:606); outputs also carry a separate is_inf byte.
+ *   - scalars: 32 bytes little-endian, 0 <= k < 2^256 (range rules of the reference are
+ *       enforced by the host shim before crossing: weierstrass.ts:904,920; curve.ts:398-404).
+ *
+ * Conventions: every function returns 0 on success or a negative ncg_status; no C++ type,
+ * exception or torch type crosses this boundary.  Pointers suffixed _dev are device (HBM)
+ * addresses valid on the context's GPU; all others are host pointers.  `stream` is a
+ * hipStream_t passed as void* (NULL = the context's own stream); *_dev calls are
+ * asynchronous on that stream, host-pointer calls return after the result is in host memory.
+ */
+#ifndef NCG_H
+#define NCG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ncg_ctx ncg_ctx;
+
+enum ncg_curve {
+  NCG_SECP256K1 = 0,     /* src/secp256k1.ts:48-64   */
+  NCG_ED25519 = 1,       /* src/ed25519.ts:49-65     */
+  NCG_BLS12_381_G1 = 2,  /* src/bls12-381.ts:134-148 */
+  NCG_BLS12_381_G2 = 3   /* src/bls12-381.ts:321-345 */
+};
+
+enum ncg_status {
+  NCG_OK = 0,
+  NCG_ERR_INVALID_ARG = -1,
+  NCG_ERR_HIP = -2,
+  NCG_ERR_NO_DEVICE = -3,
+  NCG_ERR_UNSUPPORTED = -4,
+  NCG_ERR_NOMEM = -5
+};
+
+/* ---- context ------------------------------------------------------------------------- */
+/* One context per process per GPU (one process per GPU is the deployment model; multi-GPU
+ * composition is done by the host layer over RCCL, see noble-curves_amd/distributed.py). */
+int ncg_init(int device_id, ncg_ctx** out_ctx);
+void ncg_destroy(ncg_ctx* ctx);
+const char* ncg_last_error(ncg_ctx* ctx); /* ctx may be NULL: last process-wide error */
+int ncg_sync(ncg_ctx* ctx);               /* waits for the context's own stream */
+const char* ncg_version(void);
+/* bytes per affine point / per field element for a curve (0 if unknown) */
+int ncg_point_bytes(int curve);
+int ncg_field_bytes(int curve);
+
+/* ---- batch variable-base scalar multiplication ---------------------------------------
+ * out[i] = scalars[i] * points[i].  Replaces, batch-wise, Point.multiplyUnsafe(k)
+ * (src/abstract/weierstrass.ts:915-928; GLV path :660-671 on secp256k1) and the value of
+ * Point.multiply(k) (:900-907).  k = 0 or P = infinity gives infinity.  Curves: secp256k1,
+ * bls12-381 G1, G2.  out_is_inf may be NULL. */
+int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affine,
+                      const void* scalars, void* out_affine, uint8_t* out_is_inf);
+int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev,
+                          const void* scalars_dev, void* out_affine_dev,
+                          uint8_t* out_is_inf_dev, void* stream);
+
+/* ---- measurement helpers (not on the product path) ------------------------------------ */
+/* Runs instruction-rate / field-multiply micro-benchmark `kind` (see csrc/ubench.hip) and
+ * returns the kernel time in milliseconds. */
+int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NCG_H */

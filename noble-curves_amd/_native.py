@@ -1,0 +1,176 @@
+"""ctypes binding of libncg.so (include/ncg.h) plus wire-format marshalling helpers.
+
+The library is built in-tree by `__graft_entry__.build()` (or `make -C noble-curves_amd/csrc`).
+It is loaded lazily and LOUDLY: a missing library or a missing GPU raises NativeError - no
+silent fallback exists.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+SECP256K1, ED25519, BLS12_381_G1, BLS12_381_G2 = 0, 1, 2, 3
+POINT_BYTES = {SECP256K1: 64, ED25519: 64, BLS12_381_G1: 96, BLS12_381_G2: 192}
+FIELD_BYTES = {SECP256K1: 32, ED25519: 32, BLS12_381_G1: 48, BLS12_381_G2: 48}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libncg.so")
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libncg.so and declare prototypes; raises NativeError if it is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise NativeError(
+                "noble-gpu: %s is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % path)
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError as e:  # pragma: no cover
+            raise NativeError("noble-gpu: cannot load %s: %s" % (path, e))
+        vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        lib.ncg_init.argtypes = [i32, ctypes.POINTER(vp)]
+        lib.ncg_init.restype = i32
+        lib.ncg_destroy.argtypes = [vp]
+        lib.ncg_destroy.restype = None
+        lib.ncg_last_error.argtypes = [vp]
+        lib.ncg_last_error.restype = ctypes.c_char_p
+        lib.ncg_sync.argtypes = [vp]
+        lib.ncg_sync.restype = i32
+        lib.ncg_version.argtypes = []
+        lib.ncg_version.restype = ctypes.c_char_p
+        lib.ncg_point_bytes.argtypes = [i32]
+        lib.ncg_point_bytes.restype = i32
+        lib.ncg_field_bytes.argtypes = [i32]
+        lib.ncg_field_bytes.restype = i32
+        lib.ncg_mul_var_batch.argtypes = [vp, i32, sz, vp, vp, vp, vp]
+        lib.ncg_mul_var_batch.restype = i32
+        lib.ncg_mul_var_batch_dev.argtypes = [vp, i32, sz, vp, vp, vp, vp, vp]
+        lib.ncg_mul_var_batch_dev.restype = i32
+        lib.ncg_ubench.argtypes = [vp, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_float)]
+        lib.ncg_ubench.restype = i32
+        for name, args in _OPTIONAL_PROTOS.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.argtypes = args
+                fn.restype = i32
+        _lib = lib
+        return lib
+
+
+_vp, _sz, _i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+_OPTIONAL_PROTOS = {
+    "ncg_msm": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
+    "ncg_msm_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp, _vp],
+    "ncg_msm_windows_dev": [_vp, _i32, _sz, _vp, _vp, _i32, _vp, _vp, _vp],
+    "ncg_msm_combine": [_vp, _i32, _sz, _vp, _i32, _vp, _vp],
+    "ncg_mul_base_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
+    "ncg_mul_base_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
+    "ncg_ed25519_verify_batch": [_vp, _sz, _vp, _vp, _vp, _i32, _vp],
+    "ncg_ed25519_verify_batch_dev": [_vp, _sz, _vp, _vp, _vp, _i32, _vp, _vp],
+}
+
+
+# ---------------------------------------------------------------- wire helpers (numpy, no torch)
+def ints_to_le(values, nbytes):
+    """list of non-negative ints -> uint8 array [len, nbytes], little-endian."""
+    out = np.empty((len(values), nbytes), dtype=np.uint8)
+    for i, v in enumerate(values):
+        out[i] = np.frombuffer(int(v).to_bytes(nbytes, "little"), dtype=np.uint8)
+    return out
+
+
+def le_to_ints(arr, nbytes):
+    """uint8 array [..., nbytes] -> list of ints."""
+    flat = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1, nbytes)
+    return [int.from_bytes(row.tobytes(), "little") for row in flat]
+
+
+class Engine:
+    """One native context (one GPU).  Methods take/return numpy uint8 arrays in wire format,
+    or raw device pointers for the *_dev variants (torch tensors: pass .data_ptr())."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.device = device
+        h = ctypes.c_void_p()
+        rc = self.lib.ncg_init(device, ctypes.byref(h))
+        if rc != 0:
+            raise NativeError((self.lib.ncg_last_error(None) or b"").decode() or "noble-gpu: ncg_init failed (%d)" % rc)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ncg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = (self.lib.ncg_last_error(self.h) or b"").decode()
+            raise NativeError(msg or "noble-gpu: native call failed (%d)" % rc)
+
+    def version(self):
+        return self.lib.ncg_version().decode()
+
+    def sync(self):
+        self._check(self.lib.ncg_sync(self.h))
+
+    # ---- batch variable-base multiply -------------------------------------------------------
+    def mul_var_batch(self, curve, points, scalars):
+        """points: uint8 [n, POINT_BYTES]; scalars: uint8 [n, 32] -> (out [n, PB], is_inf [n])."""
+        pb = POINT_BYTES[curve]
+        points = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, pb)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        n = points.shape[0]
+        if scalars.shape[0] != n:
+            raise ValueError("arrays of points and scalars must have equal length")
+        out = np.empty((n, pb), dtype=np.uint8)
+        inf = np.empty((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_mul_var_batch(self.h, curve, n, points.ctypes.data, scalars.ctypes.data,
+                                                   out.ctypes.data, inf.ctypes.data))
+        return out, inf
+
+    def mul_var_batch_dev(self, curve, n, d_points, d_scalars, d_out, d_inf, stream=None):
+        self._check(self.lib.ncg_mul_var_batch_dev(self.h, curve, n, d_points, d_scalars, d_out, d_inf, stream))
+
+    def ubench(self, kind, blocks, threads, iters):
+        ms = ctypes.c_float()
+        self._check(self.lib.ncg_ubench(self.h, kind, blocks, threads, iters, ctypes.byref(ms)))
+        return ms.value
+
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """Process-wide engine for `device` (default: LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    eng = _engines.get(device)
+    if eng is None:
+        eng = Engine(device)
+        _engines[device] = eng
+    return eng

@@ -1,0 +1,196 @@
+// C ABI (include/ncg.h): context, workspace and dispatch.  No torch types cross here.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/ncg.h"
+#include "host_api.hpp"
+
+namespace {
+std::mutex g_err_mu;
+std::string g_last_error;
+}  // namespace
+
+struct ncg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+  // reusable device scratch for the host-pointer entry points
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  uint32_t* ub_in = nullptr;
+  uint32_t* ub_out = nullptr;
+  size_t ub_out_words = 0;
+};
+
+static int set_err(ncg_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  {
+    std::lock_guard<std::mutex> g(g_err_mu);
+    g_last_error = buf;
+  }
+  if (ctx) ctx->last_error = buf;
+  return code;
+}
+
+#define NCG_HIP(ctx, expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return set_err(ctx, NCG_ERR_HIP, "noble-gpu: HIP error %d (%s) at %s:%d", (int)_e,    \
+                     hipGetErrorString(_e), __FILE__, __LINE__);                             \
+  } while (0)
+
+static int ensure_scratch(ncg_ctx* ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return NCG_OK;
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  ctx->scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  size_t want = bytes + (bytes >> 2) + 4096;
+  hipError_t e = hipMalloc(&ctx->scratch, want);
+  if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  ctx->scratch_bytes = want;
+  return NCG_OK;
+}
+
+extern "C" {
+
+const char* ncg_version(void) { return "noble-curves-amd 0.1 (gfx950)"; }
+
+int ncg_point_bytes(int curve) {
+  switch (curve) {
+    case NCG_SECP256K1: return 64;
+    case NCG_ED25519: return 64;
+    case NCG_BLS12_381_G1: return 96;
+    case NCG_BLS12_381_G2: return 192;
+    default: return 0;
+  }
+}
+int ncg_field_bytes(int curve) { return ncg_point_bytes(curve) / 2; }
+
+int ncg_init(int device_id, ncg_ctx** out_ctx) {
+  if (!out_ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: out_ctx is NULL");
+  *out_ctx = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return set_err(nullptr, NCG_ERR_NO_DEVICE, "noble-gpu: no HIP device visible (%s)", hipGetErrorString(e));
+  if (device_id < 0 || device_id >= count)
+    return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: device %d out of range (have %d)", device_id, count);
+  ncg_ctx* ctx = new ncg_ctx();
+  ctx->device = device_id;
+  e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    int rc = set_err(nullptr, NCG_ERR_HIP, "noble-gpu: cannot create stream on device %d: %s", device_id, hipGetErrorString(e));
+    delete ctx;
+    return rc;
+  }
+  *out_ctx = ctx;
+  return NCG_OK;
+}
+
+void ncg_destroy(ncg_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->ub_in) (void)hipFree(ctx->ub_in);
+  if (ctx->ub_out) (void)hipFree(ctx->ub_out);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* ncg_last_error(ncg_ctx* ctx) {
+  if (ctx) return ctx->last_error.c_str();
+  std::lock_guard<std::mutex> g(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_last_error;
+  return copy.c_str();
+}
+
+int ncg_sync(ncg_ctx* ctx) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
+int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev, const void* scalars_dev,
+                          void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_SECP256K1 && curve != NCG_BLS12_381_G1 && curve != NCG_BLS12_381_G2)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_var_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!points_affine_dev || !scalars_dev || !out_affine_dev || !out_is_inf_dev)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch: NULL buffer");
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  NCG_HIP(ctx, ncg::mul_var_batch(curve, (const uint32_t*)points_affine_dev, (const uint32_t*)scalars_dev,
+                                  (uint32_t*)out_affine_dev, out_is_inf_dev, (int)n, st));
+  return NCG_OK;
+}
+
+int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const void* scalars,
+                      void* out_affine, uint8_t* out_is_inf) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  int pb = ncg_point_bytes(curve);
+  if (pb == 0 || curve == NCG_ED25519)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_var_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (!points_affine || !scalars || !out_affine)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  size_t pts_b = n * pb, sc_b = n * 32, inf_b = (n + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, 2 * pts_b + sc_b + inf_b + 1024);
+  if (rc) return rc;
+  char* base = (char*)ctx->scratch;
+  char* d_pts = base;
+  char* d_out = d_pts + pts_b;
+  char* d_sc = d_out + pts_b;
+  char* d_inf = d_sc + sc_b;
+  NCG_HIP(ctx, hipMemcpyAsync(d_pts, points_affine, pts_b, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream));
+  rc = ncg_mul_var_batch_dev(ctx, curve, n, d_pts, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, pts_b, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
+int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float* out_ms) {
+  if (!ctx || !out_ms) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ubench: NULL arg");
+  if (blocks <= 0 || threads <= 0 || threads > 256 || iters <= 0)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ubench: bad geometry");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->ub_in) {
+    NCG_HIP(ctx, hipMalloc((void**)&ctx->ub_in, 1024 * 4));
+    uint32_t h[1024];
+    uint32_t x = 0x9e3779b9u;
+    for (int i = 0; i < 1024; i++) {
+      x ^= x << 13;
+      x ^= x >> 17;
+      x ^= x << 5;
+      h[i] = x;
+    }
+    NCG_HIP(ctx, hipMemcpy(ctx->ub_in, h, sizeof h, hipMemcpyHostToDevice));
+  }
+  size_t words = (size_t)blocks * threads;
+  if (ctx->ub_out_words < words) {
+    if (ctx->ub_out) (void)hipFree(ctx->ub_out);
+    ctx->ub_out = nullptr;
+    NCG_HIP(ctx, hipMalloc((void**)&ctx->ub_out, words * 4));
+    ctx->ub_out_words = words;
+  }
+  NCG_HIP(ctx, ncg::ubench_run(kind, blocks, threads, iters, ctx->ub_out, ctx->ub_in, ctx->stream, out_ms));
+  return NCG_OK;
+}
+
+}  // extern "C"

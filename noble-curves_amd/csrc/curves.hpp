@@ -1,0 +1,44 @@
+// Curve traits for the kernels.  IDs match include/ncg.h.
+#pragma once
+#include "ec_sw.hpp"
+
+namespace ncg {
+
+enum CurveId : int { CURVE_SECP256K1 = 0, CURVE_ED25519 = 1, CURVE_BLS12_381_G1 = 2, CURVE_BLS12_381_G2 = 3 };
+
+struct CurveSecp {  // src/secp256k1.ts:48-64
+  using F = FpSecp;
+  static constexpr bool GLV = true;  // h = 1: endomorphism split is always exact
+  static constexpr int SCALAR_BITS = 256;
+  static NCG_DI F beta() { return F::from_const(ParamsSecpP::BETA); }
+};
+struct CurveG1 {  // src/bls12-381.ts:134-148; no endomorphism in the reference (and inputs are
+  using F = FpBls;  // not subgroup-checked), so none here either (SURVEY 8a gotcha 1)
+  static constexpr bool GLV = false;
+  static constexpr int SCALAR_BITS = 255;
+  static NCG_DI F beta() { return F::one(); }
+};
+struct CurveG2 {  // src/bls12-381.ts:321-345
+  using F = Fp2Bls;
+  static constexpr bool GLV = false;
+  static constexpr int SCALAR_BITS = 255;
+  static NCG_DI F beta() { return F::one(); }
+};
+
+// Affine wire point (canonical residues) -> Montgomery-form Affine<F>, and back.
+template <class F>
+NCG_DI Affine<F> load_affine_wire(const uint32_t* p) {
+  constexpr int FW = FieldIO<F>::WORDS;
+  Affine<F> a;
+  a.x = f_to_mont(FieldIO<F>::load(p));
+  a.y = f_to_mont(FieldIO<F>::load(p + FW));
+  return a;
+}
+template <class F>
+NCG_DI void store_affine_wire(uint32_t* p, const Affine<F>& a) {
+  constexpr int FW = FieldIO<F>::WORDS;
+  FieldIO<F>::store(p, f_from_mont(a.x));
+  FieldIO<F>::store(p + FW, f_from_mont(a.y));
+}
+
+}  // namespace ncg

@@ -1,0 +1,206 @@
+// Short-Weierstrass a = 0 group law for secp256k1, bls12-381 G1 (Fp) and G2 (Fp2).
+//
+// The reference uses the complete projective Renes-Costello-Batina formulas
+// (src/abstract/weierstrass.ts:793-828 double, :834-880 add; 13-14 field muls each).
+// Only the *group element* is contractual (canonical affine equality), so the
+// device uses cheaper coordinates and handles the exceptional cases explicitly:
+//   * Jacobian (X, Y, Z), x = X/Z^2, y = Y/Z^3, infinity Z = 0     - scalar-mult ladders
+//       dbl-2009-l (2M+5S), madd-2007-bl-style mixed add (7M+4S), add-2007-bl (11M+5S)
+//   * XYZZ (X, Y, ZZ, ZZZ), x = X/ZZ, y = Y/ZZZ, infinity ZZ = 0   - MSM buckets
+//       madd-2008-s (8M+2S), add-2008-s (12M+2S), mdbl-2008-s-1, dbl-2008-s-1
+// P = Q, P = -Q and O are detected and routed to doubling / infinity, which is what the
+// reference's complete formulas compute implicitly (weierstrass.ts:789-792, 830-833).
+#pragma once
+#include "fp2.hpp"
+
+namespace ncg {
+
+template <class F>
+struct Affine {  // wire convention: infinity is (0, 0)  (weierstrass.ts:716, :966)
+  F x, y;
+  NCG_DI bool is_inf() const { return x.is_zero() && y.is_zero(); }
+};
+
+template <class F>
+struct Jac {
+  F X, Y, Z;
+  static NCG_DI Jac inf() { return {F::one(), F::one(), F::zero()}; }
+  NCG_DI bool is_inf() const { return Z.is_zero(); }
+};
+
+template <class F>
+struct Xyzz {
+  F X, Y, ZZ, ZZZ;
+  static NCG_DI Xyzz inf() { return {F::zero(), F::zero(), F::zero(), F::zero()}; }
+  NCG_DI bool is_inf() const { return ZZ.is_zero(); }
+};
+
+// ----------------------------------------------------------------- Jacobian
+template <class F>
+NCG_DI Jac<F> jac_from_affine(const Affine<F>& p) {
+  if (p.is_inf()) return Jac<F>::inf();
+  return {p.x, p.y, F::one()};
+}
+
+template <class F>
+NCG_DI Jac<F> jac_neg(const Jac<F>& p) {
+  return {p.X, f_neg(p.Y), p.Z};
+}
+
+// dbl-2009-l (a = 0): 2M + 5S.  Z = 0 stays Z = 0; no point of order 2 exists on these curves.
+template <class F>
+NCG_DI Jac<F> jac_dbl(const Jac<F>& p) {
+  F A = f_sqr(p.X);
+  F B = f_sqr(p.Y);
+  F C = f_sqr(B);
+  F t = f_sqr(p.X + B) - A - C;
+  F D = f_dbl(t);
+  F E = f_dbl(A) + A;
+  F Fq = f_sqr(E);
+  F X3 = Fq - f_dbl(D);
+  F C8 = f_dbl(f_dbl(f_dbl(C)));
+  F Y3 = E * (D - X3) - C8;
+  F Z3 = f_dbl(p.Y * p.Z);
+  return {X3, Y3, Z3};
+}
+
+// Jacobian + affine (madd-2007-bl without the 2x scaling): 8M + 3S, exceptional cases explicit.
+template <class F>
+NCG_DI Jac<F> jac_madd(const Jac<F>& p, const Affine<F>& q) {
+  if (q.is_inf()) return p;
+  if (p.is_inf()) return {q.x, q.y, F::one()};
+  F Z1Z1 = f_sqr(p.Z);
+  F U2 = q.x * Z1Z1;
+  F S2 = q.y * p.Z * Z1Z1;
+  F H = U2 - p.X;
+  F R = S2 - p.Y;
+  if (H.is_zero()) {
+    if (R.is_zero()) return jac_dbl(p);  // P == Q
+    return Jac<F>::inf();                // P == -Q
+  }
+  F HH = f_sqr(H);
+  F HHH = H * HH;
+  F V = p.X * HH;
+  F X3 = f_sqr(R) - HHH - f_dbl(V);
+  F Y3 = R * (V - X3) - p.Y * HHH;
+  F Z3 = p.Z * H;
+  return {X3, Y3, Z3};
+}
+
+// Jacobian + Jacobian: 12M + 4S, exceptional cases explicit.
+template <class F>
+NCG_DI Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
+  if (q.is_inf()) return p;
+  if (p.is_inf()) return q;
+  F Z1Z1 = f_sqr(p.Z);
+  F Z2Z2 = f_sqr(q.Z);
+  F U1 = p.X * Z2Z2;
+  F U2 = q.X * Z1Z1;
+  F S1 = p.Y * q.Z * Z2Z2;
+  F S2 = q.Y * p.Z * Z1Z1;
+  F H = U2 - U1;
+  F R = S2 - S1;
+  if (H.is_zero()) {
+    if (R.is_zero()) return jac_dbl(p);
+    return Jac<F>::inf();
+  }
+  F HH = f_sqr(H);
+  F HHH = H * HH;
+  F V = U1 * HH;
+  F X3 = f_sqr(R) - HHH - f_dbl(V);
+  F Y3 = R * (V - X3) - S1 * HHH;
+  F Z3 = p.Z * q.Z * H;
+  return {X3, Y3, Z3};
+}
+
+// Jacobian -> affine with a supplied inverse of Z (weierstrass.ts:951-969 toAffine(invZ)).
+template <class F>
+NCG_DI Affine<F> jac_to_affine(const Jac<F>& p, const F& zinv) {
+  if (p.is_inf()) return {F::zero(), F::zero()};
+  F zi2 = f_sqr(zinv);
+  return {p.X * zi2, p.Y * zi2 * zinv};
+}
+
+// ----------------------------------------------------------------- XYZZ
+template <class F>
+NCG_DI Xyzz<F> xyzz_from_affine(const Affine<F>& p) {
+  if (p.is_inf()) return Xyzz<F>::inf();
+  return {p.x, p.y, F::one(), F::one()};
+}
+
+// mdbl-2008-s-1 (a = 0): double an affine point into XYZZ.
+template <class F>
+NCG_DI Xyzz<F> xyzz_mdbl(const Affine<F>& p) {
+  F U = f_dbl(p.y);
+  F V = f_sqr(U);
+  F W = U * V;
+  F S = p.x * V;
+  F xx = f_sqr(p.x);
+  F M = f_dbl(xx) + xx;
+  F X3 = f_sqr(M) - f_dbl(S);
+  F Y3 = M * (S - X3) - W * p.y;
+  return {X3, Y3, V, W};
+}
+
+// dbl-2008-s-1 (a = 0)
+template <class F>
+NCG_DI Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
+  if (p.is_inf()) return p;
+  F U = f_dbl(p.Y);
+  F V = f_sqr(U);
+  F W = U * V;
+  F S = p.X * V;
+  F xx = f_sqr(p.X);
+  F M = f_dbl(xx) + xx;
+  F X3 = f_sqr(M) - f_dbl(S);
+  F Y3 = M * (S - X3) - W * p.Y;
+  return {X3, Y3, V * p.ZZ, W * p.ZZZ};
+}
+
+// madd-2008-s: XYZZ + affine, 8M + 2S; `neg` adds -q instead.
+template <class F>
+NCG_DI Xyzz<F> xyzz_madd(const Xyzz<F>& p, const Affine<F>& q_in, bool neg = false) {
+  if (q_in.is_inf()) return p;
+  Affine<F> q = q_in;
+  if (neg) q.y = f_neg(q.y);
+  if (p.is_inf()) return {q.x, q.y, F::one(), F::one()};
+  F U2 = q.x * p.ZZ;
+  F S2 = q.y * p.ZZZ;
+  F Pq = U2 - p.X;
+  F R = S2 - p.Y;
+  if (Pq.is_zero()) {
+    if (R.is_zero()) return xyzz_mdbl(q);
+    return Xyzz<F>::inf();
+  }
+  F PP = f_sqr(Pq);
+  F PPP = Pq * PP;
+  F Q = p.X * PP;
+  F X3 = f_sqr(R) - PPP - f_dbl(Q);
+  F Y3 = R * (Q - X3) - p.Y * PPP;
+  return {X3, Y3, p.ZZ * PP, p.ZZZ * PPP};
+}
+
+// add-2008-s: XYZZ + XYZZ, 12M + 2S.
+template <class F>
+NCG_DI Xyzz<F> xyzz_add(const Xyzz<F>& p, const Xyzz<F>& q) {
+  if (q.is_inf()) return p;
+  if (p.is_inf()) return q;
+  F U1 = p.X * q.ZZ;
+  F U2 = q.X * p.ZZ;
+  F S1 = p.Y * q.ZZZ;
+  F S2 = q.Y * p.ZZZ;
+  F Pq = U2 - U1;
+  F R = S2 - S1;
+  if (Pq.is_zero()) {
+    if (R.is_zero()) return xyzz_dbl(p);
+    return Xyzz<F>::inf();
+  }
+  F PP = f_sqr(Pq);
+  F PPP = Pq * PP;
+  F Q = U1 * PP;
+  F X3 = f_sqr(R) - PPP - f_dbl(Q);
+  F Y3 = R * (Q - X3) - S1 * PPP;
+  return {X3, Y3, p.ZZ * q.ZZ * PP, p.ZZZ * q.ZZZ * PPP};
+}
+
+}  // namespace ncg

@@ -1,0 +1,256 @@
+// Prime-field arithmetic for gfx950: 32-bit limbs in VGPRs, Montgomery form.
+//
+// Reproduces the *values* of the reference's `_Field` ops (src/abstract/modular.ts:940-982:
+// add/sub/neg/mul/sqr/inv = canonical residues mod ORDER) - here residues are held as
+// a*R mod p (R = 2^(32N)) so that `mul` is one interleaved multiply/reduce (CIOS) instead of
+// the reference's BigInt `a*b % p` (modular.ts:956, :50-54).  Conversion to/from canonical
+// residues happens only at kernel load/store.
+//
+// Integer-multiply throughput bounds this code (v_mad_u64_u32); there is no MFMA use.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "consts_gen.hpp"
+
+#define NCG_DI __host__ __device__ __forceinline__
+#ifndef NCG_MUL_INLINE
+#define NCG_MUL_INLINE 0
+#endif
+#if NCG_MUL_INLINE
+#define NCG_MULFN __host__ __device__ __forceinline__
+#else
+// out-of-line so an EC add (10-16 field muls) stays a few KB of code instead of ~100 KB:
+// the CU instruction cache is 64 KB.
+#define NCG_MULFN __host__ __device__ __noinline__
+#endif
+
+namespace ncg {
+
+template <class PR>
+struct Fp {
+  static constexpr int N = PR::N;
+  using Params = PR;
+  uint32_t v[N];
+
+  static NCG_DI Fp zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = 0;
+    return r;
+  }
+  static NCG_DI Fp one() {  // Montgomery form of 1
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = PR::R1[i];
+    return r;
+  }
+  template <class ARR>
+  static NCG_DI Fp from_const(const ARR& a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = a[i];
+    return r;
+  }
+  NCG_DI bool is_zero() const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) o |= v[i];
+    return o == 0;
+  }
+  NCG_DI bool operator==(const Fp& b) const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) o |= v[i] ^ b.v[i];
+    return o == 0;
+  }
+  NCG_DI bool operator!=(const Fp& b) const { return !(*this == b); }
+};
+
+// r = a - p if a >= p (a < 2p, possibly with an extra carry bit `hi`)
+template <class PR>
+NCG_DI void fp_cond_sub_p(uint32_t (&a)[PR::N], uint32_t hi) {
+  constexpr int N = PR::N;
+  uint32_t s[N];
+  uint32_t bw = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) s[j] = __builtin_subc(a[j], (uint32_t)PR::P[j], bw, &bw);
+  bool ge = (hi != 0) || (bw == 0);
+#pragma unroll
+  for (int j = 0; j < N; j++) a[j] = ge ? s[j] : a[j];
+}
+
+template <class PR>
+NCG_DI Fp<PR> operator+(const Fp<PR>& a, const Fp<PR>& b) {  // modular.ts:950
+  constexpr int N = PR::N;
+  Fp<PR> r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) r.v[j] = __builtin_addc(a.v[j], b.v[j], c, &c);
+  fp_cond_sub_p<PR>(r.v, PR::TOP_SPARE ? 0u : c);
+  return r;
+}
+
+template <class PR>
+NCG_DI Fp<PR> operator-(const Fp<PR>& a, const Fp<PR>& b) {  // modular.ts:953
+  constexpr int N = PR::N;
+  Fp<PR> r;
+  uint32_t bw = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) r.v[j] = __builtin_subc(a.v[j], b.v[j], bw, &bw);
+  // add p back when the subtraction borrowed
+  uint32_t m = 0u - bw;
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) r.v[j] = __builtin_addc(r.v[j], (uint32_t)PR::P[j] & m, c, &c);
+  return r;
+}
+
+template <class PR>
+NCG_DI Fp<PR> fp_neg(const Fp<PR>& a) {  // modular.ts:940
+  constexpr int N = PR::N;
+  Fp<PR> r;
+  uint32_t bw = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) r.v[j] = __builtin_subc((uint32_t)PR::P[j], a.v[j], bw, &bw);
+  bool z = a.is_zero();
+#pragma unroll
+  for (int j = 0; j < N; j++) r.v[j] = z ? 0u : r.v[j];
+  return r;
+}
+
+template <class PR>
+NCG_DI Fp<PR> fp_dbl(const Fp<PR>& a) {
+  return a + a;
+}
+
+// Montgomery product a*b*R^-1 mod p, CIOS with two carry chains per row
+// (lo-half chain and hi-half chain of the N partial products).
+template <class PR>
+NCG_DI void fp_mul_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], const uint32_t (&b)[PR::N]) {
+  constexpr int N = PR::N;
+  uint32_t T[N + 2];
+#pragma unroll
+  for (int i = 0; i < N + 2; i++) T[i] = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint32_t lo[N], hi[N];
+    uint32_t c;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      uint64_t t = (uint64_t)a[j] * b[i];
+      lo[j] = (uint32_t)t;
+      hi[j] = (uint32_t)(t >> 32);
+    }
+    c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) T[j] = __builtin_addc(T[j], lo[j], c, &c);
+    T[N] = __builtin_addc(T[N], 0u, c, &c);
+    T[N + 1] += c;
+    c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) T[j + 1] = __builtin_addc(T[j + 1], hi[j], c, &c);
+    T[N + 1] += c;
+    uint32_t m = T[0] * PR::INV;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      uint64_t t = (uint64_t)m * (uint32_t)PR::P[j];
+      lo[j] = (uint32_t)t;
+      hi[j] = (uint32_t)(t >> 32);
+    }
+    c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) T[j] = __builtin_addc(T[j], lo[j], c, &c);
+    T[N] = __builtin_addc(T[N], 0u, c, &c);
+    T[N + 1] += c;
+    c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) T[j + 1] = __builtin_addc(T[j + 1], hi[j], c, &c);
+    T[N + 1] += c;
+#pragma unroll
+    for (int j = 0; j < N + 1; j++) T[j] = T[j + 1];
+    T[N + 1] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < N; j++) r[j] = T[j];
+  fp_cond_sub_p<PR>(r, T[N]);
+}
+
+template <class PR>
+NCG_MULFN Fp<PR> fp_mul(Fp<PR> a, Fp<PR> b) {  // modular.ts:956
+  Fp<PR> r;
+  fp_mul_body<PR>(r.v, a.v, b.v);
+  return r;
+}
+
+template <class PR>
+NCG_MULFN Fp<PR> fp_sqr(Fp<PR> a) {  // modular.ts:947
+  Fp<PR> r;
+  fp_mul_body<PR>(r.v, a.v, a.v);
+  return r;
+}
+
+template <class PR>
+NCG_DI Fp<PR> operator*(const Fp<PR>& a, const Fp<PR>& b) {
+  return fp_mul<PR>(a, b);
+}
+
+// canonical residue (little-endian 32-bit limbs) -> Montgomery form
+template <class PR>
+NCG_DI Fp<PR> fp_to_mont(const Fp<PR>& a) {
+  return fp_mul<PR>(a, Fp<PR>::from_const(PR::R2));
+}
+// Montgomery form -> canonical residue in [0, p)
+template <class PR>
+NCG_DI Fp<PR> fp_from_mont(const Fp<PR>& a) {
+  Fp<PR> o = Fp<PR>::zero();
+  o.v[0] = 1;
+  return fp_mul<PR>(a, o);
+}
+
+// a^(2^n)
+template <class PR>
+NCG_DI Fp<PR> fp_sqr_n(Fp<PR> a, int n) {
+  for (int i = 0; i < n; i++) a = fp_sqr<PR>(a);
+  return a;
+}
+
+// Fermat inversion a^(p-2) (square-and-multiply over the constant exponent, MSB first);
+// same value as the reference's Euclidean invert() (modular.ts:159-182); 0 -> 0.
+template <class PR>
+NCG_DI Fp<PR> fp_inv(const Fp<PR>& a) {
+  Fp<PR> r = Fp<PR>::one();
+  bool started = false;
+  for (int w = PR::N - 1; w >= 0; w--) {
+    uint32_t word = PR::P[w];
+    if (w == 0) word -= 2u;  // p[0] >= 2 for every field here
+    for (int bit = 31; bit >= 0; bit--) {
+      if (started) r = fp_sqr<PR>(r);
+      if ((word >> bit) & 1u) {
+        r = started ? fp_mul<PR>(r, a) : a;
+        started = true;
+      }
+    }
+  }
+  return r;
+}
+
+// load/store of canonical residues in wire format (little-endian bytes == LE 32-bit limbs)
+template <class PR>
+NCG_DI Fp<PR> fp_load(const uint32_t* __restrict__ p) {
+  Fp<PR> r;
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) r.v[i] = p[i];
+  return r;
+}
+template <class PR>
+NCG_DI void fp_store(uint32_t* __restrict__ p, const Fp<PR>& a) {
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) p[i] = a.v[i];
+}
+
+using FpSecp = Fp<ParamsSecpP>;
+using FpEd = Fp<ParamsEdP>;
+using FpBls = Fp<ParamsBlsP>;
+
+}  // namespace ncg

@@ -1,0 +1,99 @@
+// Fp2 = Fp[u]/(u^2+1) over the bls12-381 base field, for G2.
+// Reproduces the values of the reference's `_Field2` ops (src/abstract/tower.ts:393-438):
+// mul = 3 Fp.mul Karatsuba (:420-431), sqr = 2 Fp.mul (:432-438).
+#pragma once
+#include "fp.hpp"
+
+namespace ncg {
+
+template <class PR>
+struct Fp2T {
+  using B = Fp<PR>;
+  B c0, c1;
+  static NCG_DI Fp2T zero() { return {B::zero(), B::zero()}; }
+  static NCG_DI Fp2T one() { return {B::one(), B::zero()}; }
+  NCG_DI bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  NCG_DI bool operator==(const Fp2T& o) const { return c0 == o.c0 && c1 == o.c1; }
+  NCG_DI bool operator!=(const Fp2T& o) const { return !(*this == o); }
+};
+
+template <class PR>
+NCG_DI Fp2T<PR> operator+(const Fp2T<PR>& a, const Fp2T<PR>& b) {  // tower.ts:404
+  return {a.c0 + b.c0, a.c1 + b.c1};
+}
+template <class PR>
+NCG_DI Fp2T<PR> operator-(const Fp2T<PR>& a, const Fp2T<PR>& b) {  // tower.ts:413
+  return {a.c0 - b.c0, a.c1 - b.c1};
+}
+template <class PR>
+NCG_DI Fp2T<PR> operator*(const Fp2T<PR>& a, const Fp2T<PR>& b) {  // tower.ts:420-431
+  Fp<PR> t1 = a.c0 * b.c0;
+  Fp<PR> t2 = a.c1 * b.c1;
+  Fp<PR> m = (a.c0 + a.c1) * (b.c0 + b.c1);
+  return {t1 - t2, m - (t1 + t2)};
+}
+
+using Fp2Bls = Fp2T<ParamsBlsP>;
+
+// ---- uniform "field concept" used by the curve templates (works for Fp<PR> and Fp2T<PR>)
+template <class PR> NCG_DI Fp<PR> f_sqr(const Fp<PR>& a) { return fp_sqr<PR>(a); }
+template <class PR> NCG_DI Fp<PR> f_neg(const Fp<PR>& a) { return fp_neg<PR>(a); }
+template <class PR> NCG_DI Fp<PR> f_dbl(const Fp<PR>& a) { return a + a; }
+template <class PR> NCG_DI Fp<PR> f_inv(const Fp<PR>& a) { return fp_inv<PR>(a); }
+template <class PR> NCG_DI Fp<PR> f_to_mont(const Fp<PR>& a) { return fp_to_mont<PR>(a); }
+template <class PR> NCG_DI Fp<PR> f_from_mont(const Fp<PR>& a) { return fp_from_mont<PR>(a); }
+
+template <class PR>
+NCG_DI Fp2T<PR> f_sqr(const Fp2T<PR>& a) {  // tower.ts:432-438
+  Fp<PR> s = a.c0 + a.c1;
+  Fp<PR> d = a.c0 - a.c1;
+  Fp<PR> c = a.c0 + a.c0;
+  return {s * d, c * a.c1};
+}
+template <class PR> NCG_DI Fp2T<PR> f_neg(const Fp2T<PR>& a) { return {fp_neg<PR>(a.c0), fp_neg<PR>(a.c1)}; }
+template <class PR> NCG_DI Fp2T<PR> f_dbl(const Fp2T<PR>& a) { return {a.c0 + a.c0, a.c1 + a.c1}; }
+template <class PR>
+NCG_DI Fp2T<PR> f_inv(const Fp2T<PR>& a) {  // tower.ts:458-475: (a - bu)/(a^2 + b^2)
+  Fp<PR> f = fp_inv<PR>(fp_sqr<PR>(a.c0) + fp_sqr<PR>(a.c1));
+  return {f * a.c0, f * fp_neg<PR>(a.c1)};
+}
+template <class PR> NCG_DI Fp2T<PR> f_to_mont(const Fp2T<PR>& a) { return {fp_to_mont<PR>(a.c0), fp_to_mont<PR>(a.c1)}; }
+template <class PR> NCG_DI Fp2T<PR> f_from_mont(const Fp2T<PR>& a) { return {fp_from_mont<PR>(a.c0), fp_from_mont<PR>(a.c1)}; }
+
+// wire format: Fp = N LE limbs; Fp2 = c0 then c1 (include/ncg.h)
+template <class F> struct FieldIO;
+template <class PR>
+struct FieldIO<Fp<PR>> {
+  static constexpr int WORDS = PR::N;
+  static NCG_DI Fp<PR> load(const uint32_t* p) { return fp_load<PR>(p); }
+  static NCG_DI void store(uint32_t* p, const Fp<PR>& a) { fp_store<PR>(p, a); }
+  // strided (word i at p[i*stride]) - LDS tables laid out limb-major, lane-minor
+  template <class PTR> static NCG_DI Fp<PR> load_strided(PTR p, int stride) {
+    Fp<PR> r;
+#pragma unroll
+    for (int i = 0; i < PR::N; i++) r.v[i] = p[i * stride];
+    return r;
+  }
+  template <class PTR> static NCG_DI void store_strided(PTR p, int stride, const Fp<PR>& a) {
+#pragma unroll
+    for (int i = 0; i < PR::N; i++) p[i * stride] = a.v[i];
+  }
+};
+template <class PR>
+struct FieldIO<Fp2T<PR>> {
+  static constexpr int WORDS = 2 * PR::N;
+  static NCG_DI Fp2T<PR> load(const uint32_t* p) { return {fp_load<PR>(p), fp_load<PR>(p + PR::N)}; }
+  static NCG_DI void store(uint32_t* p, const Fp2T<PR>& a) {
+    fp_store<PR>(p, a.c0);
+    fp_store<PR>(p + PR::N, a.c1);
+  }
+  template <class PTR> static NCG_DI Fp2T<PR> load_strided(PTR p, int stride) {
+    return {FieldIO<Fp<PR>>::load_strided(p, stride), FieldIO<Fp<PR>>::load_strided(p + PR::N * stride, stride)};
+  }
+  template <class PTR> static NCG_DI void store_strided(PTR p, int stride, const Fp2T<PR>& a) {
+    FieldIO<Fp<PR>>::store_strided(p, stride, a.c0);
+    FieldIO<Fp<PR>>::store_strided(p + PR::N * stride, stride, a.c1);
+  }
+};
+
+}  // namespace ncg

@@ -1,0 +1,70 @@
+// HOST-ONLY unit-test shim: runs the same __host__ __device__ templates the kernels use
+// (field arithmetic, group law, GLV split, window recoding, per-lane ladders) on the CPU so
+// their logic can be checked against the oracle without a GPU (`pytest -m "not gpu"`).
+// Built into tests/_build/libncg_hosttest.so; never linked into libncg.so, never a fallback.
+#include <vector>
+
+#include "mulvar.hpp"
+
+using namespace ncg;
+
+template <class C, int W>
+static void ht_mul_var_t(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n) {
+  constexpr int FW = MulVarCfg<C, W>::FW;
+  std::vector<uint32_t> tab(MulVarCfg<C, W>::TS * 2 * FW);
+  for (int i = 0; i < n; i++)
+    mul_var_lane<C, W>(pts + (size_t)i * 2 * FW, scalars + (size_t)i * 8, out + (size_t)i * 2 * FW, out_inf + i, true,
+                       tab.data(), 1);
+}
+
+template <class PR>
+static void ht_field_t(int op, const uint32_t* a, const uint32_t* b, uint32_t* r) {
+  Fp<PR> x = fp_to_mont<PR>(fp_load<PR>(a)), y = fp_to_mont<PR>(fp_load<PR>(b)), z;
+  switch (op) {
+    case 0: z = x * y; break;
+    case 1: z = fp_sqr<PR>(x); break;
+    case 2: z = x + y; break;
+    case 3: z = x - y; break;
+    case 4: z = fp_neg<PR>(x); break;
+    case 5: z = fp_inv<PR>(x); break;
+    default: z = Fp<PR>::zero();
+  }
+  fp_store<PR>(r, fp_from_mont<PR>(z));
+}
+
+extern "C" {
+
+int ht_mul_var(int curve, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n) {
+  switch (curve) {
+    case CURVE_SECP256K1: ht_mul_var_t<CurveSecp, 4>(pts, scalars, out, out_inf, n); return 0;
+    case CURVE_BLS12_381_G1: ht_mul_var_t<CurveG1, 3>(pts, scalars, out, out_inf, n); return 0;
+    case CURVE_BLS12_381_G2: ht_mul_var_t<CurveG2, 3>(pts, scalars, out, out_inf, n); return 0;
+  }
+  return -1;
+}
+
+// field: 0 secp256k1 p, 1 ed25519 p, 2 bls12-381 p; canonical LE limbs in and out
+int ht_field_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* r) {
+  switch (field) {
+    case 0: ht_field_t<ParamsSecpP>(op, a, b, r); return 0;
+    case 1: ht_field_t<ParamsEdP>(op, a, b, r); return 0;
+    case 2: ht_field_t<ParamsBlsP>(op, a, b, r); return 0;
+  }
+  return -1;
+}
+
+// GLV split of a 256-bit scalar: out = k1[5] k2[5] k1neg k2neg (12 words)
+int ht_glv_split(const uint32_t* k, uint32_t* out) {
+  uint32_t kk[8];
+  for (int i = 0; i < 8; i++) kk[i] = k[i];
+  GlvSplit s = secp_glv_split(kk);
+  for (int i = 0; i < 5; i++) {
+    out[i] = s.k1[i];
+    out[5 + i] = s.k2[i];
+  }
+  out[10] = s.k1neg;
+  out[11] = s.k2neg;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,29 @@
+// Launchers for the batch variable-base multiply kernels (see mulvar.hpp).
+#include "mulvar.hpp"
+
+namespace ncg {
+
+template <class C, int W>
+static hipError_t launch_mul_var(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
+                                 int n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  using Cfg = MulVarCfg<C, W>;
+  size_t lds = (size_t)Cfg::LDS_WORDS * 4;
+  auto kern = k_mul_var<C, W>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, out, out_inf, n);
+  return hipGetLastError();
+}
+
+hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
+                         int n, hipStream_t st) {
+  switch (curve) {
+    case CURVE_SECP256K1: return launch_mul_var<CurveSecp, 4>(pts, scalars, out, out_inf, n, st);
+    case CURVE_BLS12_381_G1: return launch_mul_var<CurveG1, 3>(pts, scalars, out, out_inf, n, st);
+    case CURVE_BLS12_381_G2: return launch_mul_var<CurveG2, 3>(pts, scalars, out, out_inf, n, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ncg

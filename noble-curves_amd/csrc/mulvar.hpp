@@ -1,0 +1,186 @@
+// Batch variable-base scalar multiplication: out[i] = k[i] * P[i], one lane per pair.
+//
+// Replaces, for a whole batch, the reference's Point.multiplyUnsafe(k)
+// (src/abstract/weierstrass.ts:915-928 -> pushWnafPair :660-671 -> mulAddUnsafe
+// src/abstract/curve.ts:820-836 -> wnafWalk :479-498) and - for the value - Point.multiply(k)
+// (weierstrass.ts:900-907), whose result is the same group element, Z=1-normalised.
+//
+// Why not the reference's wNAF walk: on a 64-lane wavefront a data-dependent "add when the
+// digit is non-zero" executes the add for the whole wave at nearly every bit.  The ladder here
+// is regular instead: signed-odd fixed windows of W bits (every digit odd and non-zero), so all
+// lanes do W doublings + one mixed add per scalar per window.  secp256k1 uses the GLV split
+// k = k1 + lambda*k2 (two 128-bit halves sharing the doubling chain, psi(P) = (beta*x, y)) exactly
+// as the reference does; bls12-381 G1/G2 get no endomorphism (the reference has none there and
+// inputs may lie outside the prime-order subgroup).
+//
+// Per-lane table of odd multiples [1,3,..,2^W-1]*P lives in LDS (limb-major, lane-minor: bank
+// conflict free for any digit pattern) as *affine* points of an isomorphic curve (shared-Z
+// "effective affine" trick), so every table add is a mixed add.
+#pragma once
+#include "curves.hpp"
+#include "scalar.hpp"
+
+namespace ncg {
+
+// madd that also returns the Z ratio (Z3 = Z1 * zr); used only while building the table, where
+// exceptional cases cannot occur for points of prime order.
+template <class F>
+NCG_DI Jac<F> jac_madd_zr(const Jac<F>& p, const Affine<F>& q, F& zr) {
+  F Z1Z1 = f_sqr(p.Z);
+  F U2 = q.x * Z1Z1;
+  F S2 = q.y * p.Z * Z1Z1;
+  F H = U2 - p.X;
+  F R = S2 - p.Y;
+  F HH = f_sqr(H);
+  F HHH = H * HH;
+  F V = p.X * HH;
+  F X3 = f_sqr(R) - HHH - f_dbl(V);
+  F Y3 = R * (V - X3) - p.Y * HHH;
+  zr = H;
+  return {X3, Y3, p.Z * H};
+}
+
+template <class C, int W>
+struct MulVarCfg {
+  using F = typename C::F;
+  static constexpr int FW = FieldIO<F>::WORDS;
+  static constexpr int TS = 1 << (W - 1);                 // table entries: 1,3,..,2^W-1
+  static constexpr int KBITS = C::GLV ? 129 : 257;        // bound on |k|+1 per stream
+  static constexpr int M = (KBITS + W - 1) / W;           // windows
+  static constexpr int NL = C::GLV ? 5 : 9;               // limbs of the window register
+  static constexpr int LDS_WORDS = TS * 2 * FW * 64;      // per 64-lane block
+};
+
+// Per-lane body.  `tab` is this lane's table base, consecutive words `stride` apart
+// (LDS: lds + lane, stride 64;  host unit test: a plain array, stride 1).
+template <class C, int W, class TABPTR>
+NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* __restrict__ k_wire,
+                         uint32_t* __restrict__ out_wire, uint8_t* __restrict__ out_inf, bool active,
+                         TABPTR tab, const int stride) {
+  using Cfg = MulVarCfg<C, W>;
+  using F = typename C::F;
+  constexpr int FW = Cfg::FW, TS = Cfg::TS, M = Cfg::M, NL = Cfg::NL;
+
+  Affine<F> P = load_affine_wire<F>(pt_wire);
+  uint32_t k[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) k[i] = k_wire[i];
+  const bool trivial_zero = P.is_inf() || mp_is_zero<8>(k);
+
+  // ---- table of odd multiples on the isomorphic curve ------------------------------------
+  // entry e, word w at tab[(e*2*FW + w)*stride]
+  F Zg;
+  {
+    Jac<F> D = jac_dbl(Jac<F>{P.x, P.y, F::one()});
+    F dz2 = f_sqr(D.Z);
+    F dz3 = dz2 * D.Z;
+    Affine<F> Dp{D.X, D.Y};
+    Jac<F> T{P.x * dz2, P.y * dz3, F::one()};
+    F zr[TS];
+    FieldIO<F>::store_strided(tab, stride, T.X);
+    FieldIO<F>::store_strided(tab + FW * stride, stride, T.Y);
+#pragma unroll
+    for (int j = 1; j < TS; j++) {
+      T = jac_madd_zr(T, Dp, zr[j]);
+      FieldIO<F>::store_strided(tab + (j * 2 * FW) * stride, stride, T.X);
+      FieldIO<F>::store_strided(tab + (j * 2 * FW + FW) * stride, stride, T.Y);
+    }
+    // bring every entry to the last entry's Z
+    F s = F::one();
+#pragma unroll
+    for (int j = TS - 2; j >= 0; j--) {
+      s = (j == TS - 2) ? zr[j + 1] : s * zr[j + 1];
+      F s2 = f_sqr(s);
+      F s3 = s2 * s;
+      F x = FieldIO<F>::load_strided(tab + (j * 2 * FW) * stride, stride);
+      F y = FieldIO<F>::load_strided(tab + (j * 2 * FW + FW) * stride, stride);
+      FieldIO<F>::store_strided(tab + (j * 2 * FW) * stride, stride, x * s2);
+      FieldIO<F>::store_strided(tab + (j * 2 * FW + FW) * stride, stride, y * s3);
+    }
+    Zg = D.Z * T.Z;
+  }
+
+  // ---- scalar recoding ---------------------------------------------------------------------
+  SignedOddWindows<NL, W, M> w1, w2;
+  bool neg1 = false, neg2 = false;
+  if constexpr (C::GLV) {
+    GlvSplit gs = secp_glv_split(k);
+    w1.template init<5>(gs.k1);
+    w2.template init<5>(gs.k2);
+    neg1 = gs.k1neg;
+    neg2 = gs.k2neg;
+  } else {
+    w1.template init<8>(k);
+  }
+  const F beta = C::beta();
+
+  // ---- ladder -------------------------------------------------------------------------------
+  Jac<F> R = Jac<F>::inf();
+  for (int i = 0; i < M; i++) {
+    if (i > 0) {
+#pragma unroll
+      for (int d = 0; d < W; d++) R = jac_dbl(R);
+    }
+    {
+      int d1 = w1.pop();
+      int e = ((d1 < 0 ? -d1 : d1) - 1) >> 1;
+      Affine<F> q;
+      q.x = FieldIO<F>::load_strided(tab + (e * 2 * FW) * stride, stride);
+      q.y = FieldIO<F>::load_strided(tab + (e * 2 * FW + FW) * stride, stride);
+      if ((d1 < 0) != neg1) q.y = f_neg(q.y);
+      R = jac_madd(R, q);
+    }
+    if constexpr (C::GLV) {
+      int d2 = w2.pop();
+      int e = ((d2 < 0 ? -d2 : d2) - 1) >> 1;
+      Affine<F> q;
+      q.x = FieldIO<F>::load_strided(tab + (e * 2 * FW) * stride, stride) * beta;
+      q.y = FieldIO<F>::load_strided(tab + (e * 2 * FW + FW) * stride, stride);
+      if ((d2 < 0) != neg2) q.y = f_neg(q.y);
+      R = jac_madd(R, q);
+    }
+  }
+  // even scalars were bumped by one: take the extra point back out
+  {
+    Affine<F> q;
+    q.x = FieldIO<F>::load_strided(tab, stride);
+    q.y = FieldIO<F>::load_strided(tab + FW * stride, stride);
+    if (w1.was_even) {
+      Affine<F> m = q;
+      if (!neg1) m.y = f_neg(m.y);
+      R = jac_madd(R, m);
+    }
+    if constexpr (C::GLV) {
+      if (w2.was_even) {
+        Affine<F> m{q.x * beta, q.y};
+        if (!neg2) m.y = f_neg(m.y);
+        R = jac_madd(R, m);
+      }
+    }
+  }
+  // back from the isomorphic curve, then to affine (weierstrass.ts:951-969 toAffine)
+  R.Z = R.Z * Zg;
+  bool inf = trivial_zero || R.is_inf();
+  Affine<F> A = jac_to_affine(R, f_inv(R.Z));
+  if (inf) A = {F::zero(), F::zero()};
+  if (active) {
+    store_affine_wire<F>(out_wire, A);
+    *out_inf = inf ? 1 : 0;
+  }
+}
+
+template <class C, int W>
+__global__ void __launch_bounds__(64)
+k_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars,
+          uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf, int n) {
+  constexpr int FW = MulVarCfg<C, W>::FW;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = threadIdx.x;
+  const int idx = blockIdx.x * 64 + lane;
+  const bool active = idx < n;
+  const int src = active ? idx : n - 1;  // idle lanes redo the last item, stores masked
+  mul_var_lane<C, W>(pts + (size_t)src * 2 * FW, scalars + (size_t)src * 8, out + (size_t)src * 2 * FW,
+                     out_inf + src, active, lds + lane, 64);
+}
+
+}  // namespace ncg

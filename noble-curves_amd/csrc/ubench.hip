@@ -1,0 +1,163 @@
+// Instruction-rate and field-multiply micro-benchmarks for gfx950.  Measurement tooling for
+// DESIGN.md's VALU roofline ("measure the real v_mad_u64_u32 issue rate first");
+// not on the product path.
+#include "curves.hpp"
+
+namespace ncg {
+
+enum UbKind : int {
+  UB_MAD_U64_U32 = 0,
+  UB_MUL_LO_U32 = 1,
+  UB_MUL_HI_U32 = 2,
+  UB_MAD_U32_U24 = 3,
+  UB_ADDC_U32 = 4,
+  UB_ADD_U64 = 5,
+  UB_FMA_F64 = 6,
+  UB_FMA_F32 = 7,
+  UB_MODMUL_SECP = 8,
+  UB_MODMUL_BLS = 9,
+  UB_MODSQR_BLS = 10,
+  UB_MODADD_BLS = 11,
+  UB_MUL_HI_U24 = 12,
+};
+
+__device__ __forceinline__ uint32_t __umul24hi_sub(uint32_t x, uint32_t y) {
+  uint32_t r;
+  asm volatile("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_ub_instr(uint32_t* out, const uint32_t* in, int iters) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t a = in[t & 1023] | 1u, b = in[(t + 7) & 1023] | 3u;
+  constexpr int CH = 8;  // independent chains per lane
+  if constexpr (KIND == UB_MAD_U64_U32) {
+    uint64_t acc[CH];
+    for (int c = 0; c < CH; c++) acc[c] = a + c;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int c = 0; c < CH; c++) acc[c] = (uint64_t)(uint32_t)acc[c] * b + acc[c];
+    }
+    uint64_t s = 0;
+    for (int c = 0; c < CH; c++) s ^= acc[c];
+    out[t] = (uint32_t)s ^ (uint32_t)(s >> 32);
+  } else if constexpr (KIND == UB_MUL_LO_U32 || KIND == UB_MUL_HI_U32 || KIND == UB_MAD_U32_U24 ||
+                       KIND == UB_MUL_HI_U24) {
+    uint32_t acc[CH];
+    for (int c = 0; c < CH; c++) acc[c] = a + c;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        if constexpr (KIND == UB_MUL_LO_U32) acc[c] = acc[c] * b;
+        if constexpr (KIND == UB_MUL_HI_U32) acc[c] = __umulhi(acc[c], b) + 0x9e3779b9u;
+        if constexpr (KIND == UB_MAD_U32_U24) acc[c] = __umul24(acc[c], b) + a;
+        if constexpr (KIND == UB_MUL_HI_U24) acc[c] = __umul24hi_sub(acc[c], b) ^ a;
+      }
+    }
+    uint32_t s = 0;
+    for (int c = 0; c < CH; c++) s ^= acc[c];
+    out[t] = s;
+  } else if constexpr (KIND == UB_ADDC_U32) {
+    uint32_t acc[CH];
+    for (int c = 0; c < CH; c++) acc[c] = a + c;
+    uint32_t cy = 0;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int c = 0; c < CH; c++) acc[c] = __builtin_addc(acc[c], b, cy, &cy);
+    }
+    uint32_t s = cy;
+    for (int c = 0; c < CH; c++) s ^= acc[c];
+    out[t] = s;
+  } else if constexpr (KIND == UB_ADD_U64) {
+    uint64_t acc[CH];
+    uint64_t bb = ((uint64_t)b << 32) | a;
+    for (int c = 0; c < CH; c++) acc[c] = a + c;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int c = 0; c < CH; c++) acc[c] = acc[c] + bb + (acc[c] >> 63);
+    }
+    uint64_t s = 0;
+    for (int c = 0; c < CH; c++) s ^= acc[c];
+    out[t] = (uint32_t)s ^ (uint32_t)(s >> 32);
+  } else if constexpr (KIND == UB_FMA_F64) {
+    double acc[CH];
+    double x = 1.0 + (double)(a & 0xff) * 1e-9, y = (double)(b & 0xff) * 1e-9;
+    for (int c = 0; c < CH; c++) acc[c] = (double)c;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int c = 0; c < CH; c++) acc[c] = __builtin_fma(acc[c], x, y);
+    }
+    double s = 0;
+    for (int c = 0; c < CH; c++) s += acc[c];
+    out[t] = (uint32_t)(long long)s;
+  } else if constexpr (KIND == UB_FMA_F32) {
+    float acc[CH];
+    float x = 1.0f + (float)(a & 0xff) * 1e-6f, y = (float)(b & 0xff) * 1e-6f;
+    for (int c = 0; c < CH; c++) acc[c] = (float)c;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+      for (int c = 0; c < CH; c++) acc[c] = __builtin_fmaf(acc[c], x, y);
+    }
+    float s = 0;
+    for (int c = 0; c < CH; c++) s += acc[c];
+    out[t] = (uint32_t)(int)s;
+  }
+}
+
+template <class PR, int OP>  // OP 0: mul, 1: sqr, 2: add
+__global__ void __launch_bounds__(256) k_ub_field(uint32_t* out, const uint32_t* in, int iters) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  Fp<PR> a, b;
+  for (int i = 0; i < PR::N; i++) {
+    a.v[i] = in[(t + i) & 1023];
+    b.v[i] = in[(t + 31 * i + 5) & 1023];
+  }
+  a.v[PR::N - 1] &= 0x0fffffffu;
+  b.v[PR::N - 1] &= 0x0fffffffu;
+  for (int i = 0; i < iters; i++) {
+    if constexpr (OP == 0) a = fp_mul<PR>(a, b);
+    if constexpr (OP == 1) a = fp_sqr<PR>(a);
+    if constexpr (OP == 2) a = a + b;
+  }
+  uint32_t s = 0;
+  for (int i = 0; i < PR::N; i++) s ^= a.v[i];
+  out[t] = s;
+}
+
+// Returns milliseconds for one launch of `kind` with the given geometry (after one warm-up).
+hipError_t ubench_run(int kind, int blocks, int threads, int iters, uint32_t* d_out, const uint32_t* d_in,
+                      hipStream_t st, float* ms) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; rep++) {
+    if (rep == 1) (void)hipEventRecord(e0, st);
+#define UB_LAUNCH(K) hipLaunchKernelGGL((K), dim3(blocks), dim3(threads), 0, st, d_out, d_in, iters)
+    switch (kind) {
+      case UB_MAD_U64_U32: UB_LAUNCH(k_ub_instr<UB_MAD_U64_U32>); break;
+      case UB_MUL_LO_U32: UB_LAUNCH(k_ub_instr<UB_MUL_LO_U32>); break;
+      case UB_MUL_HI_U32: UB_LAUNCH(k_ub_instr<UB_MUL_HI_U32>); break;
+      case UB_MAD_U32_U24: UB_LAUNCH(k_ub_instr<UB_MAD_U32_U24>); break;
+      case UB_MUL_HI_U24: UB_LAUNCH(k_ub_instr<UB_MUL_HI_U24>); break;
+      case UB_ADDC_U32: UB_LAUNCH(k_ub_instr<UB_ADDC_U32>); break;
+      case UB_ADD_U64: UB_LAUNCH(k_ub_instr<UB_ADD_U64>); break;
+      case UB_FMA_F64: UB_LAUNCH(k_ub_instr<UB_FMA_F64>); break;
+      case UB_FMA_F32: UB_LAUNCH(k_ub_instr<UB_FMA_F32>); break;
+      case UB_MODMUL_SECP: UB_LAUNCH((k_ub_field<ParamsSecpP, 0>)); break;
+      case UB_MODMUL_BLS: UB_LAUNCH((k_ub_field<ParamsBlsP, 0>)); break;
+      case UB_MODSQR_BLS: UB_LAUNCH((k_ub_field<ParamsBlsP, 1>)); break;
+      case UB_MODADD_BLS: UB_LAUNCH((k_ub_field<ParamsBlsP, 2>)); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef UB_LAUNCH
+  }
+  (void)hipEventRecord(e1, st);
+  hipError_t err = hipEventSynchronize(e1);
+  if (err == hipSuccess) err = hipEventElapsedTime(ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return err;
+}
+
+}  // namespace ncg

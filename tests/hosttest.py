@@ -1,0 +1,52 @@
+"""Loader for the host-only unit-test shim (tests/_build/libncg_hosttest.so), which executes
+the kernels' shared __host__ __device__ templates on the CPU.  Test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "_build", "libncg_hosttest.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        csrc = os.path.join(ROOT, "noble-curves_amd", "csrc")
+        subprocess.check_call(["make", "-C", csrc, "hosttest"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib = ctypes.CDLL(SO)
+        vp, i32 = ctypes.c_void_p, ctypes.c_int
+        _lib.ht_mul_var.argtypes = [i32, vp, vp, vp, vp, i32]
+        _lib.ht_field_op.argtypes = [i32, i32, vp, vp, vp]
+        _lib.ht_glv_split.argtypes = [vp, vp]
+    return _lib
+
+
+def mul_var(curve, pts, scalars):
+    pts = np.ascontiguousarray(pts, dtype=np.uint8)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+    n = pts.shape[0]
+    out = np.zeros_like(pts)
+    inf = np.zeros((n,), dtype=np.uint8)
+    rc = lib().ht_mul_var(curve, pts.ctypes.data, scalars.ctypes.data, out.ctypes.data, inf.ctypes.data, n)
+    assert rc == 0
+    return out, inf
+
+
+def field_op(field, op, a, b, nbytes):
+    A = np.frombuffer(int(a).to_bytes(nbytes, "little"), dtype=np.uint8).copy()
+    B = np.frombuffer(int(b).to_bytes(nbytes, "little"), dtype=np.uint8).copy()
+    R = np.zeros(nbytes, dtype=np.uint8)
+    assert lib().ht_field_op(field, op, A.ctypes.data, B.ctypes.data, R.ctypes.data) == 0
+    return int.from_bytes(R.tobytes(), "little")
+
+
+def glv_split(k):
+    K = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
+    out = np.zeros(12, dtype=np.uint32)
+    assert lib().ht_glv_split(K.ctypes.data, out.ctypes.data) == 0
+    k1 = sum(int(out[i]) << (32 * i) for i in range(5))
+    k2 = sum(int(out[5 + i]) << (32 * i) for i in range(5))
+    return bool(out[10]), k1, bool(out[11]), k2

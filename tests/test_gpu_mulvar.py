@@ -1,0 +1,110 @@
+"""GPU parity: batch variable-base scalar multiplication (ncg_mul_var_batch) against the CPU
+oracle and the reference's golden vectors.  Bit-exact on canonical affine coordinates."""
+import numpy as np
+import pytest
+
+from noble_curves_amd import get_engine
+from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, SECP256K1
+from oracle import curve as C
+from oracle.curves import BLS_R, BlsG1, BlsG2, SECP256K1_N, Secp256k1, makeRng
+from oracle.weierstrass import bls_g1_decode_uncompressed, bls_g2_decode_uncompressed, sec1_decode
+
+from helpers import (ORACLE_CURVE, load_golden, points_to_wire, scalars_to_wire, wire_to_affine)
+
+pytestmark = pytest.mark.gpu
+
+
+def run_and_check(curve, pts, scalars, expected_affine):
+    eng = get_engine()
+    out, inf = eng.mul_var_batch(curve, points_to_wire(curve, pts), scalars_to_wire(scalars))
+    Pt = ORACLE_CURVE[curve]
+    zero_aff = Pt.ZERO.toAffine()
+    for i, exp in enumerate(expected_affine):
+        got = wire_to_affine(curve, out[i])
+        assert got == exp, "item %d: k=%x" % (i, scalars[i])
+        assert bool(inf[i]) == (exp == zero_aff)
+
+
+def test_secp256k1_golden_vectors():
+    """test/secp256k1.test.ts:59-71,79-131 and test/nist.test.ts:550-559 through the GPU path."""
+    pts, ks, exp = [], [], []
+    for k, x, y in load_golden("secp256k1_privates2.json"):
+        pts.append(Secp256k1.BASE)
+        ks.append(int(k))
+        exp.append((int(x, 16), int(y, 16)))
+    for t in load_golden("secp256k1_endomorphism.json"):
+        pts.append(Secp256k1.fromAffine((int(t["ax"]), int(t["ay"]))))
+        ks.append(int(t["scalar"]))
+        exp.append((int(t["cx"]), int(t["cy"])))
+    v = load_golden("secp256k1_points.json")
+    for t in v["valid"]["pointMultiply"]:
+        if t["expected"]:
+            pts.append(sec1_decode(Secp256k1, bytes.fromhex(t["P"])))
+            ks.append(int(t["d"], 16))
+            exp.append(sec1_decode(Secp256k1, bytes.fromhex(t["expected"])).toAffine())
+    for t in v["valid"]["pointFromScalar"]:
+        pts.append(Secp256k1.BASE)
+        ks.append(int(t["d"], 16))
+        exp.append(sec1_decode(Secp256k1, bytes.fromhex(t["expected"])).toAffine())
+    run_and_check(SECP256K1, pts, ks, exp)
+
+
+def test_secp256k1_random_and_edges_vs_oracle():
+    n = SECP256K1_N
+    rng = makeRng(0x6E6F626C6502)
+    a, b = rng.rndBelow(n - 1) + 1, rng.rndBelow(n - 1) + 1
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    edge = [0, 1, 2, 3, n - 1, n - 2, n - 3, 1 << 128, (1 << 128) - 1, (1 << 128) + 1, (1 << 255), lam, lam + 1,
+            lam - 1, n - lam, (n + 1) // 2, n // 2, (1 << 64), 0xFFFFFFFF, 1 << 32, 15, 16, 17, 255, 256]
+    pts, ks = [], []
+    for i, k in enumerate(edge):
+        pts.append(Secp256k1.BASE.multiplyUnsafe((a + i * b) % n))
+        ks.append(k)
+    pts.append(Secp256k1.ZERO)      # infinity input
+    ks.append(12345)
+    pts.append(Secp256k1.ZERO)
+    ks.append(0)
+    for i in range(700):
+        pts.append(Secp256k1.BASE.multiplyUnsafe((a + (100 + i) * b) % n))
+        ks.append(rng.rndBelow(n))
+    exp = [p.multiplyUnsafe(k).toAffine() for p, k in zip(pts, ks)]
+    run_and_check(SECP256K1, pts, ks, exp)
+
+
+def test_secp256k1_non_multiple_of_wave_and_empty():
+    eng = get_engine()
+    out, inf = eng.mul_var_batch(SECP256K1, np.zeros((0, 64), np.uint8), np.zeros((0, 32), np.uint8))
+    assert out.shape == (0, 64) and inf.shape == (0,)
+    for n in (1, 63, 65):
+        pts = [Secp256k1.BASE.multiplyUnsafe(i + 1) for i in range(n)]
+        ks = [(i * 0x9E3779B97F4A7C15 + 7) % SECP256K1_N for i in range(n)]
+        run_and_check(SECP256K1, pts, ks, [p.multiplyUnsafe(k).toAffine() for p, k in zip(pts, ks)])
+
+
+@pytest.mark.parametrize("curve,decode,key", [(BLS12_381_G1, bls_g1_decode_uncompressed, "G1_Uncompressed"),
+                                              (BLS12_381_G2, bls_g2_decode_uncompressed, "G2_Uncompressed")])
+def test_bls_multiples_golden(curve, decode, key):
+    """test/bls12-381.test.ts:1463-1535: BASE.multiplyUnsafe(i) == zkcrypto i*G, i = 0..255."""
+    Pt = ORACLE_CURVE[curve]
+    rows = load_golden("bls12_381_multiples.json")[key]
+    pts = [Pt.BASE] * len(rows)
+    ks = list(range(len(rows)))
+    exp = [decode(Pt, bytes.fromhex(t)).toAffine() for t in rows]
+    run_and_check(curve, pts, ks, exp)
+
+
+@pytest.mark.parametrize("curve,count", [(BLS12_381_G1, 150), (BLS12_381_G2, 70)])
+def test_bls_random_vs_oracle(curve, count):
+    Pt = ORACLE_CURVE[curve]
+    rng = makeRng(0xB15 + curve)
+    pts, ks = [], []
+    for k in (0, 1, 2, BLS_R - 1, BLS_R - 2, 1 << 254, (1 << 255) - 19 if (1 << 255) - 19 < BLS_R else 5):
+        pts.append(Pt.BASE.multiplyUnsafe(rng.rndBelow(BLS_R - 1) + 1))
+        ks.append(k)
+    pts.append(Pt.ZERO)
+    ks.append(99)
+    for _ in range(count):
+        pts.append(Pt.BASE.multiplyUnsafe(rng.rndBelow(BLS_R - 1) + 1))
+        ks.append(rng.rndBelow(BLS_R))
+    exp = [p.multiplyUnsafe(k).toAffine() for p, k in zip(pts, ks)]
+    run_and_check(curve, pts, ks, exp)

@@ -1,0 +1,72 @@
+"""CPU execution of the kernels' shared templates (field arithmetic, group law, GLV split,
+window recoding, per-lane ladder) against the oracle - catches logic errors without a GPU."""
+import pytest
+
+import hosttest
+from helpers import ORACLE_CURVE, points_to_wire, scalars_to_wire, wire_to_affine
+from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, SECP256K1
+from oracle.curves import BLS_P, BLS_R, ED25519_P, SECP256K1_N, SECP256K1_P, Secp256k1, makeRng
+
+FIELDS = [(0, SECP256K1_P, 32), (1, ED25519_P, 32), (2, BLS_P, 48)]
+
+
+@pytest.mark.parametrize("fid,p,nb", FIELDS)
+def test_field_ops_match_bigint(fid, p, nb):
+    rng = makeRng(0xF00D + fid)
+    vals = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (1 << (8 * nb - 8)) % p] + [rng.rndBelow(p) for _ in range(40)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        assert hosttest.field_op(fid, 0, a, b, nb) == a * b % p
+        assert hosttest.field_op(fid, 1, a, b, nb) == a * a % p
+        assert hosttest.field_op(fid, 2, a, b, nb) == (a + b) % p
+        assert hosttest.field_op(fid, 3, a, b, nb) == (a - b) % p
+        assert hosttest.field_op(fid, 4, a, b, nb) == (-a) % p
+    for a in vals[:12]:
+        assert hosttest.field_op(fid, 5, a, 0, nb) == (pow(a, -1, p) if a else 0)
+
+
+def test_glv_split_is_lattice_exact_and_short():
+    """Device GLV (reciprocal-multiply rounding) vs weierstrass.ts:121-148 semantics."""
+    n = SECP256K1_N
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    rng = makeRng(0x61C)
+    ks = [0, 1, 2, n - 1, n - 2, n // 2, n // 2 + 1, lam, n - lam, 1 << 128, (1 << 256) - 1, n, n + 1]
+    ks += [rng.rndBelow(n) for _ in range(3000)]
+    for k in ks:
+        k1neg, k1, k2neg, k2 = hosttest.glv_split(k)
+        assert k1 < (1 << 128) + (1 << 100) and k2 < (1 << 128) + (1 << 100)
+        s1 = -k1 if k1neg else k1
+        s2 = -k2 if k2neg else k2
+        assert (s1 + lam * s2 - k) % n == 0
+
+
+def _check(curve, pts, ks):
+    out, inf = hosttest.mul_var(curve, points_to_wire(curve, pts), scalars_to_wire(ks))
+    Pt = ORACLE_CURVE[curve]
+    for i, (p, k) in enumerate(zip(pts, ks)):
+        exp = p.multiplyUnsafe(k).toAffine() if k < Pt.Fn.ORDER else None
+        if exp is None:
+            continue
+        assert wire_to_affine(curve, out[i]) == exp, (i, hex(k))
+        assert bool(inf[i]) == (exp == Pt.ZERO.toAffine())
+
+
+def test_lane_ladder_secp256k1():
+    n = SECP256K1_N
+    rng = makeRng(0x1A0E)
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    ks = [0, 1, 2, 3, 4, n - 1, n - 2, 1 << 128, (1 << 128) - 1, lam, lam + 1, n - lam, 15, 16, 17]
+    ks += [rng.rndBelow(n) for _ in range(60)]
+    pts = [Secp256k1.BASE.multiplyUnsafe(rng.rndBelow(n - 1) + 1) for _ in ks]
+    pts[3] = Secp256k1.ZERO
+    _check(SECP256K1, pts, ks)
+
+
+@pytest.mark.parametrize("curve,cnt", [(BLS12_381_G1, 12), (BLS12_381_G2, 6)])
+def test_lane_ladder_bls(curve, cnt):
+    Pt = ORACLE_CURVE[curve]
+    rng = makeRng(0xB0B + curve)
+    ks = [0, 1, 2, BLS_R - 1, 7] + [rng.rndBelow(BLS_R) for _ in range(cnt)]
+    pts = [Pt.BASE.multiplyUnsafe(rng.rndBelow(BLS_R - 1) + 1) for _ in ks]
+    pts[4] = Pt.ZERO
+    _check(curve, pts, ks)
