@@ -71,6 +71,17 @@ int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_
                           const void* scalars_dev, void* out_affine_dev,
                           uint8_t* out_is_inf_dev, void* stream);
 
+/* ---- multi-scalar multiplication ---------------------------------------------------------
+ * out = sum_i scalars[i] * points[i].  Replaces pippenger(c, points, scalars)
+ * (src/abstract/curve.ts:863-905); n = 0 gives infinity (:878); scalar 0 and infinity points
+ * are allowed.  The result (one affine point, canonical residues) is written to HOST memory
+ * in both variants: the last step (Horner over <= 272 window/level sums + one inversion) runs
+ * on the host, so the call returns after synchronising the stream. */
+int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const void* scalars,
+            void* out_affine, uint8_t* out_is_inf);
+int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev,
+                const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream);
+
 /* ---- measurement helpers (not on the product path) ------------------------------------ */
 /* Runs instruction-rate / field-multiply micro-benchmark `kind` (see csrc/ubench.hip) and
  * returns the kernel time in milliseconds. */

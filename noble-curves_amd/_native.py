@@ -76,8 +76,8 @@ def load_library():
 
 _vp, _sz, _i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 _OPTIONAL_PROTOS = {
-    "ncg_msm": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
-    "ncg_msm_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp, _vp],
+    "ncg_msm": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
+    "ncg_msm_dev": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_msm_windows_dev": [_vp, _i32, _sz, _vp, _vp, _i32, _vp, _vp, _vp],
     "ncg_msm_combine": [_vp, _i32, _sz, _vp, _i32, _vp, _vp],
     "ncg_mul_base_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
@@ -155,6 +155,30 @@ class Engine:
 
     def mul_var_batch_dev(self, curve, n, d_points, d_scalars, d_out, d_inf, stream=None):
         self._check(self.lib.ncg_mul_var_batch_dev(self.h, curve, n, d_points, d_scalars, d_out, d_inf, stream))
+
+    # ---- multi-scalar multiplication -----------------------------------------------------------
+    def msm(self, curve, points, scalars):
+        """sum_i scalars[i]*points[i]; returns (affine wire bytes [PB], is_inf bool)."""
+        pb = POINT_BYTES[curve]
+        points = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, pb)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        n = points.shape[0]
+        if scalars.shape[0] != n:
+            raise ValueError("arrays of points and scalars must have equal length")
+        out = np.zeros((pb,), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self._check(self.lib.ncg_msm(self.h, curve, n, points.ctypes.data if n else None,
+                                     scalars.ctypes.data if n else None, out.ctypes.data, ctypes.byref(inf)))
+        return out, bool(inf.value)
+
+    def msm_dev(self, curve, n, d_points, d_scalars, stream=None):
+        """device-resident inputs (raw pointers); result comes back to the host."""
+        pb = POINT_BYTES[curve]
+        out = np.zeros((pb,), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self._check(self.lib.ncg_msm_dev(self.h, curve, n, d_points, d_scalars, out.ctypes.data, ctypes.byref(inf),
+                                         stream))
+        return out, bool(inf.value)
 
     def ubench(self, kind, blocks, threads, iters):
         ms = ctypes.c_float()

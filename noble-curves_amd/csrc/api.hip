@@ -9,6 +9,7 @@
 
 #include "../../include/ncg.h"
 #include "host_api.hpp"
+#include "msm.hpp"
 
 namespace {
 std::mutex g_err_mu;
@@ -22,6 +23,8 @@ struct ncg_ctx {
   // reusable device scratch for the host-pointer entry points
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  void* msm_ws = nullptr;  // MSM workspace (device)
+  size_t msm_ws_bytes = 0;
   uint32_t* ub_in = nullptr;
   uint32_t* ub_out = nullptr;
   size_t ub_out_words = 0;
@@ -102,6 +105,7 @@ void ncg_destroy(ncg_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
   if (ctx->ub_in) (void)hipFree(ctx->ub_in);
   if (ctx->ub_out) (void)hipFree(ctx->ub_out);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -163,6 +167,61 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
   if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
+}
+
+int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev, const void* scalars_dev,
+                void* out_affine, uint8_t* out_is_inf, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  int pb = ncg_point_bytes(curve);
+  if (pb == 0 || curve == NCG_ED25519)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm: unsupported curve %d", curve);
+  if (!out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: NULL output");
+  uint8_t inf_local = 0;
+  if (n == 0) {  // empty MSM is the identity (reference curve.ts:878)
+    memset(out_affine, 0, pb);
+    if (out_is_inf) *out_is_inf = 1;
+    return NCG_OK;
+  }
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: too many points");
+  if (!points_affine_dev || !scalars_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  ncg::MsmPlan pl;
+  if (ncg::msm_make_plan(curve, (int)n, 0, &pl) != 0)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+  size_t need = ncg::msm_workspace_bytes(curve, pl);
+  if (ctx->msm_ws_bytes < need) {
+    if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
+    ctx->msm_ws = nullptr;
+    ctx->msm_ws_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->msm_ws, need);
+    if (e != hipSuccess)
+      return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: msm workspace hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    ctx->msm_ws_bytes = need;
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  NCG_HIP(ctx, ncg::msm_run(curve, pl, (const uint32_t*)points_affine_dev, (const uint32_t*)scalars_dev, ctx->msm_ws,
+                            (uint32_t*)out_affine, &inf_local, st));
+  if (out_is_inf) *out_is_inf = inf_local;
+  return NCG_OK;
+}
+
+int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const void* scalars, void* out_affine,
+            uint8_t* out_is_inf) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  int pb = ncg_point_bytes(curve);
+  if (pb == 0 || curve == NCG_ED25519)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm: unsupported curve %d", curve);
+  if (n == 0) return ncg_msm_dev(ctx, curve, 0, nullptr, nullptr, out_affine, out_is_inf, nullptr);
+  if (!points_affine || !scalars || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  size_t pts_b = n * pb, sc_b = n * 32;
+  int rc = ensure_scratch(ctx, pts_b + sc_b + 2048);
+  if (rc) return rc;
+  char* d_pts = (char*)ctx->scratch;
+  char* d_sc = d_pts + ((pts_b + 255) & ~(size_t)255);
+  NCG_HIP(ctx, hipMemcpyAsync(d_pts, points_affine, pts_b, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream));
+  return ncg_msm_dev(ctx, curve, n, d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
 }
 
 int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float* out_ms) {

@@ -8,6 +8,13 @@ namespace ncg {
 hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
                          int n, hipStream_t st);
 
+struct MsmPlan;
+int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl);
+size_t msm_workspace_bytes(int curve, const MsmPlan& pl);
+// d_pts / d_scalars: device; out_*: host.  Synchronises `st` (host-side Horner finish).
+hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
+                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st);
+
 hipError_t ubench_run(int kind, int blocks, int threads, int iters, uint32_t* d_out, const uint32_t* d_in,
                       hipStream_t st, float* ms);
 

@@ -1,0 +1,384 @@
+// MSM kernels and the single-GPU driver (see msm.hpp for the pipeline).
+#include "msm.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "host_api.hpp"
+
+namespace ncg {
+
+// ------------------------------------------------------------------ 1. wire -> Montgomery
+template <class C>
+__global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* __restrict__ pts, uint32_t* __restrict__ out,
+                                                        int n) {
+  using F = typename C::F;
+  constexpr int AFF = MsmSizes<C>::AFF, FW = MsmSizes<C>::FW;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> a = load_affine_wire<F>(pts + (size_t)i * AFF);
+  FieldIO<F>::store(out + (size_t)i * AFF, a.x);
+  FieldIO<F>::store(out + (size_t)i * AFF + FW, a.y);
+}
+
+// ------------------------------------------------------------------ 2. signed digits
+// digits[w*n + i] = ((k_i + H') >> (c w)) & (2^c - 1)) - 2^(c-1)
+__global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
+                                                    MsmPlan pl) {
+  __shared__ uint32_t sh[256 * 11];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t* my = sh + threadIdx.x * 11;
+  if (i < pl.n) {
+    uint32_t cy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) my[j] = __builtin_addc(scalars[(size_t)i * 8 + j], pl.hconst[j], cy, &cy);
+    my[8] = __builtin_addc(0u, pl.hconst[8], cy, &cy);
+    my[9] = pl.hconst[9] + cy;
+    my[10] = 0;
+    const uint32_t mask = (1u << pl.c) - 1u;
+    const int half = 1 << (pl.c - 1);
+    for (int w = 0; w < pl.nwin; w++) {
+      int bp = w * pl.c;
+      int limb = bp >> 5, sft = bp & 31;
+      uint64_t two = ((uint64_t)my[limb + 1] << 32) | my[limb];
+      uint32_t v = (uint32_t)(two >> sft) & mask;
+      digits[(size_t)w * pl.n + i] = (int16_t)((int)v - half);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ 3. counting sort
+// counts[(w*Q + q)*nb + b]: number of entries of chunk q in bucket b (bucket value b+1)
+__global__ void __launch_bounds__(1024) k_msm_hist(const int16_t* __restrict__ digits, uint32_t* __restrict__ counts,
+                                                   MsmPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+  const int q = blockIdx.x, w = blockIdx.y;
+  for (int b = threadIdx.x; b < pl.nb; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
+  const int16_t* dg = digits + (size_t)w * pl.n;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int d = dg[i];
+    if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+  }
+  __syncthreads();
+  uint32_t* dst = counts + ((size_t)w * pl.Q + q) * pl.nb;
+  for (int b = threadIdx.x; b < pl.nb; b += blockDim.x) dst[b] = hist[b];
+}
+
+// One block per window.  Turns counts into scatter offsets and writes bucket_start[w][0..nb].
+__global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ counts, uint32_t* __restrict__ bucket_start,
+                                                   MsmPlan pl) {
+  __shared__ uint32_t part[1024];
+  const int w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  const int per = (pl.nb + T - 1) / T;
+  const int b0 = min(pl.nb, t * per), b1 = min(pl.nb, b0 + per);
+  uint32_t* cw = counts + (size_t)w * pl.Q * pl.nb;
+  uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  uint32_t mine = 0;
+  for (int b = b0; b < b1; b++) {
+    uint32_t tot = 0;
+    for (int q = 0; q < pl.Q; q++) {
+      uint32_t v = cw[(size_t)q * pl.nb + b];
+      cw[(size_t)q * pl.nb + b] = tot;  // exclusive prefix over chunks, within the bucket
+      tot += v;
+    }
+    bs[b] = tot;  // bucket size for now; becomes the bucket start below
+    mine += tot;
+  }
+  part[t] = mine;
+  __syncthreads();
+  for (int off = 1; off < T; off <<= 1) {  // inclusive Hillis-Steele scan of per-thread totals
+    uint32_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - mine;
+  for (int b = b0; b < b1; b++) {
+    uint32_t size = bs[b];
+    bs[b] = run;
+    for (int q = 0; q < pl.Q; q++) cw[(size_t)q * pl.nb + b] += run;
+    run += size;
+  }
+  if (t == T - 1) bs[pl.nb] = part[T - 1];
+}
+
+// sorted[w*n + pos] = point index | sign<<31, grouped by bucket within the window
+__global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict__ digits,
+                                                      const uint32_t* __restrict__ counts,
+                                                      uint32_t* __restrict__ sorted, MsmPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t offs[];
+  const int q = blockIdx.x, w = blockIdx.y;
+  const uint32_t* src = counts + ((size_t)w * pl.Q + q) * pl.nb;
+  for (int b = threadIdx.x; b < pl.nb; b += blockDim.x) offs[b] = src[b];
+  __syncthreads();
+  const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
+  const int16_t* dg = digits + (size_t)w * pl.n;
+  uint32_t* dst = sorted + (size_t)w * pl.n;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    int d = dg[i];
+    if (d != 0) {
+      uint32_t pos = atomicAdd(&offs[(d < 0 ? -d : d) - 1], 1u);
+      dst[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ 4. bucket accumulation
+// One lane per (window, bucket): XYZZ accumulator += affine point for every sorted entry.
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* __restrict__ pts_mont,
+                                                   const uint32_t* __restrict__ sorted,
+                                                   const uint32_t* __restrict__ bucket_start,
+                                                   uint32_t* __restrict__ buckets, MsmPlan pl) {
+  using F = typename C::F;
+  constexpr int AFF = MsmSizes<C>::AFF, FW = MsmSizes<C>::FW, XW = MsmSizes<C>::XYZZ;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= pl.nwin * pl.nb) return;
+  const int w = t / pl.nb, b = t - w * pl.nb;
+  const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  const uint32_t lo = bs[b], hi = bs[b + 1];
+  const uint32_t* sw = sorted + (size_t)w * pl.n;
+  Xyzz<F> acc = Xyzz<F>::inf();
+  for (uint32_t j = lo; j < hi; j++) {
+    uint32_t e = sw[j];
+    const uint32_t* pp = pts_mont + (size_t)(e & 0x7fffffffu) * AFF;
+    Affine<F> p{FieldIO<F>::load(pp), FieldIO<F>::load(pp + FW)};
+    acc = xyzz_madd(acc, p, (e >> 31) != 0);
+  }
+  xyzz_store<F>(buckets + (size_t)t * XW, acc);
+}
+
+// ------------------------------------------------------------------ 5. bucket fold, one level
+// in:  [narr][nwin][n_in] XYZZ   (array 0 = S, arrays 1.. = pending R sums)
+// out: [narr+1][nwin][n_in/2]    out[a] = pairwise sums (a < narr), out[narr] = odd elements of S
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_reduce_level(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                          int narr, int nwin, int n_in) {
+  using F = typename C::F;
+  constexpr int XW = MsmSizes<C>::XYZZ;
+  const int n_out = n_in >> 1;
+  const long total = (long)(narr + 1) * nwin * n_out;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int q = (int)(t % n_out);
+  const int w = (int)((t / n_out) % nwin);
+  const int a = (int)(t / ((long)n_out * nwin));
+  Xyzz<F> r;
+  if (a < narr) {
+    const uint32_t* base = in + (((size_t)a * nwin + w) * n_in + 2 * (size_t)q) * XW;
+    r = xyzz_add(xyzz_load<F>(base), xyzz_load<F>(base + XW));
+  } else {
+    r = xyzz_load<F>(in + (((size_t)w) * n_in + 2 * (size_t)q + 1) * XW);
+  }
+  xyzz_store<F>(out + (((size_t)a * nwin + w) * n_out + q) * XW, r);
+}
+
+// ------------------------------------------------------------------ planning
+static void mp_set_bit(uint32_t* a, int bit) { a[bit >> 5] |= 1u << (bit & 31); }
+
+// Largest scalar is order-1; choose the fewest windows with (order-1) + H' < 2^(c*nwin).
+static int plan_windows(int c, const uint32_t* order8, uint32_t* hconst10) {
+  for (int nwin = (252 / c); nwin <= 300 / c + 2; nwin++) {
+    if (nwin < 1 || c * nwin > 10 * 32 - 2) continue;
+    uint32_t h[10] = {0};
+    for (int w = 0; w < nwin; w++) mp_set_bit(h, c * w + c - 1);
+    // s = (order - 1) + h
+    uint32_t s[10];
+    uint64_t cy = 0;
+    for (int i = 0; i < 10; i++) {
+      uint64_t o = i < 8 ? order8[i] : 0;
+      uint64_t t = o + h[i] + cy;
+      s[i] = (uint32_t)t;
+      cy = t >> 32;
+    }
+    // subtract 1 (order >= 1): fine to skip - being conservative by one is harmless
+    // check s < 2^(c*nwin)
+    bool ok = (cy == 0);
+    int top = c * nwin;
+    for (int bit = top; ok && bit < 320; bit++)
+      if (s[bit >> 5] & (1u << (bit & 31))) ok = false;
+    if (ok) {
+      for (int i = 0; i < 10; i++) hconst10[i] = h[i];
+      return nwin;
+    }
+  }
+  return -1;
+}
+
+static const uint32_t* curve_order(int curve) {
+  switch (curve) {
+    case CURVE_SECP256K1: return Orders::SECP_N;
+    case CURVE_ED25519: return Orders::ED_L;
+    default: return Orders::BLS_R;
+  }
+}
+
+static int ilog2(unsigned x) {
+  int r = 0;
+  while (x >>= 1) r++;
+  return r;
+}
+
+int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) {
+  int c = c_override;
+  if (c <= 0) {
+    const char* env = std::getenv("NCG_MSM_C");
+    if (env) c = std::atoi(env);
+  }
+  if (c <= 0) {
+    // accumulate cost nwin*n mixed adds vs fold cost ~2*nwin*2^(c-1) full adds: c ~ log2(n) - 4
+    c = ilog2((unsigned)std::max(n, 1)) - 4;
+  }
+  c = std::max(2, std::min(16, c));
+  pl->n = n;
+  pl->c = c;
+  pl->nb = 1 << (c - 1);
+  pl->nwin = plan_windows(c, curve_order(curve), pl->hconst);
+  if (pl->nwin < 0) return -1;
+  // sort chunks: aim for ~1024 blocks in flight, at least 4096 points per chunk
+  int Q = std::max(1, 1024 / pl->nwin);
+  Q = std::min(Q, std::max(1, n / 4096));
+  pl->Q = Q;
+  pl->chunk = (n + Q - 1) / Q;
+  return 0;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct MsmLayout {
+  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, red0, red1, total;
+};
+
+template <class C>
+static MsmLayout msm_layout(const MsmPlan& pl) {
+  MsmLayout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align256(off + bytes);
+    return o;
+  };
+  L.pts_mont = take((size_t)pl.n * MsmSizes<C>::AFF * 4);
+  L.digits = take((size_t)pl.nwin * pl.n * 2);
+  L.counts = take((size_t)pl.nwin * pl.Q * pl.nb * 4);
+  L.bucket_start = take((size_t)pl.nwin * (pl.nb + 1) * 4);
+  L.sorted = take((size_t)pl.nwin * pl.n * 4);
+  L.buckets = take((size_t)pl.nwin * pl.nb * MsmSizes<C>::XYZZ * 4);
+  // fold ping-pong: level l output holds (l+1) * nwin * nb/2^l points <= nwin*nb (l = 1, 2)
+  size_t red = (size_t)pl.nwin * std::max(pl.nb, pl.c) * MsmSizes<C>::XYZZ * 4;
+  L.red0 = take(red);
+  L.red1 = take(red);
+  L.total = off;
+  return L;
+}
+
+// ------------------------------------------------------------------ host finish
+// Horner over all surviving points (see msm.hpp step 6), then affine canonical output.
+template <class C>
+static void msm_host_finish(const std::vector<uint32_t>& fin, const MsmPlan& pl, uint32_t* out_affine,
+                            uint8_t* out_inf) {
+  using F = typename C::F;
+  constexpr int XW = MsmSizes<C>::XYZZ;
+  const int narr = pl.c;  // S + (c-1) R-arrays; for c == 1 there is a single bucket and no fold
+  auto at = [&](int a, int w) { return xyzz_load<F>(fin.data() + ((size_t)a * pl.nwin + w) * XW); };
+  Xyzz<F> acc = Xyzz<F>::inf();
+  for (int w = pl.nwin - 1; w >= 0; w--) {
+    for (int e = pl.c - 1; e >= 0; e--) {
+      acc = xyzz_dbl(acc);
+      if (e <= pl.c - 2 && e + 1 < narr) acc = xyzz_add(acc, at(e + 1, w));
+      if (e == 0) acc = xyzz_add(acc, at(0, w));
+    }
+  }
+  bool inf = acc.is_inf();
+  Affine<F> A{F::zero(), F::zero()};
+  if (!inf) {
+    // x = X/ZZ, y = Y/ZZZ; one inversion of ZZ*ZZZ
+    F t = acc.ZZ * acc.ZZZ;
+    F ti = f_inv(t);
+    F zzi = ti * acc.ZZZ;
+    F zzzi = ti * acc.ZZ;
+    A = {acc.X * zzi, acc.Y * zzzi};
+  }
+  store_affine_wire<F>(out_affine, A);
+  *out_inf = inf ? 1 : 0;
+}
+
+template <class C>
+static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
+                            uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st) {
+  using F = typename C::F;
+  constexpr int XW = MsmSizes<C>::XYZZ;
+  MsmLayout L = msm_layout<C>(pl);
+  char* base = (char*)ws;
+  uint32_t* pts_mont = (uint32_t*)(base + L.pts_mont);
+  int16_t* digits = (int16_t*)(base + L.digits);
+  uint32_t* counts = (uint32_t*)(base + L.counts);
+  uint32_t* bstart = (uint32_t*)(base + L.bucket_start);
+  uint32_t* sorted = (uint32_t*)(base + L.sorted);
+  uint32_t* buckets = (uint32_t*)(base + L.buckets);
+  uint32_t* red[2] = {(uint32_t*)(base + L.red0), (uint32_t*)(base + L.red1)};
+  const int n = pl.n;
+  hipError_t e;
+
+  hipLaunchKernelGGL(k_points_to_mont<C>, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, pts_mont, n);
+  hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl);
+  size_t lds = (size_t)pl.nb * 4;
+  e = hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_msm_hist, dim3(pl.Q, pl.nwin), dim3(1024), lds, st, digits, counts, pl);
+  hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), 0, st, counts, bstart, pl);
+  hipLaunchKernelGGL(k_msm_scatter, dim3(pl.Q, pl.nwin), dim3(1024), lds, st, digits, counts, sorted, pl);
+  {
+    int threads = pl.nwin * pl.nb;
+    hipLaunchKernelGGL(k_msm_accum<C>, dim3((threads + 255) / 256), dim3(256), 0, st, pts_mont, sorted, bstart, buckets,
+                       pl);
+  }
+  // fold: nb -> 1 per window in c-1 levels
+  const uint32_t* cur = buckets;
+  int narr = 1, n_in = pl.nb, flip = 0;
+  while (n_in > 1) {
+    long total = (long)(narr + 1) * pl.nwin * (n_in >> 1);
+    hipLaunchKernelGGL(k_msm_reduce_level<C>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cur, red[flip],
+                       narr, pl.nwin, n_in);
+    cur = red[flip];
+    flip ^= 1;
+    narr++;
+    n_in >>= 1;
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  std::vector<uint32_t> fin((size_t)narr * pl.nwin * XW);
+  e = hipMemcpyAsync(fin.data(), cur, fin.size() * 4, hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  msm_host_finish<C>(fin, pl, out_affine_host, out_inf_host);
+  (void)sizeof(F);
+  return hipSuccess;
+}
+
+size_t msm_workspace_bytes(int curve, const MsmPlan& pl) {
+  switch (curve) {
+    case CURVE_SECP256K1: return msm_layout<CurveSecp>(pl).total;
+    case CURVE_BLS12_381_G1: return msm_layout<CurveG1>(pl).total;
+    case CURVE_BLS12_381_G2: return msm_layout<CurveG2>(pl).total;
+    default: return 0;
+  }
+}
+
+hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
+                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st) {
+  switch (curve) {
+    case CURVE_SECP256K1: return msm_run_t<CurveSecp>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
+    case CURVE_BLS12_381_G1: return msm_run_t<CurveG1>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
+    case CURVE_BLS12_381_G2: return msm_run_t<CurveG2>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ncg

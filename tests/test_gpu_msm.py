@@ -1,0 +1,84 @@
+"""GPU parity: Pippenger MSM (ncg_msm) against the CPU oracle's restatement of
+curve.ts:863-905 and the arithmetic-progression identity of test/slow-curves.test.ts:185-252."""
+import numpy as np
+import pytest
+
+from noble_curves_amd import get_engine
+from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, SECP256K1
+from oracle import curve as C
+from oracle.curves import makeRng
+
+from helpers import ORACLE_CURVE, points_to_wire, scalars_to_wire, wire_to_affine
+
+pytestmark = pytest.mark.gpu
+CURVES = [SECP256K1, BLS12_381_G1, BLS12_381_G2]
+
+
+def gpu_msm(curve, pts, scalars):
+    out, inf = get_engine().msm(curve, points_to_wire(curve, pts), scalars_to_wire(scalars))
+    aff = wire_to_affine(curve, out)
+    assert inf == (aff == ORACLE_CURVE[curve].ZERO.toAffine())
+    return aff
+
+
+def progression(Pt, n, seed):
+    """P_i = (a + i b) G built with adds; s_i random with every 17th zero; returns expected point."""
+    order = Pt.Fn.ORDER
+    rng = makeRng(seed)
+    a, b = rng.rndBelow(order - 1) + 1, rng.rndBelow(order - 1) + 1
+    P = Pt.BASE.multiplyUnsafe(a)
+    step = Pt.BASE.multiplyUnsafe(b)
+    pts, ks = [], []
+    for i in range(n):
+        pts.append(P)
+        ks.append((a + i * b) % order)
+        P = P.add(step)
+    pts = C.normalizeZ(Pt, pts)
+    sc = [0 if i % 17 == 0 else rng.rndBelow(order) for i in range(n)]
+    exp = Pt.BASE.multiplyUnsafe(sum(k * s for k, s in zip(ks, sc)) % order)
+    return pts, sc, exp
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_edge_cases(curve):
+    """test/point.test.ts:264-305: empty, zeros, P/-P/ZERO, repeated points, single point."""
+    Pt = ORACLE_CURVE[curve]
+    G, Z = Pt.BASE, Pt.ZERO
+    order = Pt.Fn.ORDER
+    assert gpu_msm(curve, [], []) == Z.toAffine()
+    assert gpu_msm(curve, [G], [0]) == Z.toAffine()
+    assert gpu_msm(curve, [G], [1]) == G.toAffine()
+    assert gpu_msm(curve, [G], [order - 1]) == G.negate().toAffine()
+    assert gpu_msm(curve, [G, G.negate(), Z], [5, 5, 7]) == Z.toAffine()
+    assert gpu_msm(curve, [G, G], [0, 0]) == Z.toAffine()
+    assert gpu_msm(curve, [G] * 5, [3] * 5) == G.multiplyUnsafe(15).toAffine()
+    assert gpu_msm(curve, [Z, Z], [1, 2]) == Z.toAffine()
+    # identical points and scalars, as the reference's own benchmark feeds (benchmark/bls12-381.ts:64-79)
+    k = (order * 2) // 3
+    assert gpu_msm(curve, [G.double()] * 70, [k] * 70) == G.multiplyUnsafe(2 * 70 * k % order).toAffine()
+
+
+@pytest.mark.parametrize("curve,n", [(SECP256K1, 300), (BLS12_381_G1, 300), (BLS12_381_G2, 120)])
+def test_msm_matches_oracle_pippenger(curve, n):
+    Pt = ORACLE_CURVE[curve]
+    pts, sc, exp = progression(Pt, n, 0x6D736D00 + curve)
+    assert C.pippenger(Pt, pts, sc).toAffine() == exp.toAffine()   # oracle self-check
+    assert gpu_msm(curve, pts, sc) == exp.toAffine()
+
+
+@pytest.mark.parametrize("curve,n", [(BLS12_381_G1, 5000), (SECP256K1, 3000), (BLS12_381_G2, 1500)])
+def test_msm_progression_medium(curve, n):
+    """Sizes past what the oracle's pippenger finishes quickly: pinned by the progression identity."""
+    Pt = ORACLE_CURVE[curve]
+    pts, sc, exp = progression(Pt, n, 0xABCD00 + curve)
+    assert gpu_msm(curve, pts, sc) == exp.toAffine()
+
+
+def test_msm_non_normalised_inputs_and_window_override(monkeypatch):
+    """Points that went through add() (Z != 1 on the reference side) are normalised by the host
+    shim before crossing (SURVEY 8a gotcha 3); also exercise several window sizes."""
+    Pt = ORACLE_CURVE[BLS12_381_G1]
+    pts, sc, exp = progression(Pt, 700, 0x77)
+    for c in ("3", "7", "11", "16"):
+        monkeypatch.setenv("NCG_MSM_C", c)
+        assert gpu_msm(BLS12_381_G1, pts, sc) == exp.toAffine()
