@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X hot path (BASELINE.json metric: EC scalar-mults/s and MSM points/s).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Primary line (`value`): configs[1] - secp256k1 batch variable-base scalar multiplication
+(Point.multiplyUnsafe semantics, GLV), 2^20 (P_i, k_i) pairs per GPU, inputs resident in HBM.
+`extra.msm_g1`: configs[3] - bls12-381 G1 Pippenger MSM, 2^20 points per GPU (weak) with an
+RCCL all-gather of the per-GPU partial sums + a combine MSM; `extra.msm_g1_strong` (N > 1) is
+the same 2^20-point MSM split across the N GPUs.
+
+A "step" is one pass of the hot path over the whole synthetic batch.  Every result is verified
+before any throughput is printed: sampled outputs against the CPU oracle's C restatement, plus
+full-size identities (sum of all outputs == (sum k_i (a+i b)) G through the MSM path; MSM ==
+(sum (a+i b) s_i) G, the construction of the reference's test/slow-curves.test.ts:185-252).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+INT_MAC_PEAK = 256 * 4 * 16 * 2.4e9   # v_mad_u64_u32: 16 lanes/clk/SIMD (measured, profiles/r01_ubench*)
+
+
+def ints_to_le_bytes(vals, nbytes=32):
+    return np.frombuffer(b"".join(int(v).to_bytes(nbytes, "little") for v in vals), dtype=np.uint8).reshape(-1, nbytes)
+
+
+def dev_ptr(t):
+    return t.data_ptr()
+
+
+def gen_points(eng, curve, Pt, n, a, b, device, stream):
+    """P_i = (a + i b) G, affine wire format, generated on the GPU with the batch multiply."""
+    from helpers import affine_to_wire
+    from noble_curves_amd._native import POINT_BYTES
+    order = Pt.Fn.ORDER
+    ks = [(a + i * b) % order for i in range(n)]
+    sc = torch.from_numpy(ints_to_le_bytes(ks).copy()).to(device)
+    g = np.frombuffer(affine_to_wire(curve, Pt.BASE.toAffine()), dtype=np.uint8)
+    base = torch.from_numpy(np.tile(g, (n, 1))).to(device)
+    pb = POINT_BYTES[curve]
+    out = torch.empty((n, pb), dtype=torch.uint8, device=device)
+    inf = torch.empty((n,), dtype=torch.uint8, device=device)
+    eng.mul_var_batch_dev(curve, n, dev_ptr(base), dev_ptr(sc), dev_ptr(out), dev_ptr(inf), stream)
+    torch.cuda.synchronize()
+    assert int(inf.sum().item()) == 0
+    return out, ks
+
+
+def gen_scalars(n, order_bits_safe, seed, device, edge_order=None):
+    """uniform in [0, 2^order_bits_safe) (< group order), with k = 0, 1, n-1 at fixed indices."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
+    top_bits = order_bits_safe - 248
+    sc[:, 31] &= (1 << top_bits) - 1
+    if edge_order is not None and n >= 4:
+        sc[0] = 0
+        sc[1] = 0
+        sc[1, 0] = 1
+        sc[2] = torch.from_numpy(ints_to_le_bytes([edge_order - 1])[0].copy())
+    return sc.to(device)
+
+
+def scalars_to_ints(sc):
+    arr = sc.cpu().numpy()
+    return [int.from_bytes(arr[i].tobytes(), "little") for i in range(arr.shape[0])]
+
+
+def time_steps(fn, steps, warmup, dist_on):
+    """W warm-up steps, then exactly K steps bracketed by barrier + synchronize; returns
+    (wall seconds, HIP-event milliseconds on the launch stream)."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return wall, e0.elapsed_time(e1)
+
+
+def max_over_ranks(x, dist_on, device):
+    if not dist_on:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=20, help="items per GPU (2^log2n)")
+    ap.add_argument("--workload", default="all", choices=["all", "secp256k1", "msm_g1"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_on = world > 1
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+
+    from noble_curves_amd import get_engine
+    from noble_curves_amd._native import BLS12_381_G1, SECP256K1
+    from noble_curves_amd.distributed import msm_sharded
+    from helpers import wire_to_affine
+    from oracle import cport
+    from oracle.curves import BLS_R, BlsG1, SECP256K1_N, Secp256k1, makeRng
+
+    eng = get_engine(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    n = 1 << args.log2n
+    K, W = args.steps, args.warmup
+    result = {}
+    extra = {}
+
+    # ------------------------------------------------------------------ secp256k1 batch multiply
+    if args.workload in ("all", "secp256k1"):
+        rng = makeRng(0x6E6F626C6502 + rank)
+        a, b = rng.rndBelow(SECP256K1_N - 1) + 1, rng.rndBelow(SECP256K1_N - 1) + 1
+        pts, pks = gen_points(eng, SECP256K1, Secp256k1, n, a, b, device, stream)
+        sc = gen_scalars(n, 255, 1234 + rank, device, edge_order=SECP256K1_N)
+        out = torch.empty((n, 64), dtype=torch.uint8, device=device)
+        inf = torch.empty((n,), dtype=torch.uint8, device=device)
+
+        def step():
+            eng.mul_var_batch_dev(SECP256K1, n, dev_ptr(pts), dev_ptr(sc), dev_ptr(out), dev_ptr(inf), stream)
+
+        wall, ev_ms = time_steps(step, K, W, dist_on)
+        wall = max_over_ranks(wall, dist_on, device)
+        ev_ms = max_over_ranks(ev_ms, dist_on, device)
+        # ---- verification (outside the timed region)
+        ks = scalars_to_ints(sc)
+        expect_sum = sum(k * p for k, p in zip(ks, pks)) % SECP256K1_N
+        ones = torch.zeros((n, 32), dtype=torch.uint8, device=device)
+        ones[:, 0] = 1
+        tot, tot_inf = eng.msm_dev(SECP256K1, n, dev_ptr(out), dev_ptr(ones), stream)
+        assert wire_to_affine(SECP256K1, tot) == Secp256k1.BASE.multiplyUnsafe(expect_sum).toAffine(), \
+            "full-size checksum mismatch"
+        assert int(inf.sum().item()) == 1 and int(inf[0].item()) == 1   # only k = 0 gives infinity
+        S = 512
+        o_c, _ = cport.multiply_unsafe("secp256k1", pts[:S].cpu().numpy(), sc[:S].cpu().numpy())
+        assert np.array_equal(o_c, out[:S].cpu().numpy()), "sample mismatch vs oracle"
+        kern_ms = ev_ms / K
+        rate = world * n * K / wall
+        alg_bytes = 160.0 * n          # 64 B point + 32 B scalar in, 64 B out
+        alg_mac = 3.4e5 * n            # reference-equivalent limb-MACs per scalar-mult
+        result = {
+            "metric": "secp256k1_scalar_mults_per_sec", "value": rate, "unit": "scalar-mults/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic: P_i=(a+i*b)G, k_i uniform in [0,2^255) with k=0,1,n-1 planted; seed xorshift64",
+            "config": {"workload": "secp256k1 batch variable-base multiplyUnsafe (GLV), 2^%d pairs per GPU"
+                       % args.log2n, "items_per_gpu": n, "parallelism": "shard-by-index x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_mul_var<CurveSecp,4>", "kernel_ms": kern_ms,
+                         "valu": {"achieved_mac_per_s": alg_mac / (kern_ms * 1e-3), "peak_mac_per_s": INT_MAC_PEAK,
+                                  "frac": alg_mac / (kern_ms * 1e-3) / INT_MAC_PEAK,
+                                  "note": "reference-equivalent limb-MACs (SURVEY 8d) / v_mad_u64_u32 peak"}},
+        }
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            done, t0 = 0, time.perf_counter()
+            pts_h, sc_h = pts.cpu().numpy(), sc.cpu().numpy()
+            while time.perf_counter() - t0 < args.cpu_seconds and done + 1000 <= n:
+                o_c, _ = cport.multiply_unsafe("secp256k1", pts_h[done:done + 1000], sc_h[done:done + 1000])
+                assert np.array_equal(o_c, out[done:done + 1000].cpu().numpy())
+                done += 1000
+            dt = time.perf_counter() - t0
+            result["cpu_baseline"] = {"value": done / dt, "unit": "scalar-mults/s", "cores": 1, "kind": "port",
+                                      "sample": "first %d pairs of the same batch, oracle/c (RCB + GLV wNAF-4), "
+                                                "outputs compared bit-exactly with the GPU's" % done}
+
+    # ------------------------------------------------------------------ bls12-381 G1 MSM
+    if args.workload in ("all", "msm_g1"):
+        rng = makeRng(0x6D736D0000000003 + rank)
+        a, b = rng.rndBelow(BLS_R - 1) + 1, rng.rndBelow(BLS_R - 1) + 1
+        pts, pks = gen_points(eng, BLS12_381_G1, BlsG1, n, a, b, device, stream)
+        sc = gen_scalars(n, 254, 777 + rank, device)
+        sc[::17] = 0                                         # test/slow-curves.test.ts:215
+        ks = scalars_to_ints(sc)
+        local_expect = sum(k * p for k, p in zip(ks, pks)) % BLS_R
+        holder = {}
+
+        def step():
+            holder["r"] = msm_sharded(eng, BLS12_381_G1, n, dev_ptr(pts), dev_ptr(sc), stream, device)
+
+        wall, ev_ms = time_steps(step, K, W, dist_on)
+        wall = max_over_ranks(wall, dist_on, device)
+        if dist_on:
+            import torch.distributed as dist
+            t = torch.tensor([local_expect & ((1 << 62) - 1), local_expect >> 62 & ((1 << 62) - 1),
+                              local_expect >> 124 & ((1 << 62) - 1), local_expect >> 186 & ((1 << 62) - 1),
+                              local_expect >> 248], dtype=torch.int64, device=device)
+            parts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            tot = 0
+            for p in parts:
+                v = [int(x) for x in p.tolist()]
+                tot += v[0] + (v[1] << 62) + (v[2] << 124) + (v[3] << 186) + (v[4] << 248)
+            expect = tot % BLS_R
+        else:
+            expect = local_expect
+        got, got_inf = holder["r"]
+        assert wire_to_affine(BLS12_381_G1, got) == BlsG1.BASE.multiplyUnsafe(expect).toAffine(), "MSM mismatch"
+        msm_rate = world * n * K / wall
+        alg_bytes = 128.0 * n
+        alg_mac = 9.45e4 * n
+        msm = {"metric": "bls12_381_g1_msm_points_per_sec", "value": msm_rate, "unit": "points/s",
+               "ms_per_msm": wall / K * 1e3, "points_per_gpu": n, "total_points": world * n, "scaling": "weak",
+               "roofline": {"bound": "hbm", "achieved": alg_bytes / (wall / K) / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": alg_bytes / (wall / K) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "valu": {"achieved_mac_per_s": alg_mac / (wall / K), "peak_mac_per_s": INT_MAC_PEAK,
+                                     "frac": alg_mac / (wall / K) / INT_MAC_PEAK}}}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            m = min(n, 1 << 18)
+            t0 = time.perf_counter()
+            o_c, i_c = cport.pippenger("bls12_381_g1", pts[:m].cpu().numpy(), sc[:m].cpu().numpy())
+            dt = time.perf_counter() - t0
+            g_s, _ = eng.msm_dev(BLS12_381_G1, m, dev_ptr(pts), dev_ptr(sc), stream)
+            assert np.array_equal(o_c, g_s), "MSM sample mismatch vs oracle pippenger"
+            msm["cpu_baseline"] = {"value": m / dt, "unit": "points/s", "cores": 1, "kind": "port",
+                                   "sample": "first 2^%d points of the same MSM through oracle/c pippenger "
+                                             "(curve.ts:863-905 restated), result compared bit-exactly with the "
+                                             "GPU MSM on the same subset" % (m.bit_length() - 1)}
+        extra["msm_g1"] = msm
+        if not result:
+            result = dict(msm)
+            result.update({"n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3,
+                           "higher_is_better": True, "vs_baseline": None, "dtype": "u32",
+                           "data": "synthetic: P_i=(a+i*b)G1, s_i uniform in [0,2^254), every 17th zero",
+                           "config": {"workload": "bls12-381 G1 Pippenger MSM, 2^%d points per GPU" % args.log2n}})
+            extra = {}
+
+    if extra:
+        result["extra"] = extra
+    if rank == 0:
+        print(json.dumps(result))
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+"""ctypes loader of the oracle's C restatement (oracle/c/oracle.c -> oracle/_build/liboracle.so).
+TEST INFRASTRUCTURE: used by tests/ and bench.py's cpu_baseline leg only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            subprocess.check_call(["make", "-C", os.path.join(_HERE, "c")], stdout=subprocess.DEVNULL)
+        L = ctypes.CDLL(SO)
+        vp, sz = ctypes.c_void_p, ctypes.c_size_t
+        for name in ("orc_secp256k1_multiply_unsafe", "orc_bls12_381_g1_multiply_unsafe"):
+            getattr(L, name).argtypes = [vp, vp, vp, vp, sz]
+        for name in ("orc_bls12_381_g1_pippenger", "orc_secp256k1_pippenger"):
+            getattr(L, name).argtypes = [vp, vp, sz, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _u8(a, width):
+    return np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, width)
+
+
+def multiply_unsafe(curve_name, pts_wire, scalars_wire):
+    pb = {"secp256k1": 64, "bls12_381_g1": 96}[curve_name]
+    pts, sc = _u8(pts_wire, pb), _u8(scalars_wire, 32)
+    n = pts.shape[0]
+    out = np.zeros((n, pb), np.uint8)
+    inf = np.zeros((n,), np.uint8)
+    fn = getattr(lib(), "orc_%s_multiply_unsafe" % curve_name)
+    fn(pts.ctypes.data, sc.ctypes.data, out.ctypes.data, inf.ctypes.data, n)
+    return out, inf
+
+
+def pippenger(curve_name, pts_wire, scalars_wire):
+    pb = {"secp256k1": 64, "bls12_381_g1": 96}[curve_name]
+    pts, sc = _u8(pts_wire, pb), _u8(scalars_wire, 32)
+    n = pts.shape[0]
+    out = np.zeros((pb,), np.uint8)
+    inf = np.zeros((1,), np.uint8)
+    fn = getattr(lib(), "orc_%s_pippenger" % curve_name)
+    fn(pts.ctypes.data, sc.ctypes.data, n, out.ctypes.data, inf.ctypes.data)
+    return out, bool(inf[0])

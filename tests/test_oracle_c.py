@@ -1,0 +1,56 @@
+"""Pins the oracle's C restatement (oracle/c) to the Python oracle, which is itself pinned by
+the reference's fixtures (tests/test_oracle_golden.py)."""
+import time
+
+import pytest
+
+from helpers import load_golden, points_to_wire, scalars_to_wire, wire_to_affine
+from noble_curves_amd._native import BLS12_381_G1, SECP256K1
+from oracle import cport
+from oracle import curve as C
+from oracle.curves import BLS_R, BlsG1, SECP256K1_N, Secp256k1, makeRng
+
+
+def test_c_secp256k1_multiply_unsafe_vs_python_and_golden():
+    n = SECP256K1_N
+    rng = makeRng(0xC0DE)
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    ks = [0, 1, 2, 3, n - 1, n - 2, lam, n - lam, 1 << 128, (1 << 128) - 1] + [rng.rndBelow(n) for _ in range(120)]
+    pts = [Secp256k1.BASE.multiplyUnsafe(rng.rndBelow(n - 1) + 1) for _ in ks]
+    pts[5] = Secp256k1.ZERO
+    for t in load_golden("secp256k1_endomorphism.json"):
+        pts.append(Secp256k1.fromAffine((int(t["ax"]), int(t["ay"]))))
+        ks.append(int(t["scalar"]))
+    out, inf = cport.multiply_unsafe("secp256k1", points_to_wire(SECP256K1, pts), scalars_to_wire(ks))
+    for i, (p, k) in enumerate(zip(pts, ks)):
+        exp = p.multiplyUnsafe(k).toAffine()
+        assert wire_to_affine(SECP256K1, out[i]) == exp
+        assert bool(inf[i]) == (exp == (0, 0))
+    for t, i in zip(load_golden("secp256k1_endomorphism.json"), range(len(ks) - 3, len(ks))):
+        assert wire_to_affine(SECP256K1, out[i]) == (int(t["cx"]), int(t["cy"]))
+
+
+def test_c_g1_multiply_unsafe_vs_python():
+    rng = makeRng(0xC1)
+    ks = [0, 1, 2, BLS_R - 1] + [rng.rndBelow(BLS_R) for _ in range(30)]
+    pts = [BlsG1.BASE.multiplyUnsafe(rng.rndBelow(BLS_R - 1) + 1) for _ in ks]
+    out, inf = cport.multiply_unsafe("bls12_381_g1", points_to_wire(BLS12_381_G1, pts), scalars_to_wire(ks))
+    for i, (p, k) in enumerate(zip(pts, ks)):
+        assert wire_to_affine(BLS12_381_G1, out[i]) == p.multiplyUnsafe(k).toAffine()
+
+
+@pytest.mark.parametrize("name,curve,Pt,n", [("bls12_381_g1", BLS12_381_G1, BlsG1, 200),
+                                             ("secp256k1", SECP256K1, Secp256k1, 150)])
+def test_c_pippenger_vs_python(name, curve, Pt, n):
+    order = Pt.Fn.ORDER
+    rng = makeRng(0xC2 + curve)
+    pts = [Pt.BASE.multiplyUnsafe(rng.rndBelow(order - 1) + 1) for _ in range(n)]
+    sc = [0 if i % 17 == 0 else rng.rndBelow(order) for i in range(n)]
+    pts[3] = Pt.ZERO
+    pts[4] = pts[5].negate()
+    sc[4] = sc[5]
+    out, inf = cport.pippenger(name, points_to_wire(curve, pts), scalars_to_wire(sc))
+    exp = C.pippenger(Pt, pts, sc).toAffine()
+    assert wire_to_affine(curve, out) == exp and inf == (exp == (0, 0))
+    out, inf = cport.pippenger(name, points_to_wire(curve, []), scalars_to_wire([]))
+    assert inf
