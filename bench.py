@@ -142,7 +142,11 @@ def main():
     from oracle.curves import BLS_R, BlsG1, SECP256K1_N, Secp256k1, makeRng
 
     eng = get_engine(local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-null) stream: kernels, copies and the timing events all go on it
+    tstream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
     n = 1 << args.log2n
     K, W = args.steps, args.warmup
     result = {}
