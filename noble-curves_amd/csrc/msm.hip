@@ -67,26 +67,31 @@ __global__ void __launch_bounds__(1024) k_msm_hist(const int16_t* __restrict__ d
   for (int b = threadIdx.x; b < pl.nb; b += blockDim.x) dst[b] = hist[b];
 }
 
-// One block per window.  Turns counts into scatter offsets and writes bucket_start[w][0..nb].
-__global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ counts, uint32_t* __restrict__ bucket_start,
-                                                   MsmPlan pl) {
+// Per (window, bucket): exclusive prefix of the chunk counts (in place) and the bucket size.
+// Adjacent lanes handle adjacent buckets, so every access is coalesced.
+__global__ void __launch_bounds__(256) k_msm_bucket_totals(uint32_t* __restrict__ counts,
+                                                           uint32_t* __restrict__ bucket_start, MsmPlan pl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+  if (b >= pl.nb) return;
+  uint32_t* cw = counts + (size_t)w * pl.Q * pl.nb + b;
+  uint32_t tot = 0;
+  for (int q = 0; q < pl.Q; q++) {
+    uint32_t v = cw[(size_t)q * pl.nb];
+    cw[(size_t)q * pl.nb] = tot;
+    tot += v;
+  }
+  bucket_start[(size_t)w * (pl.nb + 1) + b] = tot;  // size for now; k_msm_scan turns it into a start
+}
+
+// One block per window: exclusive scan of the bucket sizes -> bucket_start[w][0..nb].
+__global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ bucket_start, MsmPlan pl) {
   __shared__ uint32_t part[1024];
   const int w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const int per = (pl.nb + T - 1) / T;
   const int b0 = min(pl.nb, t * per), b1 = min(pl.nb, b0 + per);
-  uint32_t* cw = counts + (size_t)w * pl.Q * pl.nb;
   uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
   uint32_t mine = 0;
-  for (int b = b0; b < b1; b++) {
-    uint32_t tot = 0;
-    for (int q = 0; q < pl.Q; q++) {
-      uint32_t v = cw[(size_t)q * pl.nb + b];
-      cw[(size_t)q * pl.nb + b] = tot;  // exclusive prefix over chunks, within the bucket
-      tot += v;
-    }
-    bs[b] = tot;  // bucket size for now; becomes the bucket start below
-    mine += tot;
-  }
+  for (int b = b0; b < b1; b++) mine += bs[b];
   part[t] = mine;
   __syncthreads();
   for (int off = 1; off < T; off <<= 1) {  // inclusive Hillis-Steele scan of per-thread totals
@@ -99,7 +104,6 @@ __global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ counts
   for (int b = b0; b < b1; b++) {
     uint32_t size = bs[b];
     bs[b] = run;
-    for (int q = 0; q < pl.Q; q++) cw[(size_t)q * pl.nb + b] += run;
     run += size;
   }
   if (t == T - 1) bs[pl.nb] = part[T - 1];
@@ -108,11 +112,13 @@ __global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ counts
 // sorted[w*n + pos] = point index | sign<<31, grouped by bucket within the window
 __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict__ digits,
                                                       const uint32_t* __restrict__ counts,
+                                                      const uint32_t* __restrict__ bucket_start,
                                                       uint32_t* __restrict__ sorted, MsmPlan pl) {
   extern __shared__ __attribute__((aligned(16))) uint32_t offs[];
   const int q = blockIdx.x, w = blockIdx.y;
   const uint32_t* src = counts + ((size_t)w * pl.Q + q) * pl.nb;
-  for (int b = threadIdx.x; b < pl.nb; b += blockDim.x) offs[b] = src[b];
+  const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  for (int b = threadIdx.x; b < pl.nb; b += blockDim.x) offs[b] = src[b] + bs[b];
   __syncthreads();
   const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
   const int16_t* dg = digits + (size_t)w * pl.n;
@@ -127,28 +133,108 @@ __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict_
 }
 
 // ------------------------------------------------------------------ 4. bucket accumulation
-// One lane per (window, bucket): XYZZ accumulator += affine point for every sorted entry.
+// Balanced, segmented: every lane owns exactly SEG consecutive entries of a window's sorted
+// list (so all lanes of a wave run the same number of mixed adds no matter how the scalars are
+// distributed - the reference's own benchmark feeds identical scalars, benchmark/bls12-381.ts:
+// 64-79).  A bucket that lies wholly inside a lane's range is written straight to
+// buckets[w][b]; a bucket cut by a range boundary leaves partial sums (at most two per lane:
+// "head" = the bucket began before the range, "tail" = it continues past the range), which
+// k_msm_fixup adds up.
+struct MsmSeg {
+  int seg;    // entries per lane
+  int nseg;   // lanes per window = ceil(n / seg)
+};
+
 template <class C>
 __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* __restrict__ pts_mont,
                                                    const uint32_t* __restrict__ sorted,
                                                    const uint32_t* __restrict__ bucket_start,
-                                                   uint32_t* __restrict__ buckets, MsmPlan pl) {
+                                                   uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_pts,
+                                                   int* __restrict__ part_meta, MsmPlan pl, MsmSeg sg) {
   using F = typename C::F;
   constexpr int AFF = MsmSizes<C>::AFF, FW = MsmSizes<C>::FW, XW = MsmSizes<C>::XYZZ;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= pl.nwin * pl.nb) return;
-  const int w = t / pl.nb, b = t - w * pl.nb;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+  if (s >= sg.nseg) return;
   const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
-  const uint32_t lo = bs[b], hi = bs[b + 1];
+  const uint32_t total = bs[pl.nb];
+  int* meta = part_meta + ((size_t)w * sg.nseg + s) * 4;  // head bucket, head continues, tail bucket, -
+  const uint32_t lo = (uint32_t)s * sg.seg;
+  if (lo >= total) {
+    meta[0] = -1;
+    meta[2] = -1;
+    return;
+  }
+  const uint32_t hi = min(total, lo + (uint32_t)sg.seg);
+  // bucket containing position lo: largest b with bs[b] <= lo  (then bs[b+1] > lo)
+  int b;
+  {
+    int l = 0, r = pl.nb;  // invariant: bs[l] <= lo < bs[r]
+    while (r - l > 1) {
+      int m = (l + r) >> 1;
+      if (bs[m] <= lo) l = m; else r = m;
+    }
+    b = l;
+  }
+  uint32_t b_start = bs[b], b_end = bs[b + 1];
   const uint32_t* sw = sorted + (size_t)w * pl.n;
+  uint32_t* hp = part_pts + (((size_t)w * sg.nseg + s) * 2) * XW;
+  int head_b = -1, head_cont = 0, tail_b = -1;
   Xyzz<F> acc = Xyzz<F>::inf();
-  for (uint32_t j = lo; j < hi; j++) {
-    uint32_t e = sw[j];
+  for (uint32_t pos = lo; pos < hi; pos++) {
+    if (pos == b_end) {  // bucket finished inside my range
+      if (b_start >= lo) {
+        xyzz_store<F>(buckets + ((size_t)w * pl.nb + b) * XW, acc);
+      } else {
+        xyzz_store<F>(hp, acc);
+        head_b = b;
+      }
+      acc = Xyzz<F>::inf();
+      do { b++; } while (bs[b + 1] <= pos);
+      b_start = bs[b];
+      b_end = bs[b + 1];
+    }
+    uint32_t e = sw[pos];
     const uint32_t* pp = pts_mont + (size_t)(e & 0x7fffffffu) * AFF;
     Affine<F> p{FieldIO<F>::load(pp), FieldIO<F>::load(pp + FW)};
     acc = xyzz_madd(acc, p, (e >> 31) != 0);
   }
-  xyzz_store<F>(buckets + (size_t)t * XW, acc);
+  const bool left = b_start >= lo, right = b_end <= hi;
+  if (left && right) {
+    xyzz_store<F>(buckets + ((size_t)w * pl.nb + b) * XW, acc);
+  } else if (!left) {
+    xyzz_store<F>(hp, acc);
+    head_b = b;
+    head_cont = right ? 0 : 1;
+  } else {
+    xyzz_store<F>(hp + XW, acc);
+    tail_b = b;
+  }
+  meta[0] = head_b;
+  meta[1] = head_cont;
+  meta[2] = tail_b;
+}
+
+// Adds up the pieces of every bucket that was cut by a lane boundary: the lane holding the
+// bucket's first piece (its "tail") walks the following lanes' "head" pieces.
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t* __restrict__ part_pts,
+                                                   const int* __restrict__ part_meta, uint32_t* __restrict__ buckets,
+                                                   MsmPlan pl, MsmSeg sg) {
+  using F = typename C::F;
+  constexpr int XW = MsmSizes<C>::XYZZ;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+  if (s >= sg.nseg) return;
+  const int* meta = part_meta + (size_t)w * sg.nseg * 4;
+  const int tb = meta[(size_t)s * 4 + 2];
+  if (tb < 0) return;
+  const uint32_t* pp = part_pts + (size_t)w * sg.nseg * 2 * XW;
+  Xyzz<F> acc = xyzz_load<F>(pp + ((size_t)s * 2 + 1) * XW);
+  for (int s2 = s + 1; s2 < sg.nseg; s2++) {
+    if (meta[(size_t)s2 * 4] != tb) break;
+    acc = xyzz_add(acc, xyzz_load<F>(pp + ((size_t)s2 * 2) * XW));
+    if (!meta[(size_t)s2 * 4 + 1]) break;
+  }
+  xyzz_store<F>(buckets + ((size_t)w * pl.nb + tb) * XW, acc);
 }
 
 // ------------------------------------------------------------------ 5. bucket fold, one level
@@ -249,8 +335,16 @@ int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) {
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct MsmLayout {
-  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, red0, red1, total;
+  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, part_pts, part_meta, red0, red1, total;
 };
+
+static MsmSeg msm_seg(const MsmPlan& pl) {
+  MsmSeg sg;
+  const char* env = std::getenv("NCG_MSM_SEG");
+  sg.seg = env ? std::max(1, std::atoi(env)) : 64;
+  sg.nseg = (pl.n + sg.seg - 1) / sg.seg;
+  return sg;
+}
 
 template <class C>
 static MsmLayout msm_layout(const MsmPlan& pl) {
@@ -267,6 +361,9 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
   L.bucket_start = take((size_t)pl.nwin * (pl.nb + 1) * 4);
   L.sorted = take((size_t)pl.nwin * pl.n * 4);
   L.buckets = take((size_t)pl.nwin * pl.nb * MsmSizes<C>::XYZZ * 4);
+  MsmSeg sg = msm_seg(pl);
+  L.part_pts = take((size_t)pl.nwin * sg.nseg * 2 * MsmSizes<C>::XYZZ * 4);
+  L.part_meta = take((size_t)pl.nwin * sg.nseg * 4 * 4);
   // fold ping-pong: level l output holds (l+1) * nwin * nb/2^l points <= nwin*nb (l = 1, 2)
   size_t red = (size_t)pl.nwin * std::max(pl.nb, pl.c) * MsmSizes<C>::XYZZ * 4;
   L.red0 = take(red);
@@ -331,12 +428,19 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
   e = hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_msm_hist, dim3(pl.Q, pl.nwin), dim3(1024), lds, st, digits, counts, pl);
-  hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), 0, st, counts, bstart, pl);
-  hipLaunchKernelGGL(k_msm_scatter, dim3(pl.Q, pl.nwin), dim3(1024), lds, st, digits, counts, sorted, pl);
+  hipLaunchKernelGGL(k_msm_bucket_totals, dim3((pl.nb + 255) / 256, pl.nwin), dim3(256), 0, st, counts, bstart, pl);
+  hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), 0, st, bstart, pl);
+  hipLaunchKernelGGL(k_msm_scatter, dim3(pl.Q, pl.nwin), dim3(1024), lds, st, digits, counts, bstart, sorted, pl);
   {
-    int threads = pl.nwin * pl.nb;
-    hipLaunchKernelGGL(k_msm_accum<C>, dim3((threads + 255) / 256), dim3(256), 0, st, pts_mont, sorted, bstart, buckets,
-                       pl);
+    MsmSeg sg = msm_seg(pl);
+    uint32_t* part_pts = (uint32_t*)(base + L.part_pts);
+    int* part_meta = (int*)(base + L.part_meta);
+    e = hipMemsetAsync(buckets, 0, (size_t)pl.nwin * pl.nb * XW * 4, st);  // empty buckets = infinity
+    if (e != hipSuccess) return e;
+    dim3 grid((sg.nseg + 255) / 256, pl.nwin);
+    hipLaunchKernelGGL(k_msm_accum<C>, grid, dim3(256), 0, st, pts_mont, sorted, bstart, buckets, part_pts, part_meta,
+                       pl, sg);
+    hipLaunchKernelGGL(k_msm_fixup<C>, grid, dim3(256), 0, st, part_pts, part_meta, buckets, pl, sg);
   }
   // fold: nb -> 1 per window in c-1 levels
   const uint32_t* cur = buckets;

@@ -82,3 +82,28 @@ def test_msm_non_normalised_inputs_and_window_override(monkeypatch):
     for c in ("3", "7", "11", "16"):
         monkeypatch.setenv("NCG_MSM_C", c)
         assert gpu_msm(BLS12_381_G1, pts, sc) == exp.toAffine()
+
+
+@pytest.mark.parametrize("seg", ["1", "3", "64", "100000"])
+def test_msm_segment_lengths_and_skewed_buckets(monkeypatch, seg):
+    """Lane-segment boundaries cutting buckets in every possible way, including one bucket that
+    holds every entry (all scalars equal) and many empty buckets."""
+    monkeypatch.setenv("NCG_MSM_SEG", seg)
+    monkeypatch.setenv("NCG_MSM_C", "6")
+    Pt = ORACLE_CURVE[BLS12_381_G1]
+    pts, sc, exp = progression(Pt, 900, 0x5E6)
+    assert gpu_msm(BLS12_381_G1, pts, sc) == exp.toAffine()
+    order = Pt.Fn.ORDER
+    k = 0x1F                                            # every point lands in the same low bucket
+    same = [k] * 900
+    ks_exp = Pt.BASE.multiplyUnsafe(1).toAffine()
+    tot = C.normalizeZ(Pt, [sum_points(Pt, pts)])[0]
+    assert gpu_msm(BLS12_381_G1, pts, same) == tot.multiplyUnsafe(k).toAffine()
+    assert ks_exp is not None and order > 0
+
+
+def sum_points(Pt, pts):
+    acc = Pt.ZERO
+    for p in pts:
+        acc = acc.add(p)
+    return acc
