@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--workload", default="all", choices=["all", "secp256k1", "msm_g1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -274,6 +275,9 @@ def main():
         result["extra"] = extra
     if rank == 0:
         print(json.dumps(result))
+        if args.out:
+            with open(args.out, "w") as f:
+                f.write(json.dumps(result) + "\n")
     if dist_on:
         import torch.distributed as dist
         dist.barrier()
