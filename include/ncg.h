@@ -82,6 +82,20 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
 int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev,
                 const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream);
 
+/* ---- ed25519 batch signature verification -------------------------------------------------
+ * out_ok[i] = eddsa.verify(sig[i], msg[i], pk[i], {zip215}) of the reference
+ * (src/abstract/edwards.ts:942-989) given the already-hashed challenge
+ * k32[i] = SHA-512(R || A || M) mod L as 32 bytes LE (edwards.ts:984, :900-906; the hash is in
+ * @noble/hashes and is computed by the host shim).  sig64 = R (32 B) || s (32 B) as on the wire;
+ * pk32 = compressed public key.  zip215 != 0 selects the reference's default (ZIP-215) decoding
+ * rules, 0 the strict RFC 8032 rules (edwards.ts:405-436, :980).  Decoding failures and
+ * s >= L give 0, exactly where the reference returns false (:967-975). */
+int ncg_ed25519_verify_batch(ncg_ctx* ctx, size_t n, const void* sig64, const void* pk32,
+                             const void* k32, int zip215, uint8_t* out_ok);
+int ncg_ed25519_verify_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev,
+                                 const void* pk32_dev, const void* k32_dev, int zip215,
+                                 uint8_t* out_ok_dev, void* stream);
+
 /* ---- measurement helpers (not on the product path) ------------------------------------ */
 /* Runs instruction-rate / field-multiply micro-benchmark `kind` (see csrc/ubench.hip) and
  * returns the kernel time in milliseconds. */

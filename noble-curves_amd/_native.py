@@ -180,6 +180,25 @@ class Engine:
                                          stream))
         return out, bool(inf.value)
 
+    # ---- ed25519 batch verify --------------------------------------------------------------------
+    def ed25519_verify_batch(self, sigs, pks, ks, zip215=True):
+        """sigs uint8 [n,64], pks [n,32], ks [n,32] (challenge scalars, LE) -> bool array [n]."""
+        sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 64)
+        pks = np.ascontiguousarray(pks, dtype=np.uint8).reshape(-1, 32)
+        ks = np.ascontiguousarray(ks, dtype=np.uint8).reshape(-1, 32)
+        n = sigs.shape[0]
+        if pks.shape[0] != n or ks.shape[0] != n:
+            raise ValueError("arrays of signatures, public keys and challenges must have equal length")
+        ok = np.zeros((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_ed25519_verify_batch(self.h, n, sigs.ctypes.data, pks.ctypes.data,
+                                                          ks.ctypes.data, 1 if zip215 else 0, ok.ctypes.data))
+        return ok.astype(bool)
+
+    def ed25519_verify_batch_dev(self, n, d_sigs, d_pks, d_ks, zip215, d_ok, stream=None):
+        self._check(self.lib.ncg_ed25519_verify_batch_dev(self.h, n, d_sigs, d_pks, d_ks, 1 if zip215 else 0,
+                                                          d_ok, stream))
+
     def ubench(self, kind, blocks, threads, iters):
         ms = ctypes.c_float()
         self._check(self.lib.ncg_ubench(self.h, kind, blocks, threads, iters, ctypes.byref(ms)))

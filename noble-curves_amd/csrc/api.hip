@@ -25,6 +25,7 @@ struct ncg_ctx {
   size_t scratch_bytes = 0;
   void* msm_ws = nullptr;  // MSM workspace (device)
   size_t msm_ws_bytes = 0;
+  uint32_t* ed_btab = nullptr;  // ed25519 base-point table (device)
   uint32_t* ub_in = nullptr;
   uint32_t* ub_out = nullptr;
   size_t ub_out_words = 0;
@@ -106,6 +107,7 @@ void ncg_destroy(ncg_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
+  if (ctx->ed_btab) (void)hipFree(ctx->ed_btab);
   if (ctx->ub_in) (void)hipFree(ctx->ub_in);
   if (ctx->ub_out) (void)hipFree(ctx->ub_out);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -222,6 +224,55 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
   NCG_HIP(ctx, hipMemcpyAsync(d_pts, points_affine, pts_b, hipMemcpyHostToDevice, ctx->stream));
   NCG_HIP(ctx, hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream));
   return ncg_msm_dev(ctx, curve, n, d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
+}
+
+static int ensure_ed_table(ncg_ctx* ctx) {
+  if (ctx->ed_btab) return NCG_OK;
+  uint32_t host[ncg::ED25519_BTAB_WORDS];
+  ncg::ed25519_build_base_table(host);
+  NCG_HIP(ctx, hipMalloc((void**)&ctx->ed_btab, sizeof host));
+  NCG_HIP(ctx, hipMemcpy(ctx->ed_btab, host, sizeof host, hipMemcpyHostToDevice));
+  return NCG_OK;
+}
+
+int ncg_ed25519_verify_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* pk32_dev,
+                                 const void* k32_dev, int zip215, uint8_t* out_ok_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64_dev || !pk32_dev || !k32_dev || !out_ok_dev)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ed25519_verify_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_ed_table(ctx);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  NCG_HIP(ctx, ncg::ed25519_verify_batch((const uint32_t*)sig64_dev, (const uint32_t*)pk32_dev,
+                                         (const uint32_t*)k32_dev, ctx->ed_btab, zip215, out_ok_dev, (int)n, st));
+  return NCG_OK;
+}
+
+int ncg_ed25519_verify_batch(ncg_ctx* ctx, size_t n, const void* sig64, const void* pk32, const void* k32,
+                             int zip215, uint8_t* out_ok) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (n == 0) return NCG_OK;
+  if (!sig64 || !pk32 || !k32 || !out_ok)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ed25519_verify_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  size_t okb = (n + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, n * 128 + okb + 1024);
+  if (rc) return rc;
+  char* d_sig = (char*)ctx->scratch;
+  char* d_pk = d_sig + n * 64;
+  char* d_k = d_pk + n * 32;
+  char* d_ok = d_k + n * 32;
+  NCG_HIP(ctx, hipMemcpyAsync(d_sig, sig64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, hipMemcpyAsync(d_pk, pk32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, hipMemcpyAsync(d_k, k32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  rc = ncg_ed25519_verify_batch_dev(ctx, n, d_sig, d_pk, d_k, zip215, (uint8_t*)d_ok, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(out_ok, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
 }
 
 int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float* out_ms) {

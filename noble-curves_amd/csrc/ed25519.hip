@@ -1,0 +1,175 @@
+// ed25519 batch signature verification: one lane per (signature, public key, challenge k).
+//
+// Reproduces, per item, the boolean of the reference's eddsa.verify (src/abstract/edwards.ts:
+// 942-989) for a challenge scalar k = SHA-512(dom || R || A || M) mod L that the host shim has
+// already computed (edwards.ts:984, :900-906; the hash lives in @noble/hashes, not on this
+// path):
+//   A = Point.fromBytes(pk, zip215), R = Point.fromBytes(sig[0:32], zip215)     (:969-970, :405-436)
+//   s = LE(sig[32:64]) must be < L (BASE.multiplyUnsafe(s) throws otherwise)       (:962, :971, :573)
+//   strict mode only: A.isSmallOrder() rejects                                     (:980)
+//   accept iff [8](R + [k]A - [s]B) == O                                           (:985-988)
+// The reference computes [s]B with its cached window table (44 adds) and [k]A with a wNAF walk;
+// here both share ONE doubling chain (Straus): signed-odd windows of 3 bits for -A (4-entry
+// per-lane table in LDS, projective Niels form) and 6 bits for B (32 precomputed affine Niels
+// multiples shared by every lane), 258 doublings, 86 + 43 additions.
+#include <mutex>
+#include <vector>
+
+#include "ec_te.hpp"
+#include "host_api.hpp"
+#include "scalar.hpp"
+
+namespace ncg {
+
+constexpr int ED_WA = 3, ED_WB = 6, ED_MA = 86, ED_MB = 43;  // 3*86 = 6*43 = 258 bits
+constexpr int ED_TA = 1 << (ED_WA - 1);                      // 4 entries: 1,3,5,7 times (-A)
+constexpr int ED_TB = 1 << (ED_WB - 1);                      // 32 entries: 1,3,..,63 times B
+constexpr int ED_LDS_WORDS = ED_TA * 32 * 64;
+
+NCG_DI bool ed_scalar_lt_L(const uint32_t (&s)[8]) {
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) (void)__builtin_subc(s[i], (uint32_t)Orders::ED_L[i], bw, &bw);
+  return bw != 0;
+}
+
+template <class PTR>
+NCG_DI void ed_store_niels(PTR tab, int stride, int e, const EdNielsProj<FpEd>& q) {
+  using IO = FieldIO<FpEd>;
+  IO::store_strided(tab + (e * 32 + 0) * stride, stride, q.yplusx);
+  IO::store_strided(tab + (e * 32 + 8) * stride, stride, q.yminusx);
+  IO::store_strided(tab + (e * 32 + 16) * stride, stride, q.Z);
+  IO::store_strided(tab + (e * 32 + 24) * stride, stride, q.t2d);
+}
+template <class PTR>
+NCG_DI EdNielsProj<FpEd> ed_load_niels(PTR tab, int stride, int e) {
+  using IO = FieldIO<FpEd>;
+  return {IO::load_strided(tab + (e * 32 + 0) * stride, stride), IO::load_strided(tab + (e * 32 + 8) * stride, stride),
+          IO::load_strided(tab + (e * 32 + 16) * stride, stride),
+          IO::load_strided(tab + (e * 32 + 24) * stride, stride)};
+}
+
+// Per-lane verification; `tab`/`stride` as in mul_var_lane.  btab: ED_TB affine Niels entries,
+// 24 words each (y+x, y-x, 2dxy), Montgomery form.
+template <class TABPTR>
+NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t* __restrict__ pk,
+                                const uint32_t* __restrict__ kscal, const uint32_t* __restrict__ btab, bool zip215,
+                                TABPTR tab, const int stride) {
+  using F = FpEd;
+  using PR = ParamsEdP;
+  uint32_t aw[8], rw[8], s[8], k[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    aw[i] = pk[i];
+    rw[i] = sig[i];
+    s[i] = sig[8 + i];
+    k[i] = kscal[i];
+  }
+  F ax, ay, rx, ry;
+  bool ok = ed_decompress(aw, zip215, ax, ay);
+  ok = ed_decompress(rw, zip215, rx, ry) && ok;
+  ok = ok && ed_scalar_lt_L(s);
+  const F d2 = EdConsts::d2();
+
+  // -A in extended coordinates, its double, and the table [1,3,5,7](-A) in Niels form
+  EdExt<F> nA{fp_neg<PR>(ax), ay, F::one(), fp_neg<PR>(ax * ay)};
+  if (!zip215) {  // strict: reject small-order A  (isSmallOrder: [8]A == O)
+    EdExt<F> t = ed_dbl(ed_dbl(ed_dbl(nA)));
+    if (ed_is_identity(t)) ok = false;
+  }
+  {
+    EdNielsProj<F> n2 = ed_to_niels(ed_dbl(nA), d2);
+    EdExt<F> cur = nA;
+    ed_store_niels(tab, stride, 0, ed_to_niels(cur, d2));
+#pragma unroll
+    for (int j = 1; j < ED_TA; j++) {
+      cur = ed_add_niels(cur, n2, false);
+      ed_store_niels(tab, stride, j, ed_to_niels(cur, d2));
+    }
+  }
+  SignedOddWindows<9, ED_WA, ED_MA> wk;
+  SignedOddWindows<9, ED_WB, ED_MB> ws;
+  wk.template init<8>(k);
+  ws.template init<8>(s);
+
+  EdExt<F> acc = EdExt<F>::identity();
+  for (int i = ED_MA - 1; i >= 0; i--) {
+    if (i != ED_MA - 1) {
+#pragma unroll
+      for (int d = 0; d < ED_WA; d++) acc = ed_dbl(acc);
+    }
+    int dA = wk.pop();
+    acc = ed_add_niels(acc, ed_load_niels(tab, stride, ((dA < 0 ? -dA : dA) - 1) >> 1), dA < 0);
+    if ((i & 1) == 0) {
+      int dB = ws.pop();
+      const uint32_t* bp = btab + (((dB < 0 ? -dB : dB) - 1) >> 1) * 24;
+      EdNielsAff<F> q{fp_load<PR>(bp), fp_load<PR>(bp + 8), fp_load<PR>(bp + 16)};
+      acc = ed_madd_niels(acc, q, dB < 0);
+    }
+  }
+  if (wk.was_even) acc = ed_add_niels(acc, ed_load_niels(tab, stride, 0), true);
+  if (ws.was_even) {
+    EdNielsAff<F> q{fp_load<PR>(btab), fp_load<PR>(btab + 8), fp_load<PR>(btab + 16)};
+    acc = ed_madd_niels(acc, q, true);
+  }
+  // acc = [s]B - [k]A ; subtract R, clear the cofactor, compare with the identity
+  acc = ed_madd_niels(acc, ed_affine_to_niels(rx, ry, d2), true);
+  acc = ed_dbl(ed_dbl(ed_dbl(acc)));
+  return ok && ed_is_identity(acc);
+}
+
+__global__ void __launch_bounds__(64)
+k_ed25519_verify(const uint32_t* __restrict__ sigs, const uint32_t* __restrict__ pks,
+                 const uint32_t* __restrict__ ks, const uint32_t* __restrict__ btab, int zip215,
+                 uint8_t* __restrict__ out_ok, int n) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = threadIdx.x;
+  const int idx = blockIdx.x * 64 + lane;
+  const int src = idx < n ? idx : n - 1;
+  bool ok = ed25519_verify_lane(sigs + (size_t)src * 16, pks + (size_t)src * 8, ks + (size_t)src * 8, btab,
+                                zip215 != 0, lds + lane, 64);
+  if (idx < n) out_ok[idx] = ok ? 1 : 0;
+}
+
+// ---- base-point table [1,3,..,63]*B in affine Niels form (host-computed with the same templates)
+void ed25519_build_base_table(uint32_t* out /* ED_TB*24 words */) {
+  using F = FpEd;
+  using PR = ParamsEdP;
+  // src/ed25519.ts:57-65 Gx, Gy
+  static const uint32_t GX[8] = {0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u,
+                                 0xcd6e53feu, 0x216936d3u};
+  static const uint32_t GY[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u,
+                                 0x66666666u, 0x66666666u};
+  F gx = fp_to_mont<PR>(fp_load<PR>(GX)), gy = fp_to_mont<PR>(fp_load<PR>(GY));
+  const F d2 = EdConsts::d2();
+  EdExt<F> B{gx, gy, F::one(), gx * gy};
+  EdNielsProj<F> n2 = ed_to_niels(ed_dbl(B), d2);
+  EdExt<F> cur = B;
+  for (int j = 0; j < ED_TB; j++) {
+    if (j > 0) cur = ed_add_niels(cur, n2, false);
+    F zi = fp_inv<PR>(cur.Z);
+    F x = cur.X * zi, y = cur.Y * zi;
+    EdNielsAff<F> q = ed_affine_to_niels(x, y, d2);
+    fp_store<PR>(out + j * 24, q.yplusx);
+    fp_store<PR>(out + j * 24 + 8, q.yminusx);
+    fp_store<PR>(out + j * 24 + 16, q.t2d);
+  }
+}
+
+hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
+                                int zip215, uint8_t* out_ok, int n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  size_t lds = (size_t)ED_LDS_WORDS * 4;
+  hipError_t e = hipFuncSetAttribute((const void*)k_ed25519_verify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_ed25519_verify, dim3((n + 63) / 64), dim3(64), lds, st, sigs, pks, ks, btab, zip215, out_ok, n);
+  return hipGetLastError();
+}
+
+// host-only: run the lane function on the CPU (unit tests through hosttest.hip)
+bool ed25519_verify_host(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, const uint32_t* btab, bool zip215) {
+  std::vector<uint32_t> tab(ED_TA * 32);
+  return ed25519_verify_lane(sig, pk, k, btab, zip215, tab.data(), 1);
+}
+
+}  // namespace ncg

@@ -15,6 +15,13 @@ size_t msm_workspace_bytes(int curve, const MsmPlan& pl);
 hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
                    uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st);
 
+// ed25519 batch verify (ed25519.hip).  btab: device copy of the table built by ed25519_build_base_table.
+constexpr int ED25519_BTAB_WORDS = 32 * 24;
+void ed25519_build_base_table(uint32_t* out_words);
+hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
+                                int zip215, uint8_t* out_ok, int n, hipStream_t st);
+bool ed25519_verify_host(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, const uint32_t* btab, bool zip215);
+
 hipError_t ubench_run(int kind, int blocks, int threads, int iters, uint32_t* d_out, const uint32_t* d_in,
                       hipStream_t st, float* ms);
 

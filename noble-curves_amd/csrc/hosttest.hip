@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "mulvar.hpp"
+#include "ed25519.hip"  // single-TU inclusion: lane function + host table builder
 
 using namespace ncg;
 
@@ -65,6 +66,17 @@ int ht_glv_split(const uint32_t* k, uint32_t* out) {
   out[10] = s.k1neg;
   out[11] = s.k2neg;
   return 0;
+}
+
+// ed25519 verify of one item on the CPU through the kernel's lane function
+int ht_ed25519_verify(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, int zip215) {
+  static uint32_t btab[ED25519_BTAB_WORDS];
+  static bool built = false;
+  if (!built) {
+    ed25519_build_base_table(btab);
+    built = true;
+  }
+  return ed25519_verify_host(sig, pk, k, btab, zip215 != 0) ? 1 : 0;
 }
 
 }  // extern "C"

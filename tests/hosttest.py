@@ -21,6 +21,7 @@ def lib():
         _lib.ht_mul_var.argtypes = [i32, vp, vp, vp, vp, i32]
         _lib.ht_field_op.argtypes = [i32, i32, vp, vp, vp]
         _lib.ht_glv_split.argtypes = [vp, vp]
+        _lib.ht_ed25519_verify.argtypes = [vp, vp, vp, i32]
     return _lib
 
 
@@ -50,3 +51,10 @@ def glv_split(k):
     k1 = sum(int(out[i]) << (32 * i) for i in range(5))
     k2 = sum(int(out[5 + i]) << (32 * i) for i in range(5))
     return bool(out[10]), k1, bool(out[11]), k2
+
+
+def ed25519_verify(sig, pk, k, zip215):
+    S = np.frombuffer(bytes(sig), dtype=np.uint8).copy()
+    P = np.frombuffer(bytes(pk), dtype=np.uint8).copy()
+    K = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
+    return bool(lib().ht_ed25519_verify(S.ctypes.data, P.ctypes.data, K.ctypes.data, 1 if zip215 else 0))

@@ -70,3 +70,37 @@ def test_lane_ladder_bls(curve, cnt):
     pts = [Pt.BASE.multiplyUnsafe(rng.rndBelow(BLS_R - 1) + 1) for _ in ks]
     pts[4] = Pt.ZERO
     _check(curve, pts, ks)
+
+
+def _ed_cases():
+    """(sig, msg, pk) triples: valid KATs, corrupted copies, ZIP-215 and edge-case vectors."""
+    from helpers import load_golden
+    cases = []
+    for row in load_golden("ed25519_vectors.json")[:40]:
+        pk, msg, sig = (bytes.fromhex(row[k]) for k in ("pk", "msg", "sig"))
+        cases.append((sig, msg, pk))
+        bad = bytearray(sig); bad[5] ^= 4
+        cases.append((bytes(bad), msg, pk))
+        bad = bytearray(sig); bad[40] ^= 1
+        cases.append((bytes(bad), msg, pk))
+        cases.append((sig, msg + b"!", pk))
+    for v in load_golden("ed25519_zip215.json"):
+        cases.append((bytes.fromhex(v["sig_bytes"]), b"Zcash", bytes.fromhex(v["vk_bytes"])))
+    for v in load_golden("ed25519_edge_cases.json"):
+        cases.append((bytes.fromhex(v["signature"]), bytes.fromhex(v["message"]), bytes.fromhex(v["pub_key"])))
+    # s >= L and s = L-1 style boundaries
+    from oracle.curves import ED25519_L
+    sig0, msg0, pk0 = cases[0]
+    for s_val in (ED25519_L, ED25519_L + 1, (1 << 256) - 1, ED25519_L - 1, 0):
+        cases.append((sig0[:32] + int(s_val).to_bytes(32, "little"), msg0, pk0))
+    return cases
+
+
+def test_ed25519_verify_lane_matches_oracle_both_modes():
+    from oracle.curves import Ed25519
+    from oracle.edwards import eddsa_hash_k, eddsa_verify
+    for sig, msg, pk in _ed_cases():
+        k = eddsa_hash_k(Ed25519.Fn, sig[:32], pk, msg)
+        for zip215 in (True, False):
+            exp = eddsa_verify(Ed25519, sig, msg, pk, zip215=zip215)
+            assert hosttest.ed25519_verify(sig, pk, k, zip215) == exp, (sig.hex(), pk.hex(), zip215)
