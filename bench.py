@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20, help="items per GPU (2^log2n)")
-    ap.add_argument("--workload", default="all", choices=["all", "secp256k1", "msm_g1"])
+    ap.add_argument("--workload", default="all", choices=["all", "secp256k1", "msm_g1", "msm_g2", "ed25519"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
@@ -270,6 +270,91 @@ def main():
                            "data": "synthetic: P_i=(a+i*b)G1, s_i uniform in [0,2^254), every 17th zero",
                            "config": {"workload": "bls12-381 G1 Pippenger MSM, 2^%d points per GPU" % args.log2n}})
             extra = {}
+
+    # ------------------------------------------------------------------ bls12-381 G2 MSM (configs[4])
+    if args.workload in ("all", "msm_g2"):
+        from noble_curves_amd._native import BLS12_381_G2
+        from oracle.curves import BlsG2
+        n2 = max(1, n >> 2)                                   # 2^18 at the default size
+        rng = makeRng(0x6D736D0000000004 + rank)
+        a, b = rng.rndBelow(BLS_R - 1) + 1, rng.rndBelow(BLS_R - 1) + 1
+        pts2, pks2 = gen_points(eng, BLS12_381_G2, BlsG2, n2, a, b, device, stream)
+        sc2 = gen_scalars(n2, 254, 999 + rank, device)
+        sc2[::17] = 0
+        ks2 = scalars_to_ints(sc2)
+        local_expect = sum(k * p for k, p in zip(ks2, pks2)) % BLS_R
+        holder2 = {}
+
+        def step_g2():
+            holder2["r"] = eng.msm_dev(BLS12_381_G2, n2, dev_ptr(pts2), dev_ptr(sc2), stream)
+
+        wall, _ = time_steps(step_g2, K, W, dist_on)
+        wall = max_over_ranks(wall, dist_on, device)
+        got, _ = holder2["r"]
+        assert wire_to_affine(BLS12_381_G2, got) == BlsG2.BASE.multiplyUnsafe(local_expect).toAffine(), "G2 MSM mismatch"
+        extra["msm_g2"] = {"metric": "bls12_381_g2_msm_points_per_sec", "value": world * n2 * K / wall,
+                           "unit": "points/s", "ms_per_msm": wall / K * 1e3, "points_per_gpu": n2,
+                           "note": "independent 2^%d-point MSM per GPU (replicas)" % (n2.bit_length() - 1),
+                           "roofline": {"bound": "hbm", "achieved": 224.0 * n2 / (wall / K) / 1e9,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": 224.0 * n2 / (wall / K) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                        "valu": {"achieved_mac_per_s": 3.0e5 * n2 / (wall / K),
+                                                 "peak_mac_per_s": INT_MAC_PEAK,
+                                                 "frac": 3.0e5 * n2 / (wall / K) / INT_MAC_PEAK}}}
+
+    # ------------------------------------------------------------------ ed25519 batch verify (configs[2])
+    if args.workload in ("all", "ed25519"):
+        import hashlib
+        from oracle.curves import ED25519_L, Ed25519
+        from oracle.edwards import eddsa_verify
+        nv = max(64, n >> 2)                                  # 2^18 at the default size
+        rng = makeRng(0x6E6F626C6503 + rank)
+        POOL = 32
+        a_s = [rng.rndBelow(ED25519_L - 1) + 1 for _ in range(POOL)]
+        r_s = [rng.rndBelow(ED25519_L - 1) + 1 for _ in range(POOL)]
+        A_b = [Ed25519.BASE.multiply(x).toBytes() for x in a_s]
+        R_b = [Ed25519.BASE.multiply(x).toBytes() for x in r_s]
+        sig_np = np.zeros((nv, 64), np.uint8)
+        pk_np = np.zeros((nv, 32), np.uint8)
+        k_np = np.zeros((nv, 32), np.uint8)
+        expect = np.ones((nv,), bool)
+        msgs = []
+        for i in range(nv):
+            ia, ir = i % POOL, (i // POOL) % POOL
+            msg = i.to_bytes(8, "little") + bytes([rank]) * 24
+            kk = int.from_bytes(hashlib.sha512(R_b[ir] + A_b[ia] + msg).digest(), "little") % ED25519_L
+            s_ = (r_s[ir] + kk * a_s[ia]) % ED25519_L
+            sig = bytearray(R_b[ir] + s_.to_bytes(32, "little"))
+            if i % 64 == 63:                                   # 1/64 corrupted
+                sig[33 + (i >> 6) % 20] ^= 1 << (i % 7)
+                expect[i] = False
+            sig_np[i] = np.frombuffer(bytes(sig), np.uint8)
+            pk_np[i] = np.frombuffer(A_b[ia], np.uint8)
+            k_np[i] = np.frombuffer(kk.to_bytes(32, "little"), np.uint8)
+            msgs.append(msg)
+        d_sig, d_pk, d_k = (torch.from_numpy(x).to(device) for x in (sig_np, pk_np, k_np))
+        d_ok = torch.empty((nv,), dtype=torch.uint8, device=device)
+
+        def step_ed():
+            eng.ed25519_verify_batch_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_k), True, dev_ptr(d_ok), stream)
+
+        wall, ev_ms = time_steps(step_ed, K, W, dist_on)
+        wall = max_over_ranks(wall, dist_on, device)
+        got = d_ok.cpu().numpy().astype(bool)
+        assert np.array_equal(got, expect), "ed25519 verdict mismatch vs construction"
+        for i in list(range(0, 40)) + list(range(63, nv, max(64, nv // 16 // 64 * 64))):
+            assert got[i] == eddsa_verify(Ed25519, sig_np[i].tobytes(), msgs[i], pk_np[i].tobytes(), zip215=True)
+        extra["ed25519_verify"] = {"metric": "ed25519_verifies_per_sec", "value": world * nv * K / wall,
+                                   "unit": "verifies/s", "ms_per_batch": wall / K * 1e3, "sigs_per_gpu": nv,
+                                   "note": "challenge k = SHA-512(R||A||M) mod L computed by the host shim (untimed); "
+                                           "1/64 of the signatures corrupted; verdicts checked against the oracle",
+                                   "roofline": {"bound": "hbm", "achieved": 129.0 * nv / (ev_ms / K * 1e-3) / 1e9,
+                                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": 129.0 * nv / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "traffic": None, "kernel": "k_ed25519_verify", "kernel_ms": ev_ms / K,
+                                                "valu": {"achieved_mac_per_s": 4.9e5 * nv / (ev_ms / K * 1e-3),
+                                                         "peak_mac_per_s": INT_MAC_PEAK,
+                                                         "frac": 4.9e5 * nv / (ev_ms / K * 1e-3) / INT_MAC_PEAK}}}
 
     if extra:
         result["extra"] = extra
