@@ -214,27 +214,53 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* __restrict__ 
   meta[2] = tail_b;
 }
 
-// Adds up the pieces of every bucket that was cut by a lane boundary: the lane holding the
-// bucket's first piece (its "tail") walks the following lanes' "head" pieces.
+// Adds up the pieces of every bucket that was cut by lane boundaries.  The pieces of one bucket
+// are the "tail" of the lane where it starts (run index 0) followed by the "head" of every later
+// lane it covers; lane s0 = bucket_start / seg and s1 = (bucket_end - 1) / seg delimit the run,
+// so every piece knows its run index without a scan.  Pass `d` (d = 1, 2, 4, ...) adds piece
+// idx + d into piece idx for idx % 2d == 0: log2(longest run) passes, each fully parallel - a
+// bucket holding every entry of a window (identical scalars; the short top window) costs
+// ~log2(n/seg) additions of latency instead of n/seg.
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_fixup(const uint32_t* __restrict__ part_pts,
-                                                   const int* __restrict__ part_meta, uint32_t* __restrict__ buckets,
-                                                   MsmPlan pl, MsmSeg sg) {
+__global__ void __launch_bounds__(256) k_msm_fixup_pass(uint32_t* __restrict__ part_pts,
+                                                        const int* __restrict__ part_meta,
+                                                        const uint32_t* __restrict__ bucket_start, MsmPlan pl,
+                                                        MsmSeg sg, int d) {
   using F = typename C::F;
   constexpr int XW = MsmSizes<C>::XYZZ;
   const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
   if (s >= sg.nseg) return;
-  const int* meta = part_meta + (size_t)w * sg.nseg * 4;
-  const int tb = meta[(size_t)s * 4 + 2];
-  if (tb < 0) return;
-  const uint32_t* pp = part_pts + (size_t)w * sg.nseg * 2 * XW;
-  Xyzz<F> acc = xyzz_load<F>(pp + ((size_t)s * 2 + 1) * XW);
-  for (int s2 = s + 1; s2 < sg.nseg; s2++) {
-    if (meta[(size_t)s2 * 4] != tb) break;
-    acc = xyzz_add(acc, xyzz_load<F>(pp + ((size_t)s2 * 2) * XW));
-    if (!meta[(size_t)s2 * 4 + 1]) break;
+  const int* meta = part_meta + ((size_t)w * sg.nseg + s) * 4;
+  const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  uint32_t* pp = part_pts + (size_t)w * sg.nseg * 2 * XW;
+  // role 0: my head piece (member idx >= 1 of its bucket's run); role 1: my tail piece (idx 0)
+#pragma unroll
+  for (int role = 0; role < 2; role++) {
+    const int b = meta[role == 0 ? 0 : 2];
+    if (b < 0) continue;
+    const int s0 = role == 0 ? (int)(bs[b] / (uint32_t)sg.seg) : s;
+    const int s1 = (int)((bs[b + 1] - 1) / (uint32_t)sg.seg);
+    const int idx = s - s0;
+    if ((idx & (2 * d - 1)) != 0 || s + d > s1) continue;
+    uint32_t* mine = pp + ((size_t)s * 2 + role) * XW;
+    const uint32_t* other = pp + ((size_t)(s + d) * 2) * XW;  // always a head piece
+    xyzz_store<F>(mine, xyzz_add(xyzz_load<F>(mine), xyzz_load<F>(other)));
   }
-  xyzz_store<F>(buckets + ((size_t)w * pl.nb + tb) * XW, acc);
+}
+
+// After the passes, the run totals sit in the tail slots: write them to their buckets.
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_fixup_write(const uint32_t* __restrict__ part_pts,
+                                                         const int* __restrict__ part_meta,
+                                                         uint32_t* __restrict__ buckets, MsmPlan pl, MsmSeg sg) {
+  using F = typename C::F;
+  constexpr int XW = MsmSizes<C>::XYZZ;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+  if (s >= sg.nseg) return;
+  const int tb = part_meta[((size_t)w * sg.nseg + s) * 4 + 2];
+  if (tb < 0) return;
+  const uint32_t* src = part_pts + (((size_t)w * sg.nseg + s) * 2 + 1) * XW;
+  xyzz_store<F>(buckets + ((size_t)w * pl.nb + tb) * XW, xyzz_load<F>(src));
 }
 
 // ------------------------------------------------------------------ 5. bucket fold, one level
@@ -440,7 +466,9 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
     dim3 grid((sg.nseg + 255) / 256, pl.nwin);
     hipLaunchKernelGGL(k_msm_accum<C>, grid, dim3(256), 0, st, pts_mont, sorted, bstart, buckets, part_pts, part_meta,
                        pl, sg);
-    hipLaunchKernelGGL(k_msm_fixup<C>, grid, dim3(256), 0, st, part_pts, part_meta, buckets, pl, sg);
+    for (int d = 1; d < sg.nseg; d <<= 1)
+      hipLaunchKernelGGL(k_msm_fixup_pass<C>, grid, dim3(256), 0, st, part_pts, part_meta, bstart, pl, sg, d);
+    hipLaunchKernelGGL(k_msm_fixup_write<C>, grid, dim3(256), 0, st, part_pts, part_meta, buckets, pl, sg);
   }
   // fold: nb -> 1 per window in c-1 levels
   const uint32_t* cur = buckets;
