@@ -1,4 +1,5 @@
-// Prime-field arithmetic for gfx950: 32-bit limbs in VGPRs, Montgomery form.
+// Prime-field arithmetic for gfx950: 32-bit limbs in VGPRs; Montgomery form for bls12-381,
+// plain residues with special-form folding for secp256k1 and ed25519 (PR::FOLD).
 //
 // Reproduces the *values* of the reference's `_Field` ops (src/abstract/modular.ts:940-982:
 // add/sub/neg/mul/sqr/inv = canonical residues mod ORDER) - here residues are held as
@@ -176,17 +177,90 @@ NCG_DI void fp_mul_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], const 
   fp_cond_sub_p<PR>(r, T[N]);
 }
 
+// ---- special-form primes p = 2^256 - c (secp256k1: c = 2^32 + 977) or 2p = 2^256 - c
+// (ed25519: 2^256 = 2p + 38): plain (non-Montgomery) residues, product folded with 2^256 = c.
+// Half the multiply-adds of the Montgomery path (72 instead of 136 v_mad_u64_u32) and no q*p
+// carry chains.  Params provide FOLD_LO (low 32 bits of c), FOLD_HI (c >> 32, 0 or 1) and
+// FINAL_SUBS (conditional subtractions of p that make the result canonical: 1 or 2).
+template <class PR>
+NCG_DI void fp_mul_fold_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], const uint32_t (&b)[PR::N]) {
+  static_assert(PR::N == 8, "fold path is for 256-bit special primes");
+  constexpr int N = 8;
+  uint32_t T[2 * N];
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) T[i] = 0;
+  // 512-bit product, two carry chains per row
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint32_t lo[N], hi[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      uint64_t t = (uint64_t)a[j] * b[i];
+      lo[j] = (uint32_t)t;
+      hi[j] = (uint32_t)(t >> 32);
+    }
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) T[i + j] = __builtin_addc(T[i + j], lo[j], c, &c);
+    T[i + N] += c;  // cannot overflow: partial sums are below 2^(32(i+9))
+    c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) T[i + j + 1] = __builtin_addc(T[i + j + 1], hi[j], c, &c);
+    if (i + N + 1 < 2 * N) T[i + N + 1] += c;
+  }
+  // first fold: U = L + H*c, c = FOLD_HI*2^32 + FOLD_LO ; U has 8 limbs + a small overflow limb
+  uint32_t U[N];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    uint64_t acc = (uint64_t)T[N + j] * PR::FOLD_LO + T[j];
+    acc += carry;
+    if (PR::FOLD_HI && j > 0) acc += T[N + j - 1];
+    U[j] = (uint32_t)acc;
+    carry = acc >> 32;
+  }
+  if (PR::FOLD_HI) carry += T[2 * N - 1];  // overflow limb < 2^34
+  // second fold of the overflow limb (needs up to 3 low limbs), then ripple
+  {
+    uint64_t acc = (uint64_t)(uint32_t)carry * PR::FOLD_LO + U[0];
+    uint64_t hi2 = (carry >> 32) * (uint64_t)PR::FOLD_LO;  // carry may have 34 bits
+    U[0] = (uint32_t)acc;
+    acc = (acc >> 32) + U[1] + (uint32_t)hi2;
+    if (PR::FOLD_HI) acc += (uint32_t)carry;
+    U[1] = (uint32_t)acc;
+    acc = (acc >> 32) + U[2] + (hi2 >> 32);
+    if (PR::FOLD_HI) acc += (carry >> 32);
+    U[2] = (uint32_t)acc;
+    uint32_t c = (uint32_t)(acc >> 32);
+#pragma unroll
+    for (int j = 3; j < N; j++) U[j] = __builtin_addc(U[j], 0u, c, &c);
+    // a carry out of limb 7 means the value wrapped 2^256 once more: add c again (cannot recur)
+    uint32_t m = 0u - c;
+    uint32_t c2 = 0;
+    U[0] = __builtin_addc(U[0], (uint32_t)PR::FOLD_LO & m, 0u, &c2);
+    U[1] = __builtin_addc(U[1], (PR::FOLD_HI ? 1u : 0u) & m, c2, &c2);
+#pragma unroll
+    for (int j = 2; j < N; j++) U[j] = __builtin_addc(U[j], 0u, c2, &c2);
+  }
+#pragma unroll
+  for (int j = 0; j < N; j++) r[j] = U[j];
+#pragma unroll
+  for (int k = 0; k < PR::FINAL_SUBS; k++) fp_cond_sub_p<PR>(r, 0u);
+}
+
 template <class PR>
 NCG_MULFN Fp<PR> fp_mul(Fp<PR> a, Fp<PR> b) {  // modular.ts:956
   Fp<PR> r;
-  fp_mul_body<PR>(r.v, a.v, b.v);
+  if constexpr (PR::FOLD) fp_mul_fold_body<PR>(r.v, a.v, b.v);
+  else fp_mul_body<PR>(r.v, a.v, b.v);
   return r;
 }
 
 template <class PR>
 NCG_MULFN Fp<PR> fp_sqr(Fp<PR> a) {  // modular.ts:947
   Fp<PR> r;
-  fp_mul_body<PR>(r.v, a.v, a.v);
+  if constexpr (PR::FOLD) fp_mul_fold_body<PR>(r.v, a.v, a.v);
+  else fp_mul_body<PR>(r.v, a.v, a.v);
   return r;
 }
 

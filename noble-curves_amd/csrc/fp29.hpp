@@ -1,0 +1,80 @@
+// Radix-2^29 Montgomery multiplication with 64-bit column accumulators ("lazy carries").
+//
+// v_mad_u64_u32 accumulates a 32x32 product into a 64-bit register at full rate on gfx950
+// (profiles/r01_ubench_instr_rates.json), but has no carry-in, so with 32-bit limbs every
+// partial product costs two extra carry instructions.  With 29-bit limbs a column of up to 28
+// products (14 a*b + 14 q*p) stays below 2^64, so the whole multiply is mads plus one
+// shift/mask per column.
+#pragma once
+#include "fp.hpp"
+
+namespace ncg {
+
+// r = a*b*R^-1 mod p (R = 2^(29N)); inputs: limbs < 2^29, values < 2^12 p; output limbs < 2^29,
+// value < a*b/R + p.
+template <class PR>
+NCG_DI void mont_mul29(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], const uint32_t (&b)[PR::N]) {
+  constexpr int N = PR::N;
+  constexpr uint32_t MASK = (1u << 29) - 1u;
+  uint64_t t[2 * N];
+#pragma unroll
+  for (int k = 0; k < 2 * N; k++) t[k] = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+#pragma unroll
+    for (int j = 0; j < N; j++) t[i + j] += (uint64_t)a[i] * b[j];
+  }
+  uint64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    uint64_t T = t[k] + carry;
+    uint32_t q = ((uint32_t)T * PR::INV) & MASK;
+    T += (uint64_t)q * (uint32_t)PR::P[0];
+    carry = T >> 29;
+#pragma unroll
+    for (int j = 1; j < N; j++) t[k + j] += (uint64_t)q * (uint32_t)PR::P[j];
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N; k++) {
+    uint64_t T = t[k] + carry;
+    r[k - N] = (uint32_t)T & MASK;
+    carry = T >> 29;
+  }
+}
+
+// squaring: off-diagonal products once, doubled
+template <class PR>
+NCG_DI void mont_sqr29(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N]) {
+  constexpr int N = PR::N;
+  constexpr uint32_t MASK = (1u << 29) - 1u;
+  uint64_t t[2 * N];
+#pragma unroll
+  for (int k = 0; k < 2 * N; k++) t[k] = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+#pragma unroll
+    for (int j = i + 1; j < N; j++) t[i + j] += (uint64_t)a[i] * a[j];
+  }
+#pragma unroll
+  for (int k = 0; k < 2 * N; k++) t[k] <<= 1;
+#pragma unroll
+  for (int i = 0; i < N; i++) t[2 * i] += (uint64_t)a[i] * a[i];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    uint64_t T = t[k] + carry;
+    uint32_t q = ((uint32_t)T * PR::INV) & MASK;
+    T += (uint64_t)q * (uint32_t)PR::P[0];
+    carry = T >> 29;
+#pragma unroll
+    for (int j = 1; j < N; j++) t[k + j] += (uint64_t)q * (uint32_t)PR::P[j];
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N; k++) {
+    uint64_t T = t[k] + carry;
+    r[k - N] = (uint32_t)T & MASK;
+    carry = T >> 29;
+  }
+}
+
+}  // namespace ncg

@@ -2,6 +2,7 @@
 // DESIGN.md's VALU roofline ("measure the real v_mad_u64_u32 issue rate first");
 // not on the product path.
 #include "curves.hpp"
+#include "fp29.hpp"
 
 namespace ncg {
 
@@ -19,6 +20,8 @@ enum UbKind : int {
   UB_MODSQR_BLS = 10,
   UB_MODADD_BLS = 11,
   UB_MUL_HI_U24 = 12,
+  UB_MODMUL_BLS29 = 13,
+  UB_MODSQR_BLS29 = 14,
 };
 
 __device__ __forceinline__ uint32_t __umul24hi_sub(uint32_t x, uint32_t y) {
@@ -125,6 +128,29 @@ __global__ void __launch_bounds__(256) k_ub_field(uint32_t* out, const uint32_t*
   out[t] = s;
 }
 
+template <int OP>
+struct UbMul29 {
+  static __device__ __noinline__ void run(uint32_t (&r)[14], const uint32_t (&a)[14], const uint32_t (&b)[14]) {
+    if constexpr (OP == 0) mont_mul29<ParamsBls29>(r, a, b);
+    else mont_sqr29<ParamsBls29>(r, a);
+  }
+};
+template <int OP>
+__global__ void __launch_bounds__(256) k_ub_field29(uint32_t* out, const uint32_t* in, int iters) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t a[14], b[14];
+  for (int i = 0; i < 14; i++) {
+    a[i] = in[(t + i) & 1023] & 0x1fffffffu;
+    b[i] = in[(t + 31 * i + 5) & 1023] & 0x1fffffffu;
+  }
+  a[13] &= 0xffffu;
+  b[13] &= 0xffffu;
+  for (int i = 0; i < iters; i++) UbMul29<OP>::run(a, a, b);
+  uint32_t s = 0;
+  for (int i = 0; i < 14; i++) s ^= a[i];
+  out[t] = s;
+}
+
 // Returns milliseconds for one launch of `kind` with the given geometry (after one warm-up).
 hipError_t ubench_run(int kind, int blocks, int threads, int iters, uint32_t* d_out, const uint32_t* d_in,
                       hipStream_t st, float* ms) {
@@ -148,6 +174,8 @@ hipError_t ubench_run(int kind, int blocks, int threads, int iters, uint32_t* d_
       case UB_MODMUL_BLS: UB_LAUNCH((k_ub_field<ParamsBlsP, 0>)); break;
       case UB_MODSQR_BLS: UB_LAUNCH((k_ub_field<ParamsBlsP, 1>)); break;
       case UB_MODADD_BLS: UB_LAUNCH((k_ub_field<ParamsBlsP, 2>)); break;
+      case UB_MODMUL_BLS29: UB_LAUNCH((k_ub_field29<0>)); break;
+      case UB_MODSQR_BLS29: UB_LAUNCH((k_ub_field29<1>)); break;
       default: return hipErrorInvalidValue;
     }
 #undef UB_LAUNCH

@@ -9,10 +9,16 @@ from noble_curves_amd import get_engine  # noqa: E402
 KINDS = {0: ("v_mad_u64_u32", 8), 1: ("v_mul_lo_u32", 8), 2: ("v_mul_hi_u32(+add)", 8), 3: ("v_mad_u32_u24", 8),
          12: ("v_mul_hi_u32_u24(+xor)", 8), 4: ("v_addc_co_u32", 8), 5: ("add_u64(+shift)", 8), 6: ("v_fma_f64", 8),
          7: ("v_fma_f32", 8), 8: ("modmul secp256k1 (N=8)", 1), 9: ("modmul bls12-381 (N=12)", 1),
-         10: ("modsqr bls12-381", 1), 11: ("modadd bls12-381", 1)}
+         10: ("modsqr bls12-381", 1), 11: ("modadd bls12-381", 1),
+         13: ("modmul bls12-381 radix-2^29 lazy", 1), 14: ("modsqr bls12-381 radix-2^29 lazy", 1)}
 
 
 def main():
+    only = [int(x) for x in sys.argv[1:]]
+    if only:
+        for k in list(KINDS):
+            if k not in only:
+                del KINDS[k]
     eng = get_engine()
     res = {}
     CUS, CLK = 256, 2.4e9
