@@ -182,32 +182,10 @@ NCG_DI void fp_mul_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], const 
 // Half the multiply-adds of the Montgomery path (72 instead of 136 v_mad_u64_u32) and no q*p
 // carry chains.  Params provide FOLD_LO (low 32 bits of c), FOLD_HI (c >> 32, 0 or 1) and
 // FINAL_SUBS (conditional subtractions of p that make the result canonical: 1 or 2).
+// r = T mod p for a 512-bit T (16 limbs), folding 2^256 = c twice, then canonical.
 template <class PR>
-NCG_DI void fp_mul_fold_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], const uint32_t (&b)[PR::N]) {
-  static_assert(PR::N == 8, "fold path is for 256-bit special primes");
+NCG_DI void fp_fold_reduce(uint32_t (&r)[8], const uint32_t (&T)[16]) {
   constexpr int N = 8;
-  uint32_t T[2 * N];
-#pragma unroll
-  for (int i = 0; i < 2 * N; i++) T[i] = 0;
-  // 512-bit product, two carry chains per row
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    uint32_t lo[N], hi[N];
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-      uint64_t t = (uint64_t)a[j] * b[i];
-      lo[j] = (uint32_t)t;
-      hi[j] = (uint32_t)(t >> 32);
-    }
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < N; j++) T[i + j] = __builtin_addc(T[i + j], lo[j], c, &c);
-    T[i + N] += c;  // cannot overflow: partial sums are below 2^(32(i+9))
-    c = 0;
-#pragma unroll
-    for (int j = 0; j < N; j++) T[i + j + 1] = __builtin_addc(T[i + j + 1], hi[j], c, &c);
-    if (i + N + 1 < 2 * N) T[i + N + 1] += c;
-  }
   // first fold: U = L + H*c, c = FOLD_HI*2^32 + FOLD_LO ; U has 8 limbs + a small overflow limb
   uint32_t U[N];
   uint64_t carry = 0;
@@ -249,6 +227,79 @@ NCG_DI void fp_mul_fold_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], c
 }
 
 template <class PR>
+NCG_DI void fp_mul_fold_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], const uint32_t (&b)[PR::N]) {
+  static_assert(PR::N == 8, "fold path is for 256-bit special primes");
+  constexpr int N = 8;
+  uint32_t T[2 * N];
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) T[i] = 0;
+  // 512-bit product, two carry chains per row
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint32_t lo[N], hi[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      uint64_t t = (uint64_t)a[j] * b[i];
+      lo[j] = (uint32_t)t;
+      hi[j] = (uint32_t)(t >> 32);
+    }
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) T[i + j] = __builtin_addc(T[i + j], lo[j], c, &c);
+    T[i + N] += c;  // cannot overflow: partial sums are below 2^(32(i+9))
+    c = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) T[i + j + 1] = __builtin_addc(T[i + j + 1], hi[j], c, &c);
+    if (i + N + 1 < 2 * N) T[i + N + 1] += c;
+  }
+  fp_fold_reduce<PR>(r, T);
+}
+
+// square: the 28 off-diagonal products once, doubled, plus the 8 squares (36 instead of 64
+// multiply-adds)
+template <class PR>
+NCG_DI void fp_sqr_fold_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N]) {
+  static_assert(PR::N == 8, "fold path is for 256-bit special primes");
+  constexpr int N = 8;
+  uint32_t T[2 * N];
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) T[i] = 0;
+#pragma unroll
+  for (int i = 0; i < N - 1; i++) {
+    uint32_t lo[N], hi[N];
+#pragma unroll
+    for (int j = i + 1; j < N; j++) {
+      uint64_t t = (uint64_t)a[j] * a[i];
+      lo[j] = (uint32_t)t;
+      hi[j] = (uint32_t)(t >> 32);
+    }
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = i + 1; j < N; j++) T[i + j] = __builtin_addc(T[i + j], lo[j], c, &c);
+    T[i + N] += c;
+    c = 0;
+#pragma unroll
+    for (int j = i + 1; j < N; j++) T[i + j + 1] = __builtin_addc(T[i + j + 1], hi[j], c, &c);
+    if (i + N + 1 < 2 * N) T[i + N + 1] += c;
+  }
+  // double (the off-diagonal sum is below 2^511)
+#pragma unroll
+  for (int k = 2 * N - 1; k > 0; k--) T[k] = (T[k] << 1) | (T[k - 1] >> 31);
+  T[0] <<= 1;
+  // add the squares a_i^2 at limb 2i
+  {
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)a[i] * a[i];
+      T[2 * i] = __builtin_addc(T[2 * i], (uint32_t)t, c, &c);
+      T[2 * i + 1] = __builtin_addc(T[2 * i + 1], (uint32_t)(t >> 32), c, &c);
+    }
+  }
+  fp_fold_reduce<PR>(r, T);
+}
+
+template <class PR>
 NCG_MULFN Fp<PR> fp_mul(Fp<PR> a, Fp<PR> b) {  // modular.ts:956
   Fp<PR> r;
   if constexpr (PR::FOLD) fp_mul_fold_body<PR>(r.v, a.v, b.v);
@@ -259,7 +310,7 @@ NCG_MULFN Fp<PR> fp_mul(Fp<PR> a, Fp<PR> b) {  // modular.ts:956
 template <class PR>
 NCG_MULFN Fp<PR> fp_sqr(Fp<PR> a) {  // modular.ts:947
   Fp<PR> r;
-  if constexpr (PR::FOLD) fp_mul_fold_body<PR>(r.v, a.v, a.v);
+  if constexpr (PR::FOLD) fp_sqr_fold_body<PR>(r.v, a.v);
   else fp_mul_body<PR>(r.v, a.v, a.v);
   return r;
 }

@@ -1,15 +1,17 @@
 // Launchers for the batch variable-base multiply kernels (see mulvar.hpp).
 #include "mulvar.hpp"
 
+#include <cstdlib>
+
 namespace ncg {
 
-template <class C, int W>
+template <class C, int W, int MINW = 1>
 static hipError_t launch_mul_var(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
                                  int n, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   using Cfg = MulVarCfg<C, W>;
   size_t lds = (size_t)Cfg::LDS_WORDS * 4;
-  auto kern = k_mul_var<C, W>;
+  auto kern = k_mul_var<C, W, MINW>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, out, out_inf, n);
@@ -19,7 +21,14 @@ static hipError_t launch_mul_var(const uint32_t* pts, const uint32_t* scalars, u
 hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
                          int n, hipStream_t st) {
   switch (curve) {
-    case CURVE_SECP256K1: return launch_mul_var<CurveSecp, 4>(pts, scalars, out, out_inf, n, st);
+    case CURVE_SECP256K1: {
+      // window width / occupancy trade-off, selectable for A/B runs (default W = 3, 2 waves/SIMD: best of the measured set, profiles/)
+      static const int w = [] { const char* e = std::getenv("NCG_SECP_W"); return e ? std::atoi(e) : 33; }();
+      if (w == 3) return launch_mul_var<CurveSecp, 3, 3>(pts, scalars, out, out_inf, n, st);
+      if (w == 33) return launch_mul_var<CurveSecp, 3, 2>(pts, scalars, out, out_inf, n, st);
+      if (w == 5) return launch_mul_var<CurveSecp, 5, 1>(pts, scalars, out, out_inf, n, st);
+      return launch_mul_var<CurveSecp, 4>(pts, scalars, out, out_inf, n, st);
+    }
     case CURVE_BLS12_381_G1: return launch_mul_var<CurveG1, 3>(pts, scalars, out, out_inf, n, st);
     case CURVE_BLS12_381_G2: return launch_mul_var<CurveG2, 3>(pts, scalars, out, out_inf, n, st);
     default: return hipErrorInvalidValue;

@@ -169,8 +169,8 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
   }
 }
 
-template <class C, int W>
-__global__ void __launch_bounds__(64)
+template <class C, int W, int MINW>
+__global__ void __launch_bounds__(64, MINW)
 k_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars,
           uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf, int n) {
   constexpr int FW = MulVarCfg<C, W>::FW;
