@@ -13,13 +13,13 @@ struct CurveSecp {  // src/secp256k1.ts:48-64
   static NCG_DI F beta() { return F::from_const(ParamsSecpP::BETA); }
 };
 struct CurveG1 {  // src/bls12-381.ts:134-148; no endomorphism in the reference (and inputs are
-  using F = FpBls;  // not subgroup-checked), so none here either (SURVEY 8a gotcha 1)
+  using F = FeBls;  // not subgroup-checked), so none here either (SURVEY 8a gotcha 1)
   static constexpr bool GLV = false;
   static constexpr int SCALAR_BITS = 255;
   static NCG_DI F beta() { return F::one(); }
 };
 struct CurveG2 {  // src/bls12-381.ts:321-345
-  using F = Fp2Bls;
+  using F = FeBls2;
   static constexpr bool GLV = false;
   static constexpr int SCALAR_BITS = 255;
   static NCG_DI F beta() { return F::one(); }
@@ -28,17 +28,17 @@ struct CurveG2 {  // src/bls12-381.ts:321-345
 // Affine wire point (canonical residues) -> Montgomery-form Affine<F>, and back.
 template <class F>
 NCG_DI Affine<F> load_affine_wire(const uint32_t* p) {
-  constexpr int FW = FieldIO<F>::WORDS;
+  constexpr int WW = FieldWire<F>::WORDS;
   Affine<F> a;
-  a.x = f_to_mont(FieldIO<F>::load(p));
-  a.y = f_to_mont(FieldIO<F>::load(p + FW));
+  a.x = FieldWire<F>::load(p);
+  a.y = FieldWire<F>::load(p + WW);
   return a;
 }
 template <class F>
 NCG_DI void store_affine_wire(uint32_t* p, const Affine<F>& a) {
-  constexpr int FW = FieldIO<F>::WORDS;
-  FieldIO<F>::store(p, f_from_mont(a.x));
-  FieldIO<F>::store(p + FW, f_from_mont(a.y));
+  constexpr int WW = FieldWire<F>::WORDS;
+  FieldWire<F>::store(p, a.x);
+  FieldWire<F>::store(p + WW, a.y);
 }
 
 }  // namespace ncg

@@ -50,17 +50,17 @@ NCG_DI Jac<F> jac_neg(const Jac<F>& p) {
 // dbl-2009-l (a = 0): 2M + 5S.  Z = 0 stays Z = 0; no point of order 2 exists on these curves.
 template <class F>
 NCG_DI Jac<F> jac_dbl(const Jac<F>& p) {
-  F A = f_sqr(p.X);
-  F B = f_sqr(p.Y);
-  F C = f_sqr(B);
-  F t = f_sqr(p.X + B) - A - C;
-  F D = f_dbl(t);
-  F E = f_dbl(A) + A;
-  F Fq = f_sqr(E);
-  F X3 = Fq - f_dbl(D);
-  F C8 = f_dbl(f_dbl(f_dbl(C)));
-  F Y3 = E * (D - X3) - C8;
-  F Z3 = f_dbl(p.Y * p.Z);
+  auto A = f_sqr(p.X);
+  auto B = f_sqr(p.Y);
+  auto C = f_sqr(B);
+  auto t = f_sqr(p.X + B) - A - C;
+  auto D = f_dbl(t);
+  auto E = f_dbl(A) + A;
+  auto Fq = f_sqr(E);
+  auto X3 = Fq - f_dbl(D);
+  auto C8 = f_dbl(f_dbl(f_dbl(C)));
+  auto Y3 = E * (D - X3) - C8;
+  auto Z3 = f_dbl(p.Y * p.Z);
   return {X3, Y3, Z3};
 }
 
@@ -69,21 +69,21 @@ template <class F>
 NCG_DI Jac<F> jac_madd(const Jac<F>& p, const Affine<F>& q) {
   if (q.is_inf()) return p;
   if (p.is_inf()) return {q.x, q.y, F::one()};
-  F Z1Z1 = f_sqr(p.Z);
-  F U2 = q.x * Z1Z1;
-  F S2 = q.y * p.Z * Z1Z1;
-  F H = U2 - p.X;
-  F R = S2 - p.Y;
-  if (H.is_zero()) {
-    if (R.is_zero()) return jac_dbl(p);  // P == Q
+  auto Z1Z1 = f_sqr(p.Z);
+  auto U2 = q.x * Z1Z1;
+  auto S2 = q.y * p.Z * Z1Z1;
+  auto H = U2 - p.X;
+  auto R = S2 - p.Y;
+  if (f_eqz(H)) {
+    if (f_eqz(R)) return jac_dbl(p);  // P == Q
     return Jac<F>::inf();                // P == -Q
   }
-  F HH = f_sqr(H);
-  F HHH = H * HH;
-  F V = p.X * HH;
-  F X3 = f_sqr(R) - HHH - f_dbl(V);
-  F Y3 = R * (V - X3) - p.Y * HHH;
-  F Z3 = p.Z * H;
+  auto HH = f_sqr(H);
+  auto HHH = H * HH;
+  auto V = p.X * HH;
+  auto X3 = f_sqr(R) - HHH - f_dbl(V);
+  auto Y3 = R * (V - X3) - p.Y * HHH;
+  auto Z3 = p.Z * H;
   return {X3, Y3, Z3};
 }
 
@@ -92,32 +92,32 @@ template <class F>
 NCG_DI Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
   if (q.is_inf()) return p;
   if (p.is_inf()) return q;
-  F Z1Z1 = f_sqr(p.Z);
-  F Z2Z2 = f_sqr(q.Z);
-  F U1 = p.X * Z2Z2;
-  F U2 = q.X * Z1Z1;
-  F S1 = p.Y * q.Z * Z2Z2;
-  F S2 = q.Y * p.Z * Z1Z1;
-  F H = U2 - U1;
-  F R = S2 - S1;
-  if (H.is_zero()) {
-    if (R.is_zero()) return jac_dbl(p);
+  auto Z1Z1 = f_sqr(p.Z);
+  auto Z2Z2 = f_sqr(q.Z);
+  auto U1 = p.X * Z2Z2;
+  auto U2 = q.X * Z1Z1;
+  auto S1 = p.Y * q.Z * Z2Z2;
+  auto S2 = q.Y * p.Z * Z1Z1;
+  auto H = U2 - U1;
+  auto R = S2 - S1;
+  if (f_eqz(H)) {
+    if (f_eqz(R)) return jac_dbl(p);
     return Jac<F>::inf();
   }
-  F HH = f_sqr(H);
-  F HHH = H * HH;
-  F V = U1 * HH;
-  F X3 = f_sqr(R) - HHH - f_dbl(V);
-  F Y3 = R * (V - X3) - S1 * HHH;
-  F Z3 = p.Z * q.Z * H;
+  auto HH = f_sqr(H);
+  auto HHH = H * HH;
+  auto V = U1 * HH;
+  auto X3 = f_sqr(R) - HHH - f_dbl(V);
+  auto Y3 = R * (V - X3) - S1 * HHH;
+  auto Z3 = p.Z * q.Z * H;
   return {X3, Y3, Z3};
 }
 
 // Jacobian -> affine with a supplied inverse of Z (weierstrass.ts:951-969 toAffine(invZ)).
-template <class F>
-NCG_DI Affine<F> jac_to_affine(const Jac<F>& p, const F& zinv) {
+template <class F, class ZI>
+NCG_DI Affine<F> jac_to_affine(const Jac<F>& p, const ZI& zinv) {
   if (p.is_inf()) return {F::zero(), F::zero()};
-  F zi2 = f_sqr(zinv);
+  auto zi2 = f_sqr(zinv);
   return {p.X * zi2, p.Y * zi2 * zinv};
 }
 
@@ -131,14 +131,14 @@ NCG_DI Xyzz<F> xyzz_from_affine(const Affine<F>& p) {
 // mdbl-2008-s-1 (a = 0): double an affine point into XYZZ.
 template <class F>
 NCG_DI Xyzz<F> xyzz_mdbl(const Affine<F>& p) {
-  F U = f_dbl(p.y);
-  F V = f_sqr(U);
-  F W = U * V;
-  F S = p.x * V;
-  F xx = f_sqr(p.x);
-  F M = f_dbl(xx) + xx;
-  F X3 = f_sqr(M) - f_dbl(S);
-  F Y3 = M * (S - X3) - W * p.y;
+  auto U = f_dbl(p.y);
+  auto V = f_sqr(U);
+  auto W = U * V;
+  auto S = p.x * V;
+  auto xx = f_sqr(p.x);
+  auto M = f_dbl(xx) + xx;
+  auto X3 = f_sqr(M) - f_dbl(S);
+  auto Y3 = M * (S - X3) - W * p.y;
   return {X3, Y3, V, W};
 }
 
@@ -146,14 +146,14 @@ NCG_DI Xyzz<F> xyzz_mdbl(const Affine<F>& p) {
 template <class F>
 NCG_DI Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
   if (p.is_inf()) return p;
-  F U = f_dbl(p.Y);
-  F V = f_sqr(U);
-  F W = U * V;
-  F S = p.X * V;
-  F xx = f_sqr(p.X);
-  F M = f_dbl(xx) + xx;
-  F X3 = f_sqr(M) - f_dbl(S);
-  F Y3 = M * (S - X3) - W * p.Y;
+  auto U = f_dbl(p.Y);
+  auto V = f_sqr(U);
+  auto W = U * V;
+  auto S = p.X * V;
+  auto xx = f_sqr(p.X);
+  auto M = f_dbl(xx) + xx;
+  auto X3 = f_sqr(M) - f_dbl(S);
+  auto Y3 = M * (S - X3) - W * p.Y;
   return {X3, Y3, V * p.ZZ, W * p.ZZZ};
 }
 
@@ -164,19 +164,19 @@ NCG_DI Xyzz<F> xyzz_madd(const Xyzz<F>& p, const Affine<F>& q_in, bool neg = fal
   Affine<F> q = q_in;
   if (neg) q.y = f_neg(q.y);
   if (p.is_inf()) return {q.x, q.y, F::one(), F::one()};
-  F U2 = q.x * p.ZZ;
-  F S2 = q.y * p.ZZZ;
-  F Pq = U2 - p.X;
-  F R = S2 - p.Y;
-  if (Pq.is_zero()) {
-    if (R.is_zero()) return xyzz_mdbl(q);
+  auto U2 = q.x * p.ZZ;
+  auto S2 = q.y * p.ZZZ;
+  auto Pq = U2 - p.X;
+  auto R = S2 - p.Y;
+  if (f_eqz(Pq)) {
+    if (f_eqz(R)) return xyzz_mdbl(q);
     return Xyzz<F>::inf();
   }
-  F PP = f_sqr(Pq);
-  F PPP = Pq * PP;
-  F Q = p.X * PP;
-  F X3 = f_sqr(R) - PPP - f_dbl(Q);
-  F Y3 = R * (Q - X3) - p.Y * PPP;
+  auto PP = f_sqr(Pq);
+  auto PPP = Pq * PP;
+  auto Q = p.X * PP;
+  auto X3 = f_sqr(R) - PPP - f_dbl(Q);
+  auto Y3 = R * (Q - X3) - p.Y * PPP;
   return {X3, Y3, p.ZZ * PP, p.ZZZ * PPP};
 }
 
@@ -185,21 +185,21 @@ template <class F>
 NCG_DI Xyzz<F> xyzz_add(const Xyzz<F>& p, const Xyzz<F>& q) {
   if (q.is_inf()) return p;
   if (p.is_inf()) return q;
-  F U1 = p.X * q.ZZ;
-  F U2 = q.X * p.ZZ;
-  F S1 = p.Y * q.ZZZ;
-  F S2 = q.Y * p.ZZZ;
-  F Pq = U2 - U1;
-  F R = S2 - S1;
-  if (Pq.is_zero()) {
-    if (R.is_zero()) return xyzz_dbl(p);
+  auto U1 = p.X * q.ZZ;
+  auto U2 = q.X * p.ZZ;
+  auto S1 = p.Y * q.ZZZ;
+  auto S2 = q.Y * p.ZZZ;
+  auto Pq = U2 - U1;
+  auto R = S2 - S1;
+  if (f_eqz(Pq)) {
+    if (f_eqz(R)) return xyzz_dbl(p);
     return Xyzz<F>::inf();
   }
-  F PP = f_sqr(Pq);
-  F PPP = Pq * PP;
-  F Q = U1 * PP;
-  F X3 = f_sqr(R) - PPP - f_dbl(Q);
-  F Y3 = R * (Q - X3) - S1 * PPP;
+  auto PP = f_sqr(Pq);
+  auto PPP = Pq * PP;
+  auto Q = U1 * PP;
+  auto X3 = f_sqr(R) - PPP - f_dbl(Q);
+  auto Y3 = R * (Q - X3) - S1 * PPP;
   return {X3, Y3, p.ZZ * q.ZZ * PP, p.ZZZ * q.ZZZ * PPP};
 }
 

@@ -2,6 +2,7 @@
 // Reproduces the values of the reference's `_Field2` ops (src/abstract/tower.ts:393-438):
 // mul = 3 Fp.mul Karatsuba (:420-431), sqr = 2 Fp.mul (:432-438).
 #pragma once
+#include "fe29.hpp"
 #include "fp.hpp"
 
 namespace ncg {
@@ -60,7 +61,11 @@ NCG_DI Fp2T<PR> f_inv(const Fp2T<PR>& a) {  // tower.ts:458-475: (a - bu)/(a^2 +
 template <class PR> NCG_DI Fp2T<PR> f_to_mont(const Fp2T<PR>& a) { return {fp_to_mont<PR>(a.c0), fp_to_mont<PR>(a.c1)}; }
 template <class PR> NCG_DI Fp2T<PR> f_from_mont(const Fp2T<PR>& a) { return {fp_from_mont<PR>(a.c0), fp_from_mont<PR>(a.c1)}; }
 
-// wire format: Fp = N LE limbs; Fp2 = c0 then c1 (include/ncg.h)
+template <class PR> NCG_DI bool f_eqz(const Fp<PR>& a) { return a.is_zero(); }  // canonical residues
+template <class PR> NCG_DI bool f_eqz(const Fp2T<PR>& a) { return a.is_zero(); }
+
+// FieldIO<F>:   internal storage format (what kernels keep in HBM / LDS), WORDS 32-bit words
+// FieldWire<F>: wire format of include/ncg.h (canonical residues, LE 32-bit limbs; Fp2 = c0, c1)
 template <class F> struct FieldIO;
 template <class PR>
 struct FieldIO<Fp<PR>> {
@@ -93,6 +98,85 @@ struct FieldIO<Fp2T<PR>> {
   template <class PTR> static NCG_DI void store_strided(PTR p, int stride, const Fp2T<PR>& a) {
     FieldIO<Fp<PR>>::store_strided(p, stride, a.c0);
     FieldIO<Fp<PR>>::store_strided(p + PR::N * stride, stride, a.c1);
+  }
+};
+
+template <class F> struct FieldWire;
+template <class PR>
+struct FieldWire<Fp<PR>> {
+  static constexpr int WORDS = PR::N;
+  static NCG_DI Fp<PR> load(const uint32_t* p) { return fp_to_mont<PR>(fp_load<PR>(p)); }
+  static NCG_DI void store(uint32_t* p, const Fp<PR>& a) { fp_store<PR>(p, fp_from_mont<PR>(a)); }
+};
+template <class PR>
+struct FieldWire<Fp2T<PR>> {
+  static constexpr int WORDS = 2 * PR::N;
+  static NCG_DI Fp2T<PR> load(const uint32_t* p) {
+    return {FieldWire<Fp<PR>>::load(p), FieldWire<Fp<PR>>::load(p + PR::N)};
+  }
+  static NCG_DI void store(uint32_t* p, const Fp2T<PR>& a) {
+    FieldWire<Fp<PR>>::store(p, a.c0);
+    FieldWire<Fp<PR>>::store(p + PR::N, a.c1);
+  }
+};
+
+// ---- Fe29 / Fe29x2 adapters
+template <int B>
+struct FieldIO<Fe29<B>> {
+  static constexpr int WORDS = 14;
+  static NCG_DI Fe29<B> load(const uint32_t* p) {
+    Fe29<B> r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.v[i] = p[i];
+    return r;
+  }
+  static NCG_DI void store(uint32_t* p, const Fe29<B>& a) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) p[i] = a.v[i];
+  }
+  template <class PTR> static NCG_DI Fe29<B> load_strided(PTR p, int stride) {
+    Fe29<B> r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.v[i] = p[i * stride];
+    return r;
+  }
+  template <class PTR> static NCG_DI void store_strided(PTR p, int stride, const Fe29<B>& a) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) p[i * stride] = a.v[i];
+  }
+};
+template <int B>
+struct FieldIO<Fe29x2<B>> {
+  static constexpr int WORDS = 28;
+  static NCG_DI Fe29x2<B> load(const uint32_t* p) { return {FieldIO<Fe29<B>>::load(p), FieldIO<Fe29<B>>::load(p + 14)}; }
+  static NCG_DI void store(uint32_t* p, const Fe29x2<B>& a) {
+    FieldIO<Fe29<B>>::store(p, a.c0);
+    FieldIO<Fe29<B>>::store(p + 14, a.c1);
+  }
+  template <class PTR> static NCG_DI Fe29x2<B> load_strided(PTR p, int stride) {
+    return {FieldIO<Fe29<B>>::load_strided(p, stride), FieldIO<Fe29<B>>::load_strided(p + 14 * stride, stride)};
+  }
+  template <class PTR> static NCG_DI void store_strided(PTR p, int stride, const Fe29x2<B>& a) {
+    FieldIO<Fe29<B>>::store_strided(p, stride, a.c0);
+    FieldIO<Fe29<B>>::store_strided(p + 14 * stride, stride, a.c1);
+  }
+};
+template <int B>
+struct FieldWire<Fe29<B>> {
+  static constexpr int WORDS = 12;
+  static NCG_DI Fe29<B> load(const uint32_t* p) { return fe29_from_wire(p); }
+  static NCG_DI void store(uint32_t* p, const Fe29<B>& a) { fe29_to_wire(p, a); }
+};
+template <int B>
+struct FieldWire<Fe29x2<B>> {
+  static constexpr int WORDS = 24;
+  static NCG_DI Fe29x2<B> load(const uint32_t* p) {
+    Fe29<B> a = fe29_from_wire(p), b = fe29_from_wire(p + 12);
+    return {a, b};
+  }
+  static NCG_DI void store(uint32_t* p, const Fe29x2<B>& a) {
+    fe29_to_wire(p, a.c0);
+    fe29_to_wire(p + 12, a.c1);
   }
 };
 

@@ -11,10 +11,10 @@ using namespace ncg;
 
 template <class C, int W>
 static void ht_mul_var_t(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n) {
-  constexpr int FW = MulVarCfg<C, W>::FW;
+  constexpr int FW = MulVarCfg<C, W>::FW, WW = MulVarCfg<C, W>::WW;
   std::vector<uint32_t> tab(MulVarCfg<C, W>::TS * 2 * FW);
   for (int i = 0; i < n; i++)
-    mul_var_lane<C, W>(pts + (size_t)i * 2 * FW, scalars + (size_t)i * 8, out + (size_t)i * 2 * FW, out_inf + i, true,
+    mul_var_lane<C, W>(pts + (size_t)i * 2 * WW, scalars + (size_t)i * 8, out + (size_t)i * 2 * WW, out_inf + i, true,
                        tab.data(), 1);
 }
 

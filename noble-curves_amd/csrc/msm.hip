@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* __restri
   constexpr int AFF = MsmSizes<C>::AFF, FW = MsmSizes<C>::FW;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Affine<F> a = load_affine_wire<F>(pts + (size_t)i * AFF);
+  Affine<F> a = load_affine_wire<F>(pts + (size_t)i * MsmSizes<C>::WIRE_AFF);
   FieldIO<F>::store(out + (size_t)i * AFF, a.x);
   FieldIO<F>::store(out + (size_t)i * AFF + FW, a.y);
 }
@@ -419,10 +419,9 @@ static void msm_host_finish(const std::vector<uint32_t>& fin, const MsmPlan& pl,
   Affine<F> A{F::zero(), F::zero()};
   if (!inf) {
     // x = X/ZZ, y = Y/ZZZ; one inversion of ZZ*ZZZ
-    F t = acc.ZZ * acc.ZZZ;
-    F ti = f_inv(t);
-    F zzi = ti * acc.ZZZ;
-    F zzzi = ti * acc.ZZ;
+    auto ti = f_inv(acc.ZZ * acc.ZZZ);
+    auto zzi = ti * acc.ZZZ;
+    auto zzzi = ti * acc.ZZ;
     A = {acc.X * zzi, acc.Y * zzzi};
   }
   store_affine_wire<F>(out_affine, A);

@@ -45,7 +45,8 @@ struct MsmPlan {
 // sizes in 32-bit words of one stored point
 template <class C> struct MsmSizes {
   using F = typename C::F;
-  static constexpr int FW = FieldIO<F>::WORDS;
+  static constexpr int FW = FieldIO<F>::WORDS;        // stored words per field element
+  static constexpr int WIRE_AFF = 2 * FieldWire<F>::WORDS;  // wire words per affine point
   static constexpr int AFF = 2 * FW;
   static constexpr int XYZZ = 4 * FW;
 };

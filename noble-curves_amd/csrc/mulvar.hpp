@@ -26,24 +26,25 @@ namespace ncg {
 // exceptional cases cannot occur for points of prime order.
 template <class F>
 NCG_DI Jac<F> jac_madd_zr(const Jac<F>& p, const Affine<F>& q, F& zr) {
-  F Z1Z1 = f_sqr(p.Z);
-  F U2 = q.x * Z1Z1;
-  F S2 = q.y * p.Z * Z1Z1;
-  F H = U2 - p.X;
-  F R = S2 - p.Y;
-  F HH = f_sqr(H);
-  F HHH = H * HH;
-  F V = p.X * HH;
-  F X3 = f_sqr(R) - HHH - f_dbl(V);
-  F Y3 = R * (V - X3) - p.Y * HHH;
-  zr = H;
+  auto Z1Z1 = f_sqr(p.Z);
+  auto U2 = q.x * Z1Z1;
+  auto S2 = q.y * p.Z * Z1Z1;
+  auto H = U2 - p.X;
+  auto R = S2 - p.Y;
+  auto HH = f_sqr(H);
+  auto HHH = H * HH;
+  auto V = p.X * HH;
+  auto X3 = f_sqr(R) - HHH - f_dbl(V);
+  auto Y3 = R * (V - X3) - p.Y * HHH;
+  zr = H * F::one();  // stored: bring the bound back under the storage bound
   return {X3, Y3, p.Z * H};
 }
 
 template <class C, int W>
 struct MulVarCfg {
   using F = typename C::F;
-  static constexpr int FW = FieldIO<F>::WORDS;
+  static constexpr int FW = FieldIO<F>::WORDS;    // stored words per field element (LDS table)
+  static constexpr int WW = FieldWire<F>::WORDS;  // wire words per field element (HBM in/out)
   static constexpr int TS = 1 << (W - 1);                 // table entries: 1,3,..,2^W-1
   static constexpr int KBITS = C::GLV ? 129 : 257;        // bound on |k|+1 per stream
   static constexpr int M = (KBITS + W - 1) / W;           // windows
@@ -72,8 +73,8 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
   F Zg;
   {
     Jac<F> D = jac_dbl(Jac<F>{P.x, P.y, F::one()});
-    F dz2 = f_sqr(D.Z);
-    F dz3 = dz2 * D.Z;
+    auto dz2 = f_sqr(D.Z);
+    auto dz3 = dz2 * D.Z;
     Affine<F> Dp{D.X, D.Y};
     Jac<F> T{P.x * dz2, P.y * dz3, F::one()};
     F zr[TS];
@@ -89,9 +90,10 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     F s = F::one();
 #pragma unroll
     for (int j = TS - 2; j >= 0; j--) {
-      s = (j == TS - 2) ? zr[j + 1] : s * zr[j + 1];
-      F s2 = f_sqr(s);
-      F s3 = s2 * s;
+      if (j == TS - 2) s = zr[j + 1];
+      else s = s * zr[j + 1];
+      auto s2 = f_sqr(s);
+      auto s3 = s2 * s;
       F x = FieldIO<F>::load_strided(tab + (j * 2 * FW) * stride, stride);
       F y = FieldIO<F>::load_strided(tab + (j * 2 * FW + FW) * stride, stride);
       FieldIO<F>::store_strided(tab + (j * 2 * FW) * stride, stride, x * s2);
@@ -173,13 +175,13 @@ template <class C, int W, int MINW>
 __global__ void __launch_bounds__(64, MINW)
 k_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars,
           uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf, int n) {
-  constexpr int FW = MulVarCfg<C, W>::FW;
+  constexpr int WW = MulVarCfg<C, W>::WW;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = threadIdx.x;
   const int idx = blockIdx.x * 64 + lane;
   const bool active = idx < n;
   const int src = active ? idx : n - 1;  // idle lanes redo the last item, stores masked
-  mul_var_lane<C, W>(pts + (size_t)src * 2 * FW, scalars + (size_t)src * 8, out + (size_t)src * 2 * FW,
+  mul_var_lane<C, W>(pts + (size_t)src * 2 * WW, scalars + (size_t)src * 8, out + (size_t)src * 2 * WW,
                      out_inf + src, active, lds + lane, 64);
 }
 
