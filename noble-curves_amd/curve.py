@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's Point / pippenger interface for the hot path.
+
+Names, argument meaning and error messages follow the reference so the parity tests read like
+its own tests:
+  * `Point` classes per curve with `BASE`, `ZERO`, `Fp`, `Fn`, `fromAffine`, `toAffine`, `equals`,
+    `negate`, `is0`, `multiply`, `multiplyUnsafe`              (src/abstract/curve.ts:56-195,
+    src/abstract/weierstrass.ts:685-969)
+  * `pippenger(c, points, scalars)`                            (src/abstract/curve.ts:863-905)
+  * array entry points `multiplyUnsafeBatch` / `multiplyBatch` (a single scalar-mult
+    is far below launch + PCIe cost, so the shim adds batch forms)
+
+All group arithmetic happens in the HIP kernels behind `libncg.so`; this file only validates
+inputs (throwing the reference's messages BEFORE crossing the boundary), marshals to the wire
+format of include/ncg.h and wraps results.  Points are held in affine form (x, y) or ZERO - the
+reference's projective (X, Y, Z) triples are representation details that are not part of the
+contract.  There is no CPU fallback: without the library / a GPU every operation
+raises NativeError.
+"""
+import numpy as np
+
+from . import _native
+from ._native import BLS12_381_G1, BLS12_381_G2, FIELD_BYTES, POINT_BYTES, SECP256K1, get_engine
+
+_BLS_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+_BLS_R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+class _Field:
+    """The slice of IField the shim needs (src/abstract/modular.ts:429-607)."""
+
+    def __init__(self, order, degree=1):
+        self.ORDER = order
+        self.BITS = order.bit_length()
+        self.BYTES = (self.BITS + 7) // 8
+        self.degree = degree
+
+    def isValid(self, n):
+        if self.degree == 2:
+            return (isinstance(n, tuple) and len(n) == 2 and all(isinstance(c, int) and 0 <= c < self.ORDER for c in n))
+        if not isinstance(n, int) or isinstance(n, bool):
+            raise TypeError("invalid field element: expected bigint, got " + type(n).__name__)
+        return 0 <= n < self.ORDER
+
+    def isValidNot0(self, n):
+        return self.isValid(n) and n != 0
+
+    def is0(self, n):
+        return n == (0, 0) if self.degree == 2 else n == 0
+
+
+def _make_point_class(name, curve_id, Fp, Fn, gx, gy):
+    fb = FIELD_BYTES[curve_id]
+    pb = POINT_BYTES[curve_id]
+    zero_xy = ((0, 0), (0, 0)) if Fp.degree == 2 else (0, 0)
+
+    class Point:
+        """Affine point or ZERO of %s (reference: weierstrass.ts:685-1020)."""
+        __slots__ = ("x", "y", "_inf")
+        CURVE_ID = curve_id
+        POINT_BYTES = pb
+
+        def __init__(self, x, y, _inf=False):
+            self.x, self.y, self._inf = x, y, _inf
+
+        # -- construction -------------------------------------------------------------------
+        @classmethod
+        def fromAffine(cls, p):
+            """weierstrass.ts:710-718: validates coordinate ranges only; (0,0) is ZERO."""
+            x, y = (p["x"], p["y"]) if isinstance(p, dict) else p
+            if not Fp.isValid(x) or not Fp.isValid(y):
+                raise ValueError("invalid affine point")
+            if Fp.is0(x) and Fp.is0(y):
+                return cls.ZERO
+            return cls(x, y)
+
+        def toAffine(self):
+            """weierstrass.ts:951-969; ZERO -> (0, 0)."""
+            return zero_xy if self._inf else (self.x, self.y)
+
+        # -- cheap host-side predicates (no field arithmetic) ---------------------------------
+        def is0(self):
+            return self._inf
+
+        def equals(self, other):
+            _apoint(other)
+            return self.toAffine() == other.toAffine()
+
+        def negate(self):
+            if self._inf:
+                return self
+            if Fp.degree == 2:
+                return Point(self.x, tuple((-c) % Fp.ORDER for c in self.y))
+            return Point(self.x, (-self.y) % Fp.ORDER)
+
+        # -- scalar multiplication (GPU, batch of one) ----------------------------------------
+        def multiply(self, scalar):
+            """weierstrass.ts:900-907: 1 <= scalar < n, result normalised."""
+            return multiplyBatch(Point, [self], [scalar])[0]
+
+        def multiplyUnsafe(self, scalar):
+            """weierstrass.ts:915-928: 0 <= scalar < n."""
+            return multiplyUnsafeBatch(Point, [self], [scalar])[0]
+
+        def add(self, other):
+            """Group addition through the MSM path with unit scalars."""
+            _apoint(other)
+            return pippenger(Point, [self, other], [1, 1])
+
+        def double(self):
+            return self.multiplyUnsafe(2) if not self._inf else self
+
+        def subtract(self, other):
+            _apoint(other)
+            return self.add(other.negate())
+
+        # -- wire format ----------------------------------------------------------------------
+        def _wire(self):
+            if self._inf:
+                return b"\x00" * pb
+            cs = (self.x + self.y) if Fp.degree == 2 else (self.x, self.y)
+            return b"".join(int(c).to_bytes(fb, "little") for c in cs)
+
+        @classmethod
+        def _from_wire(cls, row, inf):
+            if inf:
+                return cls.ZERO
+            vals = [int.from_bytes(bytes(row[i * fb:(i + 1) * fb]), "little") for i in range(pb // fb)]
+            if Fp.degree == 2:
+                return cls((vals[0], vals[1]), (vals[2], vals[3]))
+            return cls(vals[0], vals[1])
+
+        def __repr__(self):
+            return "%s.Point.ZERO" % name if self._inf else "%s.Point(%r, %r)" % (name, self.x, self.y)
+
+    def _apoint(o):
+        if not isinstance(o, Point):
+            raise TypeError("Weierstrass Point expected")
+
+    Point.__name__ = name + "Point"
+    Point.Fp = Fp
+    Point.Fn = Fn
+    Point.ZERO = Point(None, None, True)
+    Point.BASE = Point(gx, gy)
+    return Point
+
+
+# ---------------------------------------------------------------------------------- validation
+def validateMSMPoints(points, c):
+    """curve.ts:390-395."""
+    if not isinstance(points, (list, tuple)):
+        raise TypeError("array expected")
+    for i, p in enumerate(points):
+        if not isinstance(p, c):
+            raise ValueError("invalid point at index %d" % i)
+
+
+def validateMSMScalars(scalars, field):
+    """curve.ts:398-404."""
+    if not isinstance(scalars, (list, tuple)):
+        raise TypeError("array of scalars expected")
+    for i, s in enumerate(scalars):
+        if not (isinstance(s, int) and not isinstance(s, bool) and 0 <= s < field.ORDER):
+            raise ValueError("invalid scalar at index %d" % i)
+
+
+def _points_wire(points, pb):
+    arr = np.frombuffer(b"".join(p._wire() for p in points), dtype=np.uint8)
+    return arr.reshape(-1, pb) if len(points) else np.zeros((0, pb), np.uint8)
+
+
+def _scalars_wire(scalars):
+    return _native.ints_to_le(scalars, 32)
+
+
+# ---------------------------------------------------------------------------------- entry points
+def pippenger(c, points, scalars, engine=None):
+    """MSM sum_i scalars[i]*points[i] (curve.ts:863-905): same validation order and messages;
+    empty input returns ZERO (:878); zero scalars and ZERO points are allowed."""
+    validateMSMPoints(points, c)
+    validateMSMScalars(scalars, c.Fn)
+    if len(points) != len(scalars):
+        raise ValueError("arrays of points and scalars must have equal length")
+    if len(points) == 0:
+        return c.ZERO
+    eng = engine or get_engine()
+    out, inf = eng.msm(c.CURVE_ID, _points_wire(points, c.POINT_BYTES), _scalars_wire(scalars))
+    return c._from_wire(out, inf)
+
+
+def multiplyUnsafeBatch(c, points, scalars, engine=None):
+    """[p.multiplyUnsafe(k) for p, k in zip(points, scalars)] in one launch
+    (weierstrass.ts:915-928: 0 <= k < n else RangeError('invalid scalar: out of range'))."""
+    validateMSMPoints(points, c)
+    if len(points) != len(scalars):
+        raise ValueError("arrays of points and scalars must have equal length")
+    for k in scalars:
+        if not (isinstance(k, int) and not isinstance(k, bool) and 0 <= k < c.Fn.ORDER):
+            raise ValueError("invalid scalar: out of range")
+    if not points:
+        return []
+    eng = engine or get_engine()
+    out, inf = eng.mul_var_batch(c.CURVE_ID, _points_wire(points, c.POINT_BYTES), _scalars_wire(scalars))
+    return [c._from_wire(out[i], bool(inf[i])) for i in range(len(points))]
+
+
+def multiplyBatch(c, points, scalars, engine=None):
+    """[p.multiply(k) ...] (weierstrass.ts:900-907: 1 <= k < n).  Same group element as
+    multiplyUnsafe, returned normalised (the kernels always return affine points).  The GPU path
+    is not constant-time: use it for public scalars only."""
+    for k in scalars:
+        if not (isinstance(k, int) and not isinstance(k, bool) and 1 <= k < c.Fn.ORDER):
+            raise ValueError("invalid scalar: out of range")
+    return multiplyUnsafeBatch(c, points, scalars, engine)
+
+
+def normalizeZ(c, points):
+    """curve.ts:311-326.  Points of this shim are always affine (Z = 1), so this validates and
+    returns equal points."""
+    validateMSMPoints(points, c)
+    return list(points)
+
+
+# ---------------------------------------------------------------------------------- curve instances
+secp256k1_Point = _make_point_class(
+    "secp256k1", SECP256K1,
+    _Field(0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F),
+    _Field(0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141),
+    0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
+    0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8)                # secp256k1.ts:48-56
+bls12_381_G1_Point = _make_point_class(
+    "bls12_381_G1", BLS12_381_G1, _Field(_BLS_P), _Field(_BLS_R),
+    0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+    0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)  # bls12-381.ts:134-148
+bls12_381_G2_Point = _make_point_class(
+    "bls12_381_G2", BLS12_381_G2, _Field(_BLS_P, degree=2), _Field(_BLS_R),
+    (0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+     0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+    (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+     0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))  # bls12-381.ts:321-345

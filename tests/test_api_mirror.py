@@ -1,0 +1,53 @@
+"""The Python host mirror of the reference's Point / pippenger interface: input validation and
+error messages (no GPU needed) and, on a GPU, the reference's own test flow for the path
+(test/point.test.ts:264-305, test/secp256k1.test.ts:59-71)."""
+import pytest
+
+from noble_curves_amd import curve as G
+from oracle.curves import BlsG1, SECP256K1_N, Secp256k1
+
+from helpers import load_golden
+
+K1, G1, G2 = G.secp256k1_Point, G.bls12_381_G1_Point, G.bls12_381_G2_Point
+
+
+@pytest.mark.parametrize("Pt", [K1, G1, G2])
+def test_validation_messages_match_reference(Pt):
+    g, n = Pt.BASE, Pt.Fn.ORDER
+    with pytest.raises(ValueError, match="invalid point at index 1"):       # curve.ts:393
+        G.pippenger(Pt, [g, "x"], [1, 2])
+    with pytest.raises(ValueError, match="invalid scalar at index 0"):      # curve.ts:399-402
+        G.pippenger(Pt, [g, g], [n, 2])
+    with pytest.raises(ValueError, match="invalid scalar at index 1"):
+        G.pippenger(Pt, [g, g], [1, -1])
+    with pytest.raises(TypeError, match="array of scalars expected"):
+        G.pippenger(Pt, [g], 5)
+    with pytest.raises(ValueError, match="arrays of points and scalars must have equal length"):  # curve.ts:875
+        G.pippenger(Pt, [g, g], [1])
+    assert G.pippenger(Pt, [], []) is Pt.ZERO                              # curve.ts:878
+    for bad in (0, n, n + 1, -1):                                           # weierstrass.ts:904
+        with pytest.raises(ValueError, match="invalid scalar: out of range"):
+            g.multiply(bad)
+    for bad in (n, -1, 1.5):                                                # weierstrass.ts:920 (0 is allowed)
+        with pytest.raises(ValueError, match="invalid scalar: out of range"):
+            g.multiplyUnsafe(bad)
+    assert Pt.fromAffine(Pt.ZERO.toAffine()) is Pt.ZERO                     # weierstrass.ts:716
+    assert g.negate().negate().equals(g) and not g.negate().equals(g)
+    with pytest.raises(ValueError, match="invalid affine point"):
+        Pt.fromAffine((Pt.Fp.ORDER, 1) if Pt.Fp.degree == 1 else ((Pt.Fp.ORDER, 0), (0, 1)))
+
+
+@pytest.mark.gpu
+def test_reference_flow_on_gpu():
+    for k, x, y in load_golden("secp256k1_privates2.json")[:12]:
+        assert K1.BASE.multiply(int(k)).toAffine() == (int(x, 16), int(y, 16))
+    g = K1.BASE
+    assert g.multiplyUnsafe(0) is K1.ZERO and g.multiplyUnsafe(1).equals(g)
+    assert g.add(g).equals(g.double()) and g.add(g.negate()).is0() and g.subtract(g).is0()
+    a, b = g.multiplyUnsafe(0xABCDEF), g.multiplyUnsafe(SECP256K1_N - 5)
+    exp = Secp256k1.BASE.multiplyUnsafe((3 * 0xABCDEF + 7 * (SECP256K1_N - 5)) % SECP256K1_N).toAffine()
+    assert G.pippenger(K1, [a, b, K1.ZERO], [3, 7, 99]).toAffine() == exp
+    outs = G.multiplyUnsafeBatch(G1, [G1.BASE] * 4, [0, 1, 2, 12345])
+    assert [o.toAffine() for o in outs] == [BlsG1.BASE.multiplyUnsafe(k).toAffine() for k in (0, 1, 2, 12345)]
+    h = G2.BASE.multiplyUnsafe(5)
+    assert G.pippenger(G2, [G2.BASE, h], [5, G2.Fn.ORDER - 1]).is0()
