@@ -105,7 +105,7 @@ def max_over_ranks(x, dist_on, device):
     if not dist_on:
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,12 +128,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_on = world > 1
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # (dry runs may put several ranks on one GPU)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
 
     from noble_curves_amd import get_engine
@@ -142,7 +147,7 @@ def main():
     from oracle import cport
     from oracle.curves import BLS_R, BlsG1, SECP256K1_N, Secp256k1, makeRng
 
-    eng = get_engine(local_rank)
+    eng = get_engine(dev_index)
     # a real (non-null) stream: kernels, copies and the timing events all go on it
     tstream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(tstream)
@@ -230,7 +235,8 @@ def main():
             import torch.distributed as dist
             t = torch.tensor([local_expect & ((1 << 62) - 1), local_expect >> 62 & ((1 << 62) - 1),
                               local_expect >> 124 & ((1 << 62) - 1), local_expect >> 186 & ((1 << 62) - 1),
-                              local_expect >> 248], dtype=torch.int64, device=device)
+                              local_expect >> 248], dtype=torch.int64,
+                             device=device if dist.get_backend() == "nccl" else "cpu")
             parts = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
             tot = 0

@@ -38,7 +38,7 @@ def all_gather_partials(partial_wire, is_inf, device=None):
     if dist is None or dist.get_world_size() == 1:
         return mine.reshape(1, -1)
     t = torch.from_numpy(mine)
-    if device is not None:
+    if device is not None and dist.get_backend() == "nccl":
         t = t.to(device)
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, t)
