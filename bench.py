@@ -198,7 +198,7 @@ def main():
                        % args.log2n, "items_per_gpu": n, "parallelism": "shard-by-index x%d" % world},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_mul_var<CurveSecp,4>", "kernel_ms": kern_ms,
+                         "traffic": None, "kernel": "k_mul_var<CurveSecp,3> + k_jac_batch_affine", "kernel_ms": kern_ms,
                          "valu": {"achieved_mac_per_s": alg_mac / (kern_ms * 1e-3), "peak_mac_per_s": INT_MAC_PEAK,
                                   "frac": alg_mac / (kern_ms * 1e-3) / INT_MAC_PEAK,
                                   "note": "reference-equivalent limb-MACs (SURVEY 8d) / v_mad_u64_u32 peak"}},

@@ -23,6 +23,8 @@ struct ncg_ctx {
   // reusable device scratch for the host-pointer entry points
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  void* mul_ws = nullptr;  // batch-multiply Jacobian scratch (device)
+  size_t mul_ws_bytes = 0;
   void* msm_ws = nullptr;  // MSM workspace (device)
   size_t msm_ws_bytes = 0;
   uint32_t* ed_btab = nullptr;  // ed25519 base-point table (device)
@@ -107,6 +109,7 @@ void ncg_destroy(ncg_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
+  if (ctx->mul_ws) (void)hipFree(ctx->mul_ws);
   if (ctx->ed_btab) (void)hipFree(ctx->ed_btab);
   if (ctx->ub_in) (void)hipFree(ctx->ub_in);
   if (ctx->ub_out) (void)hipFree(ctx->ub_out);
@@ -138,8 +141,20 @@ int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_
   if (!points_affine_dev || !scalars_dev || !out_affine_dev || !out_is_inf_dev)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch: NULL buffer");
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  size_t need = ncg::mul_var_tmp_bytes(curve, (int)n);
+  if (ctx->mul_ws_bytes < need) {  // grows monotonically; in-flight launches keep the old buffer alive until sync
+    NCG_HIP(ctx, hipStreamSynchronize(st));
+    if (ctx->mul_ws) (void)hipFree(ctx->mul_ws);
+    ctx->mul_ws = nullptr;
+    ctx->mul_ws_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->mul_ws, need);
+    if (e != hipSuccess)
+      return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    ctx->mul_ws_bytes = need;
+  }
   NCG_HIP(ctx, ncg::mul_var_batch(curve, (const uint32_t*)points_affine_dev, (const uint32_t*)scalars_dev,
-                                  (uint32_t*)out_affine_dev, out_is_inf_dev, (int)n, st));
+                                  (uint32_t*)out_affine_dev, out_is_inf_dev, (int)n, (uint32_t*)ctx->mul_ws, st));
   return NCG_OK;
 }
 

@@ -5,8 +5,10 @@
 
 namespace ncg {
 
+// jac_tmp: device scratch of mul_var_tmp_bytes(curve, n) bytes, or nullptr (per-lane inversion)
 hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
-                         int n, hipStream_t st);
+                         int n, uint32_t* jac_tmp, hipStream_t st);
+size_t mul_var_tmp_bytes(int curve, int n);
 
 struct MsmPlan;
 int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl);

@@ -5,32 +5,53 @@
 
 namespace ncg {
 
-template <class C, int W, int MINW = 1>
+// `jac_tmp` (n * 3 * FW words, device) enables the two-kernel path: ladder -> Jacobian, then
+// one batched inversion per K points.  Without it every lane inverts its own Z.
+template <class C, int W, int MINW = 1, int K = 8>
 static hipError_t launch_mul_var(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
-                                 int n, hipStream_t st) {
+                                 int n, uint32_t* jac_tmp, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   using Cfg = MulVarCfg<C, W>;
   size_t lds = (size_t)Cfg::LDS_WORDS * 4;
-  auto kern = k_mul_var<C, W, MINW>;
+  if (jac_tmp) {
+    auto kern = k_mul_var<C, W, MINW, true>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, jac_tmp, out_inf, n);
+    int threads = (n + K - 1) / K;
+    hipLaunchKernelGGL((k_jac_batch_affine<C, K>), dim3((threads + 255) / 256), dim3(256), 0, st, jac_tmp, out, out_inf,
+                       n);
+    return hipGetLastError();
+  }
+  auto kern = k_mul_var<C, W, MINW, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, out, out_inf, n);
   return hipGetLastError();
 }
 
+size_t mul_var_tmp_bytes(int curve, int n) {
+  switch (curve) {
+    case CURVE_SECP256K1: return (size_t)n * 3 * FieldIO<CurveSecp::F>::WORDS * 4;
+    case CURVE_BLS12_381_G1: return (size_t)n * 3 * FieldIO<CurveG1::F>::WORDS * 4;
+    case CURVE_BLS12_381_G2: return (size_t)n * 3 * FieldIO<CurveG2::F>::WORDS * 4;
+    default: return 0;
+  }
+}
+
 hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
-                         int n, hipStream_t st) {
+                         int n, uint32_t* jac_tmp, hipStream_t st) {
   switch (curve) {
     case CURVE_SECP256K1: {
       // window width / occupancy trade-off, selectable for A/B runs (default W = 3, 2 waves/SIMD: best of the measured set, profiles/)
       static const int w = [] { const char* e = std::getenv("NCG_SECP_W"); return e ? std::atoi(e) : 33; }();
-      if (w == 3) return launch_mul_var<CurveSecp, 3, 3>(pts, scalars, out, out_inf, n, st);
-      if (w == 33) return launch_mul_var<CurveSecp, 3, 2>(pts, scalars, out, out_inf, n, st);
-      if (w == 5) return launch_mul_var<CurveSecp, 5, 1>(pts, scalars, out, out_inf, n, st);
-      return launch_mul_var<CurveSecp, 4>(pts, scalars, out, out_inf, n, st);
+      if (w == 3) return launch_mul_var<CurveSecp, 3, 3>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (w == 33) return launch_mul_var<CurveSecp, 3, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (w == 5) return launch_mul_var<CurveSecp, 5, 1>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      return launch_mul_var<CurveSecp, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     }
-    case CURVE_BLS12_381_G1: return launch_mul_var<CurveG1, 3>(pts, scalars, out, out_inf, n, st);
-    case CURVE_BLS12_381_G2: return launch_mul_var<CurveG2, 3>(pts, scalars, out, out_inf, n, st);
+    case CURVE_BLS12_381_G1: return launch_mul_var<CurveG1, 3, 1, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);
+    case CURVE_BLS12_381_G2: return launch_mul_var<CurveG2, 3, 1, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     default: return hipErrorInvalidValue;
   }
 }

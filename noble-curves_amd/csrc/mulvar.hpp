@@ -54,7 +54,10 @@ struct MulVarCfg {
 
 // Per-lane body.  `tab` is this lane's table base, consecutive words `stride` apart
 // (LDS: lds + lane, stride 64;  host unit test: a plain array, stride 1).
-template <class C, int W, class TABPTR>
+// JAC_OUT: write the Jacobian result (X, Y, Z in storage format, Z = 0 for infinity) to
+// `out_wire` (3*FW words) and leave the inversion to k_jac_batch_affine; otherwise invert here
+// and write the affine wire point.
+template <class C, int W, bool JAC_OUT = false, class TABPTR>
 NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* __restrict__ k_wire,
                          uint32_t* __restrict__ out_wire, uint8_t* __restrict__ out_inf, bool active,
                          TABPTR tab, const int stride) {
@@ -163,6 +166,15 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
   // back from the isomorphic curve, then to affine (weierstrass.ts:951-969 toAffine)
   R.Z = R.Z * Zg;
   bool inf = trivial_zero || R.is_inf();
+  if constexpr (JAC_OUT) {
+    if (inf) R = Jac<F>::inf();
+    if (active) {
+      FieldIO<F>::store(out_wire, R.X);
+      FieldIO<F>::store(out_wire + FW, R.Y);
+      FieldIO<F>::store(out_wire + 2 * FW, R.Z);
+    }
+    return;
+  }
   Affine<F> A = jac_to_affine(R, f_inv(R.Z));
   if (inf) A = {F::zero(), F::zero()};
   if (active) {
@@ -171,18 +183,61 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
   }
 }
 
-template <class C, int W, int MINW>
+// Batched Jacobian -> affine (the reference's normalizeZ / FpInvertBatch, src/abstract/curve.ts:
+// 311-326, src/abstract/modular.ts:728-760): each lane runs Montgomery's trick over K
+// consecutive points - one field inversion per K points instead of one per point.
+template <class C, int K>
+__global__ void __launch_bounds__(256) k_jac_batch_affine(const uint32_t* __restrict__ jac,
+                                                          uint32_t* __restrict__ out_wire,
+                                                          uint8_t* __restrict__ out_inf, int n) {
+  using F = typename C::F;
+  constexpr int FW = FieldIO<F>::WORDS, WW = FieldWire<F>::WORDS;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i0 = t * K;
+  if (i0 >= n) return;
+  F pre[K];   // pre[j] = product of the non-zero Z of points i0..i0+j-1
+  F acc = F::one();
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    pre[j] = acc;
+    if (i0 + j < n) {
+      F z = FieldIO<F>::load(jac + ((size_t)(i0 + j) * 3 + 2) * FW);
+      if (!z.is_zero()) acc = acc * z;
+    }
+  }
+  F inv = f_inv(acc);
+#pragma unroll
+  for (int j = K - 1; j >= 0; j--) {
+    if (i0 + j < n) {
+      const uint32_t* p = jac + (size_t)(i0 + j) * 3 * FW;
+      F z = FieldIO<F>::load(p + 2 * FW);
+      const bool inf = z.is_zero();
+      Affine<F> A{F::zero(), F::zero()};
+      if (!inf) {
+        F zi = inv * pre[j];
+        inv = inv * z;
+        auto zi2 = f_sqr(zi);
+        A = {FieldIO<F>::load(p) * zi2, FieldIO<F>::load(p + FW) * zi2 * zi};
+      }
+      store_affine_wire<F>(out_wire + (size_t)(i0 + j) * 2 * WW, A);
+      out_inf[i0 + j] = inf ? 1 : 0;
+    }
+  }
+}
+
+template <class C, int W, int MINW, bool JAC_OUT>
 __global__ void __launch_bounds__(64, MINW)
 k_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars,
           uint32_t* __restrict__ out, uint8_t* __restrict__ out_inf, int n) {
   constexpr int WW = MulVarCfg<C, W>::WW;
+  constexpr int OUTW = JAC_OUT ? 3 * MulVarCfg<C, W>::FW : 2 * WW;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = threadIdx.x;
   const int idx = blockIdx.x * 64 + lane;
   const bool active = idx < n;
   const int src = active ? idx : n - 1;  // idle lanes redo the last item, stores masked
-  mul_var_lane<C, W>(pts + (size_t)src * 2 * WW, scalars + (size_t)src * 8, out + (size_t)src * 2 * WW,
-                     out_inf + src, active, lds + lane, 64);
+  mul_var_lane<C, W, JAC_OUT>(pts + (size_t)src * 2 * WW, scalars + (size_t)src * 8, out + (size_t)src * OUTW,
+                              out_inf + src, active, lds + lane, 64);
 }
 
 }  // namespace ncg
