@@ -71,6 +71,16 @@ int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_
                           const void* scalars_dev, void* out_affine_dev,
                           uint8_t* out_is_inf_dev, void* stream);
 
+/* ---- batch fixed-base scalar multiplication -----------------------------------------------
+ * out[i] = scalars[i] * BASE.  Replaces, batch-wise, Point.BASE.multiply(k) / multiplyUnsafe(k)
+ * through the cached window table (ScalarMultiplier.wnafCachedCT, src/abstract/curve.ts:588-606;
+ * table :560-577) - e.g. getPublicKey.  k = 0 gives infinity.  The table (33 x 128 window
+ * multiples of BASE) is built on the device at first use and cached in the context. */
+int ncg_mul_base_batch(ncg_ctx* ctx, int curve, size_t n, const void* scalars, void* out_affine,
+                       uint8_t* out_is_inf);
+int ncg_mul_base_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* scalars_dev,
+                           void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream);
+
 /* ---- multi-scalar multiplication ---------------------------------------------------------
  * out = sum_i scalars[i] * points[i].  Replaces pippenger(c, points, scalars)
  * (src/abstract/curve.ts:863-905); n = 0 gives infinity (:878); scalar 0 and infinity points

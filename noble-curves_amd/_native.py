@@ -153,6 +153,21 @@ class Engine:
                                                    out.ctypes.data, inf.ctypes.data))
         return out, inf
 
+    def mul_base_batch(self, curve, scalars):
+        """scalars uint8 [n, 32] -> (out [n, PB], is_inf [n]) with out[i] = scalars[i] * BASE."""
+        pb = POINT_BYTES[curve]
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        n = scalars.shape[0]
+        out = np.empty((n, pb), dtype=np.uint8)
+        inf = np.empty((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_mul_base_batch(self.h, curve, n, scalars.ctypes.data, out.ctypes.data,
+                                                    inf.ctypes.data))
+        return out, inf
+
+    def mul_base_batch_dev(self, curve, n, d_scalars, d_out, d_inf, stream=None):
+        self._check(self.lib.ncg_mul_base_batch_dev(self.h, curve, n, d_scalars, d_out, d_inf, stream))
+
     def mul_var_batch_dev(self, curve, n, d_points, d_scalars, d_out, d_inf, stream=None):
         self._check(self.lib.ncg_mul_var_batch_dev(self.h, curve, n, d_points, d_scalars, d_out, d_inf, stream))
 

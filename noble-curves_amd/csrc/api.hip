@@ -9,6 +9,7 @@
 
 #include "../../include/ncg.h"
 #include "host_api.hpp"
+#include "consts_gen.hpp"
 #include "msm.hpp"
 
 namespace {
@@ -28,6 +29,7 @@ struct ncg_ctx {
   void* msm_ws = nullptr;  // MSM workspace (device)
   size_t msm_ws_bytes = 0;
   uint32_t* ed_btab = nullptr;  // ed25519 base-point table (device)
+  uint32_t* base_tab[4] = {nullptr, nullptr, nullptr, nullptr};  // fixed-base tables per curve (device)
   uint32_t* ub_in = nullptr;
   uint32_t* ub_out = nullptr;
   size_t ub_out_words = 0;
@@ -111,6 +113,8 @@ void ncg_destroy(ncg_ctx* ctx) {
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
   if (ctx->mul_ws) (void)hipFree(ctx->mul_ws);
   if (ctx->ed_btab) (void)hipFree(ctx->ed_btab);
+  for (int i = 0; i < 4; i++)
+    if (ctx->base_tab[i]) (void)hipFree(ctx->base_tab[i]);
   if (ctx->ub_in) (void)hipFree(ctx->ub_in);
   if (ctx->ub_out) (void)hipFree(ctx->ub_out);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -131,6 +135,19 @@ int ncg_sync(ncg_ctx* ctx) {
   return NCG_OK;
 }
 
+static int ensure_mul_ws(ncg_ctx* ctx, int curve, size_t n, hipStream_t st) {
+  size_t need = ncg::mul_var_tmp_bytes(curve, (int)n);
+  if (ctx->mul_ws_bytes >= need) return NCG_OK;
+  NCG_HIP(ctx, hipStreamSynchronize(st));
+  if (ctx->mul_ws) (void)hipFree(ctx->mul_ws);
+  ctx->mul_ws = nullptr;
+  ctx->mul_ws_bytes = 0;
+  hipError_t e = hipMalloc(&ctx->mul_ws, need);
+  if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+  ctx->mul_ws_bytes = need;
+  return NCG_OK;
+}
+
 int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev, const void* scalars_dev,
                           void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
@@ -142,16 +159,9 @@ int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch: NULL buffer");
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   NCG_HIP(ctx, hipSetDevice(ctx->device));
-  size_t need = ncg::mul_var_tmp_bytes(curve, (int)n);
-  if (ctx->mul_ws_bytes < need) {  // grows monotonically; in-flight launches keep the old buffer alive until sync
-    NCG_HIP(ctx, hipStreamSynchronize(st));
-    if (ctx->mul_ws) (void)hipFree(ctx->mul_ws);
-    ctx->mul_ws = nullptr;
-    ctx->mul_ws_bytes = 0;
-    hipError_t e = hipMalloc(&ctx->mul_ws, need);
-    if (e != hipSuccess)
-      return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
-    ctx->mul_ws_bytes = need;
+  {
+    int rc = ensure_mul_ws(ctx, curve, n, st);
+    if (rc) return rc;
   }
   NCG_HIP(ctx, ncg::mul_var_batch(curve, (const uint32_t*)points_affine_dev, (const uint32_t*)scalars_dev,
                                   (uint32_t*)out_affine_dev, out_is_inf_dev, (int)n, (uint32_t*)ctx->mul_ws, st));
@@ -179,6 +189,59 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
   NCG_HIP(ctx, hipMemcpyAsync(d_pts, points_affine, pts_b, hipMemcpyHostToDevice, ctx->stream));
   NCG_HIP(ctx, hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream));
   rc = ncg_mul_var_batch_dev(ctx, curve, n, d_pts, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, pts_b, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
+int ncg_mul_base_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* scalars_dev, void* out_affine_dev,
+                           uint8_t* out_is_inf_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_SECP256K1 && curve != NCG_BLS12_381_G1 && curve != NCG_BLS12_381_G2)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_base_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!scalars_dev || !out_affine_dev || !out_is_inf_dev)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_base_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  int rc = ensure_mul_ws(ctx, curve, n > 8192 ? n : 8192, st);
+  if (rc) return rc;
+  if (!ctx->base_tab[curve]) {  // built once per context with the variable-base kernel
+    const uint32_t* base = curve == NCG_SECP256K1 ? ncg::BasePoints::SECP
+                           : curve == NCG_BLS12_381_G1 ? ncg::BasePoints::G1 : ncg::BasePoints::G2;
+    uint32_t* tab = nullptr;
+    NCG_HIP(ctx, hipMalloc((void**)&tab, ncg::mul_base_table_bytes(curve)));
+    hipError_t e = ncg::mul_base_build_table(curve, base, tab, st);
+    if (e != hipSuccess) {
+      (void)hipFree(tab);
+      return set_err(ctx, NCG_ERR_HIP, "noble-gpu: building the fixed-base table failed: %s", hipGetErrorString(e));
+    }
+    ctx->base_tab[curve] = tab;
+  }
+  NCG_HIP(ctx, ncg::mul_base_batch(curve, ctx->base_tab[curve], (const uint32_t*)scalars_dev, (uint32_t*)out_affine_dev,
+                                   out_is_inf_dev, (int)n, (uint32_t*)ctx->mul_ws, st));
+  return NCG_OK;
+}
+
+int ncg_mul_base_batch(ncg_ctx* ctx, int curve, size_t n, const void* scalars, void* out_affine, uint8_t* out_is_inf) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  int pb = ncg_point_bytes(curve);
+  if (pb == 0 || curve == NCG_ED25519)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_base_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (!scalars || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_base_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  size_t pts_b = n * pb, sc_b = n * 32, inf_b = (n + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, pts_b + sc_b + inf_b + 1024);
+  if (rc) return rc;
+  char* d_out = (char*)ctx->scratch;
+  char* d_sc = d_out + pts_b;
+  char* d_inf = d_sc + sc_b;
+  NCG_HIP(ctx, hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream));
+  rc = ncg_mul_base_batch_dev(ctx, curve, n, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
   if (rc) return rc;
   NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, pts_b, hipMemcpyDeviceToHost, ctx->stream));
   if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));

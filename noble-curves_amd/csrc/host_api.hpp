@@ -10,6 +10,12 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
                          int n, uint32_t* jac_tmp, hipStream_t st);
 size_t mul_var_tmp_bytes(int curve, int n);
 
+// fixed-base batch multiply (mulbase.hip)
+size_t mul_base_table_bytes(int curve);
+hipError_t mul_base_build_table(int curve, const uint32_t* base_wire_host, uint32_t* d_table, hipStream_t st);
+hipError_t mul_base_batch(int curve, const uint32_t* table, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
+                          int n, uint32_t* jac_tmp, hipStream_t st);
+
 struct MsmPlan;
 int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl);
 size_t msm_workspace_bytes(int curve, const MsmPlan& pl);

@@ -203,6 +203,20 @@ def multiplyUnsafeBatch(c, points, scalars, engine=None):
     return [c._from_wire(out[i], bool(inf[i])) for i in range(len(points))]
 
 
+def multiplyBaseBatch(c, scalars, engine=None, unsafe=False):
+    """[c.BASE.multiply(k) for k in scalars] through the fixed-base window table
+    (curve.ts:588-606 wnafCachedCT; e.g. getPublicKey).  `unsafe` allows k = 0 like multiplyUnsafe."""
+    lo = 0 if unsafe else 1
+    for k in scalars:
+        if not (isinstance(k, int) and not isinstance(k, bool) and lo <= k < c.Fn.ORDER):
+            raise ValueError("invalid scalar: out of range")
+    if not scalars:
+        return []
+    eng = engine or get_engine()
+    out, inf = eng.mul_base_batch(c.CURVE_ID, _scalars_wire(scalars))
+    return [c._from_wire(out[i], bool(inf[i])) for i in range(len(scalars))]
+
+
 def multiplyBatch(c, points, scalars, engine=None):
     """[p.multiply(k) ...] (weierstrass.ts:900-907: 1 <= k < n).  Same group element as
     multiplyUnsafe, returned normalised (the kernels always return affine points).  The GPU path

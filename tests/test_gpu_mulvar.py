@@ -108,3 +108,25 @@ def test_bls_random_vs_oracle(curve, count):
         ks.append(rng.rndBelow(BLS_R))
     exp = [p.multiplyUnsafe(k).toAffine() for p, k in zip(pts, ks)]
     run_and_check(curve, pts, ks, exp)
+
+
+@pytest.mark.parametrize("curve", [SECP256K1, BLS12_381_G1, BLS12_381_G2])
+def test_fixed_base_batch(curve):
+    """BASE.multiply(k) through the fixed-base table (curve.ts:588-606): golden k*G vectors,
+    window-boundary and carry-chain scalars, random scalars."""
+    Pt = ORACLE_CURVE[curve]
+    n = Pt.Fn.ORDER
+    rng = makeRng(0xBA5E + curve)
+    ks = [0, 1, 2, 3, 255, 256, 257, (1 << 248) - 1, 1 << 248, (1 << 255) % n, n - 1, n - 2, n // 2, n // 2 + 1,
+          int("ff" * 31, 16), int("80" * 32, 16) % n, int("7f" * 32, 16) % n, int("01" * 32, 16) % n]
+    ks += [rng.rndBelow(n) for _ in range(60 if curve != BLS12_381_G2 else 25)]
+    out, inf = get_engine().mul_base_batch(curve, scalars_to_wire(ks))
+    for i, k in enumerate(ks):
+        exp = Pt.BASE.multiplyUnsafe(k).toAffine()
+        assert wire_to_affine(curve, out[i]) == exp, hex(k)
+        assert bool(inf[i]) == (k == 0)
+    if curve == SECP256K1:
+        rows = load_golden("secp256k1_privates2.json")
+        out, _ = get_engine().mul_base_batch(curve, scalars_to_wire([int(r[0]) for r in rows]))
+        for i, (_, x, y) in enumerate(rows):
+            assert wire_to_affine(curve, out[i]) == (int(x, 16), int(y, 16))
