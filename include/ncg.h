@@ -63,8 +63,10 @@ int ncg_field_bytes(int curve);
 /* ---- batch variable-base scalar multiplication ---------------------------------------
  * out[i] = scalars[i] * points[i].  Replaces, batch-wise, Point.multiplyUnsafe(k)
  * (src/abstract/weierstrass.ts:915-928; GLV path :660-671 on secp256k1) and the value of
- * Point.multiply(k) (:900-907).  k = 0 or P = infinity gives infinity.  Curves: secp256k1,
- * bls12-381 G1, G2.  out_is_inf may be NULL. */
+ * Point.multiply(k) (:900-907); on ed25519 Point.multiplyUnsafe / multiply
+ * (src/abstract/edwards.ts:555-577), exact integer multiples also for points with a torsion
+ * component.  k = 0 or P = infinity gives infinity.  All four curves.  out_is_inf may be NULL
+ * in the host-pointer variant. */
 int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affine,
                       const void* scalars, void* out_affine, uint8_t* out_is_inf);
 int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev,
@@ -83,8 +85,8 @@ int ncg_mul_base_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* scalar
 
 /* ---- multi-scalar multiplication ---------------------------------------------------------
  * out = sum_i scalars[i] * points[i].  Replaces pippenger(c, points, scalars)
- * (src/abstract/curve.ts:863-905); n = 0 gives infinity (:878); scalar 0 and infinity points
- * are allowed.  The result (one affine point, canonical residues) is written to HOST memory
+ * (src/abstract/curve.ts:863-905) on all four curves; n = 0 gives infinity (:878); scalar 0 and
+ * infinity points are allowed.  The result (one affine point, canonical residues) is written to HOST memory
  * in both variants: the last step (Horner over <= 272 window/level sums + one inversion) runs
  * on the host, so the call returns after synchronising the stream. */
 int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const void* scalars,

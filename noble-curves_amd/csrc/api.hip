@@ -151,7 +151,7 @@ static int ensure_mul_ws(ncg_ctx* ctx, int curve, size_t n, hipStream_t st) {
 int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev, const void* scalars_dev,
                           void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
-  if (curve != NCG_SECP256K1 && curve != NCG_BLS12_381_G1 && curve != NCG_BLS12_381_G2)
+  if (curve < NCG_SECP256K1 || curve > NCG_BLS12_381_G2)
     return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_var_batch: unsupported curve %d", curve);
   if (n == 0) return NCG_OK;
   if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
@@ -172,8 +172,7 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
                       void* out_affine, uint8_t* out_is_inf) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
   int pb = ncg_point_bytes(curve);
-  if (pb == 0 || curve == NCG_ED25519)
-    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_var_batch: unsupported curve %d", curve);
+  if (pb == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_var_batch: unsupported curve %d", curve);
   if (n == 0) return NCG_OK;
   if (!points_affine || !scalars || !out_affine)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch: NULL buffer");
@@ -253,12 +252,12 @@ int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev
                 void* out_affine, uint8_t* out_is_inf, void* stream) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
   int pb = ncg_point_bytes(curve);
-  if (pb == 0 || curve == NCG_ED25519)
-    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm: unsupported curve %d", curve);
+  if (pb == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm: unsupported curve %d", curve);
   if (!out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: NULL output");
   uint8_t inf_local = 0;
   if (n == 0) {  // empty MSM is the identity (reference curve.ts:878)
     memset(out_affine, 0, pb);
+    if (curve == NCG_ED25519) ((uint8_t*)out_affine)[32] = 1;  // Edwards identity is (0, 1)
     if (out_is_inf) *out_is_inf = 1;
     return NCG_OK;
   }
@@ -289,8 +288,7 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
             uint8_t* out_is_inf) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
   int pb = ncg_point_bytes(curve);
-  if (pb == 0 || curve == NCG_ED25519)
-    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm: unsupported curve %d", curve);
+  if (pb == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm: unsupported curve %d", curve);
   if (n == 0) return ncg_msm_dev(ctx, curve, 0, nullptr, nullptr, out_affine, out_is_inf, nullptr);
   if (!points_affine || !scalars || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));

@@ -1,6 +1,7 @@
 // Curve traits for the kernels.  IDs match include/ncg.h.
 #pragma once
 #include "ec_sw.hpp"
+#include "ec_te.hpp"
 
 namespace ncg {
 
@@ -23,6 +24,12 @@ struct CurveG2 {  // src/bls12-381.ts:321-345
   static constexpr bool GLV = false;
   static constexpr int SCALAR_BITS = 255;
   static NCG_DI F beta() { return F::one(); }
+};
+
+struct CurveEd {  // src/ed25519.ts:57-65 (twisted Edwards a = -1; cofactor 8: no subgroup tricks)
+  using F = FpEd;
+  static constexpr bool GLV = false;
+  static constexpr int SCALAR_BITS = 253;
 };
 
 // Affine wire point (canonical residues) -> Montgomery-form Affine<F>, and back.

@@ -131,6 +131,83 @@ k_ed25519_verify(const uint32_t* __restrict__ sigs, const uint32_t* __restrict__
   if (idx < n) out_ok[idx] = ok ? 1 : 0;
 }
 
+// ---- batch variable-base multiplication on ed25519: out[i] = k[i] * P[i] ---------------------
+// Point.multiplyUnsafe / the value of Point.multiply (src/abstract/edwards.ts:555-577 ->
+// wnaf.mulUnsafe -> mulAddUnsafe, src/abstract/curve.ts:752-764).  Exact integer multiples for
+// any curve point, torsion components included (test/ed25519.test.ts:355-390): the signed-odd
+// recoding is an identity over the integers.  Wire points are affine (x, y); the identity is (0, 1).
+template <class TABPTR>
+NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* __restrict__ k_wire,
+                                 uint32_t* __restrict__ out_wire, uint8_t* __restrict__ out_inf, bool active,
+                                 TABPTR tab, const int stride) {
+  using F = FpEd;
+  using PR = ParamsEdP;
+  F x = FieldWire<F>::load(pt_wire), y = FieldWire<F>::load(pt_wire + 8);
+  uint32_t k[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) k[i] = k_wire[i];
+  const bool kzero = mp_is_zero<8>(k);
+  const F d2 = EdConsts::d2();
+  EdExt<F> P{x, y, F::one(), x * y};
+  {
+    EdNielsProj<F> n2 = ed_to_niels(ed_dbl(P), d2);
+    EdExt<F> cur = P;
+    ed_store_niels(tab, stride, 0, ed_to_niels(cur, d2));
+#pragma unroll
+    for (int j = 1; j < ED_TA; j++) {
+      cur = ed_add_niels(cur, n2, false);
+      ed_store_niels(tab, stride, j, ed_to_niels(cur, d2));
+    }
+  }
+  SignedOddWindows<9, ED_WA, ED_MA> wk;
+  wk.template init<8>(k);
+  EdExt<F> acc = EdExt<F>::identity();
+  for (int i = ED_MA - 1; i >= 0; i--) {
+    if (i != ED_MA - 1) {
+#pragma unroll
+      for (int d = 0; d < ED_WA; d++) acc = ed_dbl(acc);
+    }
+    int dA = wk.pop();
+    acc = ed_add_niels(acc, ed_load_niels(tab, stride, ((dA < 0 ? -dA : dA) - 1) >> 1), dA < 0);
+  }
+  if (wk.was_even) acc = ed_add_niels(acc, ed_load_niels(tab, stride, 0), true);
+  if (kzero) acc = EdExt<F>::identity();
+  F zi = fp_inv<PR>(acc.Z);
+  F ox = acc.X * zi, oy = acc.Y * zi;
+  if (active) {
+    FieldWire<F>::store(out_wire, ox);
+    FieldWire<F>::store(out_wire + 8, oy);
+    *out_inf = (ox.is_zero() && oy == F::one()) ? 1 : 0;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_ed25519_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out,
+                  uint8_t* __restrict__ out_inf, int n) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = threadIdx.x;
+  const int idx = blockIdx.x * 64 + lane;
+  const bool active = idx < n;
+  const int src = active ? idx : n - 1;
+  ed25519_mul_var_lane(pts + (size_t)src * 16, scalars + (size_t)src * 8, out + (size_t)src * 16, out_inf + src, active,
+                       lds + lane, 64);
+}
+
+hipError_t ed25519_mul_var_batch(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
+                                 hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  size_t lds = (size_t)ED_LDS_WORDS * 4;
+  hipError_t e = hipFuncSetAttribute((const void*)k_ed25519_mul_var, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_ed25519_mul_var, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, out, out_inf, n);
+  return hipGetLastError();
+}
+
+void ed25519_mul_var_host(const uint32_t* pt, const uint32_t* k, uint32_t* out, uint8_t* out_inf) {
+  std::vector<uint32_t> tab(ED_TA * 32);
+  ed25519_mul_var_lane(pt, k, out, out_inf, true, tab.data(), 1);
+}
+
 // ---- base-point table [1,3,..,63]*B in affine Niels form (host-computed with the same templates)
 void ed25519_build_base_table(uint32_t* out /* ED_TB*24 words */) {
   using F = FpEd;

@@ -28,6 +28,9 @@ constexpr int ED25519_BTAB_WORDS = 32 * 24;
 void ed25519_build_base_table(uint32_t* out_words);
 hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
                                 int zip215, uint8_t* out_ok, int n, hipStream_t st);
+hipError_t ed25519_mul_var_batch(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
+                                 hipStream_t st);
+void ed25519_mul_var_host(const uint32_t* pt, const uint32_t* k, uint32_t* out, uint8_t* out_inf);
 bool ed25519_verify_host(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, const uint32_t* btab, bool zip215);
 
 hipError_t ubench_run(int kind, int blocks, int threads, int iters, uint32_t* d_out, const uint32_t* d_in,

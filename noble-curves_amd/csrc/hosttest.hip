@@ -68,6 +68,11 @@ int ht_glv_split(const uint32_t* k, uint32_t* out) {
   return 0;
 }
 
+int ht_ed25519_mul_var(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n) {
+  for (int i = 0; i < n; i++) ed25519_mul_var_host(pts + (size_t)i * 16, scalars + (size_t)i * 8, out + (size_t)i * 16, out_inf + i);
+  return 0;
+}
+
 // ed25519 verify of one item on the CPU through the kernel's lane function
 int ht_ed25519_verify(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, int zip215) {
   static uint32_t btab[ED25519_BTAB_WORDS];

@@ -13,13 +13,10 @@ namespace ncg {
 template <class C>
 __global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* __restrict__ pts, uint32_t* __restrict__ out,
                                                         int n) {
-  using F = typename C::F;
-  constexpr int AFF = MsmSizes<C>::AFF, FW = MsmSizes<C>::FW;
+  using G = MsmGroup<C>;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Affine<F> a = load_affine_wire<F>(pts + (size_t)i * MsmSizes<C>::WIRE_AFF);
-  FieldIO<F>::store(out + (size_t)i * AFF, a.x);
-  FieldIO<F>::store(out + (size_t)i * AFF + FW, a.y);
+  G::wire_to_storage(pts + (size_t)i * G::WIRE_AFF, out + (size_t)i * G::AFF_WORDS);
 }
 
 // ------------------------------------------------------------------ 2. signed digits
@@ -151,8 +148,9 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ bucket_start,
                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_pts,
                                                    int* __restrict__ part_meta, MsmPlan pl, MsmSeg sg) {
-  using F = typename C::F;
-  constexpr int AFF = MsmSizes<C>::AFF, FW = MsmSizes<C>::FW, XW = MsmSizes<C>::XYZZ;
+  using G = MsmGroup<C>;
+  using Acc = typename G::Acc;
+  constexpr int AFF = G::AFF_WORDS, XW = G::ACC_WORDS;
   const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
   if (s >= sg.nseg) return;
   const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
@@ -179,34 +177,33 @@ __global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* __restrict__ 
   const uint32_t* sw = sorted + (size_t)w * pl.n;
   uint32_t* hp = part_pts + (((size_t)w * sg.nseg + s) * 2) * XW;
   int head_b = -1, head_cont = 0, tail_b = -1;
-  Xyzz<F> acc = Xyzz<F>::inf();
+  Acc acc = G::identity();
   for (uint32_t pos = lo; pos < hi; pos++) {
     if (pos == b_end) {  // bucket finished inside my range
       if (b_start >= lo) {
-        xyzz_store<F>(buckets + ((size_t)w * pl.nb + b) * XW, acc);
+        G::acc_store(buckets + ((size_t)w * pl.nb + b) * XW, acc);
       } else {
-        xyzz_store<F>(hp, acc);
+        G::acc_store(hp, acc);
         head_b = b;
       }
-      acc = Xyzz<F>::inf();
+      acc = G::identity();
       do { b++; } while (bs[b + 1] <= pos);
       b_start = bs[b];
       b_end = bs[b + 1];
     }
     uint32_t e = sw[pos];
     const uint32_t* pp = pts_mont + (size_t)(e & 0x7fffffffu) * AFF;
-    Affine<F> p{FieldIO<F>::load(pp), FieldIO<F>::load(pp + FW)};
-    acc = xyzz_madd(acc, p, (e >> 31) != 0);
+    acc = G::madd(acc, G::aff_load(pp), (e >> 31) != 0);
   }
   const bool left = b_start >= lo, right = b_end <= hi;
   if (left && right) {
-    xyzz_store<F>(buckets + ((size_t)w * pl.nb + b) * XW, acc);
+    G::acc_store(buckets + ((size_t)w * pl.nb + b) * XW, acc);
   } else if (!left) {
-    xyzz_store<F>(hp, acc);
+    G::acc_store(hp, acc);
     head_b = b;
     head_cont = right ? 0 : 1;
   } else {
-    xyzz_store<F>(hp + XW, acc);
+    G::acc_store(hp + XW, acc);
     tail_b = b;
   }
   meta[0] = head_b;
@@ -226,8 +223,8 @@ __global__ void __launch_bounds__(256) k_msm_fixup_pass(uint32_t* __restrict__ p
                                                         const int* __restrict__ part_meta,
                                                         const uint32_t* __restrict__ bucket_start, MsmPlan pl,
                                                         MsmSeg sg, int d) {
-  using F = typename C::F;
-  constexpr int XW = MsmSizes<C>::XYZZ;
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
   const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
   if (s >= sg.nseg) return;
   const int* meta = part_meta + ((size_t)w * sg.nseg + s) * 4;
@@ -244,7 +241,7 @@ __global__ void __launch_bounds__(256) k_msm_fixup_pass(uint32_t* __restrict__ p
     if ((idx & (2 * d - 1)) != 0 || s + d > s1) continue;
     uint32_t* mine = pp + ((size_t)s * 2 + role) * XW;
     const uint32_t* other = pp + ((size_t)(s + d) * 2) * XW;  // always a head piece
-    xyzz_store<F>(mine, xyzz_add(xyzz_load<F>(mine), xyzz_load<F>(other)));
+    G::acc_store(mine, G::add(G::acc_load(mine), G::acc_load(other)));
   }
 }
 
@@ -253,14 +250,14 @@ template <class C>
 __global__ void __launch_bounds__(256) k_msm_fixup_write(const uint32_t* __restrict__ part_pts,
                                                          const int* __restrict__ part_meta,
                                                          uint32_t* __restrict__ buckets, MsmPlan pl, MsmSeg sg) {
-  using F = typename C::F;
-  constexpr int XW = MsmSizes<C>::XYZZ;
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
   const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
   if (s >= sg.nseg) return;
   const int tb = part_meta[((size_t)w * sg.nseg + s) * 4 + 2];
   if (tb < 0) return;
   const uint32_t* src = part_pts + (((size_t)w * sg.nseg + s) * 2 + 1) * XW;
-  xyzz_store<F>(buckets + ((size_t)w * pl.nb + tb) * XW, xyzz_load<F>(src));
+  G::acc_store(buckets + ((size_t)w * pl.nb + tb) * XW, G::acc_load(src));
 }
 
 // ------------------------------------------------------------------ 5. bucket fold, one level
@@ -269,8 +266,8 @@ __global__ void __launch_bounds__(256) k_msm_fixup_write(const uint32_t* __restr
 template <class C>
 __global__ void __launch_bounds__(256) k_msm_reduce_level(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                           int narr, int nwin, int n_in) {
-  using F = typename C::F;
-  constexpr int XW = MsmSizes<C>::XYZZ;
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
   const int n_out = n_in >> 1;
   const long total = (long)(narr + 1) * nwin * n_out;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,14 +275,14 @@ __global__ void __launch_bounds__(256) k_msm_reduce_level(const uint32_t* __rest
   const int q = (int)(t % n_out);
   const int w = (int)((t / n_out) % nwin);
   const int a = (int)(t / ((long)n_out * nwin));
-  Xyzz<F> r;
+  typename G::Acc r;
   if (a < narr) {
     const uint32_t* base = in + (((size_t)a * nwin + w) * n_in + 2 * (size_t)q) * XW;
-    r = xyzz_add(xyzz_load<F>(base), xyzz_load<F>(base + XW));
+    r = G::add(G::acc_load(base), G::acc_load(base + XW));
   } else {
-    r = xyzz_load<F>(in + (((size_t)w) * n_in + 2 * (size_t)q + 1) * XW);
+    r = G::acc_load(in + (((size_t)w) * n_in + 2 * (size_t)q + 1) * XW);
   }
-  xyzz_store<F>(out + (((size_t)a * nwin + w) * n_out + q) * XW, r);
+  G::acc_store(out + (((size_t)a * nwin + w) * n_out + q) * XW, r);
 }
 
 // ------------------------------------------------------------------ planning
@@ -381,17 +378,17 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
     off = align256(off + bytes);
     return o;
   };
-  L.pts_mont = take((size_t)pl.n * MsmSizes<C>::AFF * 4);
+  L.pts_mont = take((size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);
   L.digits = take((size_t)pl.nwin * pl.n * 2);
   L.counts = take((size_t)pl.nwin * pl.Q * pl.nb * 4);
   L.bucket_start = take((size_t)pl.nwin * (pl.nb + 1) * 4);
   L.sorted = take((size_t)pl.nwin * pl.n * 4);
-  L.buckets = take((size_t)pl.nwin * pl.nb * MsmSizes<C>::XYZZ * 4);
+  L.buckets = take((size_t)pl.nwin * pl.nb * MsmGroup<C>::ACC_WORDS * 4);
   MsmSeg sg = msm_seg(pl);
-  L.part_pts = take((size_t)pl.nwin * sg.nseg * 2 * MsmSizes<C>::XYZZ * 4);
+  L.part_pts = take((size_t)pl.nwin * sg.nseg * 2 * MsmGroup<C>::ACC_WORDS * 4);
   L.part_meta = take((size_t)pl.nwin * sg.nseg * 4 * 4);
   // fold ping-pong: level l output holds (l+1) * nwin * nb/2^l points <= nwin*nb (l = 1, 2)
-  size_t red = (size_t)pl.nwin * std::max(pl.nb, pl.c) * MsmSizes<C>::XYZZ * 4;
+  size_t red = (size_t)pl.nwin * std::max(pl.nb, pl.c) * MsmGroup<C>::ACC_WORDS * 4;
   L.red0 = take(red);
   L.red1 = take(red);
   L.total = off;
@@ -403,36 +400,26 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
 template <class C>
 static void msm_host_finish(const std::vector<uint32_t>& fin, const MsmPlan& pl, uint32_t* out_affine,
                             uint8_t* out_inf) {
-  using F = typename C::F;
-  constexpr int XW = MsmSizes<C>::XYZZ;
-  const int narr = pl.c;  // S + (c-1) R-arrays; for c == 1 there is a single bucket and no fold
-  auto at = [&](int a, int w) { return xyzz_load<F>(fin.data() + ((size_t)a * pl.nwin + w) * XW); };
-  Xyzz<F> acc = Xyzz<F>::inf();
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
+  const int narr = pl.c;  // S + (c-1) R-arrays
+  auto at = [&](int a, int w) { return G::acc_load(fin.data() + ((size_t)a * pl.nwin + w) * XW); };
+  typename G::Acc acc = G::identity();
   for (int w = pl.nwin - 1; w >= 0; w--) {
     for (int e = pl.c - 1; e >= 0; e--) {
-      acc = xyzz_dbl(acc);
-      if (e <= pl.c - 2 && e + 1 < narr) acc = xyzz_add(acc, at(e + 1, w));
-      if (e == 0) acc = xyzz_add(acc, at(0, w));
+      acc = G::dbl(acc);
+      if (e <= pl.c - 2 && e + 1 < narr) acc = G::add(acc, at(e + 1, w));
+      if (e == 0) acc = G::add(acc, at(0, w));
     }
   }
-  bool inf = acc.is_inf();
-  Affine<F> A{F::zero(), F::zero()};
-  if (!inf) {
-    // x = X/ZZ, y = Y/ZZZ; one inversion of ZZ*ZZZ
-    auto ti = f_inv(acc.ZZ * acc.ZZZ);
-    auto zzi = ti * acc.ZZZ;
-    auto zzzi = ti * acc.ZZ;
-    A = {acc.X * zzi, acc.Y * zzzi};
-  }
-  store_affine_wire<F>(out_affine, A);
-  *out_inf = inf ? 1 : 0;
+  G::to_affine_wire(acc, out_affine, out_inf);
 }
 
 template <class C>
 static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
                             uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st) {
-  using F = typename C::F;
-  constexpr int XW = MsmSizes<C>::XYZZ;
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
   MsmLayout L = msm_layout<C>(pl);
   char* base = (char*)ws;
   uint32_t* pts_mont = (uint32_t*)(base + L.pts_mont);
@@ -489,7 +476,6 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
   msm_host_finish<C>(fin, pl, out_affine_host, out_inf_host);
-  (void)sizeof(F);
   return hipSuccess;
 }
 
@@ -498,6 +484,7 @@ size_t msm_workspace_bytes(int curve, const MsmPlan& pl) {
     case CURVE_SECP256K1: return msm_layout<CurveSecp>(pl).total;
     case CURVE_BLS12_381_G1: return msm_layout<CurveG1>(pl).total;
     case CURVE_BLS12_381_G2: return msm_layout<CurveG2>(pl).total;
+    case CURVE_ED25519: return msm_layout<CurveEd>(pl).total;
     default: return 0;
   }
 }
@@ -508,6 +495,7 @@ hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const ui
     case CURVE_SECP256K1: return msm_run_t<CurveSecp>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
     case CURVE_BLS12_381_G1: return msm_run_t<CurveG1>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
     case CURVE_BLS12_381_G2: return msm_run_t<CurveG2>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
+    case CURVE_ED25519: return msm_run_t<CurveEd>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
     default: return hipErrorInvalidValue;
   }
 }

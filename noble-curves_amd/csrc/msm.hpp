@@ -42,27 +42,97 @@ struct MsmPlan {
   uint32_t hconst[10];  // H' = sum_w 2^(c-1) * 2^(c w), 10 LE limbs
 };
 
-// sizes in 32-bit words of one stored point
-template <class C> struct MsmSizes {
+// Group policy of the MSM kernels: how an input point is stored, what the bucket accumulator
+// is and the three operations on it.  Default: short-Weierstrass a = 0 (XYZZ buckets, affine
+// inputs); CurveEd specialises it for twisted Edwards (extended buckets, Niels inputs).
+template <class C>
+struct MsmGroup {
   using F = typename C::F;
-  static constexpr int FW = FieldIO<F>::WORDS;        // stored words per field element
-  static constexpr int WIRE_AFF = 2 * FieldWire<F>::WORDS;  // wire words per affine point
-  static constexpr int AFF = 2 * FW;
-  static constexpr int XYZZ = 4 * FW;
+  using Acc = Xyzz<F>;
+  using Aff = Affine<F>;
+  static constexpr int FW = FieldIO<F>::WORDS;
+  static constexpr int WIRE_AFF = 2 * FieldWire<F>::WORDS;  // wire words per input point
+  static constexpr int AFF_WORDS = 2 * FW;                  // stored words per input point
+  static constexpr int ACC_WORDS = 4 * FW;                  // stored words per accumulator
+  static NCG_DI void wire_to_storage(const uint32_t* wire, uint32_t* out) {
+    Affine<F> a = load_affine_wire<F>(wire);
+    FieldIO<F>::store(out, a.x);
+    FieldIO<F>::store(out + FW, a.y);
+  }
+  static NCG_DI Aff aff_load(const uint32_t* p) { return {FieldIO<F>::load(p), FieldIO<F>::load(p + FW)}; }
+  static NCG_DI Acc identity() { return Xyzz<F>::inf(); }
+  static NCG_DI Acc acc_load(const uint32_t* p) {  // all-zero words (memset) decode as infinity
+    return {FieldIO<F>::load(p), FieldIO<F>::load(p + FW), FieldIO<F>::load(p + 2 * FW), FieldIO<F>::load(p + 3 * FW)};
+  }
+  static NCG_DI void acc_store(uint32_t* p, const Acc& a) {
+    FieldIO<F>::store(p, a.X);
+    FieldIO<F>::store(p + FW, a.Y);
+    FieldIO<F>::store(p + 2 * FW, a.ZZ);
+    FieldIO<F>::store(p + 3 * FW, a.ZZZ);
+  }
+  static NCG_DI Acc madd(const Acc& a, const Aff& q, bool neg) { return xyzz_madd(a, q, neg); }
+  static NCG_DI Acc add(const Acc& a, const Acc& b) { return xyzz_add(a, b); }
+  static NCG_DI Acc dbl(const Acc& a) { return xyzz_dbl(a); }
+  // canonical affine wire output; infinity = (0, 0)
+  static NCG_DI void to_affine_wire(const Acc& acc, uint32_t* out, uint8_t* out_inf) {
+    bool inf = acc.is_inf();
+    Affine<F> A{F::zero(), F::zero()};
+    if (!inf) {  // x = X/ZZ, y = Y/ZZZ; one inversion of ZZ*ZZZ
+      auto ti = f_inv(acc.ZZ * acc.ZZZ);
+      auto zzi = ti * acc.ZZZ;
+      auto zzzi = ti * acc.ZZ;
+      A = {acc.X * zzi, acc.Y * zzzi};
+    }
+    store_affine_wire<F>(out, A);
+    *out_inf = inf ? 1 : 0;
+  }
 };
 
-template <class F>
-NCG_DI Xyzz<F> xyzz_load(const uint32_t* p) {
-  constexpr int FW = FieldIO<F>::WORDS;
-  return {FieldIO<F>::load(p), FieldIO<F>::load(p + FW), FieldIO<F>::load(p + 2 * FW), FieldIO<F>::load(p + 3 * FW)};
-}
-template <class F>
-NCG_DI void xyzz_store(uint32_t* p, const Xyzz<F>& a) {
-  constexpr int FW = FieldIO<F>::WORDS;
-  FieldIO<F>::store(p, a.X);
-  FieldIO<F>::store(p + FW, a.Y);
-  FieldIO<F>::store(p + 2 * FW, a.ZZ);
-  FieldIO<F>::store(p + 3 * FW, a.ZZZ);
-}
+// Twisted Edwards (ed25519): inputs stored in affine Niels form (y+x, y-x, 2dxy), buckets in
+// extended coordinates.  The formulas are complete, so the identity (0,1) needs no special
+// case; an all-zero stored accumulator (memset) decodes as the identity.
+template <>
+struct MsmGroup<CurveEd> {
+  using F = FpEd;
+  using Acc = EdExt<F>;
+  using Aff = EdNielsAff<F>;
+  static constexpr int FW = 8;
+  static constexpr int WIRE_AFF = 16;
+  static constexpr int AFF_WORDS = 24;
+  static constexpr int ACC_WORDS = 32;
+  static NCG_DI void wire_to_storage(const uint32_t* wire, uint32_t* out) {
+    F x = FieldWire<F>::load(wire), y = FieldWire<F>::load(wire + 8);
+    Aff q = ed_affine_to_niels(x, y, EdConsts::d2());
+    FieldIO<F>::store(out, q.yplusx);
+    FieldIO<F>::store(out + 8, q.yminusx);
+    FieldIO<F>::store(out + 16, q.t2d);
+  }
+  static NCG_DI Aff aff_load(const uint32_t* p) {
+    return {FieldIO<F>::load(p), FieldIO<F>::load(p + 8), FieldIO<F>::load(p + 16)};
+  }
+  static NCG_DI Acc identity() { return EdExt<F>::identity(); }
+  static NCG_DI Acc acc_load(const uint32_t* p) {
+    Acc a{FieldIO<F>::load(p), FieldIO<F>::load(p + 8), FieldIO<F>::load(p + 16), FieldIO<F>::load(p + 24)};
+    if (a.Z.is_zero()) a = EdExt<F>::identity();
+    return a;
+  }
+  static NCG_DI void acc_store(uint32_t* p, const Acc& a) {
+    FieldIO<F>::store(p, a.X);
+    FieldIO<F>::store(p + 8, a.Y);
+    FieldIO<F>::store(p + 16, a.Z);
+    FieldIO<F>::store(p + 24, a.T);
+  }
+  static NCG_DI Acc madd(const Acc& a, const Aff& q, bool neg) { return ed_madd_niels(a, q, neg); }
+  static NCG_DI Acc add(const Acc& a, const Acc& b) { return ed_add_niels(a, ed_to_niels(b, EdConsts::d2()), false); }
+  static NCG_DI Acc dbl(const Acc& a) { return ed_dbl(a); }
+  // affine (x, y) = (X/Z, Y/Z); the identity is (0, 1) on Edwards curves (edwards.ts:606)
+  static NCG_DI void to_affine_wire(const Acc& acc, uint32_t* out, uint8_t* out_inf) {
+    F zi = fp_inv<ParamsEdP>(acc.Z);
+    F x = acc.X * zi, y = acc.Y * zi;
+    FieldWire<F>::store(out, x);
+    FieldWire<F>::store(out + 8, y);
+    *out_inf = (x.is_zero() && y == F::one()) ? 1 : 0;
+  }
+};
 
 }  // namespace ncg

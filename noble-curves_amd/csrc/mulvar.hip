@@ -1,5 +1,6 @@
 // Launchers for the batch variable-base multiply kernels (see mulvar.hpp).
 #include "mulvar.hpp"
+#include "host_api.hpp"
 
 #include <cstdlib>
 
@@ -50,6 +51,7 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
       if (w == 5) return launch_mul_var<CurveSecp, 5, 1>(pts, scalars, out, out_inf, n, jac_tmp, st);
       return launch_mul_var<CurveSecp, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     }
+    case CURVE_ED25519: return ed25519_mul_var_batch(pts, scalars, out, out_inf, n, st);
     case CURVE_BLS12_381_G1: return launch_mul_var<CurveG1, 3, 1, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);
     case CURVE_BLS12_381_G2: return launch_mul_var<CurveG2, 3, 1, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     default: return hipErrorInvalidValue;

@@ -19,7 +19,7 @@ raises NativeError.
 import numpy as np
 
 from . import _native
-from ._native import BLS12_381_G1, BLS12_381_G2, FIELD_BYTES, POINT_BYTES, SECP256K1, get_engine
+from ._native import BLS12_381_G1, BLS12_381_G2, ED25519, FIELD_BYTES, POINT_BYTES, SECP256K1, get_engine
 
 _BLS_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 _BLS_R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
@@ -144,6 +144,88 @@ def _make_point_class(name, curve_id, Fp, Fn, gx, gy):
     return Point
 
 
+def _make_edwards_point_class(name, curve_id, Fp, Fn, gx, gy):
+    """Twisted-Edwards point class (reference: src/abstract/edwards.ts:368-660): affine (x, y),
+    ZERO = (0, 1) (:370, :606); coordinates are accepted below 2^(8*Fp.BYTES) like the reference
+    (ZIP-215 keeps unreduced y, :356-360) and reduced mod p when marshalled (SURVEY 8a gotcha 4)."""
+    MASK = 1 << (8 * Fp.BYTES)
+    P = Fp.ORDER
+
+    class Point:
+        __slots__ = ("x", "y")
+        CURVE_ID = curve_id
+        POINT_BYTES = 64
+
+        def __init__(self, x, y):
+            self.x, self.y = x, y
+
+        @classmethod
+        def fromAffine(cls, p):
+            x, y = (p["x"], p["y"]) if isinstance(p, dict) else p
+            for t, v in (("x", x), ("y", y)):
+                if not (isinstance(v, int) and not isinstance(v, bool) and 0 <= v < MASK):
+                    raise ValueError("expected valid coordinate %s" % t)
+            return cls(x, y)
+
+        def toAffine(self):
+            return (self.x % P, self.y % P)
+
+        def is0(self):
+            return self.toAffine() == (0, 1)
+
+        def equals(self, other):
+            _apoint(other)
+            return self.toAffine() == other.toAffine()
+
+        def negate(self):
+            return Point((-self.x) % P, self.y % P)
+
+        def multiply(self, scalar):
+            """edwards.ts:555-564: 1 <= scalar < n."""
+            if not (isinstance(scalar, int) and not isinstance(scalar, bool) and 1 <= scalar < Fn.ORDER):
+                raise ValueError("invalid scalar: expected 1 <= sc < curve.n")
+            return multiplyUnsafeBatch(Point, [self], [scalar], _err="invalid scalar: expected 0 <= sc < curve.n")[0]
+
+        def multiplyUnsafe(self, scalar):
+            """edwards.ts:571-577: 0 <= scalar < n."""
+            return multiplyUnsafeBatch(Point, [self], [scalar], _err="invalid scalar: expected 0 <= sc < curve.n")[0]
+
+        def add(self, other):
+            _apoint(other)
+            return pippenger(Point, [self, other], [1, 1])
+
+        def double(self):
+            return self.multiplyUnsafe(2)
+
+        def subtract(self, other):
+            _apoint(other)
+            return self.add(other.negate())
+
+        def _wire(self):
+            x, y = self.toAffine()
+            return x.to_bytes(32, "little") + y.to_bytes(32, "little")
+
+        @classmethod
+        def _from_wire(cls, row, inf):
+            if inf:
+                return cls.ZERO
+            return cls(int.from_bytes(bytes(row[:32]), "little"), int.from_bytes(bytes(row[32:64]), "little"))
+
+        def __repr__(self):
+            return "%s.Point(%r, %r)" % (name, self.x, self.y)
+
+    def _apoint(o):
+        if not isinstance(o, Point):
+            raise TypeError("EdwardsPoint expected")
+
+    Point.__name__ = name + "Point"
+    Point.Fp = Fp
+    Point.Fn = Fn
+    Point.ZERO = Point(0, 1)
+    Point.BASE = Point(gx, gy)
+    return Point
+
+
 # ---------------------------------------------------------------------------------- validation
 def validateMSMPoints(points, c):
     """curve.ts:390-395."""
@@ -187,7 +269,7 @@ def pippenger(c, points, scalars, engine=None):
     return c._from_wire(out, inf)
 
 
-def multiplyUnsafeBatch(c, points, scalars, engine=None):
+def multiplyUnsafeBatch(c, points, scalars, engine=None, _err="invalid scalar: out of range"):
     """[p.multiplyUnsafe(k) for p, k in zip(points, scalars)] in one launch
     (weierstrass.ts:915-928: 0 <= k < n else RangeError('invalid scalar: out of range'))."""
     validateMSMPoints(points, c)
@@ -195,7 +277,7 @@ def multiplyUnsafeBatch(c, points, scalars, engine=None):
         raise ValueError("arrays of points and scalars must have equal length")
     for k in scalars:
         if not (isinstance(k, int) and not isinstance(k, bool) and 0 <= k < c.Fn.ORDER):
-            raise ValueError("invalid scalar: out of range")
+            raise ValueError(_err)
     if not points:
         return []
     eng = engine or get_engine()
@@ -212,6 +294,8 @@ def multiplyBaseBatch(c, scalars, engine=None, unsafe=False):
             raise ValueError("invalid scalar: out of range")
     if not scalars:
         return []
+    if c.CURVE_ID == ED25519:  # no dedicated fixed-base table yet: variable-base kernel on BASE
+        return multiplyUnsafeBatch(c, [c.BASE] * len(scalars), list(scalars), engine)
     eng = engine or get_engine()
     out, inf = eng.mul_base_batch(c.CURVE_ID, _scalars_wire(scalars))
     return [c._from_wire(out[i], bool(inf[i])) for i in range(len(scalars))]
@@ -251,3 +335,8 @@ bls12_381_G2_Point = _make_point_class(
      0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
     (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
      0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))  # bls12-381.ts:321-345
+ed25519_Point = _make_edwards_point_class(
+    "ed25519", ED25519, _Field((1 << 255) - 19),
+    _Field(0x1000000000000000000000000000000014DEF9DEA2F79CD65812631A5CF5D3ED),
+    0x216936D3CD6E53FEC0A4E231FDD6DC5C692CC7609525A7B2C9562D608F25D51A,
+    0x6666666666666666666666666666666666666666666666666666666666666658)                # ed25519.ts:57-65

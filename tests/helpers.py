@@ -5,12 +5,12 @@ import os
 
 import numpy as np
 
-from noble_curves_amd._native import (BLS12_381_G1, BLS12_381_G2, FIELD_BYTES, POINT_BYTES, SECP256K1,
+from noble_curves_amd._native import (BLS12_381_G1, BLS12_381_G2, ED25519, FIELD_BYTES, POINT_BYTES, SECP256K1,
                                       ints_to_le, le_to_ints)
-from oracle.curves import BlsG1, BlsG2, Secp256k1
+from oracle.curves import BlsG1, BlsG2, Ed25519, Secp256k1
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-ORACLE_CURVE = {SECP256K1: Secp256k1, BLS12_381_G1: BlsG1, BLS12_381_G2: BlsG2}
+ORACLE_CURVE = {SECP256K1: Secp256k1, BLS12_381_G1: BlsG1, BLS12_381_G2: BlsG2, ED25519: Ed25519}
 
 
 def load_golden(name):

@@ -22,6 +22,7 @@ def lib():
         _lib.ht_field_op.argtypes = [i32, i32, vp, vp, vp]
         _lib.ht_glv_split.argtypes = [vp, vp]
         _lib.ht_ed25519_verify.argtypes = [vp, vp, vp, i32]
+        _lib.ht_ed25519_mul_var.argtypes = [vp, vp, vp, vp, i32]
     return _lib
 
 
@@ -58,3 +59,13 @@ def ed25519_verify(sig, pk, k, zip215):
     P = np.frombuffer(bytes(pk), dtype=np.uint8).copy()
     K = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
     return bool(lib().ht_ed25519_verify(S.ctypes.data, P.ctypes.data, K.ctypes.data, 1 if zip215 else 0))
+
+
+def ed25519_mul_var(pts, scalars):
+    pts = np.ascontiguousarray(pts, dtype=np.uint8)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+    n = pts.shape[0]
+    out = np.zeros_like(pts)
+    inf = np.zeros((n,), dtype=np.uint8)
+    assert lib().ht_ed25519_mul_var(pts.ctypes.data, scalars.ctypes.data, out.ctypes.data, inf.ctypes.data, n) == 0
+    return out, inf

@@ -51,3 +51,17 @@ def test_reference_flow_on_gpu():
     assert [o.toAffine() for o in outs] == [BlsG1.BASE.multiplyUnsafe(k).toAffine() for k in (0, 1, 2, 12345)]
     h = G2.BASE.multiplyUnsafe(5)
     assert G.pippenger(G2, [G2.BASE, h], [5, G2.Fn.ORDER - 1]).is0()
+    # ed25519 through the same interface (edwards.ts:555-577, ZERO = (0, 1))
+    from oracle.curves import ED25519_L, Ed25519
+    E = G.ed25519_Point
+    assert E.BASE.multiply(12345).toAffine() == Ed25519.BASE.multiply(12345).toAffine()
+    assert E.BASE.multiplyUnsafe(0).is0() and E.ZERO.toAffine() == (0, 1)
+    assert E.BASE.add(E.BASE.negate()).is0() and E.BASE.double().equals(E.BASE.add(E.BASE))
+    assert G.pippenger(E, [E.BASE, E.BASE.double()], [3, ED25519_L - 1]).equals(E.BASE)
+    with pytest.raises(ValueError, match="expected 1 <= sc < curve.n"):
+        E.BASE.multiply(0)
+    with pytest.raises(ValueError, match="expected 0 <= sc < curve.n"):
+        E.BASE.multiplyUnsafe(ED25519_L)
+    ks = [1, 2, ED25519_L - 1, 0xDEADBEEF]
+    assert [p.toAffine() for p in G.multiplyBaseBatch(E, ks)] == [Ed25519.BASE.multiplyUnsafe(k).toAffine() for k in ks]
+    assert [p.toAffine() for p in G.multiplyBaseBatch(K1, ks)] == [Secp256k1.BASE.multiplyUnsafe(k).toAffine() for k in ks]

@@ -130,3 +130,35 @@ def test_fixed_base_batch(curve):
         out, _ = get_engine().mul_base_batch(curve, scalars_to_wire([int(r[0]) for r in rows]))
         for i, (_, x, y) in enumerate(rows):
             assert wire_to_affine(curve, out[i]) == (int(x, 16), int(y, 16))
+
+
+def test_ed25519_mul_var_and_msm_gpu():
+    """ed25519 multiplyUnsafe batch (incl. torsioned points) and pippenger on the GPU."""
+    from noble_curves_amd._native import ED25519
+    from oracle.curves import ED25519_L, Ed25519
+    from test_host_logic import _ed_points_and_scalars
+    pts, ks = _ed_points_and_scalars()
+    eng = get_engine()
+    out, inf = eng.mul_var_batch(ED25519, points_to_wire(ED25519, pts), scalars_to_wire(ks))
+    for i, (p, k) in enumerate(zip(pts, ks)):
+        exp = C.naiveMul(Ed25519, p, k).toAffine()
+        assert wire_to_affine(ED25519, out[i]) == exp and bool(inf[i]) == (exp == (0, 1))
+    # MSM: progression identity + degenerate inputs
+    rng = makeRng(0xED5)
+    a, b = rng.rndBelow(ED25519_L - 1) + 1, rng.rndBelow(ED25519_L - 1) + 1
+    n = 700
+    kk = [(a + i * b) % ED25519_L for i in range(n)]
+    P = [Ed25519.BASE.multiplyUnsafe(k) for k in kk]
+    sc = [0 if i % 17 == 0 else rng.rndBelow(ED25519_L) for i in range(n)]
+    exp = Ed25519.BASE.multiplyUnsafe(sum(k * s for k, s in zip(kk, sc)) % ED25519_L).toAffine()
+    got, ginf = eng.msm(ED25519, points_to_wire(ED25519, P), scalars_to_wire(sc))
+    assert wire_to_affine(ED25519, got) == exp and not ginf
+    got, ginf = eng.msm(ED25519, points_to_wire(ED25519, [P[1], P[1].negate(), Ed25519.ZERO]), scalars_to_wire([5, 5, 9]))
+    assert wire_to_affine(ED25519, got) == (0, 1) and ginf
+    got, ginf = eng.msm(ED25519, points_to_wire(ED25519, pts[:12]), scalars_to_wire(ks[:12]))   # torsion inside an MSM
+    acc = Ed25519.ZERO
+    for p, k in zip(pts[:12], ks[:12]):
+        acc = acc.add(C.naiveMul(Ed25519, p, k))
+    assert wire_to_affine(ED25519, got) == acc.toAffine()
+    got, ginf = eng.msm(ED25519, points_to_wire(ED25519, []), scalars_to_wire([]))
+    assert wire_to_affine(ED25519, got) == (0, 1) and ginf

@@ -104,3 +104,30 @@ def test_ed25519_verify_lane_matches_oracle_both_modes():
         for zip215 in (True, False):
             exp = eddsa_verify(Ed25519, sig, msg, pk, zip215=zip215)
             assert hosttest.ed25519_verify(sig, pk, k, zip215) == exp, (sig.hex(), pk.hex(), zip215)
+
+
+def _ed_points_and_scalars():
+    from oracle.curves import ED25519_L, Ed25519
+    rng = makeRng(0xED25)
+    t8 = Ed25519.fromBytes(bytes.fromhex("c7176a703d4dd84fba3c0b760d10670f2a2053fa2c39ccc64ec7fd7792ac03fa"), True)
+    ks = [0, 1, 2, 3, 7, 8, 9, ED25519_L - 1, ED25519_L - 2, 1 << 252, (1 << 252) + 1] + [rng.rndBelow(ED25519_L) for _ in range(20)]
+    pts = [Ed25519.BASE.multiplyUnsafe(rng.rndBelow(ED25519_L - 1) + 1) for _ in ks]
+    pts[2] = Ed25519.ZERO
+    pts[5] = t8                                   # small-order point
+    pts[6] = Ed25519.BASE.add(t8)                 # torsion component: exact integer multiple required
+    pts[12] = pts[13].add(t8)
+    return pts, ks
+
+
+def test_ed25519_mul_var_lane_incl_torsion():
+    """edwards.ts:571-577 semantics; torsioned points as in test/ed25519.test.ts:355-390."""
+    from helpers import points_to_wire, scalars_to_wire, wire_to_affine
+    from noble_curves_amd._native import ED25519
+    from oracle.curves import Ed25519
+    from oracle import curve as OC
+    pts, ks = _ed_points_and_scalars()
+    out, inf = hosttest.ed25519_mul_var(points_to_wire(ED25519, pts), scalars_to_wire(ks))
+    for i, (p, k) in enumerate(zip(pts, ks)):
+        exp = OC.naiveMul(Ed25519, p, k).toAffine()
+        assert wire_to_affine(ED25519, out[i]) == exp, (i, hex(k))
+        assert bool(inf[i]) == (exp == (0, 1))
