@@ -1,0 +1,198 @@
+// N-API addon: the binding a noble-curves maintainer would add to reach libncg.so from the
+// reference's TypeScript/JavaScript side.  Synchronous, like every call on
+// the reference's path (there is no async anywhere in src/abstract/curve.ts).
+//
+//   init(deviceId = 0)                               -> undefined (throws Error('noble-gpu: ...'))
+//   msm(curveId, points: Uint8Array, scalars: Uint8Array)            -> Uint8Array PB + 1 (flag)
+//   mulVarBatch(curveId, points, scalars)            -> Uint8Array n * (PB + 1)  (points then flags)
+//   mulBaseBatch(curveId, scalars)                   -> Uint8Array n * (PB + 1)
+//   ed25519VerifyBatch(sigs, pks, ks, zip215: bool)  -> Uint8Array n (0 / 1)
+//   pointBytes(curveId) / version()
+// Buffers use the wire format of include/ncg.h.  Build: make -C addon  (g++ + /usr/include/node).
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "../include/ncg.h"
+
+static ncg_ctx* g_ctx = nullptr;
+
+#define NAPI_OK(call)                                             \
+  do {                                                            \
+    if ((call) != napi_ok) {                                      \
+      napi_throw_error(env, nullptr, "noble-gpu: N-API failure"); \
+      return nullptr;                                             \
+    }                                                             \
+  } while (0)
+
+static napi_value throw_native(napi_env env) {
+  const char* m = ncg_last_error(g_ctx);
+  napi_throw_error(env, nullptr, (m && *m) ? m : "noble-gpu: native call failed");
+  return nullptr;
+}
+
+static bool get_u8(napi_env env, napi_value v, uint8_t** data, size_t* len) {
+  bool is_ta = false;
+  if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta) return false;
+  napi_typedarray_type t;
+  napi_value ab;
+  size_t off;
+  void* p;
+  if (napi_get_typedarray_info(env, v, &t, len, &p, &ab, &off) != napi_ok || t != napi_uint8_array) return false;
+  *data = (uint8_t*)p;
+  return true;
+}
+
+static napi_value make_u8(napi_env env, size_t n, uint8_t** out) {
+  napi_value ab, arr;
+  void* p;
+  if (napi_create_arraybuffer(env, n, &p, &ab) != napi_ok) return nullptr;
+  if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &arr) != napi_ok) return nullptr;
+  *out = (uint8_t*)p;
+  return arr;
+}
+
+static napi_value Init(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  int32_t dev = 0;
+  if (argc >= 1) napi_get_value_int32(env, argv[0], &dev);
+  if (!g_ctx && ncg_init(dev, &g_ctx) != 0) {
+    napi_throw_error(env, nullptr, ncg_last_error(nullptr));
+    return nullptr;
+  }
+  return nullptr;
+}
+
+static bool need_ctx(napi_env env) {
+  if (g_ctx) return true;
+  napi_throw_error(env, nullptr, "noble-gpu: call init() first");
+  return false;
+}
+
+static napi_value Msm(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t curve;
+  uint8_t *pts, *sc, *out;
+  size_t pl, sl;
+  if (argc < 3 || napi_get_value_int32(env, argv[0], &curve) != napi_ok || !get_u8(env, argv[1], &pts, &pl) ||
+      !get_u8(env, argv[2], &sc, &sl)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: msm(curveId, Uint8Array, Uint8Array)");
+    return nullptr;
+  }
+  int pb = ncg_point_bytes(curve);
+  if (pb == 0 || sl % 32 || pl != (sl / 32) * (size_t)pb) {
+    napi_throw_error(env, nullptr, "arrays of points and scalars must have equal length");
+    return nullptr;
+  }
+  napi_value res = make_u8(env, pb + 1, &out);
+  if (!res) return nullptr;
+  if (ncg_msm(g_ctx, curve, sl / 32, pts, sc, out, out + pb) != 0) return throw_native(env);
+  return res;
+}
+
+static napi_value MulVarBatch(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t curve;
+  uint8_t *pts, *sc, *out;
+  size_t pl, sl;
+  if (argc < 3 || napi_get_value_int32(env, argv[0], &curve) != napi_ok || !get_u8(env, argv[1], &pts, &pl) ||
+      !get_u8(env, argv[2], &sc, &sl)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: mulVarBatch(curveId, Uint8Array, Uint8Array)");
+    return nullptr;
+  }
+  int pb = ncg_point_bytes(curve);
+  size_t n = sl / 32;
+  if (pb == 0 || sl % 32 || pl != n * (size_t)pb) {
+    napi_throw_error(env, nullptr, "arrays of points and scalars must have equal length");
+    return nullptr;
+  }
+  napi_value res = make_u8(env, n * (pb + 1), &out);
+  if (!res) return nullptr;
+  if (n && ncg_mul_var_batch(g_ctx, curve, n, pts, sc, out, out + n * pb) != 0) return throw_native(env);
+  return res;
+}
+
+static napi_value MulBaseBatch(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t curve;
+  uint8_t *sc, *out;
+  size_t sl;
+  if (argc < 2 || napi_get_value_int32(env, argv[0], &curve) != napi_ok || !get_u8(env, argv[1], &sc, &sl) || sl % 32) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: mulBaseBatch(curveId, Uint8Array)");
+    return nullptr;
+  }
+  int pb = ncg_point_bytes(curve);
+  size_t n = sl / 32;
+  napi_value res = make_u8(env, n * (pb + 1), &out);
+  if (!res) return nullptr;
+  if (n && ncg_mul_base_batch(g_ctx, curve, n, sc, out, out + n * pb) != 0) return throw_native(env);
+  return res;
+}
+
+static napi_value Ed25519VerifyBatch(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  uint8_t *sig, *pk, *k, *out;
+  size_t sgl, pkl, kl;
+  bool zip215 = true;
+  if (argc < 3 || !get_u8(env, argv[0], &sig, &sgl) || !get_u8(env, argv[1], &pk, &pkl) || !get_u8(env, argv[2], &k, &kl)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: ed25519VerifyBatch(sigs, pks, ks, zip215)");
+    return nullptr;
+  }
+  if (argc >= 4) napi_get_value_bool(env, argv[3], &zip215);
+  size_t n = sgl / 64;
+  if (sgl % 64 || pkl != n * 32 || kl != n * 32) {
+    napi_throw_error(env, nullptr, "arrays of signatures, public keys and challenges must have equal length");
+    return nullptr;
+  }
+  napi_value res = make_u8(env, n, &out);
+  if (!res) return nullptr;
+  if (n && ncg_ed25519_verify_batch(g_ctx, n, sig, pk, k, zip215 ? 1 : 0, out) != 0) return throw_native(env);
+  return res;
+}
+
+static napi_value PointBytes(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], r;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  int32_t curve = -1;
+  if (argc >= 1) napi_get_value_int32(env, argv[0], &curve);
+  NAPI_OK(napi_create_int32(env, ncg_point_bytes(curve), &r));
+  return r;
+}
+
+static napi_value Version(napi_env env, napi_callback_info) {
+  napi_value r;
+  NAPI_OK(napi_create_string_utf8(env, ncg_version(), NAPI_AUTO_LENGTH, &r));
+  return r;
+}
+
+NAPI_MODULE_INIT() {
+  struct {
+    const char* name;
+    napi_callback fn;
+  } fns[] = {{"init", Init},           {"msm", Msm},
+             {"mulVarBatch", MulVarBatch}, {"mulBaseBatch", MulBaseBatch},
+             {"ed25519VerifyBatch", Ed25519VerifyBatch}, {"pointBytes", PointBytes},
+             {"version", Version}};
+  for (auto& f : fns) {
+    napi_value v;
+    if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v) != napi_ok) return exports;
+    napi_set_named_property(env, exports, f.name, v);
+  }
+  return exports;
+}
