@@ -31,6 +31,20 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 INT_MAC_PEAK = 256 * 4 * 16 * 2.4e9   # v_mad_u64_u32: 16 lanes/clk/SIMD (measured, profiles/r01_ubench*)
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 correction applied: profiles/r01_pmc_traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            ks = json.load(f)["kernels"]
+        for name, v in ks.items():
+            if name.startswith(kernel_prefix):
+                return v["hbm_bytes_per_launch_corrected"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def ints_to_le_bytes(vals, nbytes=32):
     return np.frombuffer(b"".join(int(v).to_bytes(nbytes, "little") for v in vals), dtype=np.uint8).reshape(-1, nbytes)
 
@@ -198,7 +212,8 @@ def main():
                        % args.log2n, "items_per_gpu": n, "parallelism": "shard-by-index x%d" % world},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_mul_var<CurveSecp,3> + k_jac_batch_affine", "kernel_ms": kern_ms,
+                         "traffic": pmc_traffic("ncg::k_mul_var<ncg::CurveSecp") if args.log2n == 20 else None,
+                         "kernel": "k_mul_var<CurveSecp,3> (+ k_jac_batch_affine)", "kernel_ms": kern_ms,
                          "valu": {"achieved_mac_per_s": alg_mac / (kern_ms * 1e-3), "peak_mac_per_s": INT_MAC_PEAK,
                                   "frac": alg_mac / (kern_ms * 1e-3) / INT_MAC_PEAK,
                                   "note": "reference-equivalent limb-MACs (SURVEY 8d) / v_mad_u64_u32 peak"}},
@@ -254,7 +269,9 @@ def main():
         msm = {"metric": "bls12_381_g1_msm_points_per_sec", "value": msm_rate, "unit": "points/s",
                "ms_per_msm": wall / K * 1e3, "points_per_gpu": n, "total_points": world * n, "scaling": "weak",
                "roofline": {"bound": "hbm", "achieved": alg_bytes / (wall / K) / 1e9, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": alg_bytes / (wall / K) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "unit": "GB/s", "frac": alg_bytes / (wall / K) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": pmc_traffic("ncg::k_msm_accum<ncg::CurveG1") if args.log2n == 20 else None,
+                            "kernel": "k_msm_accum<CurveG1> (dominant; the figure is for the whole MSM)",
                             "valu": {"achieved_mac_per_s": alg_mac / (wall / K), "peak_mac_per_s": INT_MAC_PEAK,
                                      "frac": alg_mac / (wall / K) / INT_MAC_PEAK}}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
