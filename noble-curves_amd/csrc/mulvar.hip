@@ -49,6 +49,9 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
       if (w == 3) return launch_mul_var<CurveSecp, 3, 3>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (w == 33) return launch_mul_var<CurveSecp, 3, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (w == 5) return launch_mul_var<CurveSecp, 5, 1>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (w == 34) return launch_mul_var<CurveSecp, 3, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (w == 24) return launch_mul_var<CurveSecp, 2, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (w == 22) return launch_mul_var<CurveSecp, 2, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
       return launch_mul_var<CurveSecp, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     }
     case CURVE_ED25519: return ed25519_mul_var_batch(pts, scalars, out, out_inf, n, st);
