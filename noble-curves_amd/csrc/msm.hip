@@ -2,6 +2,8 @@
 #include "msm.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -222,9 +224,13 @@ template <class C>
 __global__ void __launch_bounds__(256) k_msm_fixup_pass(uint32_t* __restrict__ part_pts,
                                                         const int* __restrict__ part_meta,
                                                         const uint32_t* __restrict__ bucket_start, MsmPlan pl,
-                                                        MsmSeg sg, int d) {
+                                                        MsmSeg sg, int d, uint32_t* __restrict__ pass_flags,
+                                                        int pass) {
   using G = MsmGroup<C>;
   constexpr int XW = G::ACC_WORDS;
+  // a run longer than 2d pieces is also longer than d: if the previous pass found nothing to
+  // add, neither will this one (wave-uniform early exit; flags are zeroed before the passes)
+  if (pass > 0 && pass_flags[pass - 1] == 0) return;
   const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
   if (s >= sg.nseg) return;
   const int* meta = part_meta + ((size_t)w * sg.nseg + s) * 4;
@@ -239,6 +245,7 @@ __global__ void __launch_bounds__(256) k_msm_fixup_pass(uint32_t* __restrict__ p
     const int s1 = (int)((bs[b + 1] - 1) / (uint32_t)sg.seg);
     const int idx = s - s0;
     if ((idx & (2 * d - 1)) != 0 || s + d > s1) continue;
+    pass_flags[pass] = 1;
     uint32_t* mine = pp + ((size_t)s * 2 + role) * XW;
     const uint32_t* other = pp + ((size_t)(s + d) * 2) * XW;  // always a head piece
     G::acc_store(mine, G::add(G::acc_load(mine), G::acc_load(other)));
@@ -358,13 +365,24 @@ int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) {
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct MsmLayout {
-  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, part_pts, part_meta, red0, red1, total;
+  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, part_pts, part_meta, pass_flags, red0, red1, total;
 };
 
 static MsmSeg msm_seg(const MsmPlan& pl) {
   MsmSeg sg;
   const char* env = std::getenv("NCG_MSM_SEG");
-  sg.seg = env ? std::max(1, std::atoi(env)) : 64;
+  if (env) {
+    sg.seg = std::max(1, std::atoi(env));
+  } else {
+    // 64 entries per lane at full size; fewer for small MSMs so that ~4 waves/SIMD stay busy
+    // (lanes = nwin*n/seg >= 262144), but never below 16 (every lane costs up to two fix-up adds)
+    long lanes_at_64 = (long)pl.nwin * pl.n / 64;
+    sg.seg = 64;
+    while (sg.seg > 16 && lanes_at_64 < 262144) {
+      sg.seg >>= 1;
+      lanes_at_64 <<= 1;
+    }
+  }
   sg.nseg = (pl.n + sg.seg - 1) / sg.seg;
   return sg;
 }
@@ -387,6 +405,7 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
   MsmSeg sg = msm_seg(pl);
   L.part_pts = take((size_t)pl.nwin * sg.nseg * 2 * MsmGroup<C>::ACC_WORDS * 4);
   L.part_meta = take((size_t)pl.nwin * sg.nseg * 4 * 4);
+  L.pass_flags = take(64 * 4);
   // fold ping-pong: level l output holds (l+1) * nwin * nb/2^l points <= nwin*nb (l = 1, 2)
   size_t red = (size_t)pl.nwin * std::max(pl.nb, pl.c) * MsmGroup<C>::ACC_WORDS * 4;
   L.red0 = take(red);
@@ -452,8 +471,13 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
     dim3 grid((sg.nseg + 255) / 256, pl.nwin);
     hipLaunchKernelGGL(k_msm_accum<C>, grid, dim3(256), 0, st, pts_mont, sorted, bstart, buckets, part_pts, part_meta,
                        pl, sg);
-    for (int d = 1; d < sg.nseg; d <<= 1)
-      hipLaunchKernelGGL(k_msm_fixup_pass<C>, grid, dim3(256), 0, st, part_pts, part_meta, bstart, pl, sg, d);
+    uint32_t* pass_flags = (uint32_t*)(base + L.pass_flags);
+    e = hipMemsetAsync(pass_flags, 0, 64 * 4, st);
+    if (e != hipSuccess) return e;
+    int pass = 0;
+    for (int d = 1; d < sg.nseg; d <<= 1, pass++)
+      hipLaunchKernelGGL(k_msm_fixup_pass<C>, grid, dim3(256), 0, st, part_pts, part_meta, bstart, pl, sg, d,
+                         pass_flags, pass);
     hipLaunchKernelGGL(k_msm_fixup_write<C>, grid, dim3(256), 0, st, part_pts, part_meta, buckets, pl, sg);
   }
   // fold: nb -> 1 per window in c-1 levels
@@ -475,7 +499,14 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
   if (e != hipSuccess) return e;
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
+  static const bool timing = std::getenv("NCG_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
   msm_host_finish<C>(fin, pl, out_affine_host, out_inf_host);
+  if (timing) {
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[ncg] msm host finish: %.1f us (c=%d nwin=%d)\n",
+            std::chrono::duration<double, std::micro>(t1 - t0).count(), pl.c, pl.nwin);
+  }
   return hipSuccess;
 }
 
