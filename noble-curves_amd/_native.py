@@ -22,7 +22,8 @@ class NativeError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libncg.so")
+    """In-tree library; NCG_LIB overrides it (A/B runs of alternative builds)."""
+    return os.environ.get("NCG_LIB") or os.path.join(_HERE, "libncg.so")
 
 
 _lib = None

@@ -144,8 +144,11 @@ struct MsmSeg {
   int nseg;   // lanes per window = ceil(n / seg)
 };
 
+#ifndef NCG_ACCUM_MINW
+#define NCG_ACCUM_MINW 1
+#endif
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_accum(const uint32_t* __restrict__ pts_mont,
+__global__ void __launch_bounds__(256, NCG_ACCUM_MINW) k_msm_accum(const uint32_t* __restrict__ pts_mont,
                                                    const uint32_t* __restrict__ sorted,
                                                    const uint32_t* __restrict__ bucket_start,
                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_pts,
