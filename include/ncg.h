@@ -73,6 +73,18 @@ int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_
                           const void* scalars_dev, void* out_affine_dev,
                           uint8_t* out_is_inf_dev, void* stream);
 
+/* ---- batch normalisation of projective points -----------------------------------------------
+ * (X, Y, Z) -> affine (x, y) = (X/Z, Y/Z) for a batch with one field inversion per 8 points:
+ * normalizeZ(c, points) / FpInvertBatch (src/abstract/curve.ts:311-326,
+ * src/abstract/modular.ts:728-760, toAffine(invZ) src/abstract/weierstrass.ts:951-969; the same
+ * map on Edwards extended points, src/abstract/edwards.ts:595-609).  Input wire: X || Y || Z,
+ * canonical residues (3 field elements per point).  Z = 0 (Weierstrass identity) gives (0,0)
+ * and out_is_inf = 1.  All four curves. */
+int ncg_normalize_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_proj, void* out_affine,
+                        uint8_t* out_is_inf);
+int ncg_normalize_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_proj_dev,
+                            void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream);
+
 /* ---- batch fixed-base scalar multiplication -----------------------------------------------
  * out[i] = scalars[i] * BASE.  Replaces, batch-wise, Point.BASE.multiply(k) / multiplyUnsafe(k)
  * through the cached window table (ScalarMultiplier.wnafCachedCT, src/abstract/curve.ts:588-606;

@@ -77,6 +77,8 @@ def load_library():
 
 _vp, _sz, _i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 _OPTIONAL_PROTOS = {
+    "ncg_normalize_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
+    "ncg_normalize_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_msm": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
     "ncg_msm_dev": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_msm_windows_dev": [_vp, _i32, _sz, _vp, _vp, _i32, _vp, _vp, _vp],
@@ -152,6 +154,18 @@ class Engine:
         if n:
             self._check(self.lib.ncg_mul_var_batch(self.h, curve, n, points.ctypes.data, scalars.ctypes.data,
                                                    out.ctypes.data, inf.ctypes.data))
+        return out, inf
+
+    def normalize_batch(self, curve, proj):
+        """proj uint8 [n, 3*FIELD_BYTES*(2 for Fp2)] (X || Y || Z) -> (affine [n, PB], is_inf [n])."""
+        pb = POINT_BYTES[curve]
+        proj = np.ascontiguousarray(proj, dtype=np.uint8).reshape(-1, pb // 2 * 3)
+        n = proj.shape[0]
+        out = np.empty((n, pb), dtype=np.uint8)
+        inf = np.empty((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_normalize_batch(self.h, curve, n, proj.ctypes.data, out.ctypes.data,
+                                                     inf.ctypes.data))
         return out, inf
 
     def mul_base_batch(self, curve, scalars):

@@ -302,6 +302,45 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
   return ncg_msm_dev(ctx, curve, n, d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
 }
 
+int ncg_normalize_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_proj_dev, void* out_affine_dev,
+                            uint8_t* out_is_inf_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (ncg_point_bytes(curve) == 0)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: normalize_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!points_proj_dev || !out_affine_dev || !out_is_inf_dev)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: normalize_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  NCG_HIP(ctx, ncg::normalize_batch(curve, (const uint32_t*)points_proj_dev, (uint32_t*)out_affine_dev, out_is_inf_dev,
+                                    (int)n, st));
+  return NCG_OK;
+}
+
+int ncg_normalize_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_proj, void* out_affine,
+                        uint8_t* out_is_inf) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  int pb = ncg_point_bytes(curve);
+  if (pb == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: normalize_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (!points_proj || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: normalize_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  size_t in_b = n * (size_t)(pb / 2) * 3, out_b = n * (size_t)pb, inf_b = (n + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, in_b + out_b + inf_b + 2048);
+  if (rc) return rc;
+  char* d_in = (char*)ctx->scratch;
+  char* d_out = d_in + ((in_b + 255) & ~(size_t)255);
+  char* d_inf = d_out + out_b;
+  NCG_HIP(ctx, hipMemcpyAsync(d_in, points_proj, in_b, hipMemcpyHostToDevice, ctx->stream));
+  rc = ncg_normalize_batch_dev(ctx, curve, n, d_in, d_out, (uint8_t*)d_inf, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
 static int ensure_ed_table(ncg_ctx* ctx) {
   if (ctx->ed_btab) return NCG_OK;
   uint32_t host[ncg::ED25519_BTAB_WORDS];

@@ -31,6 +31,31 @@ static hipError_t launch_mul_var(const uint32_t* pts, const uint32_t* scalars, u
   return hipGetLastError();
 }
 
+hipError_t normalize_batch(int curve, const uint32_t* proj_wire, uint32_t* out_wire, uint8_t* out_inf, int n,
+                           hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  switch (curve) {
+    case CURVE_SECP256K1:
+      hipLaunchKernelGGL((k_proj_batch_affine<FpSecp, 8>), dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, proj_wire,
+                         out_wire, out_inf, n);
+      break;
+    case CURVE_ED25519:
+      hipLaunchKernelGGL((k_proj_batch_affine<FpEd, 8>), dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, proj_wire,
+                         out_wire, out_inf, n);
+      break;
+    case CURVE_BLS12_381_G1:
+      hipLaunchKernelGGL((k_proj_batch_affine<FeBls, 8>), dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, proj_wire,
+                         out_wire, out_inf, n);
+      break;
+    case CURVE_BLS12_381_G2:
+      hipLaunchKernelGGL((k_proj_batch_affine<FeBls2, 4>), dim3(((n + 3) / 4 + 255) / 256), dim3(256), 0, st, proj_wire,
+                         out_wire, out_inf, n);
+      break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 size_t mul_var_tmp_bytes(int curve, int n) {
   switch (curve) {
     case CURVE_SECP256K1: return (size_t)n * 3 * FieldIO<CurveSecp::F>::WORDS * 4;

@@ -225,6 +225,50 @@ __global__ void __launch_bounds__(256) k_jac_batch_affine(const uint32_t* __rest
   }
 }
 
+// Batch normalisation of the reference's projective points (X, Y, Z) with x = X/Z, y = Y/Z -
+// normalizeZ / toAffine(invZ) (src/abstract/curve.ts:311-326, src/abstract/weierstrass.ts:951-969,
+// src/abstract/edwards.ts:595-609; the same map on Edwards (X, Y, Z, T)).  Wire input: X || Y || Z
+// canonical residues; Z = 0 is the Weierstrass identity and comes out as (0, 0) with the flag
+// set.  One inversion per K points (FpInvertBatch, src/abstract/modular.ts:728-760).
+template <class F, int K>
+__global__ void __launch_bounds__(256) k_proj_batch_affine(const uint32_t* __restrict__ proj_wire,
+                                                           uint32_t* __restrict__ out_wire,
+                                                           uint8_t* __restrict__ out_inf, int n) {
+  constexpr int WW = FieldWire<F>::WORDS;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i0 = t * K;
+  if (i0 >= n) return;
+  F pre[K];
+  F acc = F::one();
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    pre[j] = acc;
+    if (i0 + j < n) {
+      F z = FieldWire<F>::load(proj_wire + ((size_t)(i0 + j) * 3 + 2) * WW);
+      if (!f_eqz(z)) acc = acc * z;
+    }
+  }
+  F inv = f_inv(acc);
+#pragma unroll
+  for (int j = K - 1; j >= 0; j--) {
+    if (i0 + j < n) {
+      const uint32_t* p = proj_wire + (size_t)(i0 + j) * 3 * WW;
+      F z = FieldWire<F>::load(p + 2 * WW);
+      const bool inf = f_eqz(z);
+      F x = F::zero(), y = F::zero();
+      if (!inf) {
+        F zi = inv * pre[j];
+        inv = inv * z;
+        x = FieldWire<F>::load(p) * zi;
+        y = FieldWire<F>::load(p + WW) * zi;
+      }
+      FieldWire<F>::store(out_wire + (size_t)(i0 + j) * 2 * WW, x);
+      FieldWire<F>::store(out_wire + (size_t)(i0 + j) * 2 * WW + WW, y);
+      out_inf[i0 + j] = inf ? 1 : 0;
+    }
+  }
+}
+
 template <class C, int W, int MINW, bool JAC_OUT>
 __global__ void __launch_bounds__(64, MINW)
 k_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars,

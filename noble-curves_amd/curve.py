@@ -313,9 +313,28 @@ def multiplyBatch(c, points, scalars, engine=None):
 
 def normalizeZ(c, points):
     """curve.ts:311-326.  Points of this shim are always affine (Z = 1), so this validates and
-    returns equal points."""
+    returns equal points; use `normalizeProjective` for the reference's (X, Y, Z) triples."""
     validateMSMPoints(points, c)
     return list(points)
+
+
+def normalizeProjective(c, triples, engine=None):
+    """Batch (X, Y, Z) -> Point with x = X/Z, y = Y/Z: what normalizeZ / toAffine(invZ) compute for
+    the reference's projective points (curve.ts:311-326, weierstrass.ts:951-969, edwards.ts:595-609),
+    one shared inversion per 8 points on the GPU (FpInvertBatch, modular.ts:728-760)."""
+    fb, deg = c.Fp.BYTES, c.Fp.degree
+    if not triples:
+        return []
+    rows = []
+    for i, t in enumerate(triples):
+        if len(t) != 3 or not all(c.Fp.isValid(v) for v in t):
+            raise ValueError("invalid point at index %d" % i)
+        cs = [v for co in t for v in (co if deg == 2 else (co,))]
+        rows.append(b"".join(int(v).to_bytes(fb, "little") for v in cs))
+    arr = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(triples), -1)
+    eng = engine or get_engine()
+    out, inf = eng.normalize_batch(c.CURVE_ID, arr)
+    return [c._from_wire(out[i], bool(inf[i])) for i in range(len(triples))]
 
 
 # ---------------------------------------------------------------------------------- curve instances

@@ -162,3 +162,25 @@ def test_ed25519_mul_var_and_msm_gpu():
     assert wire_to_affine(ED25519, got) == acc.toAffine()
     got, ginf = eng.msm(ED25519, points_to_wire(ED25519, []), scalars_to_wire([]))
     assert wire_to_affine(ED25519, got) == (0, 1) and ginf
+
+
+def test_normalize_projective_batch():
+    """normalizeZ / FpInvertBatch (curve.ts:311-326, modular.ts:728-760): non-normalised
+    projective points (results of add/double, as in test/slow-curves.test.ts:220), ZERO inside
+    the batch (zero Z must not poison the shared inversion), odd batch sizes."""
+    from noble_curves_amd import curve as G
+    from oracle.curves import Ed25519
+    for Pt, M in ((Secp256k1, G.secp256k1_Point), (BlsG1, G.bls12_381_G1_Point), (BlsG2, G.bls12_381_G2_Point),
+                  (Ed25519, G.ed25519_Point)):
+        pts = []
+        acc = Pt.BASE
+        for i in range(21):
+            acc = acc.double().add(Pt.BASE) if i % 2 else acc.add(acc.double())
+            pts.append(acc)
+        if Pt is not Ed25519:
+            pts[3] = Pt.ZERO
+            pts[8] = Pt.BASE.add(Pt.BASE.negate())      # (X, Y, 0) with non-trivial X, Y
+        triples = [(p.X, p.Y, p.Z) for p in pts]
+        got = G.normalizeProjective(M, triples)
+        for p, g in zip(pts, got):
+            assert g.toAffine() == p.toAffine()
