@@ -43,6 +43,21 @@ NCG_DI EdExt<F> ed_dbl(const EdExt<F>& p) {
   return {E * Fq, G * H, Fq * G, E * H};
 }
 
+// The same doubling without T3 (3M + 4S): valid when the next operation is another doubling,
+// which never reads T.
+template <class F>
+NCG_DI EdExt<F> ed_dbl_no_t(const EdExt<F>& p) {
+  F A = f_sqr(p.X);
+  F B = f_sqr(p.Y);
+  F C = f_dbl(f_sqr(p.Z));
+  F D = f_neg(A);
+  F E = f_sqr(p.X + p.Y) - A - B;
+  F G = D + B;
+  F Fq = G - C;
+  F H = D - B;
+  return {E * Fq, G * H, Fq * G, p.T};
+}
+
 template <class F>
 NCG_DI EdNielsProj<F> ed_to_niels(const EdExt<F>& p, const F& d2) {
   return {p.Y + p.X, p.Y - p.X, p.Z, p.T * d2};

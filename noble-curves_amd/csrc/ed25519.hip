@@ -9,9 +9,10 @@
 //   strict mode only: A.isSmallOrder() rejects                                     (:980)
 //   accept iff [8](R + [k]A - [s]B) == O                                           (:985-988)
 // The reference computes [s]B with its cached window table (44 adds) and [k]A with a wNAF walk;
-// here both share ONE doubling chain (Straus): signed-odd windows of 3 bits for -A (4-entry
-// per-lane table in LDS, projective Niels form) and 6 bits for B (32 precomputed affine Niels
-// multiples shared by every lane), 258 doublings, 86 + 43 additions.
+// here both share ONE doubling chain (Straus): signed-odd windows of 2 bits for -A (2-entry
+// per-lane table in LDS, projective Niels form: 16 KB per wave, so 8-10 waves fit a CU - a 3-bit
+// window measured 1.7x slower for that reason) and 6 bits for B (32 precomputed affine Niels
+// multiples shared by every lane): 258 doublings, 129 + 43 additions.
 #include <mutex>
 #include <vector>
 
@@ -21,7 +22,11 @@
 
 namespace ncg {
 
-constexpr int ED_WA = 3, ED_WB = 6, ED_MA = 86, ED_MB = 43;  // 3*86 = 6*43 = 258 bits
+#ifndef NCG_ED_WA
+#define NCG_ED_WA 2
+#endif
+constexpr int ED_WA = NCG_ED_WA, ED_WB = 6, ED_MA = 258 / ED_WA, ED_MB = 43;  // WA*MA = 6*43 = 258 bits
+static_assert(ED_WA * ED_MA == 258 && ED_WB % ED_WA == 0, "window sizes must tile 258 bits");
 constexpr int ED_TA = 1 << (ED_WA - 1);                      // 4 entries: 1,3,5,7 times (-A)
 constexpr int ED_TB = 1 << (ED_WB - 1);                      // 32 entries: 1,3,..,63 times B
 constexpr int ED_LDS_WORDS = ED_TA * 32 * 64;
@@ -96,11 +101,12 @@ NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t
   for (int i = ED_MA - 1; i >= 0; i--) {
     if (i != ED_MA - 1) {
 #pragma unroll
-      for (int d = 0; d < ED_WA; d++) acc = ed_dbl(acc);
+      for (int d = 0; d < ED_WA - 1; d++) acc = ed_dbl_no_t(acc);
+      acc = ed_dbl(acc);
     }
     int dA = wk.pop();
     acc = ed_add_niels(acc, ed_load_niels(tab, stride, ((dA < 0 ? -dA : dA) - 1) >> 1), dA < 0);
-    if ((i & 1) == 0) {
+    if (i % (ED_WB / ED_WA) == 0) {
       int dB = ws.pop();
       const uint32_t* bp = btab + (((dB < 0 ? -dB : dB) - 1) >> 1) * 24;
       EdNielsAff<F> q{fp_load<PR>(bp), fp_load<PR>(bp + 8), fp_load<PR>(bp + 16)};
@@ -118,7 +124,10 @@ NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t
   return ok && ed_is_identity(acc);
 }
 
-__global__ void __launch_bounds__(64)
+#ifndef NCG_ED_MINW
+#define NCG_ED_MINW 1
+#endif
+__global__ void __launch_bounds__(64, NCG_ED_MINW)
 k_ed25519_verify(const uint32_t* __restrict__ sigs, const uint32_t* __restrict__ pks,
                  const uint32_t* __restrict__ ks, const uint32_t* __restrict__ btab, int zip215,
                  uint8_t* __restrict__ out_ok, int n) {
@@ -165,7 +174,8 @@ NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uin
   for (int i = ED_MA - 1; i >= 0; i--) {
     if (i != ED_MA - 1) {
 #pragma unroll
-      for (int d = 0; d < ED_WA; d++) acc = ed_dbl(acc);
+      for (int d = 0; d < ED_WA - 1; d++) acc = ed_dbl_no_t(acc);
+      acc = ed_dbl(acc);
     }
     int dA = wk.pop();
     acc = ed_add_niels(acc, ed_load_niels(tab, stride, ((dA < 0 ? -dA : dA) - 1) >> 1), dA < 0);
