@@ -390,6 +390,17 @@ def main():
         assert np.array_equal(got, expect), "ed25519 verdict mismatch vs construction"
         for i in list(range(0, 40)) + list(range(63, nv, max(64, nv // 16 // 64 * 64))):
             assert got[i] == eddsa_verify(Ed25519, sig_np[i].tobytes(), msgs[i], pk_np[i].tobytes(), zip215=True)
+        ed_cpu = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            done, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < args.cpu_seconds and done + 500 <= nv:
+                o_c = cport.ed25519_verify_batch(sig_np[done:done + 500], pk_np[done:done + 500], k_np[done:done + 500], True)
+                assert np.array_equal(o_c, got[done:done + 500]), "ed25519 sample mismatch vs oracle/c"
+                done += 500
+            dt = time.perf_counter() - t0
+            ed_cpu = {"value": done / dt, "unit": "verifies/s", "cores": 1, "kind": "port",
+                      "sample": "first %d signatures of the same batch through oracle/c (edwards.ts:942-989 restated, "
+                                "challenge pre-hashed), verdicts compared with the GPU's" % done}
         extra["ed25519_verify"] = {"metric": "ed25519_verifies_per_sec", "value": world * nv * K / wall,
                                    "unit": "verifies/s", "ms_per_batch": wall / K * 1e3, "sigs_per_gpu": nv,
                                    "note": "challenge k = SHA-512(R||A||M) mod L computed by the host shim (untimed); "
@@ -401,6 +412,8 @@ def main():
                                                 "valu": {"achieved_mac_per_s": 4.9e5 * nv / (ev_ms / K * 1e-3),
                                                          "peak_mac_per_s": INT_MAC_PEAK,
                                                          "frac": 4.9e5 * nv / (ev_ms / K * 1e-3) / INT_MAC_PEAK}}}
+        if ed_cpu:
+            extra["ed25519_verify"]["cpu_baseline"] = ed_cpu
 
     if extra:
         result["extra"] = extra

@@ -332,3 +332,219 @@ int orc_bls12_381_g1_multiply_unsafe(const uint8_t* pts, const uint8_t* scalars,
   }
   return 0;
 }
+
+/* ======================================================================================
+ * ed25519 verification (src/abstract/edwards.ts:942-989) - restated for CPU timing.
+ * Field: the NL = 4 Montgomery template over p = 2^255 - 19 (only its field functions are used);
+ * group law: dbl-2008-hwcd / add-2008-hwcd exactly as edwards.ts:505-545 (a = -1).
+ * ====================================================================================== */
+#define NL 4
+#define PFX(x) ed_##x
+#include "field_tmpl.h"
+#undef NL
+#undef PFX
+
+typedef struct { ed_fe X, Y, Z, T; } ed_ext;
+static ed_ctx ED;
+static ed_fe ED_D, ED_SQRT_M1, ED_ONE;
+static ed_ext ED_BASE;
+static uint8_t ED_L_BYTES[32];
+static int ed_inited = 0;
+
+static void ed_init_once(void) {
+  if (ed_inited) return;
+  fe_set_hex(ED.p.v, 4, "7fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffed");
+  pow2_mod(ED.r1.v, ED.p.v, 4, 256);
+  pow2_mod(ED.r2.v, ED.p.v, 4, 512);
+  ED.inv = neg_inv64(ED.p.v[0]);
+  ED_ONE = ED.r1;
+  ed_fe t;
+  fe_set_hex(t.v, 4, "52036cee2b6ffe738cc740797779e89800700a4d4141d8ab75eb4dca135978a3"); /* ed25519.ts:61 */
+  ed_tomont(&ED, &ED_D, &t);
+  fe_set_hex(t.v, 4, "2b8324804fc1df0b2b4d00993dfbd7a72f431806ad2fe478c4ee1b274a0ea0b0"); /* ed25519.ts:102-104 */
+  ed_tomont(&ED, &ED_SQRT_M1, &t);
+  fe_set_hex(t.v, 4, "216936d3cd6e53fec0a4e231fdd6dc5c692cc7609525a7b2c9562d608f25d51a");
+  ed_tomont(&ED, &ED_BASE.X, &t);
+  fe_set_hex(t.v, 4, "6666666666666666666666666666666666666666666666666666666666666658");
+  ed_tomont(&ED, &ED_BASE.Y, &t);
+  ED_BASE.Z = ED_ONE;
+  ed_mul(&ED, &ED_BASE.T, &ED_BASE.X, &ED_BASE.Y);
+  uint64_t l[4];
+  fe_set_hex(l, 4, "1000000000000000000000000000000014def9dea2f79cd65812631a5cf5d3ed");
+  memcpy(ED_L_BYTES, l, 32);
+  ed_inited = 1;
+}
+
+static void ed_ext_zero(ed_ext* r) { /* (0, 1, 1, 0) edwards.ts:370 */
+  memset(r, 0, sizeof *r);
+  r->Y = ED_ONE;
+  r->Z = ED_ONE;
+}
+static void ed_ext_double(ed_ext* r, const ed_ext* p) { /* edwards.ts:505-521 */
+  ed_fe A, B, C, D, E, G, F, H, t;
+  ed_mul(&ED, &A, &p->X, &p->X);
+  ed_mul(&ED, &B, &p->Y, &p->Y);
+  ed_mul(&ED, &C, &p->Z, &p->Z);
+  ed_add(&ED, &C, &C, &C);
+  ed_neg(&ED, &D, &A); /* a = -1 */
+  ed_add(&ED, &t, &p->X, &p->Y);
+  ed_mul(&ED, &E, &t, &t);
+  ed_sub(&ED, &E, &E, &A);
+  ed_sub(&ED, &E, &E, &B);
+  ed_add(&ED, &G, &D, &B);
+  ed_sub(&ED, &F, &G, &C);
+  ed_sub(&ED, &H, &D, &B);
+  ed_mul(&ED, &r->X, &E, &F);
+  ed_mul(&ED, &r->Y, &G, &H);
+  ed_mul(&ED, &r->T, &E, &H);
+  ed_mul(&ED, &r->Z, &F, &G);
+}
+static void ed_ext_add(ed_ext* r, const ed_ext* p, const ed_ext* q) { /* edwards.ts:526-545 */
+  ed_fe A, B, C, D, E, F, G, H, t, u;
+  ed_mul(&ED, &A, &p->X, &q->X);
+  ed_mul(&ED, &B, &p->Y, &q->Y);
+  ed_mul(&ED, &C, &p->T, &ED_D);
+  ed_mul(&ED, &C, &C, &q->T);
+  ed_mul(&ED, &D, &p->Z, &q->Z);
+  ed_add(&ED, &t, &p->X, &p->Y);
+  ed_add(&ED, &u, &q->X, &q->Y);
+  ed_mul(&ED, &E, &t, &u);
+  ed_sub(&ED, &E, &E, &A);
+  ed_sub(&ED, &E, &E, &B);
+  ed_sub(&ED, &F, &D, &C);
+  ed_add(&ED, &G, &D, &C);
+  ed_add(&ED, &H, &B, &A); /* B - a*A, a = -1 */
+  ed_mul(&ED, &r->X, &E, &F);
+  ed_mul(&ED, &r->Y, &G, &H);
+  ed_mul(&ED, &r->T, &E, &H);
+  ed_mul(&ED, &r->Z, &F, &G);
+}
+static void ed_ext_neg(ed_ext* r, const ed_ext* p) {
+  *r = *p;
+  ed_neg(&ED, &r->X, &p->X);
+  ed_neg(&ED, &r->T, &p->T);
+}
+static int ed_ext_is0(const ed_ext* p) { /* equals(ZERO): X*1 == 0*Z and Y*1 == 1*Z */
+  return ed_is0(&p->X) && ed_eq(&p->Y, &p->Z);
+}
+static void ed_pow2k(ed_fe* r, const ed_fe* x, int k) {
+  *r = *x;
+  for (int i = 0; i < k; i++) ed_mul(&ED, r, r, r);
+}
+/* ed25519.ts:67-86 */
+static void ed_pow_p58(ed_fe* out, const ed_fe* x) {
+  ed_fe x2, b2, b4, b5, b10, b20, b40, b80, b160, b240, b250, t;
+  ed_mul(&ED, &x2, x, x);
+  ed_mul(&ED, &b2, &x2, x);
+  ed_pow2k(&t, &b2, 2); ed_mul(&ED, &b4, &t, &b2);
+  ed_pow2k(&t, &b4, 1); ed_mul(&ED, &b5, &t, x);
+  ed_pow2k(&t, &b5, 5); ed_mul(&ED, &b10, &t, &b5);
+  ed_pow2k(&t, &b10, 10); ed_mul(&ED, &b20, &t, &b10);
+  ed_pow2k(&t, &b20, 20); ed_mul(&ED, &b40, &t, &b20);
+  ed_pow2k(&t, &b40, 40); ed_mul(&ED, &b80, &t, &b40);
+  ed_pow2k(&t, &b80, 80); ed_mul(&ED, &b160, &t, &b80);
+  ed_pow2k(&t, &b160, 80); ed_mul(&ED, &b240, &t, &b80);
+  ed_pow2k(&t, &b240, 10); ed_mul(&ED, &b250, &t, &b10);
+  ed_pow2k(&t, &b250, 2); ed_mul(&ED, out, &t, x);
+}
+/* ed25519.ts:107-125 */
+static int ed_uv_ratio(ed_fe* xout, const ed_fe* u, const ed_fe* v) {
+  ed_fe v3, v7, pw, x, vx2, root2, negu, t;
+  ed_mul(&ED, &v3, v, v); ed_mul(&ED, &v3, &v3, v);
+  ed_mul(&ED, &v7, &v3, &v3); ed_mul(&ED, &v7, &v7, v);
+  ed_mul(&ED, &t, u, &v7);
+  ed_pow_p58(&pw, &t);
+  ed_mul(&ED, &x, u, &v3); ed_mul(&ED, &x, &x, &pw);
+  ed_mul(&ED, &vx2, &x, &x); ed_mul(&ED, &vx2, &vx2, v);
+  ed_mul(&ED, &root2, &x, &ED_SQRT_M1);
+  ed_neg(&ED, &negu, u);
+  int useRoot1 = ed_eq(&vx2, u), useRoot2 = ed_eq(&vx2, &negu);
+  ed_mul(&ED, &t, &negu, &ED_SQRT_M1);
+  int noRoot = ed_eq(&vx2, &t);
+  if (useRoot2 || noRoot) x = root2;
+  ed_fe xc;
+  ed_frommont(&ED, &xc, &x);
+  if (xc.v[0] & 1) ed_neg(&ED, &x, &x);
+  *xout = x;
+  return useRoot1 || useRoot2;
+}
+/* edwards.ts:405-436 */
+static int ed_from_bytes(ed_ext* P, const uint8_t* b, int zip215) {
+  uint8_t n[32];
+  memcpy(n, b, 32);
+  int sign = (n[31] & 0x80) != 0;
+  n[31] &= 0x7f;
+  ed_fe yraw, y, y2, u, v, x;
+  memcpy(&yraw, n, 32);
+  if (!zip215) { /* y < p */
+    int lt = 0;
+    for (int i = 3; i >= 0; i--) {
+      if (yraw.v[i] != ED.p.v[i]) { lt = yraw.v[i] < ED.p.v[i]; break; }
+    }
+    if (!lt) return 0;
+  }
+  ed_tomont(&ED, &y, &yraw);
+  ed_mul(&ED, &y2, &y, &y);
+  ed_sub(&ED, &u, &y2, &ED_ONE);
+  ed_mul(&ED, &v, &ED_D, &y2);
+  ed_add(&ED, &v, &v, &ED_ONE);
+  if (!ed_uv_ratio(&x, &u, &v)) return 0;
+  int x0 = ed_is0(&x);
+  if (!zip215 && x0 && sign) return 0;
+  if (sign && !x0) ed_neg(&ED, &x, &x);
+  P->X = x; P->Y = y; P->Z = ED_ONE;
+  ed_mul(&ED, &P->T, &x, &y);
+  return 1;
+}
+/* wNAF-4 walk (curve.ts:820-836 with one point), scalar as nbytes LE */
+static void ed_mul_unsafe(ed_ext* out, const ed_ext* p, const uint8_t* k, int nbytes) {
+  ed_ext table[4], dbl, acc, item;
+  int8_t digits[600];
+  ed_ext_double(&dbl, p);
+  table[0] = *p;
+  for (int j = 1; j < 4; j++) ed_ext_add(&table[j], &table[j - 1], &dbl);
+  int len = ed_wnaf4(digits, k, nbytes);
+  ed_ext_zero(&acc);
+  for (int bit = len - 1; bit >= 0; bit--) {
+    if (bit != len - 1) ed_ext_double(&acc, &acc);
+    int w = digits[bit];
+    if (w) {
+      item = table[((w < 0 ? -w : w) - 1) >> 1];
+      if (w < 0) ed_ext_neg(&item, &item);
+      ed_ext_add(&acc, &acc, &item);
+    }
+  }
+  *out = acc;
+}
+/* eddsa.verify (edwards.ts:942-989) with the challenge k already hashed (32 bytes LE, < L) */
+int orc_ed25519_verify_batch(const uint8_t* sigs, const uint8_t* pks, const uint8_t* ks, int zip215, uint8_t* out,
+                             size_t n) {
+  init_once();
+  ed_init_once();
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t *sig = sigs + 64 * i, *pk = pks + 32 * i, *k = ks + 32 * i;
+    ed_ext A, R, SB, kA, RkA, t;
+    out[i] = 0;
+    if (!ed_from_bytes(&A, pk, zip215)) continue;
+    if (!ed_from_bytes(&R, sig, zip215)) continue;
+    /* s < L (BASE.multiplyUnsafe throws otherwise, edwards.ts:573) */
+    int lt = 0;
+    for (int j = 31; j >= 0; j--) {
+      if (sig[32 + j] != ED_L_BYTES[j]) { lt = sig[32 + j] < ED_L_BYTES[j]; break; }
+    }
+    if (!lt) continue;
+    ed_mul_unsafe(&SB, &ED_BASE, sig + 32, 32);
+    if (!zip215) { /* isSmallOrder */
+      ed_ext_double(&t, &A); ed_ext_double(&t, &t); ed_ext_double(&t, &t);
+      if (ed_ext_is0(&t)) continue;
+    }
+    if (is_zero_bytes(k, 32)) ed_ext_zero(&kA);
+    else ed_mul_unsafe(&kA, &A, k, 32);
+    ed_ext_add(&RkA, &R, &kA);
+    ed_ext_neg(&t, &SB);
+    ed_ext_add(&t, &RkA, &t);
+    ed_ext_double(&t, &t); ed_ext_double(&t, &t); ed_ext_double(&t, &t);
+    out[i] = (uint8_t)ed_ext_is0(&t);
+  }
+  return 0;
+}

@@ -22,6 +22,7 @@ def lib():
             getattr(L, name).argtypes = [vp, vp, vp, vp, sz]
         for name in ("orc_bls12_381_g1_pippenger", "orc_secp256k1_pippenger"):
             getattr(L, name).argtypes = [vp, vp, sz, vp, vp]
+        L.orc_ed25519_verify_batch.argtypes = [vp, vp, vp, ctypes.c_int, vp, sz]
         _lib = L
     return _lib
 
@@ -50,3 +51,12 @@ def pippenger(curve_name, pts_wire, scalars_wire):
     fn = getattr(lib(), "orc_%s_pippenger" % curve_name)
     fn(pts.ctypes.data, sc.ctypes.data, n, out.ctypes.data, inf.ctypes.data)
     return out, bool(inf[0])
+
+
+def ed25519_verify_batch(sigs, pks, ks, zip215=True):
+    sigs, pks, ks = _u8(sigs, 64), _u8(pks, 32), _u8(ks, 32)
+    n = sigs.shape[0]
+    out = np.zeros((n,), np.uint8)
+    lib().orc_ed25519_verify_batch(sigs.ctypes.data, pks.ctypes.data, ks.ctypes.data, 1 if zip215 else 0,
+                                   out.ctypes.data, n)
+    return out.astype(bool)

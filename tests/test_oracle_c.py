@@ -54,3 +54,19 @@ def test_c_pippenger_vs_python(name, curve, Pt, n):
     assert wire_to_affine(curve, out) == exp and inf == (exp == (0, 0))
     out, inf = cport.pippenger(name, points_to_wire(curve, []), scalars_to_wire([]))
     assert inf
+
+
+def test_c_ed25519_verify_vs_python_both_modes():
+    import numpy as np
+    from oracle.curves import Ed25519
+    from oracle.edwards import eddsa_hash_k, eddsa_verify
+    from test_host_logic import _ed_cases
+    cases = _ed_cases()
+    sig = np.array([np.frombuffer(c[0], np.uint8) for c in cases])
+    pk = np.array([np.frombuffer(c[2], np.uint8) for c in cases])
+    ks = np.array([np.frombuffer(eddsa_hash_k(Ed25519.Fn, c[0][:32], c[2], c[1]).to_bytes(32, "little"), np.uint8)
+                   for c in cases])
+    for zip215 in (True, False):
+        got = cport.ed25519_verify_batch(sig, pk, ks, zip215)
+        exp = [eddsa_verify(Ed25519, c[0], c[1], c[2], zip215=zip215) for c in cases]
+        assert list(got) == exp
