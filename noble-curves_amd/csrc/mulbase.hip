@@ -85,37 +85,37 @@ static hipError_t build_table_t(int curve, const uint32_t* base_wire, uint32_t* 
     uint32_t* s = &h_sc[(size_t)w * 8];
     if (w < 32) {
       s[(8 * w) / 32] = 1u << ((8 * w) % 32);
-    } else {  // 2^256 mod order = 2^256 - order * floor(2^256 / order); floor = 1 for secp256k1, 2 for r
-      uint64_t bw = 0;
-      uint32_t t[8];
+    } else {
+      // 2^256 mod order = 2^256 - q*order with q = floor(2^256 / order): 1 for secp256k1's n, 2 for
+      // bls12-381's r; computed as the two's complement of q*order in 256 bits
       const int q = curve == CURVE_SECP256K1 ? 1 : 2;
-      for (int rep = 0; rep < 1; rep++) {
-        // t = -(q * order) mod 2^256
-        uint64_t cy = 0;
-        uint32_t qo[8];
-        for (int i = 0; i < 8; i++) {
-          cy += (uint64_t)order[i] * q;
-          qo[i] = (uint32_t)cy;
-          cy >>= 32;
-        }
-        for (int i = 0; i < 8; i++) {
-          uint64_t d = (uint64_t)0 - qo[i] - bw;
-          t[i] = (uint32_t)d;
-          bw = (d >> 32) & 1;
-        }
+      uint64_t cy = 0, bw = 0;
+      for (int i = 0; i < 8; i++) {
+        cy += (uint64_t)order[i] * q;
+        uint64_t d = (uint64_t)0 - (uint32_t)cy - bw;
+        s[i] = (uint32_t)d;
+        bw = (d >> 32) & 1;
+        cy >>= 32;
       }
-      for (int i = 0; i < 8; i++) s[i] = t[i];
     }
   }
-  uint32_t *d_pts = nullptr, *d_sc = nullptr, *d_out = nullptr, *d_jac = nullptr;
-  uint8_t* d_inf = nullptr;
+  struct DevBuf {  // frees on every exit path
+    void* p = nullptr;
+    ~DevBuf() {
+      if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  } b_pts, b_sc, b_out, b_inf, b_jac;
   size_t pts_b = (size_t)NT * 2 * WW * 4, sc_b = (size_t)NT * 32;
   hipError_t e;
-  if ((e = hipMalloc((void**)&d_pts, pts_b)) != hipSuccess) return e;
-  if ((e = hipMalloc((void**)&d_sc, sc_b)) != hipSuccess) return e;
-  if ((e = hipMalloc((void**)&d_out, pts_b)) != hipSuccess) return e;
-  if ((e = hipMalloc((void**)&d_inf, NT)) != hipSuccess) return e;
-  if ((e = hipMalloc((void**)&d_jac, mul_var_tmp_bytes(curve, NT))) != hipSuccess) return e;
+  if ((e = b_pts.alloc(pts_b)) != hipSuccess) return e;
+  if ((e = b_sc.alloc(sc_b)) != hipSuccess) return e;
+  if ((e = b_out.alloc(pts_b)) != hipSuccess) return e;
+  if ((e = b_inf.alloc(NT)) != hipSuccess) return e;
+  if ((e = b_jac.alloc(mul_var_tmp_bytes(curve, NT))) != hipSuccess) return e;
+  uint32_t *d_pts = (uint32_t*)b_pts.p, *d_sc = (uint32_t*)b_sc.p, *d_out = (uint32_t*)b_out.p,
+           *d_jac = (uint32_t*)b_jac.p;
+  uint8_t* d_inf = (uint8_t*)b_inf.p;
   // step 1: B_w = 2^(8w) * BASE
   (void)hipMemcpyAsync(d_pts, h_pts.data(), (size_t)NB * 2 * WW * 4, hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(d_sc, h_sc.data(), (size_t)NB * 32, hipMemcpyHostToDevice, st);
@@ -137,13 +137,7 @@ static hipError_t build_table_t(int curve, const uint32_t* base_wire, uint32_t* 
   e = mul_var_batch(curve, d_pts, d_sc, d_out, d_inf, NT, d_jac, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_wire_to_storage<C>, dim3((NT + 255) / 256), dim3(256), 0, st, d_out, d_table, NT);
-  e = hipStreamSynchronize(st);
-  (void)hipFree(d_pts);
-  (void)hipFree(d_sc);
-  (void)hipFree(d_out);
-  (void)hipFree(d_inf);
-  (void)hipFree(d_jac);
-  return e;
+  return hipStreamSynchronize(st);
 }
 
 size_t mul_base_table_bytes(int curve) {
