@@ -226,11 +226,69 @@ NCG_DI void fp_fold_reduce(uint32_t (&r)[8], const uint32_t (&T)[16]) {
   for (int k = 0; k < PR::FINAL_SUBS; k++) fp_cond_sub_p<PR>(r, 0u);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NCG_NO_ASM_PRODUCT)
+// acc (96 bits: lo64 + ex) += a*b.  v_mad_u64_u32 adds the 64-bit product into lo64 and reports
+// the carry in VCC; one v_addc folds it into `ex`.  Two instructions per partial product instead of
+// three (mad + two carry adds), and no SGPR-carried chains (which cost s_nop hazard padding).
+__device__ __forceinline__ void mac96(uint64_t& lo64, uint32_t& ex, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(lo64), "+v"(ex)
+      : "v"(a), "v"(b)
+      : "vcc");
+}
+// 512-bit product by columns (product scanning): T[k] = low word of column k after carries.
+template <int N>
+__device__ __forceinline__ void mul_columns_asm(uint32_t (&T)[2 * N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+  uint64_t lo = 0;
+  uint32_t ex = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; k++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < N) mac96(lo, ex, a[i], b[j]);
+    }
+    T[k] = (uint32_t)lo;
+    lo = (lo >> 32) | ((uint64_t)ex << 32);
+    ex = 0;
+  }
+  T[2 * N - 1] = (uint32_t)lo;
+}
+// Square by columns: off-diagonal products once, the 96-bit column sum doubled, then the
+// diagonal term and the carry from the previous column.
+template <int N>
+__device__ __forceinline__ void sqr_columns_asm(uint32_t (&T)[2 * N], const uint32_t (&a)[N]) {
+  uint64_t carry = 0;  // (column sum) >> 32 of the previous column, below 2^64
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; k++) {
+    uint64_t lo = 0;
+    uint32_t ex = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int j = k - i;
+      if (j > i && j < N) mac96(lo, ex, a[i], a[j]);
+    }
+    // double the off-diagonal sum (below 2^67, so nothing is shifted out of ex)
+    ex = (ex << 1) | (uint32_t)(lo >> 63);
+    lo <<= 1;
+    if ((k & 1) == 0) mac96(lo, ex, a[k / 2], a[k / 2]);
+    uint64_t nl = lo + carry;
+    ex += nl < lo ? 1u : 0u;
+    T[k] = (uint32_t)nl;
+    carry = (nl >> 32) | ((uint64_t)ex << 32);
+  }
+  T[2 * N - 1] = (uint32_t)carry;
+}
+#endif
+
 template <class PR>
 NCG_DI void fp_mul_fold_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], const uint32_t (&b)[PR::N]) {
   static_assert(PR::N == 8, "fold path is for 256-bit special primes");
   constexpr int N = 8;
   uint32_t T[2 * N];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NCG_NO_ASM_PRODUCT)
+  mul_columns_asm<N>(T, a, b);
+#else
 #pragma unroll
   for (int i = 0; i < 2 * N; i++) T[i] = 0;
   // 512-bit product, two carry chains per row
@@ -252,6 +310,7 @@ NCG_DI void fp_mul_fold_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], c
     for (int j = 0; j < N; j++) T[i + j + 1] = __builtin_addc(T[i + j + 1], hi[j], c, &c);
     if (i + N + 1 < 2 * N) T[i + N + 1] += c;
   }
+#endif
   fp_fold_reduce<PR>(r, T);
 }
 
@@ -262,6 +321,15 @@ NCG_DI void fp_sqr_fold_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N]) {
   static_assert(PR::N == 8, "fold path is for 256-bit special primes");
   constexpr int N = 8;
   uint32_t T[2 * N];
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NCG_ASM_SQR)
+#if NCG_ASM_SQR == 2
+  mul_columns_asm<N>(T, a, a);
+#else
+  sqr_columns_asm<N>(T, a);
+#endif
+  fp_fold_reduce<PR>(r, T);
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < 2 * N; i++) T[i] = 0;
 #pragma unroll
