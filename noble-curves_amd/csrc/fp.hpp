@@ -125,6 +125,54 @@ NCG_DI Fp<PR> fp_dbl(const Fp<PR>& a) {
   return a + a;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NCG_NO_ASM_PRODUCT)
+// acc (96 bits: lo64 + ex) += a*b.  v_mad_u64_u32 adds the 64-bit product into lo64 and reports
+// the carry in VCC; one v_addc folds it into `ex`.  Two instructions per partial product instead of
+// three (mad + two carry adds), and no SGPR-carried chains (which cost s_nop hazard padding).
+__device__ __forceinline__ void mac96(uint64_t& lo64, uint32_t& ex, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(lo64), "+v"(ex)
+      : "v"(a), "v"(b)
+      : "vcc");
+}
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NCG_NO_ASM_PRODUCT)
+// Montgomery product by columns (finely integrated product scanning) on the 96-bit accumulator:
+// 2N^2 + N multiplies, one carry instruction per multiply.
+template <class PR>
+__device__ __forceinline__ void fp_mul_fips_asm(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N],
+                                                const uint32_t (&b)[PR::N]) {
+  constexpr int N = PR::N;
+  uint32_t q[N];
+  uint64_t lo = 0;
+  uint32_t ex = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) mac96(lo, ex, a[i], b[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; i++) mac96(lo, ex, q[i], (uint32_t)PR::P[k - i]);
+    q[k] = (uint32_t)lo * PR::INV;
+    mac96(lo, ex, q[k], (uint32_t)PR::P[0]);
+    lo = (lo >> 32) | ((uint64_t)ex << 32);
+    ex = 0;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) mac96(lo, ex, a[i], b[k - i]);
+#pragma unroll
+    for (int i = k - N + 1; i < N; i++) mac96(lo, ex, q[i], (uint32_t)PR::P[k - i]);
+    r[k - N] = (uint32_t)lo;
+    lo = (lo >> 32) | ((uint64_t)ex << 32);
+    ex = 0;
+  }
+  r[N - 1] = (uint32_t)lo;
+  fp_cond_sub_p<PR>(r, (uint32_t)(lo >> 32));
+}
+#endif
+
 // Montgomery product a*b*R^-1 mod p, CIOS with two carry chains per row
 // (lo-half chain and hi-half chain of the N partial products).
 template <class PR>
@@ -227,15 +275,6 @@ NCG_DI void fp_fold_reduce(uint32_t (&r)[8], const uint32_t (&T)[16]) {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(NCG_NO_ASM_PRODUCT)
-// acc (96 bits: lo64 + ex) += a*b.  v_mad_u64_u32 adds the 64-bit product into lo64 and reports
-// the carry in VCC; one v_addc folds it into `ex`.  Two instructions per partial product instead of
-// three (mad + two carry adds), and no SGPR-carried chains (which cost s_nop hazard padding).
-__device__ __forceinline__ void mac96(uint64_t& lo64, uint32_t& ex, uint32_t a, uint32_t b) {
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(lo64), "+v"(ex)
-      : "v"(a), "v"(b)
-      : "vcc");
-}
 // 512-bit product by columns (product scanning): T[k] = low word of column k after carries.
 template <int N>
 __device__ __forceinline__ void mul_columns_asm(uint32_t (&T)[2 * N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
@@ -370,16 +409,30 @@ NCG_DI void fp_sqr_fold_body(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N]) {
 template <class PR>
 NCG_MULFN Fp<PR> fp_mul(Fp<PR> a, Fp<PR> b) {  // modular.ts:956
   Fp<PR> r;
-  if constexpr (PR::FOLD) fp_mul_fold_body<PR>(r.v, a.v, b.v);
-  else fp_mul_body<PR>(r.v, a.v, b.v);
+  if constexpr (PR::FOLD) {
+    fp_mul_fold_body<PR>(r.v, a.v, b.v);
+  } else {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NCG_NO_ASM_PRODUCT)
+    fp_mul_fips_asm<PR>(r.v, a.v, b.v);
+#else
+    fp_mul_body<PR>(r.v, a.v, b.v);
+#endif
+  }
   return r;
 }
 
 template <class PR>
 NCG_MULFN Fp<PR> fp_sqr(Fp<PR> a) {  // modular.ts:947
   Fp<PR> r;
-  if constexpr (PR::FOLD) fp_sqr_fold_body<PR>(r.v, a.v);
-  else fp_mul_body<PR>(r.v, a.v, a.v);
+  if constexpr (PR::FOLD) {
+    fp_sqr_fold_body<PR>(r.v, a.v);
+  } else {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(NCG_NO_ASM_PRODUCT)
+    fp_mul_fips_asm<PR>(r.v, a.v, a.v);
+#else
+    fp_mul_body<PR>(r.v, a.v, a.v);
+#endif
+  }
   return r;
 }
 
