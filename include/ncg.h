@@ -85,6 +85,23 @@ int ncg_normalize_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_pr
 int ncg_normalize_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_proj_dev,
                             void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream);
 
+/* ---- batch point decoding (decompression + validity checks) ---------------------------------
+ * out[i] = Point.fromBytes(encoded[i]) as an affine wire point, out_ok[i] = 0 where the reference
+ * throws.  Encodings (fixed size per curve):
+ *   NCG_SECP256K1     33 bytes SEC1 compressed (src/abstract/weierstrass.ts:566-605,
+ *                     sqrt src/secp256k1.ts:73-95)
+ *   NCG_BLS12_381_G1  48 bytes compressed with flag bits (src/bls12-381.ts:377-459); includes
+ *                     the prime-order-subgroup check of assertValidity (:567-577); the
+ *                     canonical infinity encoding gives out_is_inf = 1
+ *   NCG_ED25519       32 bytes (src/abstract/edwards.ts:405-436); flags bit 0 = zip215
+ * out_is_inf may be NULL in the host-pointer variant.  G2 is not supported yet. */
+#define NCG_DECODE_ZIP215 1
+int ncg_decode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* encoded, int flags,
+                            void* out_affine, uint8_t* out_ok, uint8_t* out_is_inf);
+int ncg_decode_points_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* encoded_dev, int flags,
+                                void* out_affine_dev, uint8_t* out_ok_dev, uint8_t* out_is_inf_dev,
+                                void* stream);
+
 /* ---- batch fixed-base scalar multiplication -----------------------------------------------
  * out[i] = scalars[i] * BASE.  Replaces, batch-wise, Point.BASE.multiply(k) / multiplyUnsafe(k)
  * through the cached window table (ScalarMultiplier.wnafCachedCT, src/abstract/curve.ts:588-606;

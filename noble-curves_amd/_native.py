@@ -77,6 +77,8 @@ def load_library():
 
 _vp, _sz, _i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 _OPTIONAL_PROTOS = {
+    "ncg_decode_points_batch": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp],
+    "ncg_decode_points_batch_dev": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp, _vp],
     "ncg_normalize_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
     "ncg_normalize_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_msm": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
@@ -155,6 +157,20 @@ class Engine:
             self._check(self.lib.ncg_mul_var_batch(self.h, curve, n, points.ctypes.data, scalars.ctypes.data,
                                                    out.ctypes.data, inf.ctypes.data))
         return out, inf
+
+    def decode_points_batch(self, curve, encoded, zip215=False):
+        """encoded uint8 [n, 33|32|48] -> (affine [n, PB], ok [n] bool, is_inf [n] bool)."""
+        enc_bytes = {SECP256K1: 33, ED25519: 32, BLS12_381_G1: 48}[curve]
+        pb = POINT_BYTES[curve]
+        enc = np.ascontiguousarray(encoded, dtype=np.uint8).reshape(-1, enc_bytes)
+        n = enc.shape[0]
+        out = np.zeros((n, pb), dtype=np.uint8)
+        ok = np.zeros((n,), dtype=np.uint8)
+        inf = np.zeros((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_decode_points_batch(self.h, curve, n, enc.ctypes.data, 1 if zip215 else 0,
+                                                         out.ctypes.data, ok.ctypes.data, inf.ctypes.data))
+        return out, ok.astype(bool), inf.astype(bool)
 
     def normalize_batch(self, curve, proj):
         """proj uint8 [n, 3*FIELD_BYTES*(2 for Fp2)] (X || Y || Z) -> (affine [n, PB], is_inf [n])."""

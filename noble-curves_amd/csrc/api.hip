@@ -341,6 +341,48 @@ int ncg_normalize_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_pr
   return NCG_OK;
 }
 
+int ncg_decode_points_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* encoded_dev, int flags,
+                                void* out_affine_dev, uint8_t* out_ok_dev, uint8_t* out_is_inf_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (ncg::decode_in_bytes(curve) == 0)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: decode_points_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!encoded_dev || !out_affine_dev || !out_ok_dev || !out_is_inf_dev)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: decode_points_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  NCG_HIP(ctx, ncg::decode_points_batch(curve, (const uint8_t*)encoded_dev, flags, (uint32_t*)out_affine_dev, out_ok_dev,
+                                        out_is_inf_dev, (int)n, st));
+  return NCG_OK;
+}
+
+int ncg_decode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* encoded, int flags, void* out_affine,
+                            uint8_t* out_ok, uint8_t* out_is_inf) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  int ib = ncg::decode_in_bytes(curve), pb = ncg_point_bytes(curve);
+  if (ib == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: decode_points_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (!encoded || !out_affine || !out_ok)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: decode_points_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  size_t in_b = (n * ib + 255) & ~(size_t)255, out_b = n * (size_t)pb, fl_b = (n + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, in_b + out_b + 2 * fl_b + 1024);
+  if (rc) return rc;
+  char* d_in = (char*)ctx->scratch;
+  char* d_out = d_in + in_b;
+  char* d_ok = d_out + out_b;
+  char* d_inf = d_ok + fl_b;
+  NCG_HIP(ctx, hipMemcpyAsync(d_in, encoded, n * ib, hipMemcpyHostToDevice, ctx->stream));
+  rc = ncg_decode_points_batch_dev(ctx, curve, n, d_in, flags, d_out, (uint8_t*)d_ok, (uint8_t*)d_inf, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipMemcpyAsync(out_ok, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
 static int ensure_ed_table(ncg_ctx* ctx) {
   if (ctx->ed_btab) return NCG_OK;
   uint32_t host[ncg::ED25519_BTAB_WORDS];

@@ -1,0 +1,256 @@
+// Batch point decoding (decompression + validity), SURVEY 8(f) row 1: the step on the input
+// side of every batch op (wire bytes -> affine point).
+//
+//   secp256k1  SEC1 compressed, 33 bytes: Point.fromBytes -> pointFromBytes
+//              (src/abstract/weierstrass.ts:566-605) + sqrtMod (src/secp256k1.ts:73-95);
+//              assertValidity (:748-766) holds by construction (h = 1)
+//   bls12-381 G1 compressed, 48 bytes: coder.decode (src/bls12-381.ts:377-433, flags :436-459,
+//              sortBit :346-351) + assertValidity incl. the subgroup check isTorsionFree
+//              [x^2]P == phi(P) (src/bls12-381.ts:567-577)
+//   ed25519    32 bytes: Point.fromBytes(bytes, zip215) (src/abstract/edwards.ts:405-436)
+// out_ok[i] = 0 exactly where the reference throws; the affine output is then (0,0).
+#include <vector>
+
+#include "curves.hpp"
+#include "host_api.hpp"
+
+namespace ncg {
+
+// ---------------------------------------------------------------------------- secp256k1
+// y = sqrt(v) = v^((p+1)/4) by the reference's addition chain (secp256k1.ts:73-95)
+NCG_DI FpSecp secp_sqrt_candidate(const FpSecp& y) {
+  using PR = ParamsSecpP;
+  FpSecp b2 = fp_sqr<PR>(y) * y;
+  FpSecp b3 = fp_sqr<PR>(b2) * y;
+  FpSecp b6 = fp_sqr_n<PR>(b3, 3) * b3;
+  FpSecp b9 = fp_sqr_n<PR>(b6, 3) * b3;
+  FpSecp b11 = fp_sqr_n<PR>(b9, 2) * b2;
+  FpSecp b22 = fp_sqr_n<PR>(b11, 11) * b11;
+  FpSecp b44 = fp_sqr_n<PR>(b22, 22) * b22;
+  FpSecp b88 = fp_sqr_n<PR>(b44, 44) * b44;
+  FpSecp b176 = fp_sqr_n<PR>(b88, 88) * b88;
+  FpSecp b220 = fp_sqr_n<PR>(b176, 44) * b44;
+  FpSecp b223 = fp_sqr_n<PR>(b220, 3) * b3;
+  FpSecp t1 = fp_sqr_n<PR>(b223, 23) * b22;
+  FpSecp t2 = fp_sqr_n<PR>(t1, 6) * b2;
+  return fp_sqr_n<PR>(t2, 2);
+}
+
+// in: 33 bytes (02/03 || x big-endian); out: x || y wire (LE limbs)
+NCG_DI bool secp_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict__ out) {
+  using PR = ParamsSecpP;
+  const uint8_t head = in[0];
+  FpSecp x;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint8_t* b = in + 1 + (7 - i) * 4;
+    x.v[i] = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3];
+  }
+  bool ok = head == 2 || head == 3;
+  {  // Fp.isValid(x): x < p
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) (void)__builtin_subc(x.v[i], (uint32_t)PR::P[i], bw, &bw);
+    ok = ok && bw != 0;
+  }
+  FpSecp seven = FpSecp::zero();
+  seven.v[0] = 7;
+  FpSecp y2 = fp_sqr<PR>(x) * x + seven;  // weierstrassEquation, a = 0, b = 7
+  FpSecp y = secp_sqrt_candidate(y2);
+  ok = ok && (fp_sqr<PR>(y) == y2);       // "Cannot find square root"
+  if (((head & 1u) != 0) != ((y.v[0] & 1u) != 0)) y = fp_neg<PR>(y);
+  if (!ok) {
+    x = FpSecp::zero();
+    y = FpSecp::zero();
+  }
+  fp_store<PR>(out, x);
+  fp_store<PR>(out + 8, y);
+  return ok;
+}
+
+// ---------------------------------------------------------------------------- bls12-381 G1
+NCG_DI Fe29<2> fe29_pow_words12(const Fe29<2>& a, const uint32_t* e) {  // square-and-multiply, MSB first
+  Fe29<2> r = Fe29<1>::one();
+  bool started = false;
+  for (int w = 11; w >= 0; w--) {
+    const uint32_t word = e[w];
+    for (int bit = 31; bit >= 0; bit--) {
+      if (started) r = f_sqr(r);
+      if ((word >> bit) & 1u) {
+        r = started ? r * a : a;
+        started = true;
+      }
+    }
+  }
+  return r;
+}
+
+// [x]P for the BLS parameter x = 0xd201000000010000 (Jacobian double-and-add; x is public and
+// identical for every lane)
+NCG_DI Jac<FeBls> g1_mul_by_x(const Jac<FeBls>& p) {
+  const uint64_t X = 0xD201000000010000ull;
+  Jac<FeBls> r = p;  // top bit
+  for (int bit = 62; bit >= 0; bit--) {
+    r = jac_dbl(r);
+    if ((X >> bit) & 1ull) r = jac_add(r, p);
+  }
+  return r;
+}
+
+// in: 48 bytes; out: x || y wire (12 + 12 LE limbs).  *inf set for the canonical infinity encoding.
+NCG_DI bool g1_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint8_t* inf) {
+  using F = FeBls;
+  const uint8_t mask = in[0] & 0xE0;
+  const bool compressed = (mask & 0x80) != 0, infinity = (mask & 0x40) != 0, sort = (mask & 0x20) != 0;
+  // validateMask (:439-446) and the 48-byte length rule
+  bool ok = compressed && !(infinity && sort);
+  uint32_t xw[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    const uint8_t* b = in + (11 - i) * 4;
+    xw[i] = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3];
+  }
+  xw[11] &= 0x1FFFFFFFu;  // clear the three flag bits
+  uint32_t any = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) any |= xw[i];
+  *inf = 0;
+  if (infinity) {  // every payload byte must be zero
+    ok = ok && any == 0;
+    for (int i = 0; i < 24; i++) out[i] = 0;
+    *inf = ok ? 1 : 0;
+    return ok;
+  }
+  {  // Fp.fromBytes: x < p
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) (void)__builtin_subc(xw[i], (uint32_t)BlsFpConsts::P32[i], bw, &bw);
+    ok = ok && bw != 0;
+  }
+  F x = fe29_from_wire(xw);
+  Fe29<1> four;
+#pragma unroll
+  for (int i = 0; i < 14; i++) four.v[i] = ParamsBls29::FOUR[i];
+  Fe29<2> rhs = (f_sqr(x) * x + four) * Fe29<1>::one();  // x^3 + 4, bound back to 2
+  Fe29<2> y = fe29_pow_words12(rhs, BlsFpConsts::SQRT_EXP);
+  ok = ok && f_eq(f_sqr(y), rhs);  // Fp.sqrt throws when there is no root
+  // sort bit: canonical y > (p-1)/2
+  uint32_t yw[12];
+  fe29_to_wire(yw, y);
+  bool big;
+  {
+    uint32_t bw = 0;  // HALF_P - y borrows  <=>  y > HALF_P
+#pragma unroll
+    for (int i = 0; i < 12; i++) (void)__builtin_subc((uint32_t)BlsFpConsts::HALF_P[i], yw[i], bw, &bw);
+    big = bw != 0;
+  }
+  if (big != sort) {  // y = p - y  (y != 0: the curve has no point of order 2)
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) yw[i] = __builtin_subc((uint32_t)BlsFpConsts::P32[i], yw[i], bw, &bw);
+    y = f_neg(y) * Fe29<1>::one();
+  }
+  // assertValidity: on the curve by construction; subgroup: [x]([x]P) negated twice == phi(P)
+  {
+    Jac<F> P{x, y, F::one()};
+    Jac<F> xP = jac_neg(g1_mul_by_x(P));
+    Jac<F> u2P = g1_mul_by_x(xP);
+    Fe29<1> beta;
+#pragma unroll
+    for (int i = 0; i < 14; i++) beta.v[i] = ParamsBls29::G1_BETA[i];
+    // u2P (X, Y, Z) == (beta*x, y) affine  <=>  X == beta*x*Z^2, Y == y*Z^3, Z != 0
+    auto zz = f_sqr(u2P.Z);
+    bool same = !f_eqz(u2P.Z) && f_eq(u2P.X, x * beta * zz) && f_eq(u2P.Y, y * zz * u2P.Z);
+    ok = ok && same;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    out[i] = ok ? xw[i] : 0u;
+    out[12 + i] = ok ? yw[i] : 0u;
+  }
+  return ok;
+}
+
+// ---------------------------------------------------------------------------- ed25519
+NCG_DI bool ed_decode_lane(const uint8_t* __restrict__ in, bool zip215, uint32_t* __restrict__ out) {
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint8_t* b = in + 4 * i;
+    w[i] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+  }
+  FpEd x, y;
+  bool ok = ed_decompress(w, zip215, x, y);
+  if (!ok) {
+    x = FpEd::zero();
+    y = FpEd::zero();
+  }
+  FieldWire<FpEd>::store(out, x);
+  FieldWire<FpEd>::store(out + 8, y);
+  return ok;
+}
+
+// ---------------------------------------------------------------------------- kernels
+__global__ void __launch_bounds__(256) k_decode_secp(const uint8_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                     uint8_t* __restrict__ ok, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ok[i] = secp_decode_lane(in + (size_t)i * 33, out + (size_t)i * 16) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_decode_g1(const uint8_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                   uint8_t* __restrict__ ok, uint8_t* __restrict__ inf, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t f = 0;
+  ok[i] = g1_decode_lane(in + (size_t)i * 48, out + (size_t)i * 24, &f) ? 1 : 0;
+  inf[i] = f;
+}
+__global__ void __launch_bounds__(256) k_decode_ed(const uint8_t* __restrict__ in, int zip215,
+                                                   uint32_t* __restrict__ out, uint8_t* __restrict__ ok, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ok[i] = ed_decode_lane(in + (size_t)i * 32, zip215 != 0, out + (size_t)i * 16) ? 1 : 0;
+}
+
+int decode_in_bytes(int curve) {
+  switch (curve) {
+    case CURVE_SECP256K1: return 33;
+    case CURVE_ED25519: return 32;
+    case CURVE_BLS12_381_G1: return 48;
+    default: return 0;
+  }
+}
+
+hipError_t decode_points_batch(int curve, const uint8_t* in, int flags, uint32_t* out, uint8_t* ok, uint8_t* inf, int n,
+                               hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  dim3 grid((n + 255) / 256), block(256);
+  switch (curve) {
+    case CURVE_SECP256K1:
+      hipLaunchKernelGGL(k_decode_secp, grid, block, 0, st, in, out, ok, n);
+      (void)hipMemsetAsync(inf, 0, n, st);
+      break;
+    case CURVE_ED25519:
+      hipLaunchKernelGGL(k_decode_ed, grid, block, 0, st, in, flags & 1, out, ok, n);
+      (void)hipMemsetAsync(inf, 0, n, st);
+      break;
+    case CURVE_BLS12_381_G1:
+      hipLaunchKernelGGL(k_decode_g1, grid, block, 0, st, in, out, ok, inf, n);
+      break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// host-side execution of the lane functions (unit tests through hosttest.hip)
+void decode_points_host(int curve, const uint8_t* in, int flags, uint32_t* out, uint8_t* ok, uint8_t* inf, int n) {
+  for (int i = 0; i < n; i++) {
+    inf[i] = 0;
+    if (curve == CURVE_SECP256K1) ok[i] = secp_decode_lane(in + (size_t)i * 33, out + (size_t)i * 16);
+    else if (curve == CURVE_ED25519) ok[i] = ed_decode_lane(in + (size_t)i * 32, (flags & 1) != 0, out + (size_t)i * 16);
+    else if (curve == CURVE_BLS12_381_G1) ok[i] = g1_decode_lane(in + (size_t)i * 48, out + (size_t)i * 24, inf + i);
+    else ok[i] = 0;
+  }
+}
+
+}  // namespace ncg

@@ -19,6 +19,12 @@ hipError_t mul_base_build_table(int curve, const uint32_t* base_wire_host, uint3
 hipError_t mul_base_batch(int curve, const uint32_t* table, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
                           int n, uint32_t* jac_tmp, hipStream_t st);
 
+// batch point decoding (decode.hip): bytes per encoded point, 0 if the curve has no decoder
+int decode_in_bytes(int curve);
+hipError_t decode_points_batch(int curve, const uint8_t* in, int flags, uint32_t* out, uint8_t* ok, uint8_t* inf, int n,
+                               hipStream_t st);
+void decode_points_host(int curve, const uint8_t* in, int flags, uint32_t* out, uint8_t* ok, uint8_t* inf, int n);
+
 struct MsmPlan;
 int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl);
 size_t msm_workspace_bytes(int curve, const MsmPlan& pl);

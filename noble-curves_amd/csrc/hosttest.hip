@@ -6,6 +6,7 @@
 
 #include "mulvar.hpp"
 #include "ed25519.hip"  // single-TU inclusion: lane function + host table builder
+#include "decode.hip"
 
 using namespace ncg;
 
@@ -70,6 +71,11 @@ int ht_glv_split(const uint32_t* k, uint32_t* out) {
 
 int ht_ed25519_mul_var(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n) {
   for (int i = 0; i < n; i++) ed25519_mul_var_host(pts + (size_t)i * 16, scalars + (size_t)i * 8, out + (size_t)i * 16, out_inf + i);
+  return 0;
+}
+
+int ht_decode_points(int curve, const uint8_t* in, int flags, uint32_t* out, uint8_t* ok, uint8_t* inf, int n) {
+  decode_points_host(curve, in, flags, out, ok, inf, n);
   return 0;
 }
 

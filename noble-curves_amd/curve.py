@@ -285,6 +285,36 @@ def multiplyUnsafeBatch(c, points, scalars, engine=None, _err="invalid scalar: o
     return [c._from_wire(out[i], bool(inf[i])) for i in range(len(points))]
 
 
+def fromBytesBatch(c, encodings, zip215=False, engine=None):
+    """[c.fromBytes(b) for b in encodings] in one launch; entries the reference would reject
+    (bad prefix / flags, x or y out of range, no square root, point outside the prime-order
+    subgroup on bls12-381 G1) come back as None instead of raising.  Encodings: secp256k1 33-byte
+    SEC1 compressed (weierstrass.ts:566-605), bls12-381 G1 48-byte compressed
+    (bls12-381.ts:377-459, :567-577), ed25519 32 bytes (edwards.ts:405-436, `zip215`)."""
+    size = {SECP256K1: 33, ED25519: 32, BLS12_381_G1: 48}.get(c.CURVE_ID)
+    if size is None:
+        raise ValueError("noble-gpu: no batch decoder for this curve")
+    if not encodings:
+        return []
+    rows = []
+    for i, b in enumerate(encodings):
+        b = bytes(b)
+        if len(b) != size:
+            raise ValueError("invalid point encoding at index %d: expected %d bytes" % (i, size))
+        rows.append(np.frombuffer(b, dtype=np.uint8))
+    eng = engine or get_engine()
+    out, ok, inf = eng.decode_points_batch(c.CURVE_ID, np.array(rows), zip215)
+    return [c._from_wire(out[i], bool(inf[i])) if ok[i] else None for i in range(len(rows))]
+
+
+def sumPoints(c, points, engine=None):
+    """Sum of a batch of points - the group operation behind bls.aggregatePublicKeys /
+    aggregateSignatures (src/abstract/bls.ts:857-873).  Runs as an MSM with unit
+    scalars: every point lands in one bucket, which the balanced accumulation and the tree
+    fix-up turn into a parallel reduction."""
+    return pippenger(c, list(points), [1] * len(points), engine)
+
+
 def multiplyBaseBatch(c, scalars, engine=None, unsafe=False):
     """[c.BASE.multiply(k) for k in scalars] through the fixed-base window table
     (curve.ts:588-606 wnafCachedCT; e.g. getPublicKey).  `unsafe` allows k = 0 like multiplyUnsafe."""

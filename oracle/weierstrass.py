@@ -319,3 +319,62 @@ def bls_g2_decode_uncompressed(Point, data):
     y1 = int.from_bytes(data[96:144], "big")
     y0 = int.from_bytes(data[144:192], "big")
     return Point.fromAffine(((x0, x1), (y0, y1)))
+
+
+BLS_X = 0xD201000000010000                               # bls12-381.ts:117
+G1_BETA = 0x5F19672FDF76CE51BA69C6076A0F77EADDB3A93BE6F89688DE17D813620A00022E01FFFFFFFEFFFE
+
+
+def bls_g1_is_torsion_free(Point, p):
+    """bls12-381.ts:567-577: [x^2]P == phi(P) with phi(X, Y, Z) = (beta X, Y, Z)."""
+    Fp = Point.Fp
+    phi = Point(Fp.mul(p.X, G1_BETA), p.Y, p.Z)
+    xP = p.multiplyUnsafe(BLS_X).negate()
+    u2P = xP.multiplyUnsafe(BLS_X)
+    return u2P.equals(phi)
+
+
+def bls_g1_decode_compressed(Point, data):
+    """G1 point decoding from the 48-byte compressed form (bls12-381.ts:377-433 coder.decode with
+    parseMask/validateMask :436-459), followed by what Point.fromBytes adds: fromAffine +
+    assertValidity, i.e. on-curve and prime-order-subgroup checks (weierstrass.ts:720-766)."""
+    Fp = Point.Fp
+    data = bytes(data)
+    if len(data) != 48:
+        raise ValueError("invalid G1 point: expected 48 bytes")
+    mask = data[0] & 0xE0
+    compressed, infinity, sort = bool(mask & 0x80), bool(mask & 0x40), bool(mask & 0x20)
+    if (not compressed and sort) or (compressed and infinity and sort):
+        raise ValueError("invalid encoding flag")
+    if not compressed:
+        raise ValueError("invalid G1 point: expected 96 bytes")
+    value = bytes([data[0] & 0x1F]) + data[1:]
+    if infinity:
+        if any(value):
+            raise ValueError("invalid G1 point: non-canonical zero")
+        return Point.ZERO
+    x = int.from_bytes(value, "big")
+    if not Fp.isValid(x):
+        raise ValueError("invalid field element: outside of range 0..ORDER")
+    y = Fp.sqrt(Fp.add(Fp.pow(x, 3), Point.CURVE["b"]))     # raises if there is no root
+    if bool((y * 2) // Fp.ORDER) != sort:                    # sortBit :346-351 (y != 0 on this curve)
+        y = Fp.neg(y)
+    P = Point.fromAffine((x, y))
+    if P.is0():
+        raise ValueError("bad point: ZERO")
+    if not bls_g1_is_torsion_free(Point, P):
+        raise ValueError("bad point: not in prime-order subgroup")
+    return P
+
+
+def bls_g1_encode_compressed(p):
+    """bls12-381.ts:400-410 coder.encode, compressed form."""
+    Fp = type(p).Fp
+    if p.is0():
+        return bytes([0xC0]) + bytes(47)
+    x, y = p.toAffine()
+    b = bytearray(x.to_bytes(48, "big"))
+    b[0] |= 0x80
+    if (y * 2) // Fp.ORDER:
+        b[0] |= 0x20
+    return bytes(b)

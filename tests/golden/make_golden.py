@@ -6,7 +6,8 @@ Run in the build container (where /root/reference is mounted):
 The GPU box has no /root/reference, so tests read only the committed JSON.
 Sources (data files, not code): /root/reference/test/vectors/...
   secp256k1/privates-2.txt     k:x:y  (test/secp256k1.test.ts:59-71)
-  secp256k1/points.json        bitcoinjs tiny-secp256k1 vectors (test/secp256k1.test.ts:79-131)
+  secp256k1/points.json        bitcoinjs tiny-secp256k1 vectors (test/secp256k1.test.ts:79-131),
+                               incl. valid.isPoint for the SEC1 decoder (:81-88)
   secp256k1/endomorphism.json  GLV multiplyUnsafe KATs (test/nist.test.ts:550-559)
   bls12-381/zkcrypto/converted.json  i*G for G1/G2 (test/bls12-381.test.ts:1463-1535)
   ed25519/vectors.txt          cr.yp.to sign.input (test/ed25519.test.ts:50-66)
@@ -41,12 +42,17 @@ def main():
         "invalid": {k: pts["invalid"][k] for k in ("pointMultiply",)},
     })
     dump("secp256k1_endomorphism.json", json.load(open(f"{REF}/secp256k1/endomorphism.json")))
+    # isPoint: compressed encodings only (33 bytes), every rejected one plus every 4th accepted one
+    isp = [v for v in pts["valid"]["isPoint"] if len(v["P"]) == 66]
+    dump("secp256k1_ispoint_compressed.json",
+         [v for i, v in enumerate(isp) if (not v["expected"]) or i % 4 == 0])
     # bls12-381: uncompressed i*G, first 256 of each
     conv = json.load(open(f"{REF}/bls12-381/zkcrypto/converted.json"))
     dump("bls12_381_multiples.json", {
         "G1_Uncompressed": conv["G1_Uncompressed"][:256],
         "G2_Uncompressed": conv["G2_Uncompressed"][:256],
     })
+    dump("bls12_381_g1_compressed.json", conv["G1_Compressed"][:256])
     # ed25519: first 160 sign.input lines (messages of 0..159 bytes)
     rows = []
     for i, line in enumerate(open(f"{REF}/ed25519/vectors.txt")):

@@ -23,6 +23,7 @@ def lib():
         _lib.ht_glv_split.argtypes = [vp, vp]
         _lib.ht_ed25519_verify.argtypes = [vp, vp, vp, i32]
         _lib.ht_ed25519_mul_var.argtypes = [vp, vp, vp, vp, i32]
+        _lib.ht_decode_points.argtypes = [i32, vp, i32, vp, vp, vp, i32]
     return _lib
 
 
@@ -69,3 +70,13 @@ def ed25519_mul_var(pts, scalars):
     inf = np.zeros((n,), dtype=np.uint8)
     assert lib().ht_ed25519_mul_var(pts.ctypes.data, scalars.ctypes.data, out.ctypes.data, inf.ctypes.data, n) == 0
     return out, inf
+
+
+def decode_points(curve, encoded, point_bytes, flags=0):
+    enc = np.ascontiguousarray(encoded, dtype=np.uint8)
+    n = enc.shape[0]
+    out = np.zeros((n, point_bytes), dtype=np.uint8)
+    ok = np.zeros((n,), dtype=np.uint8)
+    inf = np.zeros((n,), dtype=np.uint8)
+    assert lib().ht_decode_points(curve, enc.ctypes.data, flags, out.ctypes.data, ok.ctypes.data, inf.ctypes.data, n) == 0
+    return out, ok.astype(bool), inf.astype(bool)

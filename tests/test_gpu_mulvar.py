@@ -184,3 +184,29 @@ def test_normalize_projective_batch():
         got = G.normalizeProjective(M, triples)
         for p, g in zip(pts, got):
             assert g.toAffine() == p.toAffine()
+
+
+def test_from_bytes_batch_gpu():
+    """SURVEY 8(f) row 1 on the GPU: SEC1 / G1-compressed / ed25519 decoding with the
+    reference's accept/reject behaviour (isPoint vectors, zkcrypto vectors, flag and range
+    violations, points outside the G1 subgroup)."""
+    from noble_curves_amd import curve as G
+    from oracle.curves import Ed25519
+    from test_host_logic import decode_cases_g1, decode_cases_secp
+    cs = decode_cases_secp()
+    got = G.fromBytesBatch(G.secp256k1_Point, [c[0] for c in cs])
+    for (e, exp), g in zip(cs, got):
+        assert (g.toAffine() if g is not None else None) == exp, e.hex()
+    cg = decode_cases_g1()
+    got = G.fromBytesBatch(G.bls12_381_G1_Point, [c[0] for c in cg])
+    for (e, exp, is0), g in zip(cg, got):
+        assert (g.toAffine() if g is not None else None) == exp and (g is None or g.is0() == is0), e.hex()
+    encs = [bytes.fromhex(v["vk_bytes"]) for v in load_golden("ed25519_zip215.json")]
+    for zip215 in (True, False):
+        got = G.fromBytesBatch(G.ed25519_Point, encs, zip215=zip215)
+        for e, g in zip(encs, got):
+            try:
+                exp = Ed25519.fromBytes(e, zip215).toAffine()
+            except ValueError:
+                exp = None
+            assert (g.toAffine() if g is not None else None) == exp, (e.hex(), zip215)

@@ -131,3 +131,82 @@ def test_ed25519_mul_var_lane_incl_torsion():
         exp = OC.naiveMul(Ed25519, p, k).toAffine()
         assert wire_to_affine(ED25519, out[i]) == exp, (i, hex(k))
         assert bool(inf[i]) == (exp == (0, 1))
+
+
+def decode_cases_secp():
+    """(33-byte encoding, expected point or None): reference isPoint vectors + structured rejects."""
+    from helpers import load_golden
+    from oracle.curves import Secp256k1
+    from oracle.weierstrass import sec1_decode
+    cases = []
+    encs = [bytes.fromhex(v["P"]) for v in load_golden("secp256k1_ispoint_compressed.json")]
+    P = SECP256K1_P
+    encs += [b"\x02" + (P - 1).to_bytes(32, "big"), b"\x03" + P.to_bytes(32, "big"), b"\x02" + (P + 1).to_bytes(32, "big"),
+             b"\x04" + (1).to_bytes(32, "big"), b"\x00" + (1).to_bytes(32, "big"), b"\x02" + bytes(32), b"\x03" + b"\xff" * 32,
+             b"\x02" + (5).to_bytes(32, "big"), b"\x03" + (5).to_bytes(32, "big")]
+    for e in encs:
+        try:
+            cases.append((e, sec1_decode(Secp256k1, e).toAffine()))
+        except ValueError:
+            cases.append((e, None))
+    return cases
+
+
+def decode_cases_g1():
+    from helpers import load_golden
+    from oracle.curves import BlsG1, BLS_P
+    from oracle.weierstrass import bls_g1_decode_compressed, bls_g1_encode_compressed
+    encs = [bytes.fromhex(r) for r in load_golden("bls12_381_g1_compressed.json")[:24]]
+    rng = makeRng(0xDEC0DE)
+    g = bytearray(encs[3])
+    flip = bytearray(g); flip[0] ^= 0x20                        # other root: still a subgroup point
+    nocomp = bytearray(g); nocomp[0] &= 0x7F                    # compression bit cleared
+    inf_bad = bytes([0xC0]) + bytes(46) + b"\x01"               # infinity with payload
+    inf_sort = bytes([0xE0]) + bytes(47)                        # invalid flag combination
+    big = bytearray((BLS_P + 5).to_bytes(48, "big")); big[0] |= 0x80
+    encs += [bytes(flip), bytes(nocomp), inf_bad, inf_sort, bytes(big), bytes([0xC0]) + bytes(47)]
+    # random x: mostly non-residues or points outside the prime-order subgroup
+    for _ in range(14):
+        x = rng.rndBelow(BLS_P)
+        b = bytearray(x.to_bytes(48, "big")); b[0] |= 0x80 | (0x20 if rng.rnd64() & 1 else 0)
+        encs.append(bytes(b))
+    cases = []
+    for e in encs:
+        try:
+            p = bls_g1_decode_compressed(BlsG1, e)
+            cases.append((e, p.toAffine(), p.is0()))
+        except ValueError:
+            cases.append((e, None, False))
+    assert sum(1 for c in cases if c[1] is None) >= 10 and sum(1 for c in cases if c[1] is not None) >= 20
+    return cases
+
+
+def test_decode_lanes_secp256k1_g1_ed25519():
+    """decompression + validity, lane logic on the CPU vs the oracle."""
+    import numpy as np
+    from helpers import load_golden, wire_to_affine
+    from noble_curves_amd._native import ED25519
+    from oracle.curves import Ed25519
+    cs = decode_cases_secp()
+    out, ok, _ = hosttest.decode_points(SECP256K1, np.array([np.frombuffer(c[0], np.uint8) for c in cs]), 64)
+    for i, (e, exp) in enumerate(cs):
+        assert ok[i] == (exp is not None), e.hex()
+        assert wire_to_affine(SECP256K1, out[i]) == (exp if exp else (0, 0))
+    cg = decode_cases_g1()
+    out, ok, inf = hosttest.decode_points(BLS12_381_G1, np.array([np.frombuffer(c[0], np.uint8) for c in cg]), 96)
+    for i, (e, exp, is0) in enumerate(cg):
+        assert ok[i] == (exp is not None), e.hex()
+        assert wire_to_affine(BLS12_381_G1, out[i]) == (exp if exp else (0, 0)) and inf[i] == is0
+    encs = [bytes.fromhex(v["vk_bytes"]) for v in load_golden("ed25519_zip215.json")]
+    encs += [bytes.fromhex(r["pk"]) for r in load_golden("ed25519_vectors.json")[:20]]
+    for zip215 in (True, False):
+        out, ok, _ = hosttest.decode_points(ED25519, np.array([np.frombuffer(e, np.uint8) for e in encs]), 64,
+                                            1 if zip215 else 0)
+        for i, e in enumerate(encs):
+            try:
+                exp = Ed25519.fromBytes(e, zip215).toAffine()
+            except ValueError:
+                exp = None
+            assert ok[i] == (exp is not None), (e.hex(), zip215)
+            if exp:
+                assert wire_to_affine(ED25519, out[i]) == exp
