@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Throughput of the hot-path entry points that bench.py's headline lines do not cover
+(fixed-base multiply, batch decode, normalisation, other curves' multiply / MSM).  Device-resident
+inputs, HIP-event timing on an explicit stream; prints one JSON object (also to --out)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from noble_curves_amd import get_engine  # noqa: E402
+from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, ED25519, SECP256K1  # noqa: E402
+from oracle.curves import BLS_R, BlsG1, BlsG2, ED25519_L, Ed25519, SECP256K1_N, Secp256k1, makeRng  # noqa: E402
+
+
+def timeit(fn, steps=3, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(st)
+    s = st.cuda_stream
+    eng = get_engine(0)
+    res = {}
+    P = lambda t: t.data_ptr()  # noqa: E731
+
+    def rate(name, n, ms, unit):
+        res[name] = {"n": n, "ms": round(ms, 3), "per_s": n / (ms * 1e-3), "unit": unit}
+        print("%-44s n=2^%-2d %9.3f ms  %.3e %s/s" % (name, n.bit_length() - 1, ms, n / (ms * 1e-3), unit), flush=True)
+
+    # ---- secp256k1: fixed-base, decode, normalise, MSM
+    n = 1 << 20
+    sc = bench.gen_scalars(n, 255, 5, dev)
+    out = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    inf = torch.empty((n,), dtype=torch.uint8, device=dev)
+    ok = torch.empty((n,), dtype=torch.uint8, device=dev)
+    eng.mul_base_batch_dev(SECP256K1, n, P(sc), P(out), P(inf), s)
+    rate("secp256k1 fixed-base multiply", n, timeit(lambda: eng.mul_base_batch_dev(SECP256K1, n, P(sc), P(out), P(inf), s)), "scalar-mults")
+    pts = out.clone()
+    enc = torch.empty((n, 33), dtype=torch.uint8, device=dev)            # SEC1-compress on the device with torch ops
+    enc[:, 0] = 2 + (pts[:, 32] & 1)
+    enc[:, 1:] = torch.flip(pts[:, :32], dims=[1])
+    dec = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    f = lambda: eng._check(eng.lib.ncg_decode_points_batch_dev(eng.h, SECP256K1, n, P(enc), 0, P(dec), P(ok), P(inf), s))  # noqa: E731
+    f()
+    torch.cuda.synchronize()
+    assert bool((dec == pts).all().item()) and int(ok.sum().item()) == n, "secp256k1 decode mismatch"
+    rate("secp256k1 SEC1 decode (sqrt)", n, timeit(f), "points")
+    a_ = makeRng(9)
+    a, b = a_.rndBelow(SECP256K1_N - 1) + 1, a_.rndBelow(SECP256K1_N - 1) + 1
+    kpts, _ = bench.gen_points(eng, SECP256K1, Secp256k1, n, a, b, dev, s)
+    rate("secp256k1 MSM", n, timeit(lambda: eng.msm_dev(SECP256K1, n, P(kpts), P(sc), s)), "points")
+    ones = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    ones[:, 0] = 1
+    rate("secp256k1 point sum (MSM, unit scalars)", n, timeit(lambda: eng.msm_dev(SECP256K1, n, P(kpts), P(ones), s)), "points")
+    proj = torch.cat([kpts, torch.zeros((n, 32), dtype=torch.uint8, device=dev)], dim=1)
+    proj[:, 64] = 1                                                        # Z = 1
+    fn = lambda: eng._check(eng.lib.ncg_normalize_batch_dev(eng.h, SECP256K1, n, P(proj), P(dec), P(inf), s))  # noqa: E731
+    rate("secp256k1 normalizeZ batch", n, timeit(fn), "points")
+
+    # ---- ed25519: variable-base multiply, MSM, decode
+    esc = bench.gen_scalars(n, 252, 6, dev)
+    rng = makeRng(11)
+    a, b = rng.rndBelow(ED25519_L - 1) + 1, rng.rndBelow(ED25519_L - 1) + 1
+    epts, _ = bench.gen_points(eng, ED25519, Ed25519, n, a, b, dev, s)
+    eout = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    rate("ed25519 variable-base multiply", n, timeit(lambda: eng.mul_var_batch_dev(ED25519, n, P(epts), P(esc), P(eout), P(inf), s)), "scalar-mults")
+    rate("ed25519 MSM", n, timeit(lambda: eng.msm_dev(ED25519, n, P(epts), P(esc), s)), "points")
+    eenc = epts[:, 32:].clone()
+    eenc[:, 31] |= (epts[:, 0] & 1) << 7
+    fe = lambda: eng._check(eng.lib.ncg_decode_points_batch_dev(eng.h, ED25519, n, P(eenc), 1, P(eout), P(ok), P(inf), s))  # noqa: E731
+    fe()
+    torch.cuda.synchronize()
+    assert bool((eout == epts).all().item()), "ed25519 decode mismatch"
+    rate("ed25519 decode (zip215)", n, timeit(fe), "points")
+
+    # ---- bls12-381: G1/G2 variable-base + fixed-base multiply, G1 decode with subgroup check
+    m = 1 << 18
+    rng = makeRng(13)
+    a, b = rng.rndBelow(BLS_R - 1) + 1, rng.rndBelow(BLS_R - 1) + 1
+    gsc = bench.gen_scalars(m, 254, 7, dev)
+    g1, _ = bench.gen_points(eng, BLS12_381_G1, BlsG1, m, a, b, dev, s)
+    g1o = torch.empty((m, 96), dtype=torch.uint8, device=dev)
+    rate("bls12-381 G1 variable-base multiply", m, timeit(lambda: eng.mul_var_batch_dev(BLS12_381_G1, m, P(g1), P(gsc), P(g1o), P(inf), s), 2), "scalar-mults")
+    rate("bls12-381 G1 fixed-base multiply", m, timeit(lambda: eng.mul_base_batch_dev(BLS12_381_G1, m, P(gsc), P(g1o), P(inf), s), 2), "scalar-mults")
+    genc = torch.flip(g1[:, :48], dims=[1]).clone()                         # compressed: x big-endian + flags
+    y_be = torch.flip(g1[:, 48:], dims=[1]).cpu().numpy()
+    halfp = np.frombuffer(((BlsG1.Fp.ORDER - 1) // 2).to_bytes(48, "big"), dtype=np.uint8)
+    gt = np.zeros(m, dtype=bool)
+    undecided = np.ones(m, dtype=bool)
+    for j in range(48):                                                     # lexicographic y > (p-1)/2
+        gt |= undecided & (y_be[:, j] > halfp[j])
+        undecided &= y_be[:, j] == halfp[j]
+    genc[:, 0] |= 0x80
+    genc[:, 0] |= torch.from_numpy((gt.astype(np.uint8) << 5)).to(dev)
+    fg = lambda: eng._check(eng.lib.ncg_decode_points_batch_dev(eng.h, BLS12_381_G1, m, P(genc), 0, P(g1o), P(ok), P(inf), s))  # noqa: E731
+    fg()
+    torch.cuda.synchronize()
+    assert bool((g1o == g1).all().item()) and int(ok[:m].sum().item()) == m, "G1 decode mismatch"
+    rate("bls12-381 G1 decode + subgroup check", m, timeit(fg, 2), "points")
+    g2, _ = bench.gen_points(eng, BLS12_381_G2, BlsG2, m, a, b, dev, s)
+    g2o = torch.empty((m, 192), dtype=torch.uint8, device=dev)
+    rate("bls12-381 G2 variable-base multiply", m, timeit(lambda: eng.mul_var_batch_dev(BLS12_381_G2, m, P(g2), P(gsc), P(g2o), P(inf), s), 2), "scalar-mults")
+    if args.out:
+        with open(args.out, "w") as fjs:
+            json.dump(res, fjs, indent=1)
+
+
+if __name__ == "__main__":
+    main()
