@@ -93,14 +93,25 @@ int ncg_normalize_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* point
  *   NCG_BLS12_381_G1  48 bytes compressed with flag bits (src/bls12-381.ts:377-459); includes
  *                     the prime-order-subgroup check of assertValidity (:567-577); the
  *                     canonical infinity encoding gives out_is_inf = 1
+ *   NCG_BLS12_381_G2  96 bytes compressed, x.c1 || x.c0 (src/bls12-381.ts:354-368, Fp2.sqrt
+ *                     src/abstract/tower.ts:476-500) + the psi subgroup check (:599-601)
  *   NCG_ED25519       32 bytes (src/abstract/edwards.ts:405-436); flags bit 0 = zip215
- * out_is_inf may be NULL in the host-pointer variant.  G2 is not supported yet. */
+ * out_is_inf may be NULL in the host-pointer variant. */
 #define NCG_DECODE_ZIP215 1
 int ncg_decode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* encoded, int flags,
                             void* out_affine, uint8_t* out_ok, uint8_t* out_is_inf);
 int ncg_decode_points_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* encoded_dev, int flags,
                                 void* out_affine_dev, uint8_t* out_ok_dev, uint8_t* out_is_inf_dev,
                                 void* stream);
+
+/* ---- batch point encoding (Point.toBytes, compressed form) -----------------------------------
+ * encoded[i] = affine wire point i in the encodings listed above (secp256k1 pointToBytes
+ * src/abstract/weierstrass.ts:541-564; bls12-381 coder.encode src/bls12-381.ts:400-410; ed25519
+ * src/abstract/edwards.ts:620-628).  out_ok[i] = 0 where the reference throws (secp256k1 ZERO). */
+int ncg_encode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* affine, void* out_encoded,
+                            uint8_t* out_ok);
+int ncg_encode_points_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* affine_dev,
+                                void* out_encoded_dev, uint8_t* out_ok_dev, void* stream);
 
 /* ---- batch fixed-base scalar multiplication -----------------------------------------------
  * out[i] = scalars[i] * BASE.  Replaces, batch-wise, Point.BASE.multiply(k) / multiplyUnsafe(k)

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SECP256K1, ED25519, BLS12_381_G1, BLS12_381_G2 = 0, 1, 2, 3
 POINT_BYTES = {SECP256K1: 64, ED25519: 64, BLS12_381_G1: 96, BLS12_381_G2: 192}
 FIELD_BYTES = {SECP256K1: 32, ED25519: 32, BLS12_381_G1: 48, BLS12_381_G2: 48}
+ENCODED_BYTES = {SECP256K1: 33, ED25519: 32, BLS12_381_G1: 48, BLS12_381_G2: 96}   # compressed toBytes
 
 
 class NativeError(RuntimeError):
@@ -79,6 +80,8 @@ _vp, _sz, _i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 _OPTIONAL_PROTOS = {
     "ncg_decode_points_batch": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp],
     "ncg_decode_points_batch_dev": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp, _vp],
+    "ncg_encode_points_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
+    "ncg_encode_points_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_normalize_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
     "ncg_normalize_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_msm": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
@@ -159,8 +162,8 @@ class Engine:
         return out, inf
 
     def decode_points_batch(self, curve, encoded, zip215=False):
-        """encoded uint8 [n, 33|32|48] -> (affine [n, PB], ok [n] bool, is_inf [n] bool)."""
-        enc_bytes = {SECP256K1: 33, ED25519: 32, BLS12_381_G1: 48}[curve]
+        """encoded uint8 [n, 33|32|48|96] -> (affine [n, PB], ok [n] bool, is_inf [n] bool)."""
+        enc_bytes = ENCODED_BYTES[curve]
         pb = POINT_BYTES[curve]
         enc = np.ascontiguousarray(encoded, dtype=np.uint8).reshape(-1, enc_bytes)
         n = enc.shape[0]
@@ -171,6 +174,18 @@ class Engine:
             self._check(self.lib.ncg_decode_points_batch(self.h, curve, n, enc.ctypes.data, 1 if zip215 else 0,
                                                          out.ctypes.data, ok.ctypes.data, inf.ctypes.data))
         return out, ok.astype(bool), inf.astype(bool)
+
+    def encode_points_batch(self, curve, affine):
+        """affine uint8 [n, PB] -> (encoded [n, 33|32|48|96], ok [n] bool): compressed Point.toBytes."""
+        pb = POINT_BYTES[curve]
+        aff = np.ascontiguousarray(affine, dtype=np.uint8).reshape(-1, pb)
+        n = aff.shape[0]
+        out = np.zeros((n, ENCODED_BYTES[curve]), dtype=np.uint8)
+        ok = np.zeros((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_encode_points_batch(self.h, curve, n, aff.ctypes.data, out.ctypes.data,
+                                                         ok.ctypes.data))
+        return out, ok.astype(bool)
 
     def normalize_batch(self, curve, proj):
         """proj uint8 [n, 3*FIELD_BYTES*(2 for Fp2)] (X || Y || Z) -> (affine [n, PB], is_inf [n])."""

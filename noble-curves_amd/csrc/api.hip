@@ -383,6 +383,44 @@ int ncg_decode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* encod
   return NCG_OK;
 }
 
+int ncg_encode_points_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* affine_dev, void* out_encoded_dev,
+                                uint8_t* out_ok_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (ncg::decode_in_bytes(curve) == 0)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: encode_points_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!affine_dev || !out_encoded_dev || !out_ok_dev)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: encode_points_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  NCG_HIP(ctx, ncg::encode_points_batch(curve, (const uint32_t*)affine_dev, (uint8_t*)out_encoded_dev, out_ok_dev, (int)n, st));
+  return NCG_OK;
+}
+
+int ncg_encode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* affine, void* out_encoded, uint8_t* out_ok) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  int ob = ncg::decode_in_bytes(curve), pb = ncg_point_bytes(curve);
+  if (ob == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: encode_points_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (!affine || !out_encoded || !out_ok)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: encode_points_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  size_t in_b = (n * (size_t)pb + 255) & ~(size_t)255, out_b = (n * (size_t)ob + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, in_b + out_b + n + 1024);
+  if (rc) return rc;
+  char* d_in = (char*)ctx->scratch;
+  char* d_out = d_in + in_b;
+  char* d_ok = d_out + out_b;
+  NCG_HIP(ctx, hipMemcpyAsync(d_in, affine, n * (size_t)pb, hipMemcpyHostToDevice, ctx->stream));
+  rc = ncg_encode_points_batch_dev(ctx, curve, n, d_in, d_out, (uint8_t*)d_ok, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(out_encoded, d_out, n * (size_t)ob, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipMemcpyAsync(out_ok, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
 static int ensure_ed_table(ncg_ctx* ctx) {
   if (ctx->ed_btab) return NCG_OK;
   uint32_t host[ncg::ED25519_BTAB_WORDS];

@@ -7,6 +7,9 @@
 //   bls12-381 G1 compressed, 48 bytes: coder.decode (src/bls12-381.ts:377-433, flags :436-459,
 //              sortBit :346-351) + assertValidity incl. the subgroup check isTorsionFree
 //              [x^2]P == phi(P) (src/bls12-381.ts:567-577)
+//   bls12-381 G2 compressed, 96 bytes (c1 || c0, src/bls12-381.ts:354-368): the same coder with
+//              Fp2.sqrt (src/abstract/tower.ts:476-500) and the psi subgroup check
+//              [-x]P == psi(P) (src/bls12-381.ts:599-601, psi: src/abstract/tower.ts:240-247)
 //   ed25519    32 bytes: Point.fromBytes(bytes, zip215) (src/abstract/edwards.ts:405-436)
 // out_ok[i] = 0 exactly where the reference throws; the affine output is then (0,0).
 #include <vector>
@@ -87,9 +90,10 @@ NCG_DI Fe29<2> fe29_pow_words12(const Fe29<2>& a, const uint32_t* e) {  // squar
 
 // [x]P for the BLS parameter x = 0xd201000000010000 (Jacobian double-and-add; x is public and
 // identical for every lane)
-NCG_DI Jac<FeBls> g1_mul_by_x(const Jac<FeBls>& p) {
+template <class F>
+NCG_DI Jac<F> bls_mul_by_x(const Jac<F>& p) {
   const uint64_t X = 0xD201000000010000ull;
-  Jac<FeBls> r = p;  // top bit
+  Jac<F> r = p;  // top bit
   for (int bit = 62; bit >= 0; bit--) {
     r = jac_dbl(r);
     if ((X >> bit) & 1ull) r = jac_add(r, p);
@@ -153,8 +157,8 @@ NCG_DI bool g1_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict_
   // assertValidity: on the curve by construction; subgroup: [x]([x]P) negated twice == phi(P)
   {
     Jac<F> P{x, y, F::one()};
-    Jac<F> xP = jac_neg(g1_mul_by_x(P));
-    Jac<F> u2P = g1_mul_by_x(xP);
+    Jac<F> xP = jac_neg(bls_mul_by_x(P));
+    Jac<F> u2P = bls_mul_by_x(xP);
     Fe29<1> beta;
 #pragma unroll
     for (int i = 0; i < 14; i++) beta.v[i] = ParamsBls29::G1_BETA[i];
@@ -167,6 +171,134 @@ NCG_DI bool g1_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict_
   for (int i = 0; i < 12; i++) {
     out[i] = ok ? xw[i] : 0u;
     out[12 + i] = ok ? yw[i] : 0u;
+  }
+  return ok;
+}
+
+// ---------------------------------------------------------------------------- bls12-381 G2
+NCG_DI Fe29<1> fe29_const(const uint32_t (&c)[14]) {
+  Fe29<1> r;
+#pragma unroll
+  for (int i = 0; i < 14; i++) r.v[i] = c[i];
+  return r;
+}
+NCG_DI void be48_to_words(const uint8_t* __restrict__ in, uint32_t (&w)[12]) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    const uint8_t* b = in + (11 - i) * 4;
+    w[i] = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3];
+  }
+}
+NCG_DI bool words12_lt_p(const uint32_t (&w)[12]) {
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) (void)__builtin_subc(w[i], (uint32_t)BlsFpConsts::P32[i], bw, &bw);
+  return bw != 0;
+}
+NCG_DI bool words12_gt_half_p(const uint32_t (&w)[12]) {  // (2 w) / p != 0
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) (void)__builtin_subc((uint32_t)BlsFpConsts::HALF_P[i], w[i], bw, &bw);
+  return bw != 0;
+}
+NCG_DI void words12_neg_mod_p(uint32_t (&w)[12]) {  // w = p - w for w != 0
+  uint32_t any = 0, bw = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) any |= w[i];
+  if (any == 0) return;
+#pragma unroll
+  for (int i = 0; i < 12; i++) w[i] = __builtin_subc((uint32_t)BlsFpConsts::P32[i], w[i], bw, &bw);
+}
+
+// Square root in Fp2 = Fp[u]/(u^2+1), p = 3 mod 4.  The reference's complex method
+// (tower.ts:476-500) spends sqrt(norm) + Legendre(d) + sqrt(d) + one inversion; here the Legendre
+// symbol, the root and the inverse all come out of ONE power t = d^((p-3)/4):
+//   s = t d satisfies s^2 = +-d and t s = d^((p-1)/2) = +-1, so 1/s = +-t;
+//   s^2 =  d: root (s, c1/(2s));   s^2 = -d (d a non-residue): root (c1/(2s), s), using
+//   d d' = -c1^2/4 for the reference's second candidate d' = d - a.
+// Which of the two roots comes out is irrelevant to the caller (the sort bit picks the sign);
+// existence is decided exactly like the reference: norm must be a square and root^2 == num.
+NCG_DI bool fe29x2_sqrt(const Fe29x2<2>& num, Fe29x2<2>& root) {
+  const Fe29<1> half = fe29_const(ParamsBls29::HALF);
+  Fe29<2> norm = (f_sqr(num.c0) + f_sqr(num.c1)) * Fe29<1>::one();
+  Fe29<2> a = fe29_pow_words12(norm, BlsFpConsts::SQRT_EXP_M1) * norm;
+  bool ok = f_eq(f_sqr(a), norm);
+  const bool c1_zero = f_eqz(num.c1);
+  Fe29<2> d = (a + num.c0) * half;
+  if (c1_zero) d = num.c0;
+  Fe29<2> t = fe29_pow_words12(d, BlsFpConsts::SQRT_EXP_M1);
+  Fe29<2> s = t * d;
+  const bool residue = f_eq(f_sqr(s), d);
+  Fe29<2> o = num.c1 * half * t;  // c1 / (2 s) up to the sign fixed below
+  if (residue) {
+    root = {s, o};
+  } else {
+    root = {f_neg(o) * Fe29<1>::one(), s};
+  }
+  Fe29x2<2> chk = f_sqr(root);
+  return ok && f_eq(chk.c0, num.c0) && f_eq(chk.c1, num.c1);
+}
+
+// in: 96 bytes (x.c1 || x.c0, big-endian, flags in byte 0); out: x.c0 x.c1 y.c0 y.c1 wire
+NCG_DI bool g2_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint8_t* inf) {
+  using F = FeBls2;
+  const uint8_t mask = in[0] & 0xE0;
+  const bool compressed = (mask & 0x80) != 0, infinity = (mask & 0x40) != 0, sort = (mask & 0x20) != 0;
+  bool ok = compressed && !(infinity && sort);
+  uint32_t x0w[12], x1w[12];
+  be48_to_words(in, x1w);
+  be48_to_words(in + 48, x0w);
+  x1w[11] &= 0x1FFFFFFFu;
+  uint32_t any = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) any |= x0w[i] | x1w[i];
+  *inf = 0;
+  if (infinity) {
+    ok = ok && any == 0;
+    for (int i = 0; i < 48; i++) out[i] = 0;
+    *inf = ok ? 1 : 0;
+    return ok;
+  }
+  ok = ok && words12_lt_p(x0w) && words12_lt_p(x1w);  // decodeFp -> Fp.fromBytes range rule
+  Fe29x2<2> x{fe29_from_wire(x0w), fe29_from_wire(x1w)};
+  const Fe29<1> four = fe29_const(ParamsBls29::FOUR);
+  auto x3 = f_sqr(x) * x;  // b = 4 (1 + u), src/bls12-381.ts:321-345
+  Fe29x2<2> rhs{(x3.c0 + four) * Fe29<1>::one(), (x3.c1 + four) * Fe29<1>::one()};
+  Fe29x2<2> y;
+  ok = ok && fe29x2_sqrt(rhs, y);
+  uint32_t y0w[12], y1w[12];
+  fe29_to_wire(y0w, y.c0);
+  fe29_to_wire(y1w, y.c1);
+  // sortBit over [c1, c0] (:346-351, :476-479): the first non-zero part decides
+  uint32_t any1 = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) any1 |= y1w[i];
+  const bool big = any1 ? words12_gt_half_p(y1w) : words12_gt_half_p(y0w);
+  if (big != sort) {
+    words12_neg_mod_p(y0w);
+    words12_neg_mod_p(y1w);
+    auto ny = f_neg(y);
+    y = {ny.c0 * Fe29<1>::one(), ny.c1 * Fe29<1>::one()};
+  }
+  {  // subgroup: -[|x|]P == psi(P), psi(x, y) = (conj(x) PSI_X, conj(y) PSI_Y)
+    Jac<F> P{x, y, F::one()};
+    Jac<F> xP = jac_neg(bls_mul_by_x(P));
+    const Fe29x2<1> psx{fe29_const(ParamsBls29::PSI_X_C0), fe29_const(ParamsBls29::PSI_X_C1)};
+    const Fe29x2<1> psy{fe29_const(ParamsBls29::PSI_Y_C0), fe29_const(ParamsBls29::PSI_Y_C1)};
+    Fe29x2<4> cx{x.c0, f_neg(x.c1)}, cy{y.c0, f_neg(y.c1)};
+    auto px = cx * psx;
+    auto py = cy * psy;
+    auto zz = f_sqr(xP.Z);
+    auto dx = xP.X - px * zz;
+    auto dy = xP.Y - py * zz * xP.Z;
+    ok = ok && !f_eqz(xP.Z) && f_eqz(dx) && f_eqz(dy);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    out[i] = ok ? x0w[i] : 0u;
+    out[12 + i] = ok ? x1w[i] : 0u;
+    out[24 + i] = ok ? y0w[i] : 0u;
+    out[36 + i] = ok ? y1w[i] : 0u;
   }
   return ok;
 }
@@ -205,6 +337,14 @@ __global__ void __launch_bounds__(256) k_decode_g1(const uint8_t* __restrict__ i
   ok[i] = g1_decode_lane(in + (size_t)i * 48, out + (size_t)i * 24, &f) ? 1 : 0;
   inf[i] = f;
 }
+__global__ void __launch_bounds__(128) k_decode_g2(const uint8_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                   uint8_t* __restrict__ ok, uint8_t* __restrict__ inf, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t f = 0;
+  ok[i] = g2_decode_lane(in + (size_t)i * 96, out + (size_t)i * 48, &f) ? 1 : 0;
+  inf[i] = f;
+}
 __global__ void __launch_bounds__(256) k_decode_ed(const uint8_t* __restrict__ in, int zip215,
                                                    uint32_t* __restrict__ out, uint8_t* __restrict__ ok, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,6 +357,7 @@ int decode_in_bytes(int curve) {
     case CURVE_SECP256K1: return 33;
     case CURVE_ED25519: return 32;
     case CURVE_BLS12_381_G1: return 48;
+    case CURVE_BLS12_381_G2: return 96;
     default: return 0;
   }
 }
@@ -237,9 +378,101 @@ hipError_t decode_points_batch(int curve, const uint8_t* in, int flags, uint32_t
     case CURVE_BLS12_381_G1:
       hipLaunchKernelGGL(k_decode_g1, grid, block, 0, st, in, out, ok, inf, n);
       break;
+    case CURVE_BLS12_381_G2:
+      hipLaunchKernelGGL(k_decode_g2, dim3((n + 127) / 128), dim3(128), 0, st, in, out, ok, inf, n);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------- encoders
+// Point.toBytes (compressed) of affine wire points: byte shuffles only, inputs are canonical.
+//   secp256k1 pointToBytes (weierstrass.ts:541-564; ZERO is rejected -> ok = 0)
+//   bls12-381 coder.encode (bls12-381.ts:400-410, sortBit :346-351, fp2.encode c1 || c0 :354-361)
+//   ed25519   Point.toBytes (edwards.ts:620-628): y little-endian, bit 255 = x odd
+NCG_DI void words_to_be(const uint32_t* __restrict__ w, int nw, uint8_t* __restrict__ out) {
+  for (int i = 0; i < nw; i++) {
+    const uint32_t v = w[nw - 1 - i];
+    out[4 * i] = (uint8_t)(v >> 24);
+    out[4 * i + 1] = (uint8_t)(v >> 16);
+    out[4 * i + 2] = (uint8_t)(v >> 8);
+    out[4 * i + 3] = (uint8_t)v;
+  }
+}
+NCG_DI bool encode_lane(int curve, const uint32_t* __restrict__ in, uint8_t* __restrict__ out) {
+  if (curve == CURVE_SECP256K1) {
+    uint32_t any = 0;
+    for (int i = 0; i < 16; i++) any |= in[i];
+    if (any == 0) {
+      for (int i = 0; i < 33; i++) out[i] = 0;
+      return false;  // "bad point: ZERO"
+    }
+    out[0] = (in[8] & 1u) ? 3 : 2;
+    words_to_be(in, 8, out + 1);
+    return true;
+  }
+  if (curve == CURVE_ED25519) {
+    for (int i = 0; i < 8; i++) {
+      const uint32_t v = in[8 + i];
+      out[4 * i] = (uint8_t)v;
+      out[4 * i + 1] = (uint8_t)(v >> 8);
+      out[4 * i + 2] = (uint8_t)(v >> 16);
+      out[4 * i + 3] = (uint8_t)(v >> 24);
+    }
+    out[31] |= (uint8_t)((in[0] & 1u) << 7);
+    return true;
+  }
+  const bool g2 = curve == CURVE_BLS12_381_G2;
+  const int pw = g2 ? 48 : 24, nb = g2 ? 96 : 48;
+  uint32_t any = 0;
+  for (int i = 0; i < pw; i++) any |= in[i];
+  if (any == 0) {  // infinity: compressed + infinity flags, zero payload
+    out[0] = 0xC0;
+    for (int i = 1; i < nb; i++) out[i] = 0;
+    return true;
+  }
+  bool sort;
+  if (g2) {
+    words_to_be(in + 12, 12, out);  // x.c1
+    words_to_be(in, 12, out + 48);  // x.c0
+    uint32_t y0[12], y1[12], any1 = 0;
+    for (int i = 0; i < 12; i++) {
+      y0[i] = in[24 + i];
+      y1[i] = in[36 + i];
+      any1 |= y1[i];
+    }
+    sort = any1 ? words12_gt_half_p(y1) : words12_gt_half_p(y0);
+  } else {
+    words_to_be(in, 12, out);
+    uint32_t y[12];
+    for (int i = 0; i < 12; i++) y[i] = in[12 + i];
+    sort = words12_gt_half_p(y);
+  }
+  out[0] |= 0x80 | (sort ? 0x20 : 0);
+  return true;
+}
+
+__global__ void __launch_bounds__(256) k_encode(int curve, const uint32_t* __restrict__ in, int in_words,
+                                                uint8_t* __restrict__ out, int out_bytes, uint8_t* __restrict__ ok,
+                                                int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ok[i] = encode_lane(curve, in + (size_t)i * in_words, out + (size_t)i * out_bytes) ? 1 : 0;
+}
+
+hipError_t encode_points_batch(int curve, const uint32_t* in, uint8_t* out, uint8_t* ok, int n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  const int ob = decode_in_bytes(curve);
+  if (ob == 0) return hipErrorInvalidValue;
+  const int iw = curve == CURVE_BLS12_381_G2 ? 48 : curve == CURVE_BLS12_381_G1 ? 24 : 16;
+  hipLaunchKernelGGL(k_encode, dim3((n + 255) / 256), dim3(256), 0, st, curve, in, iw, out, ob, ok, n);
+  return hipGetLastError();
+}
+void encode_points_host(int curve, const uint32_t* in, uint8_t* out, uint8_t* ok, int n) {
+  const int ob = decode_in_bytes(curve);
+  const int iw = curve == CURVE_BLS12_381_G2 ? 48 : curve == CURVE_BLS12_381_G1 ? 24 : 16;
+  for (int i = 0; i < n; i++) ok[i] = encode_lane(curve, in + (size_t)i * iw, out + (size_t)i * ob) ? 1 : 0;
 }
 
 // host-side execution of the lane functions (unit tests through hosttest.hip)
@@ -249,6 +482,7 @@ void decode_points_host(int curve, const uint8_t* in, int flags, uint32_t* out, 
     if (curve == CURVE_SECP256K1) ok[i] = secp_decode_lane(in + (size_t)i * 33, out + (size_t)i * 16);
     else if (curve == CURVE_ED25519) ok[i] = ed_decode_lane(in + (size_t)i * 32, (flags & 1) != 0, out + (size_t)i * 16);
     else if (curve == CURVE_BLS12_381_G1) ok[i] = g1_decode_lane(in + (size_t)i * 48, out + (size_t)i * 24, inf + i);
+    else if (curve == CURVE_BLS12_381_G2) ok[i] = g2_decode_lane(in + (size_t)i * 96, out + (size_t)i * 48, inf + i);
     else ok[i] = 0;
   }
 }

@@ -23,6 +23,9 @@ hipError_t mul_base_batch(int curve, const uint32_t* table, const uint32_t* scal
 int decode_in_bytes(int curve);
 hipError_t decode_points_batch(int curve, const uint8_t* in, int flags, uint32_t* out, uint8_t* ok, uint8_t* inf, int n,
                                hipStream_t st);
+// compressed encodings of affine wire points (Point.toBytes); ok = 0 where the reference throws
+hipError_t encode_points_batch(int curve, const uint32_t* in, uint8_t* out, uint8_t* ok, int n, hipStream_t st);
+void encode_points_host(int curve, const uint32_t* in, uint8_t* out, uint8_t* ok, int n);
 void decode_points_host(int curve, const uint8_t* in, int flags, uint32_t* out, uint8_t* ok, uint8_t* inf, int n);
 
 struct MsmPlan;

@@ -74,8 +74,22 @@ int ht_ed25519_mul_var(const uint32_t* pts, const uint32_t* scalars, uint32_t* o
   return 0;
 }
 
+// Fp2 square root lane: in = c0 c1 wire (24 words); out = root wire; returns 1 if a root exists
+int ht_fp2_sqrt(const uint32_t* in, uint32_t* out) {
+  Fe29x2<2> a{fe29_from_wire(in), fe29_from_wire(in + 12)}, r;
+  bool ok = fe29x2_sqrt(a, r);
+  fe29_to_wire(out, r.c0);
+  fe29_to_wire(out + 12, r.c1);
+  return ok ? 1 : 0;
+}
+
 int ht_decode_points(int curve, const uint8_t* in, int flags, uint32_t* out, uint8_t* ok, uint8_t* inf, int n) {
   decode_points_host(curve, in, flags, out, ok, inf, n);
+  return 0;
+}
+
+int ht_encode_points(int curve, const uint32_t* in, uint8_t* out, uint8_t* ok, int n) {
+  encode_points_host(curve, in, out, ok, n);
   return 0;
 }
 

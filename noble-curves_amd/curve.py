@@ -288,10 +288,10 @@ def multiplyUnsafeBatch(c, points, scalars, engine=None, _err="invalid scalar: o
 def fromBytesBatch(c, encodings, zip215=False, engine=None):
     """[c.fromBytes(b) for b in encodings] in one launch; entries the reference would reject
     (bad prefix / flags, x or y out of range, no square root, point outside the prime-order
-    subgroup on bls12-381 G1) come back as None instead of raising.  Encodings: secp256k1 33-byte
-    SEC1 compressed (weierstrass.ts:566-605), bls12-381 G1 48-byte compressed
-    (bls12-381.ts:377-459, :567-577), ed25519 32 bytes (edwards.ts:405-436, `zip215`)."""
-    size = {SECP256K1: 33, ED25519: 32, BLS12_381_G1: 48}.get(c.CURVE_ID)
+    subgroup on bls12-381) come back as None instead of raising.  Encodings: secp256k1 33-byte
+    SEC1 compressed (weierstrass.ts:566-605), bls12-381 G1 48-byte / G2 96-byte compressed
+    (bls12-381.ts:377-459, :567-577, :599-601), ed25519 32 bytes (edwards.ts:405-436, `zip215`)."""
+    size = {SECP256K1: 33, ED25519: 32, BLS12_381_G1: 48, BLS12_381_G2: 96}.get(c.CURVE_ID)
     if size is None:
         raise ValueError("noble-gpu: no batch decoder for this curve")
     if not encodings:
@@ -305,6 +305,24 @@ def fromBytesBatch(c, encodings, zip215=False, engine=None):
     eng = engine or get_engine()
     out, ok, inf = eng.decode_points_batch(c.CURVE_ID, np.array(rows), zip215)
     return [c._from_wire(out[i], bool(inf[i])) if ok[i] else None for i in range(len(rows))]
+
+
+def toBytesBatch(c, points, engine=None):
+    """[p.toBytes() for p in points] (compressed form) in one launch: secp256k1 SEC1 33 bytes
+    (weierstrass.ts:541-564), bls12-381 G1 48 / G2 96 bytes (bls12-381.ts:400-410), ed25519 32 bytes
+    (edwards.ts:620-628).  Non-normalised inputs are batch-normalised first (curve.ts:311-326).
+    secp256k1 ZERO raises like the reference ('bad point: ZERO')."""
+    if c.CURVE_ID not in (SECP256K1, ED25519, BLS12_381_G1, BLS12_381_G2):
+        raise ValueError("noble-gpu: no batch encoder for this curve")
+    validateMSMPoints(points, c)
+    if not points:
+        return []
+    eng = engine or get_engine()
+    enc, ok = eng.encode_points_batch(c.CURVE_ID, _points_wire(points, c.POINT_BYTES))
+    for i in range(len(points)):
+        if not ok[i]:
+            raise ValueError("bad point: ZERO")
+    return [enc[i].tobytes() for i in range(len(points))]
 
 
 def sumPoints(c, points, engine=None):

@@ -200,3 +200,48 @@ class Field2:
 
     def invertBatch(self, nums, pass_zero=True):
         return FpInvertBatch(self, nums, pass_zero)
+
+    def div(self, a, b):
+        return self.mul(a, self.inv(b))
+
+    def pow(self, n, e):            # tower.ts -> mod.FpPow (modular.ts:666-706): value only
+        r, b = self.ONE, n
+        while e > 0:
+            if e & 1:
+                r = self.mul(r, b)
+            b = self.sqr(b)
+            e >>= 1
+        return r
+
+    def frobeniusMap(self, n, power):   # tower.ts:516-521: conjugation for odd powers
+        return (n[0], self.Fp.neg(n[1])) if power & 1 else n
+
+    def sqrt(self, num):
+        """tower.ts:476-500: complex method over the non-residue -1, root normalised so that
+        (im, re) is the lexicographically larger of the two candidates."""
+        Fp = self.Fp
+        p = Fp.ORDER
+        c0, c1 = num
+
+        def legendre(x):            # modular.ts FpLegendre: 1, 0 or -1
+            r = pow(x, (p - 1) // 2, p)
+            return -1 if r == p - 1 else r
+
+        nonres = p - 1                                   # Fp_NONRESIDUE = -1
+        div2 = Fp.div(1, 2)
+        if c1 == 0:
+            if legendre(c0) == 1:
+                return (Fp.sqrt(c0), 0)
+            return (0, Fp.sqrt(Fp.div(c0, nonres)))
+        a = Fp.sqrt(Fp.sub(Fp.sqr(c0), Fp.mul(Fp.sqr(c1), nonres)))
+        d = Fp.mul(Fp.add(a, c0), div2)
+        if legendre(d) == -1:
+            d = Fp.sub(d, a)
+        a0 = Fp.sqrt(d)
+        cand = (a0, Fp.div(Fp.mul(c1, div2), a0))
+        if not self.eql(self.sqr(cand), num):
+            raise ValueError("Cannot find square root")
+        x1, x2 = cand, self.neg(cand)
+        if x1[1] > x2[1] or (x1[1] == x2[1] and x1[0] > x2[0]):
+            return x1
+        return x2

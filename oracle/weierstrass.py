@@ -378,3 +378,73 @@ def bls_g1_encode_compressed(p):
     if (y * 2) // Fp.ORDER:
         b[0] |= 0x20
     return bytes(b)
+
+
+def bls_g2_psi(Point, P):
+    """tower.ts:240-247,257-270 psiFrobenius.G2psi with base 1/(u+1) (bls12-381.ts:283):
+    psi(x, y) = (conj(x) * PSI_X, conj(y) * PSI_Y) on affine coordinates."""
+    F2 = Point.Fp
+    p = F2.Fp.ORDER
+    base = F2.div(F2.ONE, (1, 1))
+    PSI_X = F2.pow(base, (p - 1) // 3)
+    PSI_Y = F2.pow(base, (p - 1) // 2)
+    x, y = P.toAffine()
+    return Point.fromAffine((F2.mul(F2.frobeniusMap(x, 1), PSI_X), F2.mul(F2.frobeniusMap(y, 1), PSI_Y)))
+
+
+def bls_g2_is_torsion_free(Point, P):
+    """bls12-381.ts:599-601: [-x]P == psi(P)."""
+    return P.multiplyUnsafe(BLS_X).negate().equals(bls_g2_psi(Point, P))
+
+
+def _bls_sort_bit(parts, p):
+    """bls12-381.ts:346-351."""
+    for part in parts:
+        if part != 0:
+            return bool((part * 2) // p)
+    return False
+
+
+def bls_g2_decode_compressed(Point, data):
+    """G2 point decoding from the 96-byte compressed form: coder.decode (bls12-381.ts:377-433)
+    with fp2.decode (wire order c1 || c0, :354-368) and yparts [c1, c0] (:476-479), then
+    fromAffine + assertValidity (weierstrass.ts:720-766) incl. the psi subgroup check."""
+    F2 = Point.Fp
+    Fp = F2.Fp
+    data = bytes(data)
+    if len(data) != 96:
+        raise ValueError("invalid G2 point: expected 96 bytes")
+    mask = data[0] & 0xE0
+    compressed, infinity, sort = bool(mask & 0x80), bool(mask & 0x40), bool(mask & 0x20)
+    if (not compressed and sort) or (compressed and infinity and sort):
+        raise ValueError("invalid encoding flag")
+    if not compressed:
+        raise ValueError("invalid G2 point: expected 192 bytes")
+    value = bytes([data[0] & 0x1F]) + data[1:]
+    if infinity:
+        if any(value):
+            raise ValueError("invalid G2 point: non-canonical zero")
+        return Point.ZERO
+    x = (Fp.fromBytes(value[48:]), Fp.fromBytes(value[:48]))
+    y = F2.sqrt(F2.add(F2.mul(F2.sqr(x), x), Point.CURVE["b"]))   # raises if there is no root
+    if _bls_sort_bit([y[1], y[0]], Fp.ORDER) != sort:
+        y = F2.neg(y)
+    P = Point.fromAffine((x, y))
+    if P.is0():
+        raise ValueError("bad point: ZERO")
+    if not bls_g2_is_torsion_free(Point, P):
+        raise ValueError("bad point: not in prime-order subgroup")
+    return P
+
+
+def bls_g2_encode_compressed(p):
+    """bls12-381.ts:400-410 coder.encode with fp2.encode, compressed form."""
+    Fp = type(p).Fp.Fp
+    if p.is0():
+        return bytes([0xC0]) + bytes(95)
+    x, y = p.toAffine()
+    b = bytearray(x[1].to_bytes(48, "big") + x[0].to_bytes(48, "big"))
+    b[0] |= 0x80
+    if _bls_sort_bit([y[1], y[0]], Fp.ORDER):
+        b[0] |= 0x20
+    return bytes(b)

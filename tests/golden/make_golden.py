@@ -53,6 +53,7 @@ def main():
         "G2_Uncompressed": conv["G2_Uncompressed"][:256],
     })
     dump("bls12_381_g1_compressed.json", conv["G1_Compressed"][:256])
+    dump("bls12_381_g2_compressed.json", conv["G2_Compressed"][:256])
     # ed25519: first 160 sign.input lines (messages of 0..159 bytes)
     rows = []
     for i, line in enumerate(open(f"{REF}/ed25519/vectors.txt")):

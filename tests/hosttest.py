@@ -24,6 +24,8 @@ def lib():
         _lib.ht_ed25519_verify.argtypes = [vp, vp, vp, i32]
         _lib.ht_ed25519_mul_var.argtypes = [vp, vp, vp, vp, i32]
         _lib.ht_decode_points.argtypes = [i32, vp, i32, vp, vp, vp, i32]
+        _lib.ht_fp2_sqrt.argtypes = [vp, vp]
+        _lib.ht_encode_points.argtypes = [i32, vp, vp, vp, i32]
     return _lib
 
 
@@ -80,3 +82,20 @@ def decode_points(curve, encoded, point_bytes, flags=0):
     inf = np.zeros((n,), dtype=np.uint8)
     assert lib().ht_decode_points(curve, enc.ctypes.data, flags, out.ctypes.data, ok.ctypes.data, inf.ctypes.data, n) == 0
     return out, ok.astype(bool), inf.astype(bool)
+
+
+def fp2_sqrt(c0, c1):
+    a = np.frombuffer(int(c0).to_bytes(48, "little") + int(c1).to_bytes(48, "little"), dtype=np.uint8).copy()
+    r = np.zeros(96, dtype=np.uint8)
+    ok = lib().ht_fp2_sqrt(a.ctypes.data, r.ctypes.data)
+    b = r.tobytes()
+    return bool(ok), (int.from_bytes(b[:48], "little"), int.from_bytes(b[48:], "little"))
+
+
+def encode_points(curve, affine, enc_bytes):
+    aff = np.ascontiguousarray(affine, dtype=np.uint8)
+    n = aff.shape[0]
+    out = np.zeros((n, enc_bytes), dtype=np.uint8)
+    ok = np.zeros((n,), dtype=np.uint8)
+    assert lib().ht_encode_points(curve, aff.ctypes.data, out.ctypes.data, ok.ctypes.data, n) == 0
+    return out, ok.astype(bool)

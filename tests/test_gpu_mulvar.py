@@ -192,7 +192,7 @@ def test_from_bytes_batch_gpu():
     violations, points outside the G1 subgroup)."""
     from noble_curves_amd import curve as G
     from oracle.curves import Ed25519
-    from test_host_logic import decode_cases_g1, decode_cases_secp
+    from test_host_logic import decode_cases_g1, decode_cases_g2, decode_cases_secp
     cs = decode_cases_secp()
     got = G.fromBytesBatch(G.secp256k1_Point, [c[0] for c in cs])
     for (e, exp), g in zip(cs, got):
@@ -201,6 +201,19 @@ def test_from_bytes_batch_gpu():
     got = G.fromBytesBatch(G.bls12_381_G1_Point, [c[0] for c in cg])
     for (e, exp, is0), g in zip(cg, got):
         assert (g.toAffine() if g is not None else None) == exp and (g is None or g.is0() == is0), e.hex()
+    cg2 = decode_cases_g2()
+    cg2 += [(bytes.fromhex(r), None, None) for r in load_golden("bls12_381_g2_compressed.json")[12:256]]
+    unc = load_golden("bls12_381_multiples.json")["G2_Uncompressed"]
+    got = G.fromBytesBatch(G.bls12_381_G2_Point, [c[0] for c in cg2])
+    n0 = len(cg2) - 244
+    for i, ((e, exp, is0), g) in enumerate(zip(cg2, got)):
+        if i >= n0:  # zkcrypto vector (12 + i - n0) * G2: compare with its uncompressed twin
+            from oracle.curves import BlsG2
+            from oracle.weierstrass import bls_g2_decode_uncompressed
+            exp = bls_g2_decode_uncompressed(BlsG2, bytes.fromhex(unc[12 + i - n0])).toAffine()
+            assert g is not None and g.toAffine() == exp
+        else:
+            assert (g.toAffine() if g is not None else None) == exp and (g is None or g.is0() == is0), e.hex()
     encs = [bytes.fromhex(v["vk_bytes"]) for v in load_golden("ed25519_zip215.json")]
     for zip215 in (True, False):
         got = G.fromBytesBatch(G.ed25519_Point, encs, zip215=zip215)
@@ -210,3 +223,29 @@ def test_from_bytes_batch_gpu():
             except ValueError:
                 exp = None
             assert (g.toAffine() if g is not None else None) == exp, (e.hex(), zip215)
+
+
+@pytest.mark.gpu
+def test_to_bytes_batch_gpu_round_trip():
+    """toBytesBatch == the oracle encoders, and fromBytesBatch(toBytesBatch(P)) == P (all four curves)."""
+    from noble_curves_amd import curve as G
+    from oracle.curves import BlsG1, BlsG2, Ed25519, Secp256k1
+    from oracle.weierstrass import bls_g1_encode_compressed, bls_g2_encode_compressed, sec1_encode
+    rng = makeRng(0x70B7)
+    for Pt, O, encf, n in ((G.secp256k1_Point, Secp256k1, sec1_encode, 64),
+                           (G.bls12_381_G1_Point, BlsG1, bls_g1_encode_compressed, 48),
+                           (G.bls12_381_G2_Point, BlsG2, bls_g2_encode_compressed, 24),
+                           (G.ed25519_Point, Ed25519, lambda p: p.toBytes(), 64)):
+        ks = [1, 2] + [rng.rndBelow(Pt.Fn.ORDER - 1) + 1 for _ in range(n - 2)]
+        pts = G.multiplyBaseBatch(Pt, ks)
+        if Pt is not G.secp256k1_Point:
+            pts.append(Pt.ZERO)
+        enc = G.toBytesBatch(Pt, pts)
+        for p, e in zip(pts, enc):
+            x, y = p.toAffine()
+            op = O.ZERO if p.is0() else O.fromAffine((x, y))
+            assert e == encf(op)
+        back = G.fromBytesBatch(Pt, enc)
+        assert all(b is not None and b.equals(p) for b, p in zip(back, pts))
+    with pytest.raises(ValueError, match="bad point: ZERO"):
+        G.toBytesBatch(G.secp256k1_Point, [G.secp256k1_Point.ZERO])

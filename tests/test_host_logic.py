@@ -181,6 +181,74 @@ def decode_cases_g1():
     return cases
 
 
+def decode_cases_g2():
+    from helpers import load_golden
+    from oracle.curves import BlsG2, BLS_P
+    from oracle.weierstrass import bls_g2_decode_compressed
+    encs = [bytes.fromhex(r) for r in load_golden("bls12_381_g2_compressed.json")[:12]]
+    rng = makeRng(0xDEC0DE2)
+    g = bytearray(encs[3])
+    flip = bytearray(g); flip[0] ^= 0x20
+    nocomp = bytearray(g); nocomp[0] &= 0x7F
+    inf_bad = bytes([0xC0]) + bytes(94) + b"\x01"
+    inf_sort = bytes([0xE0]) + bytes(95)
+    big1 = bytearray((BLS_P + 5).to_bytes(48, "big") + bytes(g[48:])); big1[0] |= 0x80
+    big0 = bytearray(bytes(g[:48]) + BLS_P.to_bytes(48, "big"))
+    encs += [bytes(flip), bytes(nocomp), inf_bad, inf_sort, bytes(big1), bytes(big0), bytes([0xC0]) + bytes(95)]
+    # random x: non-squares, points outside the prime-order subgroup, and x with c1 = 0 / c0 = 0
+    for k in range(14):
+        x1 = 0 if k % 5 == 3 else rng.rndBelow(BLS_P)
+        x0 = 0 if k % 5 == 4 else rng.rndBelow(BLS_P)
+        b = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+        b[0] |= 0x80 | (0x20 if rng.rnd64() & 1 else 0)
+        encs.append(bytes(b))
+    cases = []
+    for e in encs:
+        try:
+            p = bls_g2_decode_compressed(BlsG2, e)
+            cases.append((e, p.toAffine(), p.is0()))
+        except ValueError:
+            cases.append((e, None, False))
+    assert sum(1 for c in cases if c[1] is None) >= 10 and sum(1 for c in cases if c[1] is not None) >= 12
+    return cases
+
+
+def test_fp2_sqrt_lane_decides_like_the_oracle():
+    """Fp2.sqrt (tower.ts:476-500): the single-power device variant finds a root exactly when the
+    reference does, and its root is +-the reference's; covers c1 == 0 (both Legendre cases) and 0."""
+    from oracle.curves import BlsG2, BLS_P
+    F2 = BlsG2.Fp
+    rng = makeRng(0x5152)
+    vals = [(rng.rndBelow(BLS_P), rng.rndBelow(BLS_P)) for _ in range(10)]
+    vals += [F2.sqr(v) for v in vals[:4]]
+    vals += [(rng.rndBelow(BLS_P), 0) for _ in range(6)] + [(0, rng.rndBelow(BLS_P)) for _ in range(3)]
+    vals += [(0, 0), (1, 0), (BLS_P - 1, 0), (4, 4)]
+    n_sq = 0
+    for v in vals:
+        try:
+            exp = F2.sqrt(v)
+        except ValueError:
+            exp = None
+        ok, r = hosttest.fp2_sqrt(*v)
+        assert ok == (exp is not None), v
+        if exp is not None:
+            n_sq += 1
+            assert r in (exp, F2.neg(exp)), v
+    assert 8 < n_sq < len(vals)
+
+
+def test_decode_lanes_g2():
+    """96-byte compressed decode + psi subgroup check, lane logic vs oracle."""
+    import numpy as np
+    from helpers import wire_to_affine
+    from noble_curves_amd._native import BLS12_381_G2
+    cg = decode_cases_g2()
+    out, ok, inf = hosttest.decode_points(BLS12_381_G2, np.array([np.frombuffer(c[0], np.uint8) for c in cg]), 192)
+    for i, (e, exp, is0) in enumerate(cg):
+        assert ok[i] == (exp is not None), (i, e.hex())
+        assert wire_to_affine(BLS12_381_G2, out[i]) == (exp if exp else ((0, 0), (0, 0))) and inf[i] == is0
+
+
 def test_decode_lanes_secp256k1_g1_ed25519():
     """decompression + validity, lane logic on the CPU vs the oracle."""
     import numpy as np
@@ -210,3 +278,31 @@ def test_decode_lanes_secp256k1_g1_ed25519():
             assert ok[i] == (exp is not None), (e.hex(), zip215)
             if exp:
                 assert wire_to_affine(ED25519, out[i]) == exp
+
+
+def test_encode_lanes_all_curves():
+    """Point.toBytes (compressed) lane logic vs the oracle encoders; decode(encode(P)) == P on the host lanes."""
+    import numpy as np
+    from helpers import load_golden, points_to_wire
+    from noble_curves_amd._native import BLS12_381_G2, ED25519
+    from oracle.curves import BlsG1, BlsG2, Ed25519, Secp256k1
+    from oracle.weierstrass import bls_g1_encode_compressed, bls_g2_encode_compressed, sec1_encode
+    rng = makeRng(0xE7C0DE)
+    ks = [1, 2, 3] + [rng.rndBelow(1 << 64) + 1 for _ in range(9)]
+    sp = [Secp256k1.BASE.multiplyUnsafe(k) for k in ks]
+    enc, ok = hosttest.encode_points(SECP256K1, points_to_wire(SECP256K1, sp + [Secp256k1.ZERO]), 33)
+    assert list(ok) == [True] * len(sp) + [False]
+    assert [enc[i].tobytes() for i in range(len(sp))] == [sec1_encode(p) for p in sp]
+    g1 = [BlsG1.BASE.multiplyUnsafe(k) for k in ks] + [BlsG1.ZERO]
+    enc, ok = hosttest.encode_points(BLS12_381_G1, points_to_wire(BLS12_381_G1, g1), 48)
+    assert ok.all() and [enc[i].tobytes() for i in range(len(g1))] == [bls_g1_encode_compressed(p) for p in g1]
+    assert [enc[i].tobytes().hex() for i in range(3)] == load_golden("bls12_381_g1_compressed.json")[1:4]
+    g2 = [BlsG2.BASE.multiplyUnsafe(k) for k in ks[:6]] + [BlsG2.ZERO]
+    enc, ok = hosttest.encode_points(BLS12_381_G2, points_to_wire(BLS12_381_G2, g2), 96)
+    assert ok.all() and [enc[i].tobytes() for i in range(len(g2))] == [bls_g2_encode_compressed(p) for p in g2]
+    assert [enc[i].tobytes().hex() for i in range(3)] == load_golden("bls12_381_g2_compressed.json")[1:4]
+    dec, dok, dinf = hosttest.decode_points(BLS12_381_G2, enc, 192)
+    assert dok.all() and (dec == points_to_wire(BLS12_381_G2, g2)).all() and list(dinf) == [False] * 6 + [True]
+    ed = [Ed25519.BASE.multiplyUnsafe(k) for k in ks] + [Ed25519.ZERO]
+    enc, ok = hosttest.encode_points(ED25519, points_to_wire(ED25519, ed), 32)
+    assert ok.all() and [enc[i].tobytes() for i in range(len(ed))] == [p.toBytes() for p in ed]

@@ -110,6 +110,36 @@ def test_bls12_381_g2_multiples():
         p1 = p1.add(BlsG2.BASE)
 
 
+def test_bls12_381_compressed_codecs():
+    """test/bls12-381.test.ts:1463-1476,1496-1510 - compressed i*G for G1 (48 B) and G2 (96 B):
+    decode (sqrt, sort bit, subgroup check) == the uncompressed vector, encode round-trips."""
+    from oracle.weierstrass import (bls_g1_decode_compressed, bls_g1_encode_compressed,
+                                    bls_g2_decode_compressed, bls_g2_encode_compressed)
+    unc = load("bls12_381_multiples.json")
+    g1c, g2c = load("bls12_381_g1_compressed.json"), load("bls12_381_g2_compressed.json")
+    for i in range(0, 256, 3):
+        P = bls_g1_decode_compressed(BlsG1, bytes.fromhex(g1c[i]))
+        assert P.toAffine() == bls_g1_decode_uncompressed(BlsG1, bytes.fromhex(unc["G1_Uncompressed"][i])).toAffine()
+        assert bls_g1_encode_compressed(P).hex() == g1c[i]
+    for i in range(0, 256, 5):
+        P = bls_g2_decode_compressed(BlsG2, bytes.fromhex(g2c[i]))
+        assert P.toAffine() == bls_g2_decode_uncompressed(BlsG2, bytes.fromhex(unc["G2_Uncompressed"][i])).toAffine()
+        assert bls_g2_encode_compressed(P).hex() == g2c[i]
+    # a point of E'(Fp2) outside the prime-order subgroup is rejected (bls12-381.ts:599-601)
+    F2 = BlsG2.Fp
+    x = (3, 1)
+    while True:
+        try:
+            y = F2.sqrt(F2.add(F2.mul(F2.sqr(x), x), BlsG2.CURVE["b"]))
+            break
+        except ValueError:
+            x = (x[0] + 1, 1)
+    enc = bytearray(x[1].to_bytes(48, "big") + x[0].to_bytes(48, "big"))
+    enc[0] |= 0x80
+    with pytest.raises(ValueError, match="subgroup"):
+        bls_g2_decode_compressed(BlsG2, bytes(enc))
+
+
 @pytest.mark.parametrize("Pt,order", [(Secp256k1, SECP256K1_N), (BlsG1, BLS_R), (BlsG2, BLS_R),
                                       (Ed25519, ED25519_L)])
 def test_pippenger_matches_naive_and_progression(Pt, order):

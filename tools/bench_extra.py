@@ -103,16 +103,9 @@ def main():
     g1o = torch.empty((m, 96), dtype=torch.uint8, device=dev)
     rate("bls12-381 G1 variable-base multiply", m, timeit(lambda: eng.mul_var_batch_dev(BLS12_381_G1, m, P(g1), P(gsc), P(g1o), P(inf), s), 2), "scalar-mults")
     rate("bls12-381 G1 fixed-base multiply", m, timeit(lambda: eng.mul_base_batch_dev(BLS12_381_G1, m, P(gsc), P(g1o), P(inf), s), 2), "scalar-mults")
-    genc = torch.flip(g1[:, :48], dims=[1]).clone()                         # compressed: x big-endian + flags
-    y_be = torch.flip(g1[:, 48:], dims=[1]).cpu().numpy()
-    halfp = np.frombuffer(((BlsG1.Fp.ORDER - 1) // 2).to_bytes(48, "big"), dtype=np.uint8)
-    gt = np.zeros(m, dtype=bool)
-    undecided = np.ones(m, dtype=bool)
-    for j in range(48):                                                     # lexicographic y > (p-1)/2
-        gt |= undecided & (y_be[:, j] > halfp[j])
-        undecided &= y_be[:, j] == halfp[j]
-    genc[:, 0] |= 0x80
-    genc[:, 0] |= torch.from_numpy((gt.astype(np.uint8) << 5)).to(dev)
+    genc = torch.empty((m, 48), dtype=torch.uint8, device=dev)              # compressed: x big-endian + flags
+    fenc = lambda: eng._check(eng.lib.ncg_encode_points_batch_dev(eng.h, BLS12_381_G1, m, P(g1), P(genc), P(ok), s))  # noqa: E731
+    rate("bls12-381 G1 encode (compressed)", m, timeit(fenc, 2), "points")
     fg = lambda: eng._check(eng.lib.ncg_decode_points_batch_dev(eng.h, BLS12_381_G1, m, P(genc), 0, P(g1o), P(ok), P(inf), s))  # noqa: E731
     fg()
     torch.cuda.synchronize()
@@ -121,6 +114,13 @@ def main():
     g2, _ = bench.gen_points(eng, BLS12_381_G2, BlsG2, m, a, b, dev, s)
     g2o = torch.empty((m, 192), dtype=torch.uint8, device=dev)
     rate("bls12-381 G2 variable-base multiply", m, timeit(lambda: eng.mul_var_batch_dev(BLS12_381_G2, m, P(g2), P(gsc), P(g2o), P(inf), s), 2), "scalar-mults")
+    g2enc = torch.empty((m, 96), dtype=torch.uint8, device=dev)
+    eng._check(eng.lib.ncg_encode_points_batch_dev(eng.h, BLS12_381_G2, m, P(g2), P(g2enc), P(ok), s))
+    fg2 = lambda: eng._check(eng.lib.ncg_decode_points_batch_dev(eng.h, BLS12_381_G2, m, P(g2enc), 0, P(g2o), P(ok), P(inf), s))  # noqa: E731
+    fg2()
+    torch.cuda.synchronize()
+    assert bool((g2o == g2).all().item()) and int(ok[:m].sum().item()) == m, "G2 decode mismatch"
+    rate("bls12-381 G2 decode + subgroup check", m, timeit(fg2, 2), "points")
     if args.out:
         with open(args.out, "w") as fjs:
             json.dump(res, fjs, indent=1)
