@@ -113,6 +113,24 @@ int ncg_encode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* affin
 int ncg_encode_points_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* affine_dev,
                                 void* out_encoded_dev, uint8_t* out_ok_dev, void* stream);
 
+/* ---- number-theoretic transform over a scalar field ------------------------------------------
+ * out = FFT(roots, Fr).direct(in, brpInput, brpOutput) / .inverse(...) of the reference
+ * (src/abstract/fft.ts:518-577 over FFTCore :422-480; tables rootsOfUnity :230-312) for `batch`
+ * polynomials of N = 2^log2n coefficients each, stored back to back.  Elements: canonical
+ * residues, 32 bytes little-endian.  `omega` (HOST pointer, 32 bytes, canonical) is the primitive
+ * N-th root roots.omega(log2n) = G^((r-1)/N); the table roots(log2n) is built on the device at
+ * first use and cached per size.  The inverse transform walks the reversed table
+ * (roots.inverse, :296-304) and scales by 1/N (:568-570).  in and out may alias. */
+#define NCG_FIELD_BLS12_381_FR 0
+#define NCG_NTT_INVERSE 1
+#define NCG_NTT_BRP_INPUT 2
+#define NCG_NTT_BRP_OUTPUT 4
+#define NCG_NTT_MAX_LOG2N 28
+int ncg_ntt(ncg_ctx* ctx, int field, int log2n, size_t batch, const void* omega, const void* in,
+            void* out, int flags);
+int ncg_ntt_dev(ncg_ctx* ctx, int field, int log2n, size_t batch, const void* omega,
+                const void* in_dev, void* out_dev, int flags, void* stream);
+
 /* ---- batch fixed-base scalar multiplication -----------------------------------------------
  * out[i] = scalars[i] * BASE.  Replaces, batch-wise, Point.BASE.multiply(k) / multiplyUnsafe(k)
  * through the cached window table (ScalarMultiplier.wnafCachedCT, src/abstract/curve.ts:588-606;

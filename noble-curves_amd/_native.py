@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SECP256K1, ED25519, BLS12_381_G1, BLS12_381_G2 = 0, 1, 2, 3
 POINT_BYTES = {SECP256K1: 64, ED25519: 64, BLS12_381_G1: 96, BLS12_381_G2: 192}
 FIELD_BYTES = {SECP256K1: 32, ED25519: 32, BLS12_381_G1: 48, BLS12_381_G2: 48}
+FIELD_BLS12_381_FR = 0
 ENCODED_BYTES = {SECP256K1: 33, ED25519: 32, BLS12_381_G1: 48, BLS12_381_G2: 96}   # compressed toBytes
 
 
@@ -82,6 +83,8 @@ _OPTIONAL_PROTOS = {
     "ncg_decode_points_batch_dev": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp, _vp],
     "ncg_encode_points_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
     "ncg_encode_points_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
+    "ncg_ntt": [_vp, _i32, _i32, _sz, _vp, _vp, _vp, _i32],
+    "ncg_ntt_dev": [_vp, _i32, _i32, _sz, _vp, _vp, _vp, _i32, _vp],
     "ncg_normalize_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
     "ncg_normalize_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_msm": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
@@ -259,6 +262,30 @@ class Engine:
     def ed25519_verify_batch_dev(self, n, d_sigs, d_pks, d_ks, zip215, d_ok, stream=None):
         self._check(self.lib.ncg_ed25519_verify_batch_dev(self.h, n, d_sigs, d_pks, d_ks, 1 if zip215 else 0,
                                                           d_ok, stream))
+
+    @staticmethod
+    def _ntt_flags(inverse, brp_input, brp_output):
+        return (1 if inverse else 0) | (2 if brp_input else 0) | (4 if brp_output else 0)
+
+    def ntt(self, log2n, data, omega, inverse=False, brp_input=False, brp_output=False):
+        """data uint8 [batch * 2^log2n, 32] (canonical LE residues of bls12-381 Fr) -> transformed
+        copy; omega: int, the primitive 2^log2n-th root of unity (roots.omega(log2n))."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 32)
+        n = 1 << log2n
+        if data.shape[0] % n:
+            raise ValueError("noble-gpu: ntt: data is not a whole number of 2^%d-point polynomials" % log2n)
+        out = np.empty_like(data)
+        om = np.frombuffer(int(omega).to_bytes(32, "little"), dtype=np.uint8).copy()
+        if data.shape[0]:
+            self._check(self.lib.ncg_ntt(self.h, FIELD_BLS12_381_FR, log2n, data.shape[0] // n, om.ctypes.data,
+                                         data.ctypes.data, out.ctypes.data,
+                                         self._ntt_flags(inverse, brp_input, brp_output)))
+        return out
+
+    def ntt_dev(self, log2n, batch, omega, d_in, d_out, stream, inverse=False, brp_input=False, brp_output=False):
+        om = np.frombuffer(int(omega).to_bytes(32, "little"), dtype=np.uint8).copy()
+        self._check(self.lib.ncg_ntt_dev(self.h, FIELD_BLS12_381_FR, log2n, batch, om.ctypes.data, d_in, d_out,
+                                         self._ntt_flags(inverse, brp_input, brp_output), stream))
 
     def ubench(self, kind, blocks, threads, iters):
         ms = ctypes.c_float()

@@ -33,6 +33,11 @@ struct ncg_ctx {
   uint32_t* ub_in = nullptr;
   uint32_t* ub_out = nullptr;
   size_t ub_out_words = 0;
+  // NTT: one twiddle table per transform size (device), keyed by the root it was built from
+  uint32_t* ntt_tab[NCG_NTT_MAX_LOG2N + 1] = {};
+  uint32_t ntt_omega[NCG_NTT_MAX_LOG2N + 1][8] = {};
+  void* ntt_ws = nullptr;
+  size_t ntt_ws_bytes = 0;
 };
 
 static int set_err(ncg_ctx* ctx, int code, const char* fmt, ...) {
@@ -117,6 +122,9 @@ void ncg_destroy(ncg_ctx* ctx) {
     if (ctx->base_tab[i]) (void)hipFree(ctx->base_tab[i]);
   if (ctx->ub_in) (void)hipFree(ctx->ub_in);
   if (ctx->ub_out) (void)hipFree(ctx->ub_out);
+  for (int i = 0; i <= NCG_NTT_MAX_LOG2N; i++)
+    if (ctx->ntt_tab[i]) (void)hipFree(ctx->ntt_tab[i]);
+  if (ctx->ntt_ws) (void)hipFree(ctx->ntt_ws);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -417,6 +425,106 @@ int ncg_encode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* affin
   if (rc) return rc;
   NCG_HIP(ctx, hipMemcpyAsync(out_encoded, d_out, n * (size_t)ob, hipMemcpyDeviceToHost, ctx->stream));
   NCG_HIP(ctx, hipMemcpyAsync(out_ok, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
+// twiddle table for (log2n, omega): built on first use, rebuilt if a different root is passed
+static int ensure_ntt_table(ncg_ctx* ctx, int log2n, const uint32_t* omega) {
+  if (ctx->ntt_tab[log2n] && memcmp(ctx->ntt_omega[log2n], omega, 32) == 0) return NCG_OK;
+  if (ctx->ntt_tab[log2n]) {
+    NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->ntt_tab[log2n]);
+    ctx->ntt_tab[log2n] = nullptr;
+  }
+  uint32_t* tab = nullptr;
+  void* tmp = nullptr;
+  hipError_t e = hipMalloc((void**)&tab, ncg::ntt_table_bytes(log2n));
+  if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: ntt table hipMalloc failed: %s", hipGetErrorString(e));
+  e = hipMalloc(&tmp, ncg::ntt_small_bytes(log2n) + 32);
+  if (e != hipSuccess) {
+    (void)hipFree(tab);
+    return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: ntt table hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  uint32_t* d_omega = (uint32_t*)tmp;
+  uint32_t* d_small = d_omega + 8;
+  uint32_t probe[8] = {0};
+  e = hipMemcpyAsync(d_omega, omega, 32, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = ncg::ntt_build_table(log2n, d_omega, d_small, tab, ctx->stream);
+  // primitive-root check: omega^(N/2) == -1 (N = 1: omega == 1); table entries are in Montgomery form
+  const size_t probe_idx = log2n ? ((size_t)1 << (log2n - 1)) : 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(probe, tab + probe_idx * 8, 32, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) {
+    (void)hipFree(tab);
+    return set_err(ctx, NCG_ERR_HIP, "noble-gpu: ntt table build failed: %s", hipGetErrorString(e));
+  }
+  uint32_t expect[8];  // R mod r for +1, r - (R mod r) for -1
+  if (log2n == 0) {
+    for (int i = 0; i < 8; i++) expect[i] = ncg::ParamsBlsR::R1[i];
+  } else {
+    uint64_t bw = 0;
+    for (int i = 0; i < 8; i++) {
+      uint64_t d = (uint64_t)ncg::ParamsBlsR::P[i] - ncg::ParamsBlsR::R1[i] - bw;
+      expect[i] = (uint32_t)d;
+      bw = (d >> 32) & 1;
+    }
+  }
+  if (memcmp(probe, expect, 32) != 0) {
+    (void)hipFree(tab);
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: omega is not a primitive 2^%d-th root of unity", log2n);
+  }
+  ctx->ntt_tab[log2n] = tab;
+  memcpy(ctx->ntt_omega[log2n], omega, 32);
+  return NCG_OK;
+}
+
+int ncg_ntt_dev(ncg_ctx* ctx, int field, int log2n, size_t batch, const void* omega, const void* in_dev, void* out_dev,
+                int flags, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (field != NCG_FIELD_BLS12_381_FR) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ntt: unsupported field %d", field);
+  if (log2n < 0 || log2n > NCG_NTT_MAX_LOG2N)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: log2n %d out of range 0..%d", log2n, NCG_NTT_MAX_LOG2N);
+  if (batch == 0) return NCG_OK;
+  if (batch > 65535) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: batch too large");
+  if (!omega || !in_dev || !out_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_ntt_table(ctx, log2n, (const uint32_t*)omega);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  const bool fold = ((flags >> 1) & 1) == ((flags >> 2) & 1);
+  const size_t bytes = (batch << log2n) * 32;
+  if (fold && log2n > 10 && ctx->ntt_ws_bytes < bytes) {
+    if (ctx->ntt_ws) {
+      NCG_HIP(ctx, hipDeviceSynchronize());
+      (void)hipFree(ctx->ntt_ws);
+      ctx->ntt_ws = nullptr;
+      ctx->ntt_ws_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ctx->ntt_ws, bytes);
+    if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: ntt workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    ctx->ntt_ws_bytes = bytes;
+  }
+  NCG_HIP(ctx, ncg::ntt_run(log2n, batch, (const uint32_t*)in_dev, (uint32_t*)out_dev, (uint32_t*)ctx->ntt_ws,
+                            ctx->ntt_tab[log2n], log2n, flags, st));
+  return NCG_OK;
+}
+
+int ncg_ntt(ncg_ctx* ctx, int field, int log2n, size_t batch, const void* omega, const void* in, void* out, int flags) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (log2n < 0 || log2n > NCG_NTT_MAX_LOG2N)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: log2n %d out of range 0..%d", log2n, NCG_NTT_MAX_LOG2N);
+  if (batch == 0) return NCG_OK;
+  if (!omega || !in || !out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (batch << log2n) * 32;
+  int rc = ensure_scratch(ctx, bytes + 1024);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(ctx->scratch, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  rc = ncg_ntt_dev(ctx, field, log2n, batch, omega, ctx->scratch, ctx->scratch, flags, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(out, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }

@@ -28,6 +28,14 @@ hipError_t encode_points_batch(int curve, const uint32_t* in, uint8_t* out, uint
 void encode_points_host(int curve, const uint32_t* in, uint8_t* out, uint8_t* ok, int n);
 void decode_points_host(int curve, const uint8_t* in, int flags, uint32_t* out, uint8_t* ok, uint8_t* inf, int n);
 
+// radix-2 NTT over bls12-381 Fr (ntt.hip)
+size_t ntt_table_bytes(int n);
+size_t ntt_small_bytes(int n);
+hipError_t ntt_build_table(int n, const uint32_t* d_omega, uint32_t* d_small, uint32_t* d_tab, hipStream_t st);
+hipError_t ntt_run(int n, size_t batch, const uint32_t* src, uint32_t* dst, uint32_t* ws, const uint32_t* tab,
+                   int tab_log, int flags, hipStream_t st);
+void ntt_host(int n, const uint32_t* omega_wire, const uint32_t* src, uint32_t* dst, int flags);
+
 struct MsmPlan;
 int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl);
 size_t msm_workspace_bytes(int curve, const MsmPlan& pl);

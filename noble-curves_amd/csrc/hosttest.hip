@@ -7,6 +7,7 @@
 #include "mulvar.hpp"
 #include "ed25519.hip"  // single-TU inclusion: lane function + host table builder
 #include "decode.hip"
+#include "ntt.hip"
 
 using namespace ncg;
 
@@ -91,6 +92,22 @@ int ht_decode_points(int curve, const uint8_t* in, int flags, uint32_t* out, uin
 int ht_encode_points(int curve, const uint32_t* in, uint8_t* out, uint8_t* ok, int n) {
   encode_points_host(curve, in, out, ok, n);
   return 0;
+}
+
+// NTT over Fr on the CPU through the device field code (butterflies + table walk of ntt.hip)
+int ht_ntt(int n, const uint32_t* omega, const uint32_t* in, uint32_t* out, int flags) {
+  ntt_host(n, omega, in, out, flags);
+  return 0;
+}
+// the pass planner of ntt_run: writes s_lo/T pairs, returns the number of passes
+int ht_ntt_plan(int n, int* out) {
+  int s_lo[8], T[8];
+  int np = ntt_plan(n, s_lo, T);
+  for (int i = 0; i < np; i++) {
+    out[2 * i] = s_lo[i];
+    out[2 * i + 1] = T[i];
+  }
+  return np;
 }
 
 // ed25519 verify of one item on the CPU through the kernel's lane function

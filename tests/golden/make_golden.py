@@ -63,6 +63,25 @@ def main():
         sk_pk, pk, msg, sig_msg = parts[0], parts[1], parts[2], parts[3]
         rows.append({"sk": sk_pk[:64], "pk": pk, "msg": msg, "sig": sig_msg[:128]})
     dump("ed25519_vectors.json", rows)
+    # FFT known answers are inline in test/fft.test.ts (:155-183 roots/brp tables, :221-237 Basic FFT)
+    import re
+    ts = open(f"{REF}/../fft.test.ts").read()
+
+    def bigints(block):
+        return [str(int(x)) for x in re.findall(r"(\d+)n", block)]
+    i0 = ts.index("roots = fft.rootsOfUnity(bls12_381.fields.Fr, 7n);\n      eql(")
+    i1 = ts.index("'bls12_381 roots'")
+    i2 = ts.index("'bls12_381 brp'")
+    j0 = ts.index("it('Basic FFT'")
+    j1 = ts.index("eql(fftFr.direct(input), exp);")
+    basic = ts[j0:j1]
+    dump("fft_kat.json", {
+        "generator": "7",
+        "roots3": bigints(ts[i0:i1])[1:],            # drop the generator literal 7n
+        "brp3": bigints(ts[i1:i2]),
+        "basic_input": bigints(basic[basic.index("const input"):basic.index("const exp")]),
+        "basic_exp": bigints(basic[basic.index("const exp"):]),
+    })
     dump("ed25519_zip215.json", json.load(open(f"{REF}/ed25519/zip215.json")))
     dump("ed25519_edge_cases.json", json.load(open(f"{REF}/ed25519/edge-cases.json")))
 

@@ -26,6 +26,8 @@ def lib():
         _lib.ht_decode_points.argtypes = [i32, vp, i32, vp, vp, vp, i32]
         _lib.ht_fp2_sqrt.argtypes = [vp, vp]
         _lib.ht_encode_points.argtypes = [i32, vp, vp, vp, i32]
+        _lib.ht_ntt.argtypes = [i32, vp, vp, vp, i32]
+        _lib.ht_ntt_plan.argtypes = [i32, vp]
     return _lib
 
 
@@ -99,3 +101,20 @@ def encode_points(curve, affine, enc_bytes):
     ok = np.zeros((n,), dtype=np.uint8)
     assert lib().ht_encode_points(curve, aff.ctypes.data, out.ctypes.data, ok.ctypes.data, n) == 0
     return out, ok.astype(bool)
+
+
+def ntt(log2n, values, omega, flags):
+    """values: list of ints (one polynomial); returns list of ints."""
+    n = 1 << log2n
+    a = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in values), dtype=np.uint8).copy()
+    om = np.frombuffer(int(omega).to_bytes(32, "little"), dtype=np.uint8).copy()
+    out = np.zeros(n * 32, dtype=np.uint8)
+    assert lib().ht_ntt(log2n, om.ctypes.data, a.ctypes.data, out.ctypes.data, flags) == 0
+    b = out.tobytes()
+    return [int.from_bytes(b[32 * i:32 * i + 32], "little") for i in range(n)]
+
+
+def ntt_plan(log2n):
+    buf = np.zeros(16, dtype=np.int32)
+    np_ = lib().ht_ntt_plan(log2n, buf.ctypes.data)
+    return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(np_)]

@@ -1,0 +1,112 @@
+"""GPU parity for the NTT over bls12-381 Fr through the C ABI (`ncg_ntt`)."""
+import numpy as np
+import pytest
+
+from noble_curves_amd import fft as G
+from noble_curves_amd import get_engine
+from noble_curves_amd._native import ints_to_le, le_to_ints
+from oracle.curves import Fr_bls, makeRng
+from oracle.fft import FFT, RootsOfUnity, bitReversalPermutation
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+R = Fr_bls.ORDER
+
+
+
+def test_fft_known_answers_gpu():
+    """test/fft.test.ts:155-183, :221-251 through the mirror (same calls as the reference's test)."""
+    kat = load_golden("fft_kat.json")
+    roots = G.rootsOfUnity(G.bls12_381_Fr, 7)
+    assert roots.roots(3) == [int(x) for x in kat["roots3"]]
+    assert roots.brp(3) == [int(x) for x in kat["brp3"]]
+    fftFr = G.FFT(roots, G.bls12_381_Fr)
+    inp, exp = [int(x) for x in kat["basic_input"]], [int(x) for x in kat["basic_exp"]]
+    brp = G.bitReversalPermutation
+    assert fftFr.direct(inp) == exp
+    assert fftFr.direct(brp(inp), True) == exp
+    assert brp(fftFr.direct(inp, False, True)) == exp
+    assert brp(fftFr.direct(brp(inp), True, True)) == exp
+    assert fftFr.inverse(fftFr.direct(inp)) == inp
+    assert fftFr.inverse(fftFr.direct(inp, False, True), True) == inp
+    assert brp(fftFr.inverse(fftFr.direct(inp), False, True)) == inp
+    assert brp(fftFr.inverse(fftFr.direct(inp, False, True), True, True)) == inp
+    assert fftFr.direct([5]) == [5] and fftFr.inverse([5]) == [5]
+    with pytest.raises(ValueError, match="FFT: Polynomial size should be power of two"):
+        fftFr.inverse([])
+    with pytest.raises(ValueError, match="FFT: Polynomial size should be power of two"):
+        fftFr.direct([1, 2, 3])
+    with pytest.raises(ValueError, match="rootsOfUnity: wrong bits"):
+        roots.roots(33)
+
+
+@pytest.mark.parametrize("bits", [1, 2, 5, 9, 10, 11, 12, 14])
+def test_ntt_matches_oracle_all_orderings(bits):
+    """every (inverse, brpInput, brpOutput) combination; sizes straddle the 1-pass / 2-pass boundary"""
+    rng = makeRng(0x4E77 + bits)
+    oroots = RootsOfUnity(Fr_bls, 7)
+    of = FFT(oroots, Fr_bls)
+    f = G.FFT(G.rootsOfUnity(G.bls12_381_Fr, 7))
+    x = [rng.rndBelow(R) for _ in range(1 << bits)]
+    x[0], x[1] = 0, R - 1
+    for flags in range(8):
+        inv, bi, bo = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+        exp = (of.inverse if inv else of.direct)(x, bi, bo)
+        got = (f.inverse if inv else f.direct)(x, bi, bo)
+        assert got == exp, (bits, flags)
+
+
+def test_ntt_three_pass_size_matches_oracle():
+    """2^19 = 10 + 5 + 4 stages: three passes, both butterfly kinds, folded bit reversal through the workspace"""
+    bits = 19
+    rng = makeRng(0x4E7719)
+    oroots = RootsOfUnity(Fr_bls, 7)
+    f = G.FFT(G.rootsOfUnity(G.bls12_381_Fr, 7))
+    x = [rng.rndBelow(R) for _ in range(1 << bits)]
+    # oracle via the defining sum at a few output indices (an O(N) check per index)
+    w = oroots.omega(bits)
+    y = f.direct(x)
+    for k in (0, 1, 2, 12345, (1 << bits) - 1, 1 << 18):
+        wk = pow(w, k, R)
+        acc, cur = 0, 1
+        for xi in x:
+            acc = (acc + xi * cur) % R
+            cur = cur * wk % R
+        assert y[k] == acc, k
+    yb = f.direct(x, False, True)
+    assert yb == bitReversalPermutation(y)
+    assert f.inverse(yb, True) == x
+    assert f.inverse(y) == x
+    assert f.direct(bitReversalPermutation(x), True) == y
+
+
+def test_ntt_batch_and_raw_arrays():
+    """a batch of polynomials in one call == the transforms one by one; uint8 arrays pass through"""
+    eng = get_engine()
+    roots = G.rootsOfUnity(G.bls12_381_Fr, 7)
+    rng = makeRng(0xBA7C4)
+    bits, batch = 11, 5
+    polys = [[rng.rndBelow(R) for _ in range(1 << bits)] for _ in range(batch)]
+    data = ints_to_le([v for p in polys for v in p], 32)
+    for flags in (0, 1, 4, 7):
+        out = eng.ntt(bits, data, roots.omega(bits), inverse=bool(flags & 1), brp_input=bool(flags & 2),
+                      brp_output=bool(flags & 4))
+        for b in range(batch):
+            one = eng.ntt(bits, data[b << bits:(b + 1) << bits], roots.omega(bits), inverse=bool(flags & 1),
+                          brp_input=bool(flags & 2), brp_output=bool(flags & 4))
+            assert (out[b << bits:(b + 1) << bits] == one).all()
+    f = G.FFT(roots)
+    raw = f.direct(data[:1 << bits])
+    assert isinstance(raw, np.ndarray) and le_to_ints(raw, 32) == f.direct(polys[0])
+
+
+def test_ntt_rejects_bad_root_and_range():
+    eng = get_engine()
+    from noble_curves_amd._native import NativeError
+    data = ints_to_le([1, 2, 3, 4], 32)
+    with pytest.raises(NativeError, match="primitive 2\\^2-th root"):
+        eng.ntt(2, data, 5)
+    f = G.FFT(G.rootsOfUnity(G.bls12_381_Fr, 7))
+    with pytest.raises(ValueError, match="outside of range"):
+        f.direct([R, 0])

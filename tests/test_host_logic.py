@@ -306,3 +306,35 @@ def test_encode_lanes_all_curves():
     ed = [Ed25519.BASE.multiplyUnsafe(k) for k in ks] + [Ed25519.ZERO]
     enc, ok = hosttest.encode_points(ED25519, points_to_wire(ED25519, ed), 32)
     assert ok.all() and [enc[i].tobytes() for i in range(len(ed))] == [p.toBytes() for p in ed]
+
+
+def test_ntt_lane_code_matches_oracle_all_orderings():
+    """the device butterflies + table walk (ntt.hip, executed on the CPU) against
+    the oracle FFT for every (inverse, brpInput, brpOutput) combination and the reference's KAT."""
+    from helpers import load_golden
+    from oracle.curves import Fr_bls
+    from oracle.fft import FFT, RootsOfUnity
+    roots = RootsOfUnity(Fr_bls, 7)
+    f = FFT(roots, Fr_bls)
+    kat = load_golden("fft_kat.json")
+    assert hosttest.ntt(3, [int(x) for x in kat["basic_input"]], roots.omega(3), 0) == [int(x) for x in kat["basic_exp"]]
+    rng = makeRng(0x177)
+    for bits in (0, 1, 2, 5, 7):
+        x = [rng.rndBelow(Fr_bls.ORDER) for _ in range(1 << bits)]
+        if bits >= 2:
+            x[0], x[1] = 0, Fr_bls.ORDER - 1
+        for flags in range(8):
+            inv, bi, bo = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+            exp = (f.inverse if inv else f.direct)(x, bi, bo)
+            assert hosttest.ntt(bits, x, roots.omega(bits), flags) == exp, (bits, flags)
+
+
+def test_ntt_pass_plan_covers_every_stage_once():
+    for n in range(1, 29):
+        plan = hosttest.ntt_plan(n)
+        s = 1
+        for k, (s_lo, t) in enumerate(plan):
+            assert s_lo == s and 1 <= t <= (10 if k == 0 else 8)
+            s += t
+        assert s == n + 1
+    assert hosttest.ntt_plan(0) == []

@@ -271,3 +271,35 @@ def test_ed25519_torsion_exact():
     for k in (1, 2, 7, 8, 9, 12345, ED25519_L - 1):
         assert P.multiplyUnsafe(k).equals(C.naiveMul(Ed25519, P, k))
         assert P.multiply(k).equals(C.naiveMul(Ed25519, P, k))
+
+
+def test_fft_known_answers():
+    """test/fft.test.ts:155-183 (roots / brp tables for bls12-381 Fr, generator 7) and :221-251
+    ('Basic FFT': all four orderings, inverse round trips)."""
+    from oracle.curves import Fr_bls
+    from oracle.fft import FFT, RootsOfUnity, bitReversalPermutation
+    kat = load("fft_kat.json")
+    roots = RootsOfUnity(Fr_bls, int(kat["generator"]))
+    assert roots.roots(3) == [int(x) for x in kat["roots3"]]
+    assert roots.brp(3) == [int(x) for x in kat["brp3"]]
+    f = FFT(roots, Fr_bls)
+    inp, exp = [int(x) for x in kat["basic_input"]], [int(x) for x in kat["basic_exp"]]
+    brp = bitReversalPermutation
+    assert f.direct(inp) == exp
+    assert f.direct(brp(inp), True) == exp
+    assert brp(f.direct(inp, False, True)) == exp
+    assert brp(f.direct(brp(inp), True, True)) == exp
+    assert f.inverse(f.direct(inp)) == inp
+    assert f.inverse(f.direct(inp, False, True), True) == inp
+    assert brp(f.inverse(f.direct(inp), False, True)) == inp
+    assert brp(f.inverse(f.direct(inp, False, True), True, True)) == inp
+    # size-1 transform is the identity (test/fft.test.ts:253-261)
+    assert f.direct([5]) == [5] and f.inverse([5]) == [5]
+    with pytest.raises(ValueError, match="power of two"):
+        f.inverse([])
+    # naive DFT definition on a random 16-point input
+    rng = makeRng(0xFF7)
+    x = [rng.rndBelow(Fr_bls.ORDER) for _ in range(16)]
+    w = roots.omega(4)
+    naive = [sum(x[i] * pow(w, i * k, Fr_bls.ORDER) for i in range(16)) % Fr_bls.ORDER for k in range(16)]
+    assert f.direct(x) == naive
