@@ -113,6 +113,20 @@ int ncg_encode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* affin
 int ncg_encode_points_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* affine_dev,
                                 void* out_encoded_dev, uint8_t* out_ok_dev, void* stream);
 
+/* ---- batch map-to-curve (hash-to-curve without the byte hashing) ------------------------------
+ * out[i] = clearCofactor( sum_j mapToCurve(u[i][j]) ), j < count, for NCG_BLS12_381_G1 / _G2:
+ * count = 2 is createHasher(...).hashToCurve after hash_to_field, count = 1 is encodeToCurve /
+ * mapToCurve (src/abstract/hash-to-curve.ts:441-548; SWU :652-717, isogeny :381-410; suite
+ * constants and clearCofactor src/bls12-381.ts:560-619, :668-862).  The byte-level
+ * hash_to_field / expand_message_xmd (:189-228, :312-378) is done by the host shim.
+ * u: n * count field elements, each one Fp (48 bytes LE) for G1 or Fp2 (c0 then c1, 96 bytes)
+ * for G2, any value below 2^384 (reduced mod p like Fp.create).  ZERO gives out_is_inf = 1 and
+ * (0, 0).  out_is_inf may be NULL in the host-pointer variant. */
+int ncg_map_to_curve_batch(ncg_ctx* ctx, int curve, size_t n, int count, const void* u,
+                           void* out_affine, uint8_t* out_is_inf);
+int ncg_map_to_curve_batch_dev(ncg_ctx* ctx, int curve, size_t n, int count, const void* u_dev,
+                               void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream);
+
 /* ---- number-theoretic transform over a scalar field ------------------------------------------
  * out = FFT(roots, Fr).direct(in, brpInput, brpOutput) / .inverse(...) of the reference
  * (src/abstract/fft.ts:518-577 over FFTCore :422-480; tables rootsOfUnity :230-312) for `batch`

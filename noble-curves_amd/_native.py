@@ -83,6 +83,8 @@ _OPTIONAL_PROTOS = {
     "ncg_decode_points_batch_dev": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp, _vp],
     "ncg_encode_points_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
     "ncg_encode_points_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
+    "ncg_map_to_curve_batch": [_vp, _i32, _sz, _i32, _vp, _vp, _vp],
+    "ncg_map_to_curve_batch_dev": [_vp, _i32, _sz, _i32, _vp, _vp, _vp, _vp],
     "ncg_ntt": [_vp, _i32, _i32, _sz, _vp, _vp, _vp, _i32],
     "ncg_ntt_dev": [_vp, _i32, _i32, _sz, _vp, _vp, _vp, _i32, _vp],
     "ncg_normalize_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
@@ -262,6 +264,22 @@ class Engine:
     def ed25519_verify_batch_dev(self, n, d_sigs, d_pks, d_ks, zip215, d_ok, stream=None):
         self._check(self.lib.ncg_ed25519_verify_batch_dev(self.h, n, d_sigs, d_pks, d_ks, 1 if zip215 else 0,
                                                           d_ok, stream))
+
+    def map_to_curve_batch(self, curve, u, count):
+        """u uint8 [n, count * FIELD_BYTES * (2 for G2)] -> (affine [n, PB], is_inf [n]):
+        clearCofactor(sum of the `count` mapped points) per row (bls12-381 G1 / G2)."""
+        pb = POINT_BYTES[curve]
+        u = np.ascontiguousarray(u, dtype=np.uint8).reshape(-1, count * pb // 2)
+        n = u.shape[0]
+        out = np.empty((n, pb), dtype=np.uint8)
+        inf = np.empty((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_map_to_curve_batch(self.h, curve, n, count, u.ctypes.data, out.ctypes.data,
+                                                        inf.ctypes.data))
+        return out, inf
+
+    def map_to_curve_batch_dev(self, curve, n, count, d_u, d_out, d_inf, stream):
+        self._check(self.lib.ncg_map_to_curve_batch_dev(self.h, curve, n, count, d_u, d_out, d_inf, stream))
 
     @staticmethod
     def _ntt_flags(inverse, brp_input, brp_output):

@@ -429,6 +429,48 @@ int ncg_encode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* affin
   return NCG_OK;
 }
 
+int ncg_map_to_curve_batch_dev(ncg_ctx* ctx, int curve, size_t n, int count, const void* u_dev, void* out_affine_dev,
+                               uint8_t* out_is_inf_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_BLS12_381_G1 && curve != NCG_BLS12_381_G2)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: map_to_curve_batch: unsupported curve %d", curve);
+  if (count != 1 && count != 2) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: map_to_curve_batch: count must be 1 or 2");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!u_dev || !out_affine_dev || !out_is_inf_dev)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: map_to_curve_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  NCG_HIP(ctx, ncg::map_to_curve_batch(curve, (const uint32_t*)u_dev, count, (uint32_t*)out_affine_dev, out_is_inf_dev,
+                                       (int)n, st));
+  return NCG_OK;
+}
+
+int ncg_map_to_curve_batch(ncg_ctx* ctx, int curve, size_t n, int count, const void* u, void* out_affine,
+                           uint8_t* out_is_inf) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_BLS12_381_G1 && curve != NCG_BLS12_381_G2)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: map_to_curve_batch: unsupported curve %d", curve);
+  if (count != 1 && count != 2) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: map_to_curve_batch: count must be 1 or 2");
+  if (n == 0) return NCG_OK;
+  if (!u || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: map_to_curve_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  const int pb = ncg_point_bytes(curve);
+  const size_t in_b = (n * (size_t)count * (pb / 2) + 255) & ~(size_t)255, out_b = n * (size_t)pb;
+  int rc = ensure_scratch(ctx, in_b + out_b + n + 1024);
+  if (rc) return rc;
+  char* d_in = (char*)ctx->scratch;
+  char* d_out = d_in + in_b;
+  char* d_inf = d_out + out_b;
+  NCG_HIP(ctx, hipMemcpyAsync(d_in, u, n * (size_t)count * (pb / 2), hipMemcpyHostToDevice, ctx->stream));
+  rc = ncg_map_to_curve_batch_dev(ctx, curve, n, count, d_in, d_out, (uint8_t*)d_inf, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
 // twiddle table for (log2n, omega): built on first use, rebuilt if a different root is passed
 static int ensure_ntt_table(ncg_ctx* ctx, int log2n, const uint32_t* omega) {
   if (ctx->ntt_tab[log2n] && memcmp(ctx->ntt_omega[log2n], omega, 32) == 0) return NCG_OK;

@@ -14,7 +14,7 @@
 // out_ok[i] = 0 exactly where the reference throws; the affine output is then (0,0).
 #include <vector>
 
-#include "curves.hpp"
+#include "bls_lanes.hpp"
 #include "host_api.hpp"
 
 namespace ncg {
@@ -72,35 +72,6 @@ NCG_DI bool secp_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restric
 }
 
 // ---------------------------------------------------------------------------- bls12-381 G1
-NCG_DI Fe29<2> fe29_pow_words12(const Fe29<2>& a, const uint32_t* e) {  // square-and-multiply, MSB first
-  Fe29<2> r = Fe29<1>::one();
-  bool started = false;
-  for (int w = 11; w >= 0; w--) {
-    const uint32_t word = e[w];
-    for (int bit = 31; bit >= 0; bit--) {
-      if (started) r = f_sqr(r);
-      if ((word >> bit) & 1u) {
-        r = started ? r * a : a;
-        started = true;
-      }
-    }
-  }
-  return r;
-}
-
-// [x]P for the BLS parameter x = 0xd201000000010000 (Jacobian double-and-add; x is public and
-// identical for every lane)
-template <class F>
-NCG_DI Jac<F> bls_mul_by_x(const Jac<F>& p) {
-  const uint64_t X = 0xD201000000010000ull;
-  Jac<F> r = p;  // top bit
-  for (int bit = 62; bit >= 0; bit--) {
-    r = jac_dbl(r);
-    if ((X >> bit) & 1ull) r = jac_add(r, p);
-  }
-  return r;
-}
-
 // in: 48 bytes; out: x || y wire (12 + 12 LE limbs).  *inf set for the canonical infinity encoding.
 NCG_DI bool g1_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint8_t* inf) {
   using F = FeBls;
@@ -176,69 +147,6 @@ NCG_DI bool g1_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------- bls12-381 G2
-NCG_DI Fe29<1> fe29_const(const uint32_t (&c)[14]) {
-  Fe29<1> r;
-#pragma unroll
-  for (int i = 0; i < 14; i++) r.v[i] = c[i];
-  return r;
-}
-NCG_DI void be48_to_words(const uint8_t* __restrict__ in, uint32_t (&w)[12]) {
-#pragma unroll
-  for (int i = 0; i < 12; i++) {
-    const uint8_t* b = in + (11 - i) * 4;
-    w[i] = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3];
-  }
-}
-NCG_DI bool words12_lt_p(const uint32_t (&w)[12]) {
-  uint32_t bw = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) (void)__builtin_subc(w[i], (uint32_t)BlsFpConsts::P32[i], bw, &bw);
-  return bw != 0;
-}
-NCG_DI bool words12_gt_half_p(const uint32_t (&w)[12]) {  // (2 w) / p != 0
-  uint32_t bw = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) (void)__builtin_subc((uint32_t)BlsFpConsts::HALF_P[i], w[i], bw, &bw);
-  return bw != 0;
-}
-NCG_DI void words12_neg_mod_p(uint32_t (&w)[12]) {  // w = p - w for w != 0
-  uint32_t any = 0, bw = 0;
-#pragma unroll
-  for (int i = 0; i < 12; i++) any |= w[i];
-  if (any == 0) return;
-#pragma unroll
-  for (int i = 0; i < 12; i++) w[i] = __builtin_subc((uint32_t)BlsFpConsts::P32[i], w[i], bw, &bw);
-}
-
-// Square root in Fp2 = Fp[u]/(u^2+1), p = 3 mod 4.  The reference's complex method
-// (tower.ts:476-500) spends sqrt(norm) + Legendre(d) + sqrt(d) + one inversion; here the Legendre
-// symbol, the root and the inverse all come out of ONE power t = d^((p-3)/4):
-//   s = t d satisfies s^2 = +-d and t s = d^((p-1)/2) = +-1, so 1/s = +-t;
-//   s^2 =  d: root (s, c1/(2s));   s^2 = -d (d a non-residue): root (c1/(2s), s), using
-//   d d' = -c1^2/4 for the reference's second candidate d' = d - a.
-// Which of the two roots comes out is irrelevant to the caller (the sort bit picks the sign);
-// existence is decided exactly like the reference: norm must be a square and root^2 == num.
-NCG_DI bool fe29x2_sqrt(const Fe29x2<2>& num, Fe29x2<2>& root) {
-  const Fe29<1> half = fe29_const(ParamsBls29::HALF);
-  Fe29<2> norm = (f_sqr(num.c0) + f_sqr(num.c1)) * Fe29<1>::one();
-  Fe29<2> a = fe29_pow_words12(norm, BlsFpConsts::SQRT_EXP_M1) * norm;
-  bool ok = f_eq(f_sqr(a), norm);
-  const bool c1_zero = f_eqz(num.c1);
-  Fe29<2> d = (a + num.c0) * half;
-  if (c1_zero) d = num.c0;
-  Fe29<2> t = fe29_pow_words12(d, BlsFpConsts::SQRT_EXP_M1);
-  Fe29<2> s = t * d;
-  const bool residue = f_eq(f_sqr(s), d);
-  Fe29<2> o = num.c1 * half * t;  // c1 / (2 s) up to the sign fixed below
-  if (residue) {
-    root = {s, o};
-  } else {
-    root = {f_neg(o) * Fe29<1>::one(), s};
-  }
-  Fe29x2<2> chk = f_sqr(root);
-  return ok && f_eq(chk.c0, num.c0) && f_eq(chk.c1, num.c1);
-}
-
 // in: 96 bytes (x.c1 || x.c0, big-endian, flags in byte 0); out: x.c0 x.c1 y.c0 y.c1 wire
 NCG_DI bool g2_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint8_t* inf) {
   using F = FeBls2;

@@ -1,0 +1,234 @@
+// Batch map-to-curve for bls12-381 G1 / G2: everything of
+// createHasher(...).hashToCurve / encodeToCurve / mapToCurve (src/abstract/hash-to-curve.ts:
+// 441-548) that is field and curve arithmetic.  The byte-level hash_to_field (expand_message_xmd
+// over SHA-256, :189-228, :312-378) stays in the host shim - the same split as ed25519 verify,
+// whose SHA-512 challenge is hashed by the shim.
+//
+// Per output point: `count` field elements u_j (1 = encodeToCurve / mapToCurve, 2 = hashToCurve):
+//   Q_j = isogeny(SWU(u_j))   mapToCurveSimpleSWU :652-717 with sqrt_ratio :552-651, isogenyMap
+//                             :381-410; constants src/bls12-381.ts:668-851 (RFC 9380 8.8, E.2, E.3)
+//   R   = clearCofactor(Q_0 [+ Q_1])   G1: [|x|]P + P (bls12-381.ts:578-581)
+//                                      G2: psi-based formula (:604-618)
+//   out = R.toAffine(), ZERO stays ZERO (createHasher.clear :476-483)
+// The map is a function of u alone, so the device is free in HOW it evaluates it:
+//   * the isogeny lands directly in Jacobian coordinates (Z = xd yd), no inversion;
+//   * G1 sqrt_ratio is the reference's 3 mod 4 variant (one power);
+//   * G2 sqrt_ratio(u, v) = sqrt(u / v) or sqrt(Z u / v) through fe29x2_sqrt (bls_lanes.hpp) and
+//     the inverse of tv4 that SWU needs anyway (v = tv4^3) - the reference's generic F.2.1.1
+//     ladder in Fp2 is ~2x the field work.  Either root is fine: SWU fixes the sign of y by
+//     sgn0(u) == sgn0(y) (:707-708).
+#include <vector>
+
+#include "bls_lanes.hpp"
+#include "host_api.hpp"
+
+namespace ncg {
+
+template <int A>
+NCG_DI Fe29<2> nrm(const Fe29<A>& a) {
+  return a * Fe29<1>::one();
+}
+template <int A>
+NCG_DI Fe29x2<2> nrm(const Fe29x2<A>& a) {
+  return {a.c0 * Fe29<1>::one(), a.c1 * Fe29<1>::one()};
+}
+NCG_DI Fe29x2<1> fe29x2_const(const uint32_t (&c)[2][14]) { return {fe29_const(c[0]), fe29_const(c[1])}; }
+
+// Horner evaluation of sum_i k[i] x^i, coefficients ascending like the reference's tables
+template <int N>
+NCG_DI Fe29<3> horner1(const uint32_t (&k)[N][14], const Fe29<2>& x) {
+  Fe29<3> acc = fe29_const(k[N - 1]);
+  for (int i = N - 2; i >= 0; i--) acc = acc * x + fe29_const(k[i]);
+  return acc;
+}
+template <int N>
+NCG_DI Fe29x2<7> horner2(const uint32_t (&k)[N][2][14], const Fe29x2<2>& x) {
+  Fe29x2<7> acc = fe29x2_const(k[N - 1]);
+  for (int i = N - 2; i >= 0; i--) acc = acc * x + fe29x2_const(k[i]);
+  return acc;
+}
+
+// sgn0 (RFC 9380 4.1; Fp.isOdd modular.ts:934, Fp2.isOdd tower.ts:502-509)
+NCG_DI bool sgn0(const Fe29<2>& a) {
+  uint32_t w[12];
+  fe29_to_wire(w, a);
+  return (w[0] & 1u) != 0;
+}
+NCG_DI bool sgn0(const Fe29x2<2>& a) {
+  uint32_t w0[12], w1[12];
+  fe29_to_wire(w0, a.c0);
+  fe29_to_wire(w1, a.c1);
+  uint32_t any0 = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) any0 |= w0[i];
+  return (w0[0] & 1u) || (any0 == 0 && (w1[0] & 1u));
+}
+
+// ------------------------------------------------------------------------------------- G1
+// mapToG1(u) (bls12-381.ts:853-856) as a Jacobian point of E
+NCG_DI Jac<FeBls> g1_map(const Fe29<2>& u) {
+  const Fe29<1> A = fe29_const(BlsH2c::SWU1_A), B = fe29_const(BlsH2c::SWU1_B), Z = fe29_const(BlsH2c::SWU1_Z);
+  Fe29<2> tv1 = f_sqr(u) * Z;                                  // 1-2
+  auto tv2a = f_sqr(tv1) + tv1;                                // 3-4
+  Fe29<2> tv3 = (tv2a + Fe29<1>::one()) * B;                   // 5-6
+  Fe29<2> sel = f_eqz(tv2a) ? Fe29<2>(Z) : nrm(f_neg(tv2a));   // 7
+  Fe29<2> tv4 = sel * A;                                       // 8
+  Fe29<2> tv6 = f_sqr(tv4);                                    // 10
+  auto gxn = (f_sqr(tv3) + tv6 * A) * tv3;                     // 9, 11-13
+  tv6 = tv6 * tv4;                                             // 14
+  Fe29<2> gx = nrm(gxn + tv6 * B);                             // 15-16: numerator of g(x1); denominator tv6
+  Fe29<2> x = tv1 * tv3;                                       // 17
+  // sqrt_ratio_3mod4(gx, tv6)  (hash-to-curve.ts:629-645)
+  Fe29<2> t2 = gx * tv6;
+  Fe29<2> t1 = f_sqr(tv6) * t2;
+  Fe29<2> y1 = fe29_pow_words12(t1, BlsFpConsts::SQRT_EXP_M1) * t2;
+  const bool isQR = f_eq(f_sqr(y1) * tv6, gx);
+  Fe29<2> value = isQR ? y1 : y1 * fe29_const(BlsH2c::SWU1_C2);
+  Fe29<2> y = tv1 * u * value;                                 // 19-20
+  if (isQR) {                                                  // 21-22
+    x = tv3;
+    y = value;
+  }
+  if (sgn0(u) != sgn0(y)) y = nrm(f_neg(y));                   // 23-24
+  x = x * f_inv(tv4);                                          // 25 (tv4 != 0: A != 0 and Z, -tv2 != 0)
+  // 11-isogeny E' -> E (isogenyMap :381-410), straight into Jacobian coordinates:
+  // Z = xd yd, X = xn yd Z, Y = y yn xd Z^2; a zero denominator is the identity (:404-408)
+  auto xn = horner1(BlsH2c::ISO1_XNUM, x), xd = horner1(BlsH2c::ISO1_XDEN, x);
+  auto yn = horner1(BlsH2c::ISO1_YNUM, x), yd = horner1(BlsH2c::ISO1_YDEN, x);
+  if (f_eqz(xd) || f_eqz(yd)) return Jac<FeBls>::inf();
+  Fe29<2> Zj = xd * yd;
+  return {xn * yd * Zj, y * yn * xd * f_sqr(Zj), Zj};
+}
+
+NCG_DI Jac<FeBls> g1_clear_cofactor(const Jac<FeBls>& P) {  // bls12-381.ts:578-581: [x]P + P
+  return jac_add(bls_mul_by_x(P), P);
+}
+
+// ------------------------------------------------------------------------------------- G2
+NCG_DI Jac<FeBls2> g2_map(const Fe29x2<2>& u) {  // mapToG2 (bls12-381.ts:859-862)
+  const Fe29x2<1> A = fe29x2_const(BlsH2c::SWU2_A), B = fe29x2_const(BlsH2c::SWU2_B), Z = fe29x2_const(BlsH2c::SWU2_Z);
+  Fe29x2<2> tv1 = nrm(f_sqr(u) * Z);
+  auto tv2a = f_sqr(tv1) + tv1;
+  Fe29x2<2> tv3 = nrm((tv2a + Fe29x2<1>::one()) * B);
+  Fe29x2<2> sel = f_eqz(tv2a) ? Fe29x2<2>(Z) : nrm(f_neg(tv2a));
+  Fe29x2<2> tv4 = nrm(sel * A);
+  Fe29x2<2> tv6 = f_sqr(tv4);
+  auto gxn = (f_sqr(tv3) + tv6 * A) * tv3;
+  tv6 = nrm(tv6 * tv4);
+  Fe29x2<2> gx = nrm(gxn + tv6 * B);
+  Fe29x2<2> x = nrm(tv1 * tv3);
+  // sqrt_ratio(gx, tv6), tv6 = tv4^3: w = gx / tv6 through the inverse of tv4
+  Fe29x2<2> inv4 = f_inv(tv4);
+  Fe29x2<2> w = nrm(gx * (f_sqr(inv4) * inv4));
+  Fe29x2<2> value;
+  const bool isQR = fe29x2_sqrt(w, value);
+  if (!isQR) {
+    Fe29x2<2> zw = nrm(w * Z);
+    (void)fe29x2_sqrt(zw, value);  // Z is a non-square, so Z w is a square
+  }
+  Fe29x2<2> y = nrm(tv1 * u * value);
+  if (isQR) {
+    x = tv3;
+    y = value;
+  }
+  if (sgn0(u) != sgn0(y)) y = nrm(f_neg(y));
+  x = nrm(x * inv4);
+  // 3-isogeny E' -> E
+  auto xn = horner2(BlsH2c::ISO2_XNUM, x), xd = horner2(BlsH2c::ISO2_XDEN, x);
+  auto yn = horner2(BlsH2c::ISO2_YNUM, x), yd = horner2(BlsH2c::ISO2_YDEN, x);
+  if (f_eqz(xd) || f_eqz(yd)) return Jac<FeBls2>::inf();
+  Fe29x2<2> Zj = nrm(xd * yd);
+  return {xn * yd * Zj, y * yn * xd * f_sqr(Zj), Zj};
+}
+
+// psi / psi^2 on Jacobian coordinates: conjugation commutes with x = X/Z^2, y = Y/Z^3
+// (tower.ts:242-256: psi(x, y) = (conj(x) PSI_X, conj(y) PSI_Y), psi2(x, y) = (x PSI2_X, -y))
+NCG_DI Jac<FeBls2> g2_psi(const Jac<FeBls2>& P) {
+  const Fe29x2<1> psx{fe29_const(ParamsBls29::PSI_X_C0), fe29_const(ParamsBls29::PSI_X_C1)};
+  const Fe29x2<1> psy{fe29_const(ParamsBls29::PSI_Y_C0), fe29_const(ParamsBls29::PSI_Y_C1)};
+  if (P.is_inf()) return P;
+  Fe29x2<64> cx{P.X.c0, f_neg(P.X.c1)}, cy{P.Y.c0, f_neg(P.Y.c1)}, cz{P.Z.c0, f_neg(P.Z.c1)};
+  return {cx * psx, cy * psy, cz};
+}
+NCG_DI Jac<FeBls2> g2_psi2(const Jac<FeBls2>& P) {
+  const Fe29<1> k = fe29_const(BlsH2c::PSI2_X);
+  if (P.is_inf()) return P;
+  Fe29x2<2> X{P.X.c0 * k, P.X.c1 * k};
+  return {X, f_neg(P.Y), P.Z};
+}
+NCG_DI Jac<FeBls2> g2_clear_cofactor(const Jac<FeBls2>& P) {  // bls12-381.ts:604-618
+  Jac<FeBls2> t1 = jac_neg(bls_mul_by_x(P));   // [-x]P
+  Jac<FeBls2> t2 = g2_psi(P);                  // psi(P)
+  Jac<FeBls2> t3 = g2_psi2(jac_dbl(P));        // psi^2(2P)
+  t3 = jac_add(t3, jac_neg(t2));
+  t2 = jac_add(t1, t2);
+  t2 = jac_neg(bls_mul_by_x(t2));
+  t3 = jac_add(t3, t2);
+  t3 = jac_add(t3, jac_neg(t1));
+  return jac_add(t3, jac_neg(P));
+}
+
+// ------------------------------------------------------------------------------------- lanes
+// u: count field elements (G1: 12 words each; G2: 24 words, c0 then c1), any value below 2^384 -
+// reduced mod p like Fp.create (bls12-381.ts:854, :860).  out: affine wire; *inf = 1 for ZERO.
+NCG_DI void g1_map_lane(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out, uint8_t* inf) {
+  Jac<FeBls> acc = g1_map(fe29_from_wire(u));
+  if (count == 2) acc = jac_add(acc, g1_map(fe29_from_wire(u + 12)));
+  Jac<FeBls> R = g1_clear_cofactor(acc);
+  const bool z = R.is_inf();
+  Affine<FeBls> a = jac_to_affine(R, f_inv(R.Z));
+  if (z) a = {FeBls::zero(), FeBls::zero()};
+  store_affine_wire<FeBls>(out, a);
+  *inf = z ? 1 : 0;
+}
+NCG_DI void g2_map_lane(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out, uint8_t* inf) {
+  Fe29x2<2> u0{fe29_from_wire(u), fe29_from_wire(u + 12)};
+  Jac<FeBls2> acc = g2_map(u0);
+  if (count == 2) {
+    Fe29x2<2> u1{fe29_from_wire(u + 24), fe29_from_wire(u + 36)};
+    acc = jac_add(acc, g2_map(u1));
+  }
+  Jac<FeBls2> R = g2_clear_cofactor(acc);
+  const bool z = R.is_inf();
+  Affine<FeBls2> a = jac_to_affine(R, f_inv(R.Z));
+  if (z) a = {FeBls2::zero(), FeBls2::zero()};
+  store_affine_wire<FeBls2>(out, a);
+  *inf = z ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(128) k_map_to_g1(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out,
+                                                   uint8_t* __restrict__ inf, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t f;
+  g1_map_lane(u + (size_t)i * count * 12, count, out + (size_t)i * 24, &f);
+  inf[i] = f;
+}
+__global__ void __launch_bounds__(64) k_map_to_g2(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out,
+                                                  uint8_t* __restrict__ inf, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t f;
+  g2_map_lane(u + (size_t)i * count * 24, count, out + (size_t)i * 48, &f);
+  inf[i] = f;
+}
+
+hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (curve == CURVE_BLS12_381_G1)
+    hipLaunchKernelGGL(k_map_to_g1, dim3((n + 127) / 128), dim3(128), 0, st, u, count, out, inf, n);
+  else if (curve == CURVE_BLS12_381_G2)
+    hipLaunchKernelGGL(k_map_to_g2, dim3((n + 63) / 64), dim3(64), 0, st, u, count, out, inf, n);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+void map_to_curve_host(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n) {
+  for (int i = 0; i < n; i++) {
+    if (curve == CURVE_BLS12_381_G1) g1_map_lane(u + (size_t)i * count * 12, count, out + (size_t)i * 24, inf + i);
+    else g2_map_lane(u + (size_t)i * count * 24, count, out + (size_t)i * 48, inf + i);
+  }
+}
+
+}  // namespace ncg

@@ -8,6 +8,7 @@
 #include "ed25519.hip"  // single-TU inclusion: lane function + host table builder
 #include "decode.hip"
 #include "ntt.hip"
+#include "h2c.hip"
 
 using namespace ncg;
 
@@ -91,6 +92,11 @@ int ht_decode_points(int curve, const uint8_t* in, int flags, uint32_t* out, uin
 
 int ht_encode_points(int curve, const uint32_t* in, uint8_t* out, uint8_t* ok, int n) {
   encode_points_host(curve, in, out, ok, n);
+  return 0;
+}
+
+int ht_map_to_curve(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n) {
+  map_to_curve_host(curve, u, count, out, inf, n);
   return 0;
 }
 

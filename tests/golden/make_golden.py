@@ -63,6 +63,14 @@ def main():
         sk_pk, pk, msg, sig_msg = parts[0], parts[1], parts[2], parts[3]
         rows.append({"sk": sk_pk[:64], "pk": pk, "msg": msg, "sig": sig_msg[:128]})
     dump("ed25519_vectors.json", rows)
+    # hash-to-curve: EIP-2537 mapToCurve vectors (test/bls12-381.test.ts:1605-1626) and the head of the
+    # priv:msg:sig signature vectors that pin hashToCurve end to end (:953-966, :1003-1012)
+    dump("bls12_381_eip2537.json", json.load(open(f"{REF}/bls12-381/eip2537.json")))
+    sig = {}
+    for g in ("g1", "g2"):
+        rows = [l.strip().split(":") for l in open(f"{REF}/bls12-381/bls12-381-{g}-test-vectors.txt") if l.strip()]
+        sig[g] = [{"priv": r[0], "msg": r[1], "sig": r[2]} for r in rows[:48]]
+    dump("bls12_381_sig_vectors.json", sig)
     # FFT known answers are inline in test/fft.test.ts (:155-183 roots/brp tables, :221-237 Basic FFT)
     import re
     ts = open(f"{REF}/../fft.test.ts").read()

@@ -26,6 +26,7 @@ def lib():
         _lib.ht_decode_points.argtypes = [i32, vp, i32, vp, vp, vp, i32]
         _lib.ht_fp2_sqrt.argtypes = [vp, vp]
         _lib.ht_encode_points.argtypes = [i32, vp, vp, vp, i32]
+        _lib.ht_map_to_curve.argtypes = [i32, vp, i32, vp, vp, i32]
         _lib.ht_ntt.argtypes = [i32, vp, vp, vp, i32]
         _lib.ht_ntt_plan.argtypes = [i32, vp]
     return _lib
@@ -118,3 +119,13 @@ def ntt_plan(log2n):
     buf = np.zeros(16, dtype=np.int32)
     np_ = lib().ht_ntt_plan(log2n, buf.ctypes.data)
     return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(np_)]
+
+
+def map_to_curve(curve, u, count, point_bytes):
+    """u: uint8 [n, count * field bytes] -> (affine [n, point_bytes], inf [n] bool)"""
+    uu = np.ascontiguousarray(u, dtype=np.uint8)
+    n = uu.shape[0]
+    out = np.zeros((n, point_bytes), dtype=np.uint8)
+    inf = np.zeros((n,), dtype=np.uint8)
+    assert lib().ht_map_to_curve(curve, uu.ctypes.data, count, out.ctypes.data, inf.ctypes.data, n) == 0
+    return out, inf.astype(bool)

@@ -338,3 +338,51 @@ def test_ntt_pass_plan_covers_every_stage_once():
             s += t
         assert s == n + 1
     assert hosttest.ntt_plan(0) == []
+
+
+def h2c_cases(m, count, n):
+    """n random field-element tuples for hash_to_field-shaped input plus edge values."""
+    from oracle.curves import BLS_P
+    rng = makeRng(0x42C0 + 16 * m + count)
+    rows = []
+    for i in range(n):
+        rows.append([rng.rndBelow(BLS_P) for _ in range(m * count)])
+    rows[0] = [0] * (m * count)                       # u = 0: tv2 == 0 branch of SWU step 7
+    rows[1] = [1] + [0] * (m * count - 1)
+    rows[2] = [BLS_P - 1] * (m * count)
+    return rows
+
+
+def test_map_to_curve_lanes_match_oracle():
+    """SWU + isogeny + add + clearCofactor lane code vs the oracle hasher for
+    G1 and G2, count = 1 (mapToCurve / encodeToCurve) and 2 (hashToCurve); EIP-2537 vectors."""
+    import numpy as np
+    from helpers import load_golden, wire_to_affine
+    from noble_curves_amd._native import BLS12_381_G2
+    from oracle.curves import BlsG1, BlsG2
+    from oracle.h2c import G1_hasher, G2_hasher
+    eip = load_golden("bls12_381_eip2537.json")
+    u = np.array([np.frombuffer(int(v["Input"], 16).to_bytes(48, "little"), np.uint8) for v in eip["G1"]])
+    out, inf = hosttest.map_to_curve(BLS12_381_G1, u, 1, 96)
+    for i, v in enumerate(eip["G1"]):
+        x, y = wire_to_affine(BLS12_381_G1, out[i])
+        assert "%0128x%0128x" % (x, y) == v["Expected"] and not inf[i]
+    u = np.array([np.frombuffer(int(v["Input"][:128], 16).to_bytes(48, "little") + int(v["Input"][128:], 16).to_bytes(48, "little"), np.uint8)
+                  for v in eip["G2"]])
+    out, inf = hosttest.map_to_curve(BLS12_381_G2, u, 1, 192)
+    for i, v in enumerate(eip["G2"]):
+        x, y = wire_to_affine(BLS12_381_G2, out[i])
+        assert "%0128x%0128x%0128x%0128x" % (x[0], x[1], y[0], y[1]) == v["Expected"] and not inf[i]
+    # kernel of the isogeny maps to ZERO (test/bls12-381.test.ts:1621-1625)
+    t = 1006044755431560595281793557931171729984964515682961911911398807521437683216171091013202870577238485832047490326971
+    out, inf = hosttest.map_to_curve(BLS12_381_G1, np.array([np.frombuffer(t.to_bytes(48, "little"), np.uint8)]), 1, 96)
+    assert inf[0] and not out.any()
+    for curve, hasher, Pt, m, pb in ((BLS12_381_G1, G1_hasher, BlsG1, 1, 96), (BLS12_381_G2, G2_hasher, BlsG2, 2, 192)):
+        for count in (1, 2):
+            rows = h2c_cases(m, count, 6 if m == 1 else 4)
+            u = np.array([np.frombuffer(b"".join(v.to_bytes(48, "little") for v in r), np.uint8) for r in rows])
+            out, inf = hosttest.map_to_curve(curve, u, count, pb)
+            for i, r in enumerate(rows):
+                pts = [hasher.map(r[j * m:(j + 1) * m]) for j in range(count)]
+                exp = hasher.clear(pts[0] if count == 1 else pts[0].add(pts[1]))
+                assert wire_to_affine(curve, out[i]) == exp.toAffine() and inf[i] == exp.is0(), (curve, count, i)

@@ -303,3 +303,31 @@ def test_fft_known_answers():
     w = roots.omega(4)
     naive = [sum(x[i] * pow(w, i * k, Fr_bls.ORDER) for i in range(16)) % Fr_bls.ORDER for k in range(16)]
     assert f.direct(x) == naive
+
+
+def test_hash_to_curve_vectors():
+    """test/bls12-381.test.ts:1605-1626 (EIP-2537 mapToCurve for G1/G2, kernel of the isogeny -> ZERO)
+    and :953-966 / :1003-1012 (sig = priv * hashToCurve(msg) for the long- and short-signature suites)."""
+    from oracle.h2c import G1_hasher, G2_hasher, expand_message_xmd
+    from oracle.weierstrass import bls_g1_encode_compressed, bls_g2_encode_compressed
+    eip = load("bls12_381_eip2537.json")
+    for v in eip["G1"]:
+        x, y = G1_hasher.mapToCurve(int(v["Input"], 16)).toAffine()
+        assert "%0128x%0128x" % (x, y) == v["Expected"]
+    for v in eip["G2"]:
+        i1, i2 = int(v["Input"][:128], 16), int(v["Input"][128:], 16)
+        x, y = G2_hasher.mapToCurve([i1, i2]).toAffine()
+        assert "%0128x%0128x%0128x%0128x" % (x[0], x[1], y[0], y[1]) == v["Expected"]
+    t = 1006044755431560595281793557931171729984964515682961911911398807521437683216171091013202870577238485832047490326971
+    assert G1_hasher.mapToCurve(t).is0()
+    sig = load("bls12_381_sig_vectors.json")
+    for r in sig["g2"][:16]:
+        S = G2_hasher.hashToCurve(bytes.fromhex(r["msg"])).multiply(int(r["priv"], 16) % BLS_R)
+        assert bls_g2_encode_compressed(S).hex() == r["sig"]
+    for r in sig["g1"][:16]:
+        S = G1_hasher.hashToCurve(bytes.fromhex(r["msg"])).multiply(int(r["priv"], 16) % BLS_R)
+        assert bls_g1_encode_compressed(S).hex() == r["sig"]
+    # RFC 9380 K.1 expand_message_xmd(SHA-256) shape rules the reference enforces (hash-to-curve.ts:203-205)
+    assert len(expand_message_xmd(b"abc", b"QUUX-V01-CS02-with-expander-SHA256-128", 0x80)) == 0x80
+    with pytest.raises(ValueError, match="invalid lenInBytes"):
+        expand_message_xmd(b"", b"dst", 65536)
