@@ -121,6 +121,19 @@ def main():
     torch.cuda.synchronize()
     assert bool((g2o == g2).all().item()) and int(ok[:m].sum().item()) == m, "G2 decode mismatch"
     rate("bls12-381 G2 decode + subgroup check", m, timeit(fg2, 2), "points")
+    # ---- hash-to-curve (device part): 2 field elements per point -> SWU, isogeny, add, clearCofactor
+    hm = 1 << 18
+    u1 = torch.randint(0, 256, (hm, 2 * 48), dtype=torch.uint8, device=dev)
+    u1[:, 47] &= 0x0F
+    u1[:, 95] &= 0x0F                                                     # < 2^380 < p
+    rate("bls12-381 G1 hashToCurve map (count=2)", hm,
+         timeit(lambda: eng.map_to_curve_batch_dev(BLS12_381_G1, hm, 2, P(u1), P(g1o), P(inf), s), 2), "points")
+    hm2 = 1 << 16
+    u2 = torch.randint(0, 256, (hm2, 4 * 48), dtype=torch.uint8, device=dev)
+    for k in range(4):
+        u2[:, 48 * k + 47] &= 0x0F
+    rate("bls12-381 G2 hashToCurve map (count=2)", hm2,
+         timeit(lambda: eng.map_to_curve_batch_dev(BLS12_381_G2, hm2, 2, P(u2), P(g2o), P(inf), s), 2), "points")
     if args.out:
         with open(args.out, "w") as fjs:
             json.dump(res, fjs, indent=1)
