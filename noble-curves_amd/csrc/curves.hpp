@@ -26,6 +26,21 @@ struct CurveG2 {  // src/bls12-381.ts:321-345
   static NCG_DI F beta() { return F::one(); }
 };
 
+// Device form of CurveG2 for the heavy kernels: one Fp2 element per lane PAIR (fe29.hpp), so
+// kernels run 2 lanes per item (LANE_SHIFT).  Storage and wire formats are CurveG2's.
+struct CurveG2P {
+  using F = FeBls2P;
+  static constexpr bool GLV = false;
+  static constexpr int SCALAR_BITS = 255;
+  static constexpr int LANE_SHIFT = 1;
+  static NCG_DI F beta() { return F::one(); }
+};
+template <class C> struct LaneShift { static constexpr int value = 0; };
+template <> struct LaneShift<CurveG2P> { static constexpr int value = 1; };
+// curve type the device kernels are instantiated with
+template <class C> struct DeviceCurve { using type = C; };
+template <> struct DeviceCurve<CurveG2> { using type = CurveG2P; };
+
 struct CurveEd {  // src/ed25519.ts:57-65 (twisted Edwards a = -1; cofactor 8: no subgroup tricks)
   using F = FpEd;
   static constexpr bool GLV = false;

@@ -328,8 +328,197 @@ NCG_DI Fe29x2<2> f_inv(const Fe29x2<A>& a) {  // tower.ts:458-475
   return {f * a.c0, f * f_neg(a.c1)};
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lane-paired Fp2: ONE element lives on two adjacent lanes (even lane: c0, odd lane: c1), so a
+// G2 point costs each lane the registers of a G1 point - the unpaired form above needs ~2x the
+// registers and runs the heavy kernels at 1 wave/SIMD with accumulator-register spills.  The
+// partner's half arrives by DPP quad_perm [1,0,3,2] (a full-rate VALU move, no LDS).  Same mad
+// count as Karatsuba: mul = 2 lanes x (2 products + 1 reduction), sqr = 2 lanes x 1 product.
+// Every data-dependent decision (is_zero, f_eqz) is made pair-uniform, so the two lanes of a
+// pair always follow the same control flow.  Device only.
+NCG_DI uint32_t pair_swap(uint32_t v) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+#else
+  return v;
+#endif
+}
+NCG_DI bool pair_odd() {
+#ifdef __HIP_DEVICE_COMPILE__
+  return (threadIdx.x & 1u) != 0;
+#else
+  return false;
+#endif
+}
+template <int B>
+NCG_DI Fe29<B> pair_swap(const Fe29<B>& a) {
+  Fe29<B> r;
+#pragma unroll
+  for (int i = 0; i < 14; i++) r.v[i] = pair_swap(a.v[i]);
+  return r;
+}
+template <int B>
+NCG_DI Fe29<B> fe29_select(bool c, const Fe29<B>& a, const Fe29<B>& b) {  // c ? a : b
+  Fe29<B> r;
+#pragma unroll
+  for (int i = 0; i < 14; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+
+// Paired product, out of line: takes only this lane's halves; the partner's halves are fetched
+// inside, phase by phase, so the caller keeps 28 argument registers live instead of 56.
+//   even lane: a0 b0 + (2^K p - a1) b1      odd lane: a0 b1 + a1 b0
+template <int K>
+NCG_MULFN Fe29Raw fe29x2p_mul_raw(Fe29Raw a, Fe29Raw b) {
+  Fe29Raw r;
+#ifdef __HIP_DEVICE_COMPILE__
+  constexpr int N = 14;
+  constexpr uint32_t MASK = (1u << 29) - 1u;
+  const bool odd = pair_odd();
+  uint64_t t[2 * N];
+#pragma unroll
+  for (int k = 0; k < 2 * N; k++) t[k] = 0;
+  {  // phase 1: (odd ? a_partner : a_own) * b_own
+    uint32_t x[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const uint32_t pa = pair_swap(a.v[i]);
+      x[i] = odd ? pa : a.v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+      for (int j = 0; j < N; j++) t[i + j] += (uint64_t)x[i] * b.v[j];
+    }
+  }
+  {  // phase 2: (odd ? a_own : -a_partner) * b_partner
+    uint32_t z[N], w[N];
+    int32_t c = 0;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const uint32_t pa = pair_swap(a.v[i]);
+      any |= pa;
+      int32_t d = (int32_t)ParamsBls29::PMUL[K][i] - (int32_t)pa + c;
+      const uint32_t neg = i < N - 1 ? ((uint32_t)d & MASK) : (uint32_t)d;
+      c = i < N - 1 ? (d >> 29) : 0;
+      z[i] = odd ? a.v[i] : neg;
+      w[i] = pair_swap(b.v[i]);
+    }
+    if (!odd && any == 0) {  // -0 = 0 (keeps products of literal zeros literal)
+#pragma unroll
+      for (int i = 0; i < N; i++) z[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+      for (int j = 0; j < N; j++) t[i + j] += (uint64_t)z[i] * w[j];
+    }
+  }
+  uint64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    uint64_t T = t[k] + carry;
+    uint32_t q = ((uint32_t)T * ParamsBls29::INV) & MASK;
+    T += (uint64_t)q * (uint32_t)ParamsBls29::P[0];
+    carry = T >> 29;
+#pragma unroll
+    for (int j = 1; j < N; j++) t[k + j] += (uint64_t)q * (uint32_t)ParamsBls29::P[j];
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N; k++) {
+    uint64_t T = t[k] + carry;
+    r.v[k - N] = (uint32_t)T & MASK;
+    carry = T >> 29;
+  }
+#else
+  for (int i = 0; i < 14; i++) r.v[i] = 0;
+#endif
+  return r;
+}
+
+template <int B>
+struct Fe29x2P {
+  Fe29<B> h;  // this lane's component
+  static constexpr int BOUND = B;
+  Fe29x2P() = default;
+  NCG_DI explicit Fe29x2P(const Fe29<B>& a) : h(a) {}
+  template <int B2, class = typename std::enable_if<(B2 < B)>::type>
+  NCG_DI Fe29x2P(const Fe29x2P<B2>& o) : h(o.h) {}
+  static NCG_DI Fe29x2P zero() { return Fe29x2P(Fe29<B>::zero()); }
+  static NCG_DI Fe29x2P one() { return Fe29x2P(fe29_select(pair_odd(), Fe29<B>::zero(), Fe29<B>::one())); }
+  NCG_DI bool is_zero() const {  // literal, both halves
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) o |= h.v[i];
+    o |= pair_swap(o);
+    return o == 0;
+  }
+};
+template <int A, int B>
+NCG_DI Fe29x2P<A + B> operator+(const Fe29x2P<A>& a, const Fe29x2P<B>& b) {
+  return Fe29x2P<A + B>(a.h + b.h);
+}
+template <int A, int B>
+NCG_DI Fe29x2P<A + (1 << fe29_pow2ceil_log(B))> operator-(const Fe29x2P<A>& a, const Fe29x2P<B>& b) {
+  return Fe29x2P<A + (1 << fe29_pow2ceil_log(B))>(a.h - b.h);
+}
+template <int A>
+NCG_DI Fe29x2P<2 * A> f_dbl(const Fe29x2P<A>& a) {
+  return Fe29x2P<2 * A>(a.h + a.h);
+}
+template <int A>
+NCG_DI Fe29x2P<(1 << fe29_pow2ceil_log(A))> f_neg(const Fe29x2P<A>& a) {
+  return Fe29x2P<(1 << fe29_pow2ceil_log(A))>(f_neg(a.h));
+}
+// (a0 + a1 u)(b0 + b1 u): even lane a0 b0 + (-a1) b1, odd lane a0 b1 + a1 b0  (tower.ts:420-431 value)
+template <int A, int B>
+NCG_DI Fe29x2P<2> operator*(const Fe29x2P<A>& a, const Fe29x2P<B>& b) {
+  constexpr int K = fe29_pow2ceil_log(A);
+  static_assert(4L * (1 << K) * B <= (1L << 25), "paired Fp2 product would exceed 2p: reduce an operand");
+  Fe29Raw x, y;
+#pragma unroll
+  for (int i = 0; i < 14; i++) {
+    x.v[i] = a.h.v[i];
+    y.v[i] = b.h.v[i];
+  }
+  Fe29Raw r = fe29x2p_mul_raw<K>(x, y);
+  Fe29<2> o;
+#pragma unroll
+  for (int i = 0; i < 14; i++) o.v[i] = r.v[i];
+  return Fe29x2P<2>(o);
+}
+// even lane (a0 + a1)(a0 - a1), odd lane (a0 + a0) a1  (tower.ts:432-438 value)
+template <int A>
+NCG_DI Fe29x2P<2> f_sqr(const Fe29x2P<A>& a) {
+  constexpr int KA = 1 << fe29_pow2ceil_log(A);
+  static_assert(2L * A * (A + KA) <= (1L << 24), "paired Fp2 square would exceed 2p");
+  const bool odd = pair_odd();
+  const Fe29<A> pa = pair_swap(a.h);
+  const Fe29<A> a0 = fe29_select(odd, pa, a.h), a1 = fe29_select(odd, a.h, pa);
+  const Fe29<2 * A> s = a0 + fe29_select(odd, a0, a1);
+  const Fe29<A + KA> d = a0 - a1;
+  const Fe29<A + KA> y = fe29_select(odd, Fe29<A + KA>(a1), d);
+  return Fe29x2P<2>(s * y);
+}
+template <int A>
+NCG_DI bool f_eqz(const Fe29x2P<A>& a) {
+  uint32_t e = f_eqz(a.h) ? 1u : 0u;
+  e &= pair_swap(e);
+  return e != 0;
+}
+template <int A>
+NCG_DI Fe29x2P<2> f_inv(const Fe29x2P<A>& a) {  // conj(a) / (a0^2 + a1^2)  (tower.ts:458-475 value)
+  constexpr int KA = 1 << fe29_pow2ceil_log(A);
+  Fe29<2> n = f_sqr(a.h);
+  Fe29<2> inv = f_inv(n + pair_swap(n));
+  const Fe29<KA> num = fe29_select(pair_odd(), f_neg(a.h), Fe29<KA>(a.h));
+  return Fe29x2P<2>(inv * num);
+}
+
 // storage types used by the curve templates (every stored coordinate is below 64 p)
 using FeBls = Fe29<64>;
 using FeBls2 = Fe29x2<64>;
+using FeBls2P = Fe29x2P<64>;
 
 }  // namespace ncg

@@ -70,6 +70,7 @@ template <class F> struct FieldIO;
 template <class PR>
 struct FieldIO<Fp<PR>> {
   static constexpr int WORDS = PR::N;
+  static constexpr int LANE_WORDS = WORDS;  // words one lane holds (differs for lane-paired Fp2)
   static NCG_DI Fp<PR> load(const uint32_t* p) { return fp_load<PR>(p); }
   static NCG_DI void store(uint32_t* p, const Fp<PR>& a) { fp_store<PR>(p, a); }
   // strided (word i at p[i*stride]) - LDS tables laid out limb-major, lane-minor
@@ -87,6 +88,7 @@ struct FieldIO<Fp<PR>> {
 template <class PR>
 struct FieldIO<Fp2T<PR>> {
   static constexpr int WORDS = 2 * PR::N;
+  static constexpr int LANE_WORDS = WORDS;
   static NCG_DI Fp2T<PR> load(const uint32_t* p) { return {fp_load<PR>(p), fp_load<PR>(p + PR::N)}; }
   static NCG_DI void store(uint32_t* p, const Fp2T<PR>& a) {
     fp_store<PR>(p, a.c0);
@@ -124,6 +126,7 @@ struct FieldWire<Fp2T<PR>> {
 template <int B>
 struct FieldIO<Fe29<B>> {
   static constexpr int WORDS = 14;
+  static constexpr int LANE_WORDS = WORDS;
   static NCG_DI Fe29<B> load(const uint32_t* p) {
     Fe29<B> r;
 #pragma unroll
@@ -148,6 +151,7 @@ struct FieldIO<Fe29<B>> {
 template <int B>
 struct FieldIO<Fe29x2<B>> {
   static constexpr int WORDS = 28;
+  static constexpr int LANE_WORDS = WORDS;
   static NCG_DI Fe29x2<B> load(const uint32_t* p) { return {FieldIO<Fe29<B>>::load(p), FieldIO<Fe29<B>>::load(p + 14)}; }
   static NCG_DI void store(uint32_t* p, const Fe29x2<B>& a) {
     FieldIO<Fe29<B>>::store(p, a.c0);
@@ -160,6 +164,26 @@ struct FieldIO<Fe29x2<B>> {
     FieldIO<Fe29<B>>::store_strided(p, stride, a.c0);
     FieldIO<Fe29<B>>::store_strided(p + 14 * stride, stride, a.c1);
   }
+};
+// lane-paired Fp2: same storage as Fe29x2 (c0 then c1, 14 words each); each lane moves its half
+template <int B>
+struct FieldIO<Fe29x2P<B>> {
+  static constexpr int WORDS = 28;
+  static constexpr int LANE_WORDS = 14;  // per-lane tables (LDS) hold this lane's half only
+  template <class PTR> static NCG_DI Fe29x2P<B> load_strided(PTR p, int stride) {
+    return Fe29x2P<B>(FieldIO<Fe29<B>>::load_strided(p, stride));
+  }
+  template <class PTR> static NCG_DI void store_strided(PTR p, int stride, const Fe29x2P<B>& a) {
+    FieldIO<Fe29<B>>::store_strided(p, stride, a.h);
+  }
+  static NCG_DI Fe29x2P<B> load(const uint32_t* p) { return Fe29x2P<B>(FieldIO<Fe29<B>>::load(p + (pair_odd() ? 14 : 0))); }
+  static NCG_DI void store(uint32_t* p, const Fe29x2P<B>& a) { FieldIO<Fe29<B>>::store(p + (pair_odd() ? 14 : 0), a.h); }
+};
+template <int B>
+struct FieldWire<Fe29x2P<B>> {
+  static constexpr int WORDS = 24;
+  static NCG_DI Fe29x2P<B> load(const uint32_t* p) { return Fe29x2P<B>(Fe29<B>(fe29_from_wire(p + (pair_odd() ? 12 : 0)))); }
+  static NCG_DI void store(uint32_t* p, const Fe29x2P<B>& a) { fe29_to_wire(p + (pair_odd() ? 12 : 0), a.h); }
 };
 template <int B>
 struct FieldWire<Fe29<B>> {

@@ -16,7 +16,7 @@ template <class C>
 __global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* __restrict__ pts, uint32_t* __restrict__ out,
                                                         int n) {
   using G = MsmGroup<C>;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
   if (i >= n) return;
   G::wire_to_storage(pts + (size_t)i * G::WIRE_AFF, out + (size_t)i * G::AFF_WORDS);
 }
@@ -147,8 +147,12 @@ struct MsmSeg {
 #ifndef NCG_ACCUM_MINW
 #define NCG_ACCUM_MINW 1
 #endif
+// lane-paired G2 sits 24 registers above the 2-waves/SIMD line: ask for 2 (a little scratch
+// traffic in a loop of ~17k instructions per add is cheaper than half the occupancy)
+template <class C> struct AccumMinWaves { static constexpr int value = NCG_ACCUM_MINW; };
+template <> struct AccumMinWaves<CurveG2P> { static constexpr int value = 2; };
 template <class C>
-__global__ void __launch_bounds__(256, NCG_ACCUM_MINW) k_msm_accum(const uint32_t* __restrict__ pts_mont,
+__global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(const uint32_t* __restrict__ pts_mont,
                                                    const uint32_t* __restrict__ sorted,
                                                    const uint32_t* __restrict__ bucket_start,
                                                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ part_pts,
@@ -156,7 +160,7 @@ __global__ void __launch_bounds__(256, NCG_ACCUM_MINW) k_msm_accum(const uint32_
   using G = MsmGroup<C>;
   using Acc = typename G::Acc;
   constexpr int AFF = G::AFF_WORDS, XW = G::ACC_WORDS;
-  const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+  const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value, w = blockIdx.y;
   if (s >= sg.nseg) return;
   const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
   const uint32_t total = bs[pl.nb];
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(256) k_msm_fixup_pass(uint32_t* __restrict__ p
   // a run longer than 2d pieces is also longer than d: if the previous pass found nothing to
   // add, neither will this one (wave-uniform early exit; flags are zeroed before the passes)
   if (pass > 0 && pass_flags[pass - 1] == 0) return;
-  const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+  const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value, w = blockIdx.y;
   if (s >= sg.nseg) return;
   const int* meta = part_meta + ((size_t)w * sg.nseg + s) * 4;
   const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
@@ -262,7 +266,7 @@ __global__ void __launch_bounds__(256) k_msm_fixup_write(const uint32_t* __restr
                                                          uint32_t* __restrict__ buckets, MsmPlan pl, MsmSeg sg) {
   using G = MsmGroup<C>;
   constexpr int XW = G::ACC_WORDS;
-  const int s = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+  const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value, w = blockIdx.y;
   if (s >= sg.nseg) return;
   const int tb = part_meta[((size_t)w * sg.nseg + s) * 4 + 2];
   if (tb < 0) return;
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(256) k_msm_reduce_level(const uint32_t* __rest
   constexpr int XW = G::ACC_WORDS;
   const int n_out = n_in >> 1;
   const long total = (long)(narr + 1) * nwin * n_out;
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long t = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
   if (t >= total) return;
   const int q = (int)(t % n_out);
   const int w = (int)((t / n_out) % nwin);
@@ -348,11 +352,14 @@ int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) {
     if (env) c = std::atoi(env);
   }
   if (c <= 0) {
-    // accumulate cost nwin*n mixed adds vs fold cost ~2*nwin*2^(c-1) full adds: c ~ log2(n) - 4
-    c = ilog2((unsigned)std::max(n, 1)) - 4;
+    // accumulate cost nwin*n mixed adds vs fold cost ~2*nwin*2^(c-1) full adds: c ~ log2(n) - 4.
+    // G2 (measured at 2^18, profiles/): one bit more - its per-window fix-up / fold latency is
+    // 3x G1's, and c = 15 also fills the top window of a 255-bit scalar (c = 14 leaves 3 bits)
+    c = ilog2((unsigned)std::max(n, 1)) - (curve == CURVE_BLS12_381_G2 ? 3 : 4);
   }
   c = std::max(2, std::min(16, c));
   pl->n = n;
+  pl->ls = curve == CURVE_BLS12_381_G2 ? 1 : 0;  // lane-paired kernels: 2 lanes per item
   pl->c = c;
   pl->nb = 1 << (c - 1);
   pl->nwin = plan_windows(c, curve_order(curve), pl->hconst);
@@ -379,7 +386,7 @@ static MsmSeg msm_seg(const MsmPlan& pl) {
   } else {
     // 64 entries per lane at full size; fewer for small MSMs so that ~4 waves/SIMD stay busy
     // (lanes = nwin*n/seg >= 262144), but never below 16 (every lane costs up to two fix-up adds)
-    long lanes_at_64 = (long)pl.nwin * pl.n / 64;
+    long lanes_at_64 = ((long)pl.nwin * pl.n / 64) << pl.ls;
     sg.seg = 64;
     while (sg.seg > 16 && lanes_at_64 < 262144) {
       sg.seg >>= 1;
@@ -441,6 +448,8 @@ template <class C>
 static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
                             uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st) {
   using G = MsmGroup<C>;
+  using D = typename DeviceCurve<C>::type;  // kernels: lane-paired form for G2
+  constexpr int LS = LaneShift<D>::value;
   constexpr int XW = G::ACC_WORDS;
   MsmLayout L = msm_layout<C>(pl);
   char* base = (char*)ws;
@@ -454,7 +463,8 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
   const int n = pl.n;
   hipError_t e;
 
-  hipLaunchKernelGGL(k_points_to_mont<C>, dim3((n + 255) / 256), dim3(256), 0, st, d_pts, pts_mont, n);
+  hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts,
+                     pts_mont, n);
   hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl);
   size_t lds = (size_t)pl.nb * 4;
   e = hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -471,24 +481,24 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
     int* part_meta = (int*)(base + L.part_meta);
     e = hipMemsetAsync(buckets, 0, (size_t)pl.nwin * pl.nb * XW * 4, st);  // empty buckets = infinity
     if (e != hipSuccess) return e;
-    dim3 grid((sg.nseg + 255) / 256, pl.nwin);
-    hipLaunchKernelGGL(k_msm_accum<C>, grid, dim3(256), 0, st, pts_mont, sorted, bstart, buckets, part_pts, part_meta,
+    dim3 grid((unsigned)((((size_t)sg.nseg << LS) + 255) / 256), pl.nwin);
+    hipLaunchKernelGGL(k_msm_accum<D>, grid, dim3(256), 0, st, pts_mont, sorted, bstart, buckets, part_pts, part_meta,
                        pl, sg);
     uint32_t* pass_flags = (uint32_t*)(base + L.pass_flags);
     e = hipMemsetAsync(pass_flags, 0, 64 * 4, st);
     if (e != hipSuccess) return e;
     int pass = 0;
     for (int d = 1; d < sg.nseg; d <<= 1, pass++)
-      hipLaunchKernelGGL(k_msm_fixup_pass<C>, grid, dim3(256), 0, st, part_pts, part_meta, bstart, pl, sg, d,
+      hipLaunchKernelGGL(k_msm_fixup_pass<D>, grid, dim3(256), 0, st, part_pts, part_meta, bstart, pl, sg, d,
                          pass_flags, pass);
-    hipLaunchKernelGGL(k_msm_fixup_write<C>, grid, dim3(256), 0, st, part_pts, part_meta, buckets, pl, sg);
+    hipLaunchKernelGGL(k_msm_fixup_write<D>, grid, dim3(256), 0, st, part_pts, part_meta, buckets, pl, sg);
   }
   // fold: nb -> 1 per window in c-1 levels
   const uint32_t* cur = buckets;
   int narr = 1, n_in = pl.nb, flip = 0;
   while (n_in > 1) {
     long total = (long)(narr + 1) * pl.nwin * (n_in >> 1);
-    hipLaunchKernelGGL(k_msm_reduce_level<C>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cur, red[flip],
+    hipLaunchKernelGGL(k_msm_reduce_level<D>, dim3((unsigned)(((total << LS) + 255) / 256)), dim3(256), 0, st, cur, red[flip],
                        narr, pl.nwin, n_in);
     cur = red[flip];
     flip ^= 1;

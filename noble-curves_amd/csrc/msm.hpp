@@ -39,6 +39,7 @@ struct MsmPlan {
   int nb = 0;      // buckets per window = 2^(c-1)
   int Q = 0;       // sort chunks (blocks per window)
   int chunk = 0;   // points per chunk
+  int ls = 0;      // lanes per item = 1 << ls (lane-paired Fp2 kernels)
   uint32_t hconst[10];  // H' = sum_w 2^(c-1) * 2^(c w), 10 LE limbs
 };
 

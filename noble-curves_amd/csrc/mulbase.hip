@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) k_mul_base(const uint32_t* __restrict__ t
                                                   int n) {
   using F = typename C::F;
   constexpr int FW = FieldIO<F>::WORDS;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
   if (i >= n) return;
   uint32_t k[8];
 #pragma unroll
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_wire_to_storage(const uint32_t* __restr
                                                          int n) {
   using F = typename C::F;
   constexpr int FW = FieldIO<F>::WORDS, WW = FieldWire<F>::WORDS;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
   if (i >= n) return;
   Affine<F> a = load_affine_wire<F>(wire + (size_t)i * 2 * WW);
   FieldIO<F>::store(out + (size_t)i * 2 * FW, a.x);
@@ -136,7 +136,9 @@ static hipError_t build_table_t(int curve, const uint32_t* base_wire, uint32_t* 
   (void)hipMemcpyAsync(d_sc, h_sc.data(), sc_b, hipMemcpyHostToDevice, st);
   e = mul_var_batch(curve, d_pts, d_sc, d_out, d_inf, NT, d_jac, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_wire_to_storage<C>, dim3((NT + 255) / 256), dim3(256), 0, st, d_out, d_table, NT);
+  using D = typename DeviceCurve<C>::type;
+  hipLaunchKernelGGL(k_wire_to_storage<D>, dim3(((NT << LaneShift<D>::value) + 255) / 256), dim3(256), 0, st, d_out,
+                     d_table, NT);
   return hipStreamSynchronize(st);
 }
 
@@ -161,8 +163,10 @@ hipError_t mul_base_build_table(int curve, const uint32_t* base_wire, uint32_t* 
 template <class C, int K>
 static hipError_t mul_base_t(const uint32_t* table, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
                              uint32_t* jac_tmp, hipStream_t st) {
-  hipLaunchKernelGGL(k_mul_base<C>, dim3((n + 255) / 256), dim3(256), 0, st, table, scalars, jac_tmp, n);
-  int threads = (n + K - 1) / K;
+  constexpr int LS = LaneShift<C>::value;
+  hipLaunchKernelGGL(k_mul_base<C>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, table, scalars,
+                     jac_tmp, n);
+  int threads = ((n + K - 1) / K) << LS;
   hipLaunchKernelGGL((k_jac_batch_affine<C, K>), dim3((threads + 255) / 256), dim3(256), 0, st, jac_tmp, out, out_inf, n);
   return hipGetLastError();
 }
@@ -173,7 +177,7 @@ hipError_t mul_base_batch(int curve, const uint32_t* table, const uint32_t* scal
   switch (curve) {
     case CURVE_SECP256K1: return mul_base_t<CurveSecp, 8>(table, scalars, out, out_inf, n, jac_tmp, st);
     case CURVE_BLS12_381_G1: return mul_base_t<CurveG1, 8>(table, scalars, out, out_inf, n, jac_tmp, st);
-    case CURVE_BLS12_381_G2: return mul_base_t<CurveG2, 4>(table, scalars, out, out_inf, n, jac_tmp, st);
+    case CURVE_BLS12_381_G2: return mul_base_t<CurveG2P, 4>(table, scalars, out, out_inf, n, jac_tmp, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -13,13 +13,15 @@ static hipError_t launch_mul_var(const uint32_t* pts, const uint32_t* scalars, u
                                  int n, uint32_t* jac_tmp, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   using Cfg = MulVarCfg<C, W>;
+  constexpr int LS = LaneShift<C>::value;  // lanes per item = 1 << LS
+  const unsigned blocks = (unsigned)((((size_t)n << LS) + 63) / 64);
   size_t lds = (size_t)Cfg::LDS_WORDS * 4;
   if (jac_tmp) {
     auto kern = k_mul_var<C, W, MINW, true>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, jac_tmp, out_inf, n);
-    int threads = (n + K - 1) / K;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, st, pts, scalars, jac_tmp, out_inf, n);
+    int threads = ((n + K - 1) / K) << LS;
     hipLaunchKernelGGL((k_jac_batch_affine<C, K>), dim3((threads + 255) / 256), dim3(256), 0, st, jac_tmp, out, out_inf,
                        n);
     return hipGetLastError();
@@ -27,7 +29,7 @@ static hipError_t launch_mul_var(const uint32_t* pts, const uint32_t* scalars, u
   auto kern = k_mul_var<C, W, MINW, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, out, out_inf, n);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, st, pts, scalars, out, out_inf, n);
   return hipGetLastError();
 }
 
@@ -80,8 +82,20 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
       return launch_mul_var<CurveSecp, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     }
     case CURVE_ED25519: return ed25519_mul_var_batch(pts, scalars, out, out_inf, n, st);
-    case CURVE_BLS12_381_G1: return launch_mul_var<CurveG1, 3, 1, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);
-    case CURVE_BLS12_381_G2: return launch_mul_var<CurveG2, 3, 1, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
+    case CURVE_BLS12_381_G1: {
+      static const int w = [] { const char* e = std::getenv("NCG_G1_W"); return e ? std::atoi(e) : 31; }();
+      if (w == 22) return launch_mul_var<CurveG1, 2, 2, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (w == 21) return launch_mul_var<CurveG1, 2, 1, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (w == 32) return launch_mul_var<CurveG1, 3, 2, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      return launch_mul_var<CurveG1, 3, 1, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);
+    }
+    case CURVE_BLS12_381_G2: {
+      static const int w = [] { const char* e = std::getenv("NCG_G2_W"); return e ? std::atoi(e) : 22; }();
+      if (w == 31) return launch_mul_var<CurveG2P, 3, 1, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (w == 22) return launch_mul_var<CurveG2P, 2, 2, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (w == 0) return launch_mul_var<CurveG2, 3, 1, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);  // unpaired
+      return launch_mul_var<CurveG2P, 3, 2, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
+    }
     default: return hipErrorInvalidValue;
   }
 }

@@ -43,13 +43,14 @@ NCG_DI Jac<F> jac_madd_zr(const Jac<F>& p, const Affine<F>& q, F& zr) {
 template <class C, int W>
 struct MulVarCfg {
   using F = typename C::F;
-  static constexpr int FW = FieldIO<F>::WORDS;    // stored words per field element (LDS table)
+  static constexpr int FW = FieldIO<F>::WORDS;    // stored words per field element (HBM scratch)
+  static constexpr int TW = FieldIO<F>::LANE_WORDS;  // words per field element in this lane's LDS table
   static constexpr int WW = FieldWire<F>::WORDS;  // wire words per field element (HBM in/out)
   static constexpr int TS = 1 << (W - 1);                 // table entries: 1,3,..,2^W-1
   static constexpr int KBITS = C::GLV ? 129 : 257;        // bound on |k|+1 per stream
   static constexpr int M = (KBITS + W - 1) / W;           // windows
   static constexpr int NL = C::GLV ? 5 : 9;               // limbs of the window register
-  static constexpr int LDS_WORDS = TS * 2 * FW * 64;      // per 64-lane block
+  static constexpr int LDS_WORDS = TS * 2 * TW * 64;      // per 64-lane block
 };
 
 // Per-lane body.  `tab` is this lane's table base, consecutive words `stride` apart
@@ -63,7 +64,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
                          TABPTR tab, const int stride) {
   using Cfg = MulVarCfg<C, W>;
   using F = typename C::F;
-  constexpr int FW = Cfg::FW, TS = Cfg::TS, M = Cfg::M, NL = Cfg::NL;
+  constexpr int FW = Cfg::FW, TW = Cfg::TW, TS = Cfg::TS, M = Cfg::M, NL = Cfg::NL;
 
   Affine<F> P = load_affine_wire<F>(pt_wire);
   uint32_t k[8];
@@ -82,12 +83,12 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     Jac<F> T{P.x * dz2, P.y * dz3, F::one()};
     F zr[TS];
     FieldIO<F>::store_strided(tab, stride, T.X);
-    FieldIO<F>::store_strided(tab + FW * stride, stride, T.Y);
+    FieldIO<F>::store_strided(tab + TW * stride, stride, T.Y);
 #pragma unroll
     for (int j = 1; j < TS; j++) {
       T = jac_madd_zr(T, Dp, zr[j]);
-      FieldIO<F>::store_strided(tab + (j * 2 * FW) * stride, stride, T.X);
-      FieldIO<F>::store_strided(tab + (j * 2 * FW + FW) * stride, stride, T.Y);
+      FieldIO<F>::store_strided(tab + (j * 2 * TW) * stride, stride, T.X);
+      FieldIO<F>::store_strided(tab + (j * 2 * TW + TW) * stride, stride, T.Y);
     }
     // bring every entry to the last entry's Z
     F s = F::one();
@@ -97,10 +98,10 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
       else s = s * zr[j + 1];
       auto s2 = f_sqr(s);
       auto s3 = s2 * s;
-      F x = FieldIO<F>::load_strided(tab + (j * 2 * FW) * stride, stride);
-      F y = FieldIO<F>::load_strided(tab + (j * 2 * FW + FW) * stride, stride);
-      FieldIO<F>::store_strided(tab + (j * 2 * FW) * stride, stride, x * s2);
-      FieldIO<F>::store_strided(tab + (j * 2 * FW + FW) * stride, stride, y * s3);
+      F x = FieldIO<F>::load_strided(tab + (j * 2 * TW) * stride, stride);
+      F y = FieldIO<F>::load_strided(tab + (j * 2 * TW + TW) * stride, stride);
+      FieldIO<F>::store_strided(tab + (j * 2 * TW) * stride, stride, x * s2);
+      FieldIO<F>::store_strided(tab + (j * 2 * TW + TW) * stride, stride, y * s3);
     }
     Zg = D.Z * T.Z;
   }
@@ -130,8 +131,8 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
       int d1 = w1.pop();
       int e = ((d1 < 0 ? -d1 : d1) - 1) >> 1;
       Affine<F> q;
-      q.x = FieldIO<F>::load_strided(tab + (e * 2 * FW) * stride, stride);
-      q.y = FieldIO<F>::load_strided(tab + (e * 2 * FW + FW) * stride, stride);
+      q.x = FieldIO<F>::load_strided(tab + (e * 2 * TW) * stride, stride);
+      q.y = FieldIO<F>::load_strided(tab + (e * 2 * TW + TW) * stride, stride);
       if ((d1 < 0) != neg1) q.y = f_neg(q.y);
       R = jac_madd(R, q);
     }
@@ -139,8 +140,8 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
       int d2 = w2.pop();
       int e = ((d2 < 0 ? -d2 : d2) - 1) >> 1;
       Affine<F> q;
-      q.x = FieldIO<F>::load_strided(tab + (e * 2 * FW) * stride, stride) * beta;
-      q.y = FieldIO<F>::load_strided(tab + (e * 2 * FW + FW) * stride, stride);
+      q.x = FieldIO<F>::load_strided(tab + (e * 2 * TW) * stride, stride) * beta;
+      q.y = FieldIO<F>::load_strided(tab + (e * 2 * TW + TW) * stride, stride);
       if ((d2 < 0) != neg2) q.y = f_neg(q.y);
       R = jac_madd(R, q);
     }
@@ -149,7 +150,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
   {
     Affine<F> q;
     q.x = FieldIO<F>::load_strided(tab, stride);
-    q.y = FieldIO<F>::load_strided(tab + FW * stride, stride);
+    q.y = FieldIO<F>::load_strided(tab + TW * stride, stride);
     if (w1.was_even) {
       Affine<F> m = q;
       if (!neg1) m.y = f_neg(m.y);
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(256) k_jac_batch_affine(const uint32_t* __rest
                                                           uint8_t* __restrict__ out_inf, int n) {
   using F = typename C::F;
   constexpr int FW = FieldIO<F>::WORDS, WW = FieldWire<F>::WORDS;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
   const int i0 = t * K;
   if (i0 >= n) return;
   F pre[K];   // pre[j] = product of the non-zero Z of points i0..i0+j-1
@@ -277,7 +278,7 @@ k_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars
   constexpr int OUTW = JAC_OUT ? 3 * MulVarCfg<C, W>::FW : 2 * WW;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = threadIdx.x;
-  const int idx = blockIdx.x * 64 + lane;
+  const int idx = (blockIdx.x * 64 + lane) >> LaneShift<C>::value;
   const bool active = idx < n;
   const int src = active ? idx : n - 1;  // idle lanes redo the last item, stores masked
   mul_var_lane<C, W, JAC_OUT>(pts + (size_t)src * 2 * WW, scalars + (size_t)src * 8, out + (size_t)src * OUTW,
