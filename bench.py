@@ -45,6 +45,18 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
+def pmc_traffic_ntt(bits):
+    """HBM bytes per 2^bits transform: sum over its k_ntt_pass launches (grid sizes of the pass plan)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            bg = json.load(f)["kernels"]["ncg::k_ntt_pass"]["by_grid"]
+        n = 1 << bits
+        grids = [n >> 1, n >> 1, n >> 2] if bits == 22 else None   # 6 + 6 stages on 2^T x 4 tiles (256 thr), 10 on 2^10
+        return sum(bg[str(g)]["hbm_bytes_per_launch_corrected"] for g in grids) if grids else None
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def ints_to_le_bytes(vals, nbytes=32):
     return np.frombuffer(b"".join(int(v).to_bytes(nbytes, "little") for v in vals), dtype=np.uint8).reshape(-1, nbytes)
 
@@ -130,7 +142,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20, help="items per GPU (2^log2n)")
-    ap.add_argument("--workload", default="all", choices=["all", "secp256k1", "msm_g1", "msm_g2", "ed25519"])
+    ap.add_argument("--workload", default="all", choices=["all", "secp256k1", "msm_g1", "msm_g2", "ed25519", "ntt"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
@@ -414,6 +426,66 @@ def main():
                                                          "frac": 4.9e5 * nv / (ev_ms / K * 1e-3) / INT_MAC_PEAK}}}
         if ed_cpu:
             extra["ed25519_verify"]["cpu_baseline"] = ed_cpu
+
+    # ------------------------------------------------------------------ NTT over Fr
+    if args.workload in ("all", "ntt"):
+        from noble_curves_amd import fft as gfft
+        bits = min(22, args.log2n + 2)                         # 2^22 coefficients per GPU at the default size
+        nn = 1 << bits
+        roots = gfft.rootsOfUnity(gfft.bls12_381_Fr, 7)
+        om = roots.omega(bits)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(0x4E77 + rank)
+        x = torch.randint(0, 256, (nn, 32), dtype=torch.uint8, device=device, generator=gen)
+        x[:, 31] &= 0x3F                                       # < 2^254 < r: canonical residues
+        y = torch.empty_like(x)
+        z = torch.empty_like(x)
+
+        def step_ntt():
+            eng.ntt_dev(bits, 1, om, dev_ptr(x), dev_ptr(y), stream)
+
+        wall, ev_ms = time_steps(step_ntt, K, W, dist_on)
+        wall = max_over_ranks(wall, dist_on, device)
+        # checks: inverse(direct(x)) == x on the device; y[0] = sum x_i and a 2^12-point prefix transform
+        # against the oracle's C restatement of the reference loop
+        eng.ntt_dev(bits, 1, om, dev_ptr(y), dev_ptr(z), stream, inverse=True)
+        torch.cuda.synchronize()
+        assert bool((z == x).all().item()), "NTT: inverse(direct(x)) != x"
+        xs = x.cpu().numpy()
+        from oracle.curves import BLS_R as _R
+        le = xs.view("<u8").reshape(nn, 4).astype(object)
+        acc = (int(le[:, 0].sum()) + (int(le[:, 1].sum()) << 64) + (int(le[:, 2].sum()) << 128) + (int(le[:, 3].sum()) << 192)) % _R
+        assert int.from_bytes(y[0].cpu().numpy().tobytes(), "little") == acc, "NTT: y[0] != sum of inputs"
+        sb = 12
+        ys = eng.ntt(sb, xs[:1 << sb], roots.omega(sb))
+        assert np.array_equal(ys, cport.fft_fr(sb, xs[:1 << sb], roots.omega(sb))), "NTT sample mismatch vs oracle/c"
+        ntt_cpu = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cb = 18
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < min(args.cpu_seconds, 6.0):
+                yc = cport.fft_fr(cb, xs[:1 << cb], roots.omega(cb))
+                reps += 1
+            dt = time.perf_counter() - t0
+            assert np.array_equal(yc, eng.ntt(cb, xs[:1 << cb], roots.omega(cb))), "NTT 2^18 mismatch vs oracle/c"
+            ntt_cpu = {"value": reps * (1 << cb) / dt, "unit": "elements/s", "cores": 1, "kind": "port",
+                       "sample": "%d transforms of 2^%d of the same coefficients through oracle/c (fft.ts:422-480 loop "
+                                 "restated; includes its roots-table build), output compared with the GPU's" % (reps, cb)}
+        extra["ntt_fr"] = {"metric": "bls12_381_fr_ntt_elements_per_sec", "value": world * nn * K / wall,
+                           "unit": "elements/s", "ms_per_transform": wall / K * 1e3, "log2n": bits,
+                           "note": "FFT(roots, Fr).direct, natural in / natural out, one 2^%d transform per GPU" % bits,
+                           "roofline": {"bound": "hbm", "achieved": 64.0 * nn / (ev_ms / K * 1e-3) / 1e9,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": 64.0 * nn / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "traffic": pmc_traffic_ntt(bits),
+                                        "kernel": "k_ntt_pass (3 launches per 2^22 transform; achieved and traffic are per transform)",
+                                        "kernel_ms": ev_ms / K,
+                                        "valu": {"achieved_mac_per_s": 136.0 * (nn / 2 * bits) / (ev_ms / K * 1e-3),
+                                                 "peak_mac_per_s": INT_MAC_PEAK,
+                                                 "frac": 136.0 * (nn / 2 * bits) / (ev_ms / K * 1e-3) / INT_MAC_PEAK}}}
+        if ntt_cpu:
+            extra["ntt_fr"]["cpu_baseline"] = ntt_cpu
 
     if extra:
         result["extra"] = extra

@@ -548,3 +548,106 @@ int orc_ed25519_verify_batch(const uint8_t* sigs, const uint8_t* pks, const uint
   }
   return 0;
 }
+
+/* ======================================================================================
+ * FFT over the bls12-381 scalar field Fr: FFT(roots, Fr).direct / .inverse
+ * (src/abstract/fft.ts:518-577) through the reference's own loop shapes: natural in / natural out
+ * is bitReversalInplace + DIT butterflies (FFTCore :445-480 with dit = true, brp = true), the
+ * brpOutput form is DIF without the final permutation.  Roots table: rootsOfUnity.roots(bits)
+ * (:262-277) built from omega by the multiplication chain; inverse walks the reversed table
+ * (:296-304) and scales by 1/N (:566-571).  Values: canonical 32-byte LE residues.
+ * ====================================================================================== */
+#define NL 4
+#define PFX(x) fr_##x
+#include "field_tmpl.h"
+#undef NL
+#undef PFX
+
+static fr_ctx FR;
+static int fr_inited = 0;
+static void fr_init_once(void) {
+  if (fr_inited) return;
+  fe_set_hex(FR.p.v, 4, "73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001"); /* bls12-381.ts Fr */
+  pow2_mod(FR.r1.v, FR.p.v, 4, 256);
+  pow2_mod(FR.r2.v, FR.p.v, 4, 512);
+  FR.inv = neg_inv64(FR.p.v[0]);
+  fr_inited = 1;
+}
+static size_t brev(size_t i, int bits) {
+  size_t r = 0;
+  for (int b = 0; b < bits; b++) r |= ((i >> b) & 1) << (bits - 1 - b);
+  return r;
+}
+/* flags: bit 0 inverse, bit 1 brpInput, bit 2 brpOutput.  omega32: primitive 2^bits-th root. */
+int orc_fft_fr(int bits, const uint8_t* omega32, const uint8_t* in, uint8_t* out, int flags) {
+  fr_init_once();
+  const size_t N = (size_t)1 << bits;
+  const int inverse = flags & 1, brp_in = (flags >> 1) & 1, brp_out = (flags >> 2) & 1;
+  fr_fe* v = (fr_fe*)malloc(N * sizeof(fr_fe));
+  fr_fe* roots = (fr_fe*)malloc(N * sizeof(fr_fe));
+  if (!v || !roots) return -1;
+  fr_fe w, t;
+  memcpy(t.v, omega32, 32);
+  fr_tomont(&FR, &w, &t);
+  roots[0] = FR.r1;
+  for (size_t k = 1; k < N; k++) fr_mul(&FR, &roots[k], &roots[k - 1], &w);
+  for (size_t i = 0; i < N; i++) {
+    memcpy(t.v, in + 32 * i, 32);
+    fr_tomont(&FR, &v[i], &t);
+  }
+  const int dit = !(brp_out && !brp_in) && !(brp_in && brp_out); /* FFT.getLoop :530-541 */
+  if (brp_in && brp_out && bits) /* core(bitReversalInplace(values)) with DIF, brp = false */
+    for (size_t i = 0; i < N; i++) {
+      size_t j = brev(i, bits);
+      if (i < j) { fr_fe s = v[i]; v[i] = v[j]; v[j] = s; }
+    }
+  if (dit && !brp_in && bits) /* dit && brp: bitReversalInplace first */
+    for (size_t i = 0; i < N; i++) {
+      size_t j = brev(i, bits);
+      if (i < j) { fr_fe s = v[i]; v[i] = v[j]; v[j] = s; }
+    }
+  for (int i = 0; i < bits; i++) {
+    const int s = dit ? i + 1 : bits - i;
+    const size_t m = (size_t)1 << s, m2 = m >> 1, stride = N >> s;
+    for (size_t k = 0; k < N; k += m)
+      for (size_t j = 0; j < m2; j++) {
+        size_t pos = j * stride;
+        if (inverse && pos) pos = N - pos; /* roots.inverse(bits)[pos] */
+        fr_fe a = v[k + j], b = v[k + j + m2], x;
+        if (dit) {
+          fr_mul(&FR, &x, &b, &roots[pos]);
+          fr_add(&FR, &v[k + j], &a, &x);
+          fr_sub(&FR, &v[k + j + m2], &a, &x);
+        } else {
+          fr_add(&FR, &v[k + j], &a, &b);
+          fr_sub(&FR, &x, &a, &b);
+          fr_mul(&FR, &v[k + j + m2], &x, &roots[pos]);
+        }
+      }
+  }
+  fr_fe ninv = FR.r1;
+  if (inverse) { /* 1/N = ((r + 1) / 2)^bits */
+    fr_fe half, one;
+    memset(&one, 0, sizeof one);
+    one.v[0] = 1;
+    /* (r + 1) / 2 */
+    unsigned __int128 cy = 1;
+    uint64_t tmp[4];
+    for (int i = 0; i < 4; i++) { cy += FR.p.v[i]; tmp[i] = (uint64_t)cy; cy >>= 64; }
+    for (int i = 0; i < 4; i++) t.v[i] = (tmp[i] >> 1) | (i < 3 ? tmp[i + 1] << 63 : (uint64_t)cy << 63);
+    fr_tomont(&FR, &half, &t);
+    for (int i = 0; i < bits; i++) fr_mul(&FR, &ninv, &ninv, &half);
+  }
+  fr_fe one_raw;
+  memset(&one_raw, 0, sizeof one_raw);
+  one_raw.v[0] = 1;
+  for (size_t i = 0; i < N; i++) {
+    fr_fe x = v[i];
+    if (inverse) fr_mul(&FR, &x, &x, &ninv);
+    fr_mul(&FR, &t, &x, &one_raw); /* out of Montgomery form */
+    memcpy(out + 32 * i, t.v, 32);
+  }
+  free(v);
+  free(roots);
+  return 0;
+}

@@ -23,6 +23,7 @@ def lib():
         for name in ("orc_bls12_381_g1_pippenger", "orc_secp256k1_pippenger"):
             getattr(L, name).argtypes = [vp, vp, sz, vp, vp]
         L.orc_ed25519_verify_batch.argtypes = [vp, vp, vp, ctypes.c_int, vp, sz]
+        L.orc_fft_fr.argtypes = [ctypes.c_int, vp, vp, vp, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -60,3 +61,15 @@ def ed25519_verify_batch(sigs, pks, ks, zip215=True):
     lib().orc_ed25519_verify_batch(sigs.ctypes.data, pks.ctypes.data, ks.ctypes.data, 1 if zip215 else 0,
                                    out.ctypes.data, n)
     return out.astype(bool)
+
+
+def fft_fr(bits, data, omega, inverse=False, brp_input=False, brp_output=False):
+    """FFT(roots, Fr).direct / .inverse on uint8 [2^bits, 32] canonical LE residues (fft.ts:518-577)."""
+    d = _u8(data, 32)
+    assert d.shape[0] == 1 << bits
+    out = np.empty_like(d)
+    om = np.frombuffer(int(omega).to_bytes(32, "little"), dtype=np.uint8).copy()
+    flags = (1 if inverse else 0) | (2 if brp_input else 0) | (4 if brp_output else 0)
+    rc = lib().orc_fft_fr(bits, om.ctypes.data, d.ctypes.data, out.ctypes.data, flags)
+    assert rc == 0
+    return out

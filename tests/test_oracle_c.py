@@ -70,3 +70,23 @@ def test_c_ed25519_verify_vs_python_both_modes():
         got = cport.ed25519_verify_batch(sig, pk, ks, zip215)
         exp = [eddsa_verify(Ed25519, c[0], c[1], c[2], zip215=zip215) for c in cases]
         assert list(got) == exp
+
+
+def test_c_fft_matches_python_oracle():
+    """oracle/c FFT over Fr == the Python restatement (itself pinned to test/fft.test.ts) for every
+    (inverse, brpInput, brpOutput) combination."""
+    import numpy as np
+    from oracle import cport
+    from oracle.curves import Fr_bls, makeRng
+    from oracle.fft import FFT, RootsOfUnity
+    roots = RootsOfUnity(Fr_bls, 7)
+    f = FFT(roots, Fr_bls)
+    rng = makeRng(0xCFF7)
+    for bits in (0, 1, 3, 6):
+        x = [rng.rndBelow(Fr_bls.ORDER) for _ in range(1 << bits)]
+        data = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in x), dtype=np.uint8).reshape(-1, 32)
+        for flags in range(8):
+            inv, bi, bo = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+            got = cport.fft_fr(bits, data, roots.omega(bits), inv, bi, bo)
+            exp = (f.inverse if inv else f.direct)(x, bi, bo)
+            assert [int.from_bytes(r.tobytes(), "little") for r in got] == exp, (bits, flags)
