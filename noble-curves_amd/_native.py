@@ -91,8 +91,6 @@ _OPTIONAL_PROTOS = {
     "ncg_normalize_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_msm": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
     "ncg_msm_dev": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
-    "ncg_msm_windows_dev": [_vp, _i32, _sz, _vp, _vp, _i32, _vp, _vp, _vp],
-    "ncg_msm_combine": [_vp, _i32, _sz, _vp, _i32, _vp, _vp],
     "ncg_mul_base_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
     "ncg_mul_base_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_ed25519_verify_batch": [_vp, _sz, _vp, _vp, _vp, _i32, _vp],

@@ -299,6 +299,34 @@ __global__ void __launch_bounds__(256) k_msm_reduce_level(const uint32_t* __rest
   G::acc_store(out + (((size_t)a * nwin + w) * n_out + q) * XW, r);
 }
 
+// ------------------------------------------------------------------ 5b. group the pending sums
+// After the fold every window holds narr = c points: array 0 = S (weight 1) and array a >= 1 =
+// the level-a pending sum (weight 2^(a-1)), i.e. terms u_e = at(e+1) (+ at(0) for e = 0) with
+// weight 2^e, e < c-1.  The host Horner would spend one addition per term; here g consecutive
+// terms are pre-combined, V_j = sum_{i<g} 2^i u_{jg+i} (g-1 doublings + additions per lane, all
+// groups in parallel), so the host does one addition per GROUP - its doublings (one per scalar
+// bit) are the part only a latency-optimised core can do quickly.
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_group_pending(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                           int narr, int nwin, int g, int ngroups) {
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
+  if (t >= ngroups * nwin) return;
+  const int j = t / nwin, w = t % nwin;
+  auto at = [&](int a) { return G::acc_load(in + ((size_t)a * nwin + w) * XW); };
+  const int e_lo = j * g;
+  const int e_hi = min((j + 1) * g, narr - 1) - 1;
+  typename G::Acc acc = at(e_hi + 1);
+  if (e_hi == 0) acc = G::add(acc, at(0));
+  for (int e = e_hi - 1; e >= e_lo; e--) {
+    acc = G::dbl(acc);
+    acc = G::add(acc, at(e + 1));
+    if (e == 0) acc = G::add(acc, at(0));
+  }
+  G::acc_store(out + ((size_t)j * nwin + w) * XW, acc);
+}
+
 // ------------------------------------------------------------------ planning
 static void mp_set_bit(uint32_t* a, int bit) { a[bit >> 5] |= 1u << (bit & 31); }
 
@@ -426,19 +454,23 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
 
 // ------------------------------------------------------------------ host finish
 // Horner over all surviving points (see msm.hpp step 6), then affine canonical output.
+// fin: [ngroups][nwin] grouped sums V_j (k_msm_group_pending): window sum W_w = sum_j 2^(g j) V_j,
+// result = sum_w 2^(c w) W_w - c doublings per window in total, one addition per group.
+constexpr int MSM_GROUP = 3;
+static int msm_ngroups(int c) { return c >= 2 ? (c - 1 + MSM_GROUP - 1) / MSM_GROUP : 1; }
 template <class C>
 static void msm_host_finish(const std::vector<uint32_t>& fin, const MsmPlan& pl, uint32_t* out_affine,
                             uint8_t* out_inf) {
   using G = MsmGroup<C>;
   constexpr int XW = G::ACC_WORDS;
-  const int narr = pl.c;  // S + (c-1) R-arrays
-  auto at = [&](int a, int w) { return G::acc_load(fin.data() + ((size_t)a * pl.nwin + w) * XW); };
+  const int ng = msm_ngroups(pl.c);
+  auto at = [&](int j, int w) { return G::acc_load(fin.data() + ((size_t)j * pl.nwin + w) * XW); };
   typename G::Acc acc = G::identity();
   for (int w = pl.nwin - 1; w >= 0; w--) {
-    for (int e = pl.c - 1; e >= 0; e--) {
-      acc = G::dbl(acc);
-      if (e <= pl.c - 2 && e + 1 < narr) acc = G::add(acc, at(e + 1, w));
-      if (e == 0) acc = G::add(acc, at(0, w));
+    for (int j = ng - 1; j >= 0; j--) {
+      const int shift = j == ng - 1 ? pl.c - MSM_GROUP * j : MSM_GROUP;
+      for (int d = 0; d < shift; d++) acc = G::dbl(acc);
+      acc = G::add(acc, at(j, w));
     }
   }
   G::to_affine_wire(acc, out_affine, out_inf);
@@ -505,9 +537,16 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
     narr++;
     n_in >>= 1;
   }
+  const int ng = msm_ngroups(pl.c);
+  {
+    const size_t lanes = ((size_t)ng * pl.nwin) << LS;
+    hipLaunchKernelGGL(k_msm_group_pending<D>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, cur, red[flip],
+                       narr, pl.nwin, MSM_GROUP, ng);
+    cur = red[flip];
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  std::vector<uint32_t> fin((size_t)narr * pl.nwin * XW);
+  std::vector<uint32_t> fin((size_t)ng * pl.nwin * XW);
   e = hipMemcpyAsync(fin.data(), cur, fin.size() * 4, hipMemcpyDeviceToHost, st);
   if (e != hipSuccess) return e;
   e = hipStreamSynchronize(st);
