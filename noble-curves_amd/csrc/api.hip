@@ -74,6 +74,8 @@ static int ensure_scratch(ncg_ctx* ctx, size_t bytes) {
   return NCG_OK;
 }
 
+// only the C ABI of include/ncg.h is exported (the objects are built with -fvisibility=hidden)
+#pragma GCC visibility push(default)
 extern "C" {
 
 const char* ncg_version(void) { return "noble-curves-amd 0.1 (gfx950)"; }
@@ -649,3 +651,4 @@ int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float
 }
 
 }  // extern "C"
+#pragma GCC visibility pop
