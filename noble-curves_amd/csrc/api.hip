@@ -6,6 +6,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/ncg.h"
 #include "host_api.hpp"
@@ -208,7 +209,7 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
 int ncg_mul_base_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* scalars_dev, void* out_affine_dev,
                            uint8_t* out_is_inf_dev, void* stream) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
-  if (curve != NCG_SECP256K1 && curve != NCG_BLS12_381_G1 && curve != NCG_BLS12_381_G2)
+  if (curve < NCG_SECP256K1 || curve > NCG_BLS12_381_G2)
     return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_base_batch: unsupported curve %d", curve);
   if (n == 0) return NCG_OK;
   if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
@@ -218,6 +219,23 @@ int ncg_mul_base_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* scalar
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   int rc = ensure_mul_ws(ctx, curve, n > 8192 ? n : 8192, st);
   if (rc) return rc;
+  if (curve == NCG_ED25519) {  // table computed on the host (33 x 128 affine Niels points), cached per context
+    if (!ctx->base_tab[curve]) {
+      std::vector<uint32_t> host(ncg::ed25519_fixed_table_words());
+      ncg::ed25519_build_fixed_table(host.data());
+      uint32_t* tab = nullptr;
+      NCG_HIP(ctx, hipMalloc((void**)&tab, host.size() * 4));
+      hipError_t e = hipMemcpy(tab, host.data(), host.size() * 4, hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        (void)hipFree(tab);
+        return set_err(ctx, NCG_ERR_HIP, "noble-gpu: uploading the ed25519 fixed-base table failed: %s", hipGetErrorString(e));
+      }
+      ctx->base_tab[curve] = tab;
+    }
+    NCG_HIP(ctx, ncg::ed25519_mul_base_batch(ctx->base_tab[curve], (const uint32_t*)scalars_dev, (uint32_t*)out_affine_dev,
+                                             out_is_inf_dev, (int)n, (uint32_t*)ctx->mul_ws, st));
+    return NCG_OK;
+  }
   if (!ctx->base_tab[curve]) {  // built once per context with the variable-base kernel
     const uint32_t* base = curve == NCG_SECP256K1 ? ncg::BasePoints::SECP
                            : curve == NCG_BLS12_381_G1 ? ncg::BasePoints::G1 : ncg::BasePoints::G2;
@@ -238,8 +256,7 @@ int ncg_mul_base_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* scalar
 int ncg_mul_base_batch(ncg_ctx* ctx, int curve, size_t n, const void* scalars, void* out_affine, uint8_t* out_is_inf) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
   int pb = ncg_point_bytes(curve);
-  if (pb == 0 || curve == NCG_ED25519)
-    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_base_batch: unsupported curve %d", curve);
+  if (pb == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: mul_base_batch: unsupported curve %d", curve);
   if (n == 0) return NCG_OK;
   if (!scalars || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_base_batch: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));

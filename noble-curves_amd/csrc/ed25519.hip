@@ -145,7 +145,9 @@ k_ed25519_verify(const uint32_t* __restrict__ sigs, const uint32_t* __restrict__
 // wnaf.mulUnsafe -> mulAddUnsafe, src/abstract/curve.ts:752-764).  Exact integer multiples for
 // any curve point, torsion components included (test/ed25519.test.ts:355-390): the signed-odd
 // recoding is an identity over the integers.  Wire points are affine (x, y); the identity is (0, 1).
-template <class TABPTR>
+// PROJ_OUT: write (X, Y, Z) (8 words each) to out_wire and leave the inversion to
+// k_ed_batch_affine (one inversion per 8 points instead of one ~265-multiplication chain per lane).
+template <bool PROJ_OUT = false, class TABPTR>
 NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* __restrict__ k_wire,
                                  uint32_t* __restrict__ out_wire, uint8_t* __restrict__ out_inf, bool active,
                                  TABPTR tab, const int stride) {
@@ -182,6 +184,14 @@ NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uin
   }
   if (wk.was_even) acc = ed_add_niels(acc, ed_load_niels(tab, stride, 0), true);
   if (kzero) acc = EdExt<F>::identity();
+  if constexpr (PROJ_OUT) {
+    if (active) {
+      fp_store<PR>(out_wire, acc.X);
+      fp_store<PR>(out_wire + 8, acc.Y);
+      fp_store<PR>(out_wire + 16, acc.Z);
+    }
+    return;
+  }
   F zi = fp_inv<PR>(acc.Z);
   F ox = acc.X * zi, oy = acc.Y * zi;
   if (active) {
@@ -191,6 +201,7 @@ NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uin
   }
 }
 
+template <bool PROJ_OUT>
 __global__ void __launch_bounds__(64)
 k_ed25519_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out,
                   uint8_t* __restrict__ out_inf, int n) {
@@ -199,37 +210,163 @@ k_ed25519_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__
   const int idx = blockIdx.x * 64 + lane;
   const bool active = idx < n;
   const int src = active ? idx : n - 1;
-  ed25519_mul_var_lane(pts + (size_t)src * 16, scalars + (size_t)src * 8, out + (size_t)src * 16, out_inf + src, active,
-                       lds + lane, 64);
+  ed25519_mul_var_lane<PROJ_OUT>(pts + (size_t)src * 16, scalars + (size_t)src * 8,
+                                 out + (size_t)src * (PROJ_OUT ? 24 : 16), out_inf + src, active, lds + lane, 64);
 }
 
+// (X, Y, Z) -> affine wire (x, y) = (X/Z, Y/Z) with Montgomery's trick over K consecutive points
+// (toAffine edwards.ts:595-609 / FpInvertBatch modular.ts:728-760); flag = 1 for the identity (0, 1)
+template <int K>
+__global__ void __launch_bounds__(256) k_ed_batch_affine(const uint32_t* __restrict__ proj, uint32_t* __restrict__ out_wire,
+                                                         uint8_t* __restrict__ out_inf, int n) {
+  using F = FpEd;
+  using PR = ParamsEdP;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i0 = t * K;
+  if (i0 >= n) return;
+  F pre[K];
+  F acc = F::one();
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    pre[j] = acc;
+    if (i0 + j < n) acc = acc * fp_load<PR>(proj + ((size_t)(i0 + j) * 3 + 2) * 8);  // Z != 0 on Edwards curves
+  }
+  F inv = fp_inv<PR>(acc);
+#pragma unroll
+  for (int j = K - 1; j >= 0; j--) {
+    if (i0 + j < n) {
+      const uint32_t* p = proj + (size_t)(i0 + j) * 24;
+      F z = fp_load<PR>(p + 16);
+      F zi = inv * pre[j];
+      inv = inv * z;
+      F x = fp_load<PR>(p) * zi, y = fp_load<PR>(p + 8) * zi;
+      FieldWire<F>::store(out_wire + (size_t)(i0 + j) * 16, x);
+      FieldWire<F>::store(out_wire + (size_t)(i0 + j) * 16 + 8, y);
+      out_inf[i0 + j] = (x.is_zero() && y == F::one()) ? 1 : 0;
+    }
+  }
+}
+
+// proj_tmp: n * 24 words of device scratch, or nullptr (per-lane inversion)
 hipError_t ed25519_mul_var_batch(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
-                                 hipStream_t st) {
+                                 uint32_t* proj_tmp, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   size_t lds = (size_t)ED_LDS_WORDS * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)k_ed25519_mul_var, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (proj_tmp) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_ed25519_mul_var<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ed25519_mul_var<true>, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, proj_tmp, out_inf, n);
+    hipLaunchKernelGGL(k_ed_batch_affine<8>, dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, proj_tmp, out, out_inf, n);
+    return hipGetLastError();
+  }
+  hipError_t e = hipFuncSetAttribute((const void*)k_ed25519_mul_var<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_ed25519_mul_var, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, out, out_inf, n);
+  hipLaunchKernelGGL(k_ed25519_mul_var<false>, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, out, out_inf, n);
+  return hipGetLastError();
+}
+
+// ---- batch fixed-base multiplication out[i] = k[i] * BASE ---------------------------------------
+// BASE.multiply(k) through the cached window table of the reference (wnafCachedCT,
+// src/abstract/curve.ts:588-606; e.g. getPublicKey): signed-odd 8-bit windows, table[w][j] =
+// (2j+1) 2^(8w) B as affine Niels points (33 x 128 x 96 B = 405 KB, L2-resident), so one multiply
+// is 33 mixed additions (7M each) and no doublings.
+constexpr int ED_FB_W = 8, ED_FB_M = 33, ED_FB_T = 1 << (ED_FB_W - 1);
+__global__ void __launch_bounds__(256) k_ed_mul_base(const uint32_t* __restrict__ table, const uint32_t* __restrict__ scalars,
+                                                     uint32_t* __restrict__ proj_out, int n) {
+  using F = FpEd;
+  using PR = ParamsEdP;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) k[j] = scalars[(size_t)i * 8 + j];
+  const bool zero = mp_is_zero<8>(k);
+  SignedOddWindows<9, ED_FB_W, ED_FB_M> win;
+  win.template init<8>(k);
+  EdExt<F> acc = EdExt<F>::identity();
+  for (int w = ED_FB_M - 1; w >= 0; w--) {
+    const int d = win.pop();
+    const uint32_t* e = table + ((size_t)w * ED_FB_T + (((d < 0 ? -d : d) - 1) >> 1)) * 24;
+    EdNielsAff<F> q{fp_load<PR>(e), fp_load<PR>(e + 8), fp_load<PR>(e + 16)};
+    acc = ed_madd_niels(acc, q, d < 0);
+  }
+  if (win.was_even) {  // the scalar was bumped by one: take BASE back out
+    EdNielsAff<F> q{fp_load<PR>(table), fp_load<PR>(table + 8), fp_load<PR>(table + 16)};
+    acc = ed_madd_niels(acc, q, true);
+  }
+  if (zero) acc = EdExt<F>::identity();
+  uint32_t* o = proj_out + (size_t)i * 24;
+  fp_store<PR>(o, acc.X);
+  fp_store<PR>(o + 8, acc.Y);
+  fp_store<PR>(o + 16, acc.Z);
+}
+
+hipError_t ed25519_mul_base_batch(const uint32_t* table, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
+                                  uint32_t* proj_tmp, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_ed_mul_base, dim3((n + 255) / 256), dim3(256), 0, st, table, scalars, proj_tmp, n);
+  hipLaunchKernelGGL(k_ed_batch_affine<8>, dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, proj_tmp, out, out_inf, n);
   return hipGetLastError();
 }
 
 void ed25519_mul_var_host(const uint32_t* pt, const uint32_t* k, uint32_t* out, uint8_t* out_inf) {
   std::vector<uint32_t> tab(ED_TA * 32);
-  ed25519_mul_var_lane(pt, k, out, out_inf, true, tab.data(), 1);
+  ed25519_mul_var_lane<false>(pt, k, out, out_inf, true, tab.data(), 1);
+}
+
+static EdExt<FpEd> ed_base_point() {  // src/ed25519.ts:57-65 Gx, Gy
+  using PR = ParamsEdP;
+  static const uint32_t GX[8] = {0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u,
+                                 0xcd6e53feu, 0x216936d3u};
+  static const uint32_t GY[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u,
+                                 0x66666666u, 0x66666666u};
+  FpEd gx = fp_to_mont<PR>(fp_load<PR>(GX)), gy = fp_to_mont<PR>(fp_load<PR>(GY));
+  return {gx, gy, FpEd::one(), gx * gy};
+}
+
+// fixed-base table for k_ed_mul_base, computed on the host with the same templates: 33 x 128
+// entries of 24 words, entry [w][j] = (2j+1) 2^(8w) B; one batched inversion for all 4224 points
+size_t ed25519_fixed_table_words() { return (size_t)ED_FB_M * ED_FB_T * 24; }
+void ed25519_build_fixed_table(uint32_t* out) {
+  using F = FpEd;
+  using PR = ParamsEdP;
+  const F d2 = EdConsts::d2();
+  const int NT = ED_FB_M * ED_FB_T;
+  std::vector<EdExt<F>> pts(NT);
+  EdExt<F> bw = ed_base_point();
+  for (int w = 0; w < ED_FB_M; w++) {
+    EdNielsProj<F> n2 = ed_to_niels(ed_dbl(bw), d2);
+    EdExt<F> cur = bw;
+    for (int j = 0; j < ED_FB_T; j++) {
+      if (j > 0) cur = ed_add_niels(cur, n2, false);
+      pts[(size_t)w * ED_FB_T + j] = cur;
+    }
+    for (int d = 0; d < ED_FB_W; d++) bw = ed_dbl(bw);
+  }
+  std::vector<F> pre(NT);
+  F acc = F::one();
+  for (int i = 0; i < NT; i++) {
+    pre[i] = acc;
+    acc = acc * pts[i].Z;
+  }
+  F inv = fp_inv<PR>(acc);
+  for (int i = NT - 1; i >= 0; i--) {
+    F zi = inv * pre[i];
+    inv = inv * pts[i].Z;
+    F x = pts[i].X * zi, y = pts[i].Y * zi;
+    EdNielsAff<F> q = ed_affine_to_niels(x, y, d2);
+    fp_store<PR>(out + (size_t)i * 24, q.yplusx);
+    fp_store<PR>(out + (size_t)i * 24 + 8, q.yminusx);
+    fp_store<PR>(out + (size_t)i * 24 + 16, q.t2d);
+  }
 }
 
 // ---- base-point table [1,3,..,63]*B in affine Niels form (host-computed with the same templates)
 void ed25519_build_base_table(uint32_t* out /* ED_TB*24 words */) {
   using F = FpEd;
   using PR = ParamsEdP;
-  // src/ed25519.ts:57-65 Gx, Gy
-  static const uint32_t GX[8] = {0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u,
-                                 0xcd6e53feu, 0x216936d3u};
-  static const uint32_t GY[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u,
-                                 0x66666666u, 0x66666666u};
-  F gx = fp_to_mont<PR>(fp_load<PR>(GX)), gy = fp_to_mont<PR>(fp_load<PR>(GY));
   const F d2 = EdConsts::d2();
-  EdExt<F> B{gx, gy, F::one(), gx * gy};
+  EdExt<F> B = ed_base_point();
   EdNielsProj<F> n2 = ed_to_niels(ed_dbl(B), d2);
   EdExt<F> cur = B;
   for (int j = 0; j < ED_TB; j++) {

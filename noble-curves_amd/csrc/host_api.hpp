@@ -54,7 +54,12 @@ void ed25519_build_base_table(uint32_t* out_words);
 hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
                                 int zip215, uint8_t* out_ok, int n, hipStream_t st);
 hipError_t ed25519_mul_var_batch(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
-                                 hipStream_t st);
+                                 uint32_t* proj_tmp, hipStream_t st);
+// fixed-base multiply: table of ed25519_fixed_table_words() words built by ed25519_build_fixed_table (host)
+size_t ed25519_fixed_table_words();
+void ed25519_build_fixed_table(uint32_t* out_words);
+hipError_t ed25519_mul_base_batch(const uint32_t* table, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
+                                  uint32_t* proj_tmp, hipStream_t st);
 void ed25519_mul_var_host(const uint32_t* pt, const uint32_t* k, uint32_t* out, uint8_t* out_inf);
 bool ed25519_verify_host(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, const uint32_t* btab, bool zip215);
 

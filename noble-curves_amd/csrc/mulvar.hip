@@ -63,6 +63,7 @@ size_t mul_var_tmp_bytes(int curve, int n) {
     case CURVE_SECP256K1: return (size_t)n * 3 * FieldIO<CurveSecp::F>::WORDS * 4;
     case CURVE_BLS12_381_G1: return (size_t)n * 3 * FieldIO<CurveG1::F>::WORDS * 4;
     case CURVE_BLS12_381_G2: return (size_t)n * 3 * FieldIO<CurveG2::F>::WORDS * 4;
+    case CURVE_ED25519: return (size_t)n * 3 * 8 * 4;  // (X, Y, Z)
     default: return 0;
   }
 }
@@ -81,7 +82,7 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
       if (w == 22) return launch_mul_var<CurveSecp, 2, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
       return launch_mul_var<CurveSecp, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     }
-    case CURVE_ED25519: return ed25519_mul_var_batch(pts, scalars, out, out_inf, n, st);
+    case CURVE_ED25519: return ed25519_mul_var_batch(pts, scalars, out, out_inf, n, jac_tmp, st);
     case CURVE_BLS12_381_G1: {
       static const int w = [] { const char* e = std::getenv("NCG_G1_W"); return e ? std::atoi(e) : 31; }();
       if (w == 22) return launch_mul_var<CurveG1, 2, 2, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);

@@ -342,8 +342,6 @@ def multiplyBaseBatch(c, scalars, engine=None, unsafe=False):
             raise ValueError("invalid scalar: out of range")
     if not scalars:
         return []
-    if c.CURVE_ID == ED25519:  # no dedicated fixed-base table yet: variable-base kernel on BASE
-        return multiplyUnsafeBatch(c, [c.BASE] * len(scalars), list(scalars), engine)
     eng = engine or get_engine()
     out, inf = eng.mul_base_batch(c.CURVE_ID, _scalars_wire(scalars))
     return [c._from_wire(out[i], bool(inf[i])) for i in range(len(scalars))]

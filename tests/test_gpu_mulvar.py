@@ -249,3 +249,27 @@ def test_to_bytes_batch_gpu_round_trip():
         assert all(b is not None and b.equals(p) for b, p in zip(back, pts))
     with pytest.raises(ValueError, match="bad point: ZERO"):
         G.toBytesBatch(G.secp256k1_Point, [G.secp256k1_Point.ZERO])
+
+
+@pytest.mark.gpu
+def test_ed25519_fixed_base_table_gpu():
+    """BASE.multiply(k) for ed25519 through the dedicated window table (curve.ts:588-606): edge scalars,
+    every window digit sign, k = 0 / 1 / L - 1, equality with the variable-base kernel on BASE."""
+    from noble_curves_amd import curve as G
+    from noble_curves_amd._native import ED25519
+    from oracle.curves import ED25519_L, Ed25519
+    rng = makeRng(0xEDB45E)
+    ks = [0, 1, 2, 3, 127, 128, 129, 255, 256, 257, (1 << 252) + 1, ED25519_L - 1, ED25519_L - 2, 1 << 200,
+          (1 << 253) - 1 if (1 << 253) - 1 < ED25519_L else 12345]
+    ks += [rng.rndBelow(ED25519_L) for _ in range(200)]
+    eng = get_engine()
+    sc = scalars_to_wire(ks)
+    out, inf = eng.mul_base_batch(ED25519, sc)
+    for i, k in enumerate(ks[:60]):
+        exp = Ed25519.BASE.multiplyUnsafe(k)
+        assert wire_to_affine(ED25519, out[i]) == exp.toAffine() and bool(inf[i]) == exp.is0(), k
+    base = np.tile(points_to_wire(ED25519, [Ed25519.BASE]), (len(ks), 1))
+    out2, inf2 = eng.mul_var_batch(ED25519, base, sc)
+    assert (out == out2).all() and (inf == inf2).all()
+    got = G.multiplyBaseBatch(G.ed25519_Point, [k for k in ks if k])
+    assert all(p.toAffine() == Ed25519.BASE.multiplyUnsafe(k).toAffine() for p, k in zip(got[:20], [k for k in ks if k][:20]))

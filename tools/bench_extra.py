@@ -85,6 +85,7 @@ def main():
     epts, _ = bench.gen_points(eng, ED25519, Ed25519, n, a, b, dev, s)
     eout = torch.empty((n, 64), dtype=torch.uint8, device=dev)
     rate("ed25519 variable-base multiply", n, timeit(lambda: eng.mul_var_batch_dev(ED25519, n, P(epts), P(esc), P(eout), P(inf), s)), "scalar-mults")
+    rate("ed25519 fixed-base multiply", n, timeit(lambda: eng.mul_base_batch_dev(ED25519, n, P(esc), P(eout), P(inf), s)), "scalar-mults")
     rate("ed25519 MSM", n, timeit(lambda: eng.msm_dev(ED25519, n, P(epts), P(esc), s)), "points")
     eenc = epts[:, 32:].clone()
     eenc[:, 31] |= (epts[:, 0] & 1) << 7
