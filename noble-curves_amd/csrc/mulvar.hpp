@@ -58,7 +58,9 @@ struct MulVarCfg {
 // JAC_OUT: write the Jacobian result (X, Y, Z in storage format, Z = 0 for infinity) to
 // `out_wire` (3*FW words) and leave the inversion to k_jac_batch_affine; otherwise invert here
 // and write the affine wire point.
-template <class C, int W, bool JAC_OUT = false, class TABPTR>
+// ZR_IN_TAB: keep the TS Z-ratios of the table build behind the table (TS more elements per lane)
+// instead of in registers - for tables in device memory, where space is free and registers are not.
+template <class C, int W, bool JAC_OUT = false, bool ZR_IN_TAB = false, class TABPTR>
 NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* __restrict__ k_wire,
                          uint32_t* __restrict__ out_wire, uint8_t* __restrict__ out_inf, bool active,
                          TABPTR tab, const int stride) {
@@ -81,12 +83,22 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     auto dz3 = dz2 * D.Z;
     Affine<F> Dp{D.X, D.Y};
     Jac<F> T{P.x * dz2, P.y * dz3, F::one()};
-    F zr[TS];
+    F zr[ZR_IN_TAB ? 1 : TS];
+    auto zr_put = [&](int j, const F& v) {
+      if constexpr (ZR_IN_TAB) FieldIO<F>::store_strided(tab + (TS * 2 * TW + j * TW) * stride, stride, v);
+      else zr[j] = v;
+    };
+    auto zr_get = [&](int j) -> F {
+      if constexpr (ZR_IN_TAB) return FieldIO<F>::load_strided(tab + (TS * 2 * TW + j * TW) * stride, stride);
+      else return zr[j];
+    };
     FieldIO<F>::store_strided(tab, stride, T.X);
     FieldIO<F>::store_strided(tab + TW * stride, stride, T.Y);
 #pragma unroll
     for (int j = 1; j < TS; j++) {
-      T = jac_madd_zr(T, Dp, zr[j]);
+      F zj;
+      T = jac_madd_zr(T, Dp, zj);
+      zr_put(j, zj);
       FieldIO<F>::store_strided(tab + (j * 2 * TW) * stride, stride, T.X);
       FieldIO<F>::store_strided(tab + (j * 2 * TW + TW) * stride, stride, T.Y);
     }
@@ -94,8 +106,8 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     F s = F::one();
 #pragma unroll
     for (int j = TS - 2; j >= 0; j--) {
-      if (j == TS - 2) s = zr[j + 1];
-      else s = s * zr[j + 1];
+      if (j == TS - 2) s = zr_get(j + 1);
+      else s = s * zr_get(j + 1);
       auto s2 = f_sqr(s);
       auto s3 = s2 * s;
       F x = FieldIO<F>::load_strided(tab + (j * 2 * TW) * stride, stride);
@@ -268,6 +280,23 @@ __global__ void __launch_bounds__(256) k_proj_batch_affine(const uint32_t* __res
       out_inf[i0 + j] = inf ? 1 : 0;
     }
   }
+}
+
+// Variant with the per-lane table in device memory (item-major, each entry contiguous) instead of
+// LDS: no LDS footprint, so the window width is no longer tied to occupancy.
+template <class C, int W, int MINW, bool JAC_OUT>
+__global__ void __launch_bounds__(64, MINW)
+k_mul_var_gtab(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out,
+               uint8_t* __restrict__ out_inf, uint32_t* __restrict__ gtab, int n) {
+  using Cfg = MulVarCfg<C, W>;
+  constexpr int WW = Cfg::WW;
+  constexpr int OUTW = JAC_OUT ? 3 * Cfg::FW : 2 * WW;
+  const int lane_idx = blockIdx.x * 64 + threadIdx.x;  // table slot: one per LANE (a lane pair has two)
+  const int idx = lane_idx >> LaneShift<C>::value;
+  const bool active = idx < n;
+  const int src = active ? idx : n - 1;
+  mul_var_lane<C, W, JAC_OUT, true>(pts + (size_t)src * 2 * WW, scalars + (size_t)src * 8, out + (size_t)src * OUTW,
+                                    out_inf + src, active, gtab + (size_t)lane_idx * (Cfg::TS * 3 * Cfg::TW), 1);
 }
 
 template <class C, int W, int MINW, bool JAC_OUT>
