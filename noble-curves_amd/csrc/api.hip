@@ -610,8 +610,11 @@ int ncg_ed25519_verify_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, 
   int rc = ensure_ed_table(ctx);
   if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  rc = ensure_mul_ws(ctx, NCG_ED25519, n, st);  // per-item window tables live in the multiply scratch
+  if (rc) return rc;
   NCG_HIP(ctx, ncg::ed25519_verify_batch((const uint32_t*)sig64_dev, (const uint32_t*)pk32_dev,
-                                         (const uint32_t*)k32_dev, ctx->ed_btab, zip215, out_ok_dev, (int)n, st));
+                                         (const uint32_t*)k32_dev, ctx->ed_btab, zip215, out_ok_dev, (int)n,
+                                         (uint32_t*)ctx->mul_ws, st));
   return NCG_OK;
 }
 

@@ -13,6 +13,7 @@
 // per-lane table in LDS, projective Niels form: 16 KB per wave, so 8-10 waves fit a CU - a 3-bit
 // window measured 1.7x slower for that reason) and 6 bits for B (32 precomputed affine Niels
 // multiples shared by every lane): 258 doublings, 129 + 43 additions.
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -22,14 +23,21 @@
 
 namespace ncg {
 
-#ifndef NCG_ED_WA
-#define NCG_ED_WA 2
-#endif
-constexpr int ED_WA = NCG_ED_WA, ED_WB = 6, ED_MA = 258 / ED_WA, ED_MB = 43;  // WA*MA = 6*43 = 258 bits
-static_assert(ED_WA * ED_MA == 258 && ED_WB % ED_WA == 0, "window sizes must tile 258 bits");
-constexpr int ED_TA = 1 << (ED_WA - 1);                      // 4 entries: 1,3,5,7 times (-A)
-constexpr int ED_TB = 1 << (ED_WB - 1);                      // 32 entries: 1,3,..,63 times B
-constexpr int ED_LDS_WORDS = ED_TA * 32 * 64;
+// Window configuration of the shared doubling chain: WA-bit signed-odd windows for the per-item
+// point (table of TA projective Niels entries per lane), WB-bit windows for B (shared affine table
+// of 128 entries, the first TB = 2^(WB-1) are used).  WA * MA = WB * MB = BITS >= 254.
+//   EdCfgLds  (2, 6): 258 bits - per-lane table in LDS (16 KB per wave)
+//   EdCfgGtab (4, 8): 264 bits - per-lane table in device memory (1 KB per item), half the additions
+template <int WA_, int WB_, int BITS_>
+struct EdCfg {
+  static constexpr int WA = WA_, WB = WB_, BITS = BITS_;
+  static constexpr int MA = BITS / WA, MB = BITS / WB;
+  static constexpr int TA = 1 << (WA - 1), TB = 1 << (WB - 1);
+  static constexpr int LDS_WORDS = TA * 32 * 64;
+  static_assert(WA * MA == BITS && WB * MB == BITS && WB % WA == 0 && BITS >= 254 && TB <= 128, "window tiling");
+};
+using EdCfgLds = EdCfg<2, 6, 258>;
+using EdCfgGtab = EdCfg<4, 8, 264>;
 
 NCG_DI bool ed_scalar_lt_L(const uint32_t (&s)[8]) {
   uint32_t bw = 0;
@@ -54,9 +62,9 @@ NCG_DI EdNielsProj<FpEd> ed_load_niels(PTR tab, int stride, int e) {
           IO::load_strided(tab + (e * 32 + 24) * stride, stride)};
 }
 
-// Per-lane verification; `tab`/`stride` as in mul_var_lane.  btab: ED_TB affine Niels entries,
-// 24 words each (y+x, y-x, 2dxy), Montgomery form.
-template <class TABPTR>
+// Per-lane verification; `tab`/`stride` as in mul_var_lane.  btab: 128 affine Niels entries
+// [1,3,..,255]B, 24 words each (y+x, y-x, 2dxy).
+template <class CFG, class TABPTR>
 NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t* __restrict__ pk,
                                 const uint32_t* __restrict__ kscal, const uint32_t* __restrict__ btab, bool zip215,
                                 TABPTR tab, const int stride) {
@@ -87,26 +95,26 @@ NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t
     EdExt<F> cur = nA;
     ed_store_niels(tab, stride, 0, ed_to_niels(cur, d2));
 #pragma unroll
-    for (int j = 1; j < ED_TA; j++) {
+    for (int j = 1; j < CFG::TA; j++) {
       cur = ed_add_niels(cur, n2, false);
       ed_store_niels(tab, stride, j, ed_to_niels(cur, d2));
     }
   }
-  SignedOddWindows<9, ED_WA, ED_MA> wk;
-  SignedOddWindows<9, ED_WB, ED_MB> ws;
+  SignedOddWindows<9, CFG::WA, CFG::MA> wk;
+  SignedOddWindows<9, CFG::WB, CFG::MB> ws;
   wk.template init<8>(k);
   ws.template init<8>(s);
 
   EdExt<F> acc = EdExt<F>::identity();
-  for (int i = ED_MA - 1; i >= 0; i--) {
-    if (i != ED_MA - 1) {
+  for (int i = CFG::MA - 1; i >= 0; i--) {
+    if (i != CFG::MA - 1) {
 #pragma unroll
-      for (int d = 0; d < ED_WA - 1; d++) acc = ed_dbl_no_t(acc);
+      for (int d = 0; d < CFG::WA - 1; d++) acc = ed_dbl_no_t(acc);
       acc = ed_dbl(acc);
     }
     int dA = wk.pop();
     acc = ed_add_niels(acc, ed_load_niels(tab, stride, ((dA < 0 ? -dA : dA) - 1) >> 1), dA < 0);
-    if (i % (ED_WB / ED_WA) == 0) {
+    if (i % (CFG::WB / CFG::WA) == 0) {
       int dB = ws.pop();
       const uint32_t* bp = btab + (((dB < 0 ? -dB : dB) - 1) >> 1) * 24;
       EdNielsAff<F> q{fp_load<PR>(bp), fp_load<PR>(bp + 8), fp_load<PR>(bp + 16)};
@@ -124,19 +132,23 @@ NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t
   return ok && ed_is_identity(acc);
 }
 
-#ifndef NCG_ED_MINW
-#define NCG_ED_MINW 1
-#endif
-__global__ void __launch_bounds__(64, NCG_ED_MINW)
+// GTAB: per-lane table in device memory at gtab + idx * TA * 32 (item-major, stride 1), no LDS
+template <class CFG, bool GTAB, int MINW>
+__global__ void __launch_bounds__(64, MINW)
 k_ed25519_verify(const uint32_t* __restrict__ sigs, const uint32_t* __restrict__ pks,
                  const uint32_t* __restrict__ ks, const uint32_t* __restrict__ btab, int zip215,
-                 uint8_t* __restrict__ out_ok, int n) {
+                 uint8_t* __restrict__ out_ok, uint32_t* __restrict__ gtab, int n) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = threadIdx.x;
   const int idx = blockIdx.x * 64 + lane;
   const int src = idx < n ? idx : n - 1;
-  bool ok = ed25519_verify_lane(sigs + (size_t)src * 16, pks + (size_t)src * 8, ks + (size_t)src * 8, btab,
-                                zip215 != 0, lds + lane, 64);
+  bool ok;
+  if constexpr (GTAB)
+    ok = ed25519_verify_lane<CFG>(sigs + (size_t)src * 16, pks + (size_t)src * 8, ks + (size_t)src * 8, btab, zip215 != 0,
+                                  gtab + (size_t)idx * (CFG::TA * 32), 1);
+  else
+    ok = ed25519_verify_lane<CFG>(sigs + (size_t)src * 16, pks + (size_t)src * 8, ks + (size_t)src * 8, btab, zip215 != 0,
+                                  lds + lane, 64);
   if (idx < n) out_ok[idx] = ok ? 1 : 0;
 }
 
@@ -147,7 +159,7 @@ k_ed25519_verify(const uint32_t* __restrict__ sigs, const uint32_t* __restrict__
 // recoding is an identity over the integers.  Wire points are affine (x, y); the identity is (0, 1).
 // PROJ_OUT: write (X, Y, Z) (8 words each) to out_wire and leave the inversion to
 // k_ed_batch_affine (one inversion per 8 points instead of one ~265-multiplication chain per lane).
-template <bool PROJ_OUT = false, class TABPTR>
+template <class CFG, bool PROJ_OUT = false, class TABPTR>
 NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* __restrict__ k_wire,
                                  uint32_t* __restrict__ out_wire, uint8_t* __restrict__ out_inf, bool active,
                                  TABPTR tab, const int stride) {
@@ -165,18 +177,18 @@ NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uin
     EdExt<F> cur = P;
     ed_store_niels(tab, stride, 0, ed_to_niels(cur, d2));
 #pragma unroll
-    for (int j = 1; j < ED_TA; j++) {
+    for (int j = 1; j < CFG::TA; j++) {
       cur = ed_add_niels(cur, n2, false);
       ed_store_niels(tab, stride, j, ed_to_niels(cur, d2));
     }
   }
-  SignedOddWindows<9, ED_WA, ED_MA> wk;
+  SignedOddWindows<9, CFG::WA, CFG::MA> wk;
   wk.template init<8>(k);
   EdExt<F> acc = EdExt<F>::identity();
-  for (int i = ED_MA - 1; i >= 0; i--) {
-    if (i != ED_MA - 1) {
+  for (int i = CFG::MA - 1; i >= 0; i--) {
+    if (i != CFG::MA - 1) {
 #pragma unroll
-      for (int d = 0; d < ED_WA - 1; d++) acc = ed_dbl_no_t(acc);
+      for (int d = 0; d < CFG::WA - 1; d++) acc = ed_dbl_no_t(acc);
       acc = ed_dbl(acc);
     }
     int dA = wk.pop();
@@ -201,17 +213,22 @@ NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uin
   }
 }
 
-template <bool PROJ_OUT>
-__global__ void __launch_bounds__(64)
+template <class CFG, bool PROJ_OUT, bool GTAB, int MINW>
+__global__ void __launch_bounds__(64, MINW)
 k_ed25519_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out,
-                  uint8_t* __restrict__ out_inf, int n) {
+                  uint8_t* __restrict__ out_inf, uint32_t* __restrict__ gtab, int n) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = threadIdx.x;
   const int idx = blockIdx.x * 64 + lane;
   const bool active = idx < n;
   const int src = active ? idx : n - 1;
-  ed25519_mul_var_lane<PROJ_OUT>(pts + (size_t)src * 16, scalars + (size_t)src * 8,
-                                 out + (size_t)src * (PROJ_OUT ? 24 : 16), out_inf + src, active, lds + lane, 64);
+  if constexpr (GTAB)
+    ed25519_mul_var_lane<CFG, PROJ_OUT>(pts + (size_t)src * 16, scalars + (size_t)src * 8,
+                                        out + (size_t)src * (PROJ_OUT ? 24 : 16), out_inf + src, active,
+                                        gtab + (size_t)idx * (CFG::TA * 32), 1);
+  else
+    ed25519_mul_var_lane<CFG, PROJ_OUT>(pts + (size_t)src * 16, scalars + (size_t)src * 8,
+                                        out + (size_t)src * (PROJ_OUT ? 24 : 16), out_inf + src, active, lds + lane, 64);
 }
 
 // (X, Y, Z) -> affine wire (x, y) = (X/Z, Y/Z) with Montgomery's trick over K consecutive points
@@ -247,21 +264,24 @@ __global__ void __launch_bounds__(256) k_ed_batch_affine(const uint32_t* __restr
   }
 }
 
-// proj_tmp: n * 24 words of device scratch, or nullptr (per-lane inversion)
+// proj_tmp: ed25519_tmp_words(n) words of device scratch ((X, Y, Z) per item + the per-item window
+// tables), or nullptr (LDS table, per-lane inversion)
+size_t ed25519_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * (24 + EdCfgGtab::TA * 32); }
 hipError_t ed25519_mul_var_batch(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
                                  uint32_t* proj_tmp, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  size_t lds = (size_t)ED_LDS_WORDS * 4;
   if (proj_tmp) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_ed25519_mul_var<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ed25519_mul_var<true>, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, proj_tmp, out_inf, n);
+    uint32_t* gtab = proj_tmp + ((size_t)n + 63) / 64 * 64 * 24;
+    hipLaunchKernelGGL((k_ed25519_mul_var<EdCfgGtab, true, true, 4>), dim3((n + 63) / 64), dim3(64), 0, st, pts, scalars,
+                       proj_tmp, out_inf, gtab, n);
     hipLaunchKernelGGL(k_ed_batch_affine<8>, dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, proj_tmp, out, out_inf, n);
     return hipGetLastError();
   }
-  hipError_t e = hipFuncSetAttribute((const void*)k_ed25519_mul_var<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  size_t lds = (size_t)EdCfgLds::LDS_WORDS * 4;
+  auto kern = k_ed25519_mul_var<EdCfgLds, false, false, 1>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_ed25519_mul_var<false>, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, out, out_inf, n);
+  hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, st, pts, scalars, out, out_inf, (uint32_t*)nullptr, n);
   return hipGetLastError();
 }
 
@@ -310,8 +330,8 @@ hipError_t ed25519_mul_base_batch(const uint32_t* table, const uint32_t* scalars
 }
 
 void ed25519_mul_var_host(const uint32_t* pt, const uint32_t* k, uint32_t* out, uint8_t* out_inf) {
-  std::vector<uint32_t> tab(ED_TA * 32);
-  ed25519_mul_var_lane<false>(pt, k, out, out_inf, true, tab.data(), 1);
+  std::vector<uint32_t> tab(EdCfgGtab::TA * 32);
+  ed25519_mul_var_lane<EdCfgGtab, false>(pt, k, out, out_inf, true, tab.data(), 1);
 }
 
 static EdExt<FpEd> ed_base_point() {  // src/ed25519.ts:57-65 Gx, Gy
@@ -362,14 +382,14 @@ void ed25519_build_fixed_table(uint32_t* out) {
 }
 
 // ---- base-point table [1,3,..,63]*B in affine Niels form (host-computed with the same templates)
-void ed25519_build_base_table(uint32_t* out /* ED_TB*24 words */) {
+void ed25519_build_base_table(uint32_t* out /* 128 * 24 words */) {
   using F = FpEd;
   using PR = ParamsEdP;
   const F d2 = EdConsts::d2();
   EdExt<F> B = ed_base_point();
   EdNielsProj<F> n2 = ed_to_niels(ed_dbl(B), d2);
   EdExt<F> cur = B;
-  for (int j = 0; j < ED_TB; j++) {
+  for (int j = 0; j < 128; j++) {
     if (j > 0) cur = ed_add_niels(cur, n2, false);
     F zi = fp_inv<PR>(cur.Z);
     F x = cur.X * zi, y = cur.Y * zi;
@@ -380,20 +400,36 @@ void ed25519_build_base_table(uint32_t* out /* ED_TB*24 words */) {
   }
 }
 
+// gtab: n_pad * TA * 32 words of device scratch for the per-item tables, or nullptr (LDS variant)
+size_t ed25519_verify_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * EdCfgGtab::TA * 32; }
 hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
-                                int zip215, uint8_t* out_ok, int n, hipStream_t st) {
+                                int zip215, uint8_t* out_ok, int n, uint32_t* gtab, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  size_t lds = (size_t)ED_LDS_WORDS * 4;
-  hipError_t e = hipFuncSetAttribute((const void*)k_ed25519_verify, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const int variant = [] { const char* e = std::getenv("NCG_ED_VARIANT"); return e ? std::atoi(e) : 4; }();
+  if (gtab && variant > 0) {
+    if (variant == 2)
+      hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 2>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
+                         zip215, out_ok, gtab, n);
+    else if (variant == 4)
+      hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 4>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
+                         zip215, out_ok, gtab, n);
+    else
+      hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 3>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
+                         zip215, out_ok, gtab, n);
+    return hipGetLastError();
+  }
+  size_t lds = (size_t)EdCfgLds::LDS_WORDS * 4;
+  auto kern = k_ed25519_verify<EdCfgLds, false, 1>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_ed25519_verify, dim3((n + 63) / 64), dim3(64), lds, st, sigs, pks, ks, btab, zip215, out_ok, n);
+  hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, st, sigs, pks, ks, btab, zip215, out_ok, (uint32_t*)nullptr, n);
   return hipGetLastError();
 }
 
 // host-only: run the lane function on the CPU (unit tests through hosttest.hip)
 bool ed25519_verify_host(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, const uint32_t* btab, bool zip215) {
-  std::vector<uint32_t> tab(ED_TA * 32);
-  return ed25519_verify_lane(sig, pk, k, btab, zip215, tab.data(), 1);
+  std::vector<uint32_t> tab(EdCfgGtab::TA * 32);
+  return ed25519_verify_lane<EdCfgGtab>(sig, pk, k, btab, zip215, tab.data(), 1);
 }
 
 }  // namespace ncg

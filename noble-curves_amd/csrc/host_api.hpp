@@ -49,10 +49,12 @@ hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const ui
                    uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st);
 
 // ed25519 batch verify (ed25519.hip).  btab: device copy of the table built by ed25519_build_base_table.
-constexpr int ED25519_BTAB_WORDS = 32 * 24;
+constexpr int ED25519_BTAB_WORDS = 128 * 24;  // [1,3,..,255]B, affine Niels
 void ed25519_build_base_table(uint32_t* out_words);
+size_t ed25519_verify_tmp_words(int n);
+size_t ed25519_tmp_words(int n);
 hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
-                                int zip215, uint8_t* out_ok, int n, hipStream_t st);
+                                int zip215, uint8_t* out_ok, int n, uint32_t* gtab, hipStream_t st);
 hipError_t ed25519_mul_var_batch(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
                                  uint32_t* proj_tmp, hipStream_t st);
 // fixed-base multiply: table of ed25519_fixed_table_words() words built by ed25519_build_fixed_table (host)

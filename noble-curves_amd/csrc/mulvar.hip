@@ -85,7 +85,7 @@ size_t mul_var_tmp_bytes(int curve, int n) {
     case CURVE_SECP256K1: return pad64(n) * (3 * FieldIO<CurveSecp::F>::WORDS + gtab_words_per_item<CurveSecp, 5>()) * 4;
     case CURVE_BLS12_381_G1: return pad64(n) * (3 * FieldIO<CurveG1::F>::WORDS + gtab_words_per_item<CurveG1, 4>()) * 4;
     case CURVE_BLS12_381_G2: return pad64(n) * (3 * FieldIO<CurveG2::F>::WORDS + 2 * gtab_words_per_item<CurveG2P, 4>()) * 4;
-    case CURVE_ED25519: return (size_t)n * 3 * 8 * 4;  // (X, Y, Z)
+    case CURVE_ED25519: return ed25519_tmp_words(n) * 4;  // (X, Y, Z) + per-item window tables
     default: return 0;
   }
 }
