@@ -224,8 +224,8 @@ def main():
                        % args.log2n, "items_per_gpu": n, "parallelism": "shard-by-index x%d" % world},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("ncg::k_mul_var<ncg::CurveSecp") if args.log2n == 20 else None,
-                         "kernel": "k_mul_var<CurveSecp,3> (+ k_jac_batch_affine)", "kernel_ms": kern_ms,
+                         "traffic": pmc_traffic("ncg::k_mul_var_gtab<ncg::CurveSecp") if args.log2n == 20 else None,
+                         "kernel": "k_mul_var_gtab<CurveSecp,5> (+ k_jac_batch_affine); traffic includes the per-item window tables kept in device memory", "kernel_ms": kern_ms,
                          "valu": {"achieved_mac_per_s": alg_mac / (kern_ms * 1e-3), "peak_mac_per_s": INT_MAC_PEAK,
                                   "frac": alg_mac / (kern_ms * 1e-3) / INT_MAC_PEAK,
                                   "note": "reference-equivalent limb-MACs (SURVEY 8d) / v_mad_u64_u32 peak"}},
@@ -420,7 +420,8 @@ def main():
                                    "roofline": {"bound": "hbm", "achieved": 129.0 * nv / (ev_ms / K * 1e-3) / 1e9,
                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac": 129.0 * nv / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                "traffic": None, "kernel": "k_ed25519_verify", "kernel_ms": ev_ms / K,
+                                                "traffic": pmc_traffic("ncg::k_ed25519_verify") if nv == 1 << 18 else None,
+                                                "kernel": "k_ed25519_verify", "kernel_ms": ev_ms / K,
                                                 "valu": {"achieved_mac_per_s": 4.9e5 * nv / (ev_ms / K * 1e-3),
                                                          "peak_mac_per_s": INT_MAC_PEAK,
                                                          "frac": 4.9e5 * nv / (ev_ms / K * 1e-3) / INT_MAC_PEAK}}}
