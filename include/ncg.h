@@ -19,6 +19,15 @@
  * addresses valid on the context's GPU; all others are host pointers.  `stream` is a
  * hipStream_t passed as void* (NULL = the context's own stream); *_dev calls are
  * asynchronous on that stream, host-pointer calls return after the result is in host memory.
+ *
+ * Threading and memory: a context is not thread-safe - use it from one host thread at a time (the
+ * reference is single-threaded); several contexts per process are fine.  The context
+ * owns its device workspaces (grown on demand, reused across calls, released by ncg_destroy): the
+ * batch multiplies keep a Jacobian scratch plus a per-item window table (secp256k1 1.6 KB, ed25519
+ * 1.1 KB, bls12-381 G1 2.9 KB / G2 5.7 KB per item), the MSM about 650 B per point at 2^20, the NTT
+ * a twiddle table of N elements per transform size.  Because these buffers are shared, *_dev calls
+ * on one context must be issued in stream order (same stream, or externally ordered); growing a
+ * workspace synchronises the stream it was used on.
  */
 #ifndef NCG_H
 #define NCG_H
