@@ -24,7 +24,7 @@
  * reference is single-threaded); several contexts per process are fine.  The context
  * owns its device workspaces (grown on demand, reused across calls, released by ncg_destroy): the
  * batch multiplies keep a Jacobian scratch plus a per-item window table (secp256k1 1.6 KB, ed25519
- * 1.1 KB, bls12-381 G1 2.9 KB / G2 5.7 KB per item), the MSM about 650 B per point at 2^20, the NTT
+ * 1.1 KB, bls12-381 G1 1.5 KB / G2 3.0 KB per item), the MSM about 650 B per point at 2^20, the NTT
  * a twiddle table of N elements per transform size.  Because these buffers are shared, *_dev calls
  * on one context must be issued in stream order (same stream, or externally ordered); growing a
  * workspace synchronises the stream it was used on.
