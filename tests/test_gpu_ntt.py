@@ -110,3 +110,61 @@ def test_ntt_rejects_bad_root_and_range():
     f = G.FFT(G.rootsOfUnity(G.bls12_381_Fr, 7))
     with pytest.raises(ValueError, match="outside of range"):
         f.direct([R, 0])
+
+
+def test_fft_algebra_properties_gpu():
+    """test/fft.test.ts:544-640 'random and algebra properties' through the device transform: round trips,
+    additivity, scalar multiples, constant / zero polynomials, the convolution theorem, eval(a*b) = eval(a) eval(b)."""
+    rng = makeRng(0xA16EB7A)
+    f = G.FFT(G.rootsOfUnity(G.bls12_381_Fr, 7))
+    for n in (8, 256, 2048):
+        a = [rng.rndBelow(R) for _ in range(n)]
+        b = [rng.rndBelow(R) for _ in range(n)]
+        c = rng.rndBelow(R - 1) + 1
+        assert f.inverse(f.direct(a)) == a and f.direct(f.inverse(a)) == a
+        fa, fb = f.direct(a), f.direct(b)
+        assert f.direct([(x + y) % R for x, y in zip(a, b)]) == [(x + y) % R for x, y in zip(fa, fb)]
+        assert f.direct([x * c % R for x in a]) == [x * c % R for x in fa]
+        out = f.direct([c] * n)
+        assert out[0] == c * n % R and not any(out[1:])
+        assert not any(f.direct([0] * n))
+        # convolution theorem on zero-padded halves: direct(a) .* direct(b) = direct(a (*) b)
+        h = n // 2
+        a0, b0 = a[:h] + [0] * h, b[:h] + [0] * h
+        conv = [0] * n
+        if n <= 256:
+            for i in range(h):
+                for j in range(h):
+                    conv[i + j] = (conv[i + j] + a0[i] * b0[j]) % R
+            assert f.inverse([x * y % R for x, y in zip(f.direct(a0), f.direct(b0))]) == conv
+        # eval(a*b)(x) = eval(a)(x) eval(b)(x) through the transform-domain product
+        prod = f.inverse([x * y % R for x, y in zip(f.direct(a0), f.direct(b0))])
+        x = rng.rndBelow(R)
+
+        def ev(p):
+            acc = 0
+            for coef in reversed(p):
+                acc = (acc * x + coef) % R
+            return acc
+        assert ev(prod) == ev(a0) * ev(b0) % R
+
+
+def test_fft_is_evaluation_at_roots_gpu():
+    """test/fft.test.ts:642-648 'direct == eval at roots' (and the bit-reversed form)"""
+    rng = makeRng(0xD0F7)
+    roots = G.rootsOfUnity(G.bls12_381_Fr, 7)
+    f = G.FFT(roots)
+    for bits in (3, 6):
+        n = 1 << bits
+        a = [rng.rndBelow(R) for _ in range(n)]
+        om = roots.roots(bits)
+
+        def ev(p, x):
+            acc = 0
+            for coef in reversed(p):
+                acc = (acc * x + coef) % R
+            return acc
+        exp = [ev(a, w) for w in om]
+        assert f.direct(a) == exp
+        assert f.direct(a, False, True) == G.bitReversalPermutation(exp)
+        assert roots.inverse(bits)[1:] == om[1:][::-1] and roots.inverse(bits)[0] == 1
