@@ -7,6 +7,10 @@
 //   mulVarBatch(curveId, points, scalars)            -> Uint8Array n * (PB + 1)  (points then flags)
 //   mulBaseBatch(curveId, scalars)                   -> Uint8Array n * (PB + 1)
 //   ed25519VerifyBatch(sigs, pks, ks, zip215: bool)  -> Uint8Array n (0 / 1)
+//   decodePoints(curveId, encoded, zip215: bool)     -> Uint8Array n * (PB + 2)  (points, ok flags, inf flags)
+//   encodePoints(curveId, points)                    -> Uint8Array n * (EB + 1)  (encodings, ok flags)
+//   ntt(log2n, omega: Uint8Array 32, data, flags)    -> Uint8Array (same length)
+//   mapToCurve(curveId, count, u)                    -> Uint8Array n * (PB + 1)
 //   pointBytes(curveId) / version()
 // Buffers use the wire format of include/ncg.h.  Build: make -C addon  (g++ + /usr/include/node).
 #include <node_api.h>
@@ -165,6 +169,110 @@ static napi_value Ed25519VerifyBatch(napi_env env, napi_callback_info info) {
   return res;
 }
 
+static int encoded_bytes(int curve) { return curve == 0 ? 33 : curve == 1 ? 32 : curve == 2 ? 48 : curve == 3 ? 96 : 0; }
+
+static napi_value DecodePoints(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t curve;
+  uint8_t *enc, *out;
+  size_t el;
+  bool zip215 = false;
+  if (argc < 2 || napi_get_value_int32(env, argv[0], &curve) != napi_ok || !get_u8(env, argv[1], &enc, &el)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: decodePoints(curveId, Uint8Array, zip215)");
+    return nullptr;
+  }
+  if (argc >= 3) napi_get_value_bool(env, argv[2], &zip215);
+  int eb = encoded_bytes(curve), pb = ncg_point_bytes(curve);
+  if (!eb || el % eb) {
+    napi_throw_error(env, nullptr, "noble-gpu: decodePoints: bad curve or length");
+    return nullptr;
+  }
+  size_t n = el / eb;
+  napi_value res = make_u8(env, n * (pb + 2), &out);
+  if (!res) return nullptr;
+  if (n && ncg_decode_points_batch(g_ctx, curve, n, enc, zip215 ? NCG_DECODE_ZIP215 : 0, out, out + n * pb, out + n * pb + n) != 0)
+    return throw_native(env);
+  return res;
+}
+
+static napi_value EncodePoints(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t curve;
+  uint8_t *pts, *out;
+  size_t pl;
+  if (argc < 2 || napi_get_value_int32(env, argv[0], &curve) != napi_ok || !get_u8(env, argv[1], &pts, &pl)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: encodePoints(curveId, Uint8Array)");
+    return nullptr;
+  }
+  int eb = encoded_bytes(curve), pb = ncg_point_bytes(curve);
+  if (!eb || pl % pb) {
+    napi_throw_error(env, nullptr, "noble-gpu: encodePoints: bad curve or length");
+    return nullptr;
+  }
+  size_t n = pl / pb;
+  napi_value res = make_u8(env, n * (eb + 1), &out);
+  if (!res) return nullptr;
+  if (n && ncg_encode_points_batch(g_ctx, curve, n, pts, out, out + n * eb) != 0) return throw_native(env);
+  return res;
+}
+
+static napi_value Ntt(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t log2n, flags = 0;
+  uint8_t *om, *data, *out;
+  size_t ol, dl;
+  if (argc < 3 || napi_get_value_int32(env, argv[0], &log2n) != napi_ok || !get_u8(env, argv[1], &om, &ol) || ol != 32 ||
+      !get_u8(env, argv[2], &data, &dl)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: ntt(log2n, omega32, data, flags)");
+    return nullptr;
+  }
+  if (argc >= 4) napi_get_value_int32(env, argv[3], &flags);
+  if (log2n < 0 || log2n > NCG_NTT_MAX_LOG2N || dl % ((size_t)32 << log2n)) {
+    napi_throw_error(env, nullptr, "FFT: Polynomial size should be power of two");
+    return nullptr;
+  }
+  napi_value res = make_u8(env, dl, &out);
+  if (!res) return nullptr;
+  size_t batch = dl / ((size_t)32 << log2n);
+  if (batch && ncg_ntt(g_ctx, NCG_FIELD_BLS12_381_FR, log2n, batch, om, data, out, flags) != 0) return throw_native(env);
+  return res;
+}
+
+static napi_value MapToCurve(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t curve, count;
+  uint8_t *u, *out;
+  size_t ul;
+  if (argc < 3 || napi_get_value_int32(env, argv[0], &curve) != napi_ok || napi_get_value_int32(env, argv[1], &count) != napi_ok ||
+      !get_u8(env, argv[2], &u, &ul)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: mapToCurve(curveId, count, Uint8Array)");
+    return nullptr;
+  }
+  int pb = ncg_point_bytes(curve);
+  size_t per = (size_t)count * (pb / 2);
+  if ((curve != NCG_BLS12_381_G1 && curve != NCG_BLS12_381_G2) || (count != 1 && count != 2) || ul % per) {
+    napi_throw_error(env, nullptr, "noble-gpu: mapToCurve: bad curve, count or length");
+    return nullptr;
+  }
+  size_t n = ul / per;
+  napi_value res = make_u8(env, n * (pb + 1), &out);
+  if (!res) return nullptr;
+  if (n && ncg_map_to_curve_batch(g_ctx, curve, n, count, u, out, out + n * pb) != 0) return throw_native(env);
+  return res;
+}
+
 static napi_value PointBytes(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1], r;
@@ -188,6 +296,8 @@ NAPI_MODULE_INIT() {
   } fns[] = {{"init", Init},           {"msm", Msm},
              {"mulVarBatch", MulVarBatch}, {"mulBaseBatch", MulBaseBatch},
              {"ed25519VerifyBatch", Ed25519VerifyBatch}, {"pointBytes", PointBytes},
+             {"decodePoints", DecodePoints}, {"encodePoints", EncodePoints},
+             {"ntt", Ntt},               {"mapToCurve", MapToCurve},
              {"version", Version}};
   for (auto& f : fns) {
     napi_value v;

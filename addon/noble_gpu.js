@@ -116,4 +116,91 @@ function ed25519VerifyBatch(items, zip215) {   // items: [{sig, msg, publicKey}]
   return Array.from(native.ed25519VerifyBatch(sig, pk, ks, zip215 !== false)).map((x) => x === 1);
 }
 
-module.exports = { CURVE, init, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch, native };
+
+// ---- codecs: array forms of Point.fromBytes / toBytes (compressed) --------------------------------
+//   weierstrass.ts:541-605, bls12-381.ts:377-459 (+ subgroup checks :567-577, :599-601), edwards.ts:405-436,620-628
+// fromBytesBatch returns null where the reference would throw.
+const ENC = [33, 32, 48, 96];
+function fromBytesBatch(c, encodings, zip215) {
+  const id = curveId(c), eb = ENC[id], pb = native.pointBytes(id), n = encodings.length;
+  const buf = new Uint8Array(n * eb);
+  encodings.forEach((e, i) => {
+    if (!(e instanceof Uint8Array) || e.length !== eb) throw new Error('invalid point encoding at index ' + i + ': expected ' + eb + ' bytes');
+    buf.set(e, i * eb);
+  });
+  if (n === 0) return [];
+  init();
+  const out = native.decodePoints(id, buf, !!zip215);
+  const res = [];
+  for (let i = 0; i < n; i++) res.push(out[n * pb + i] ? unmarshalPoint(c, id, out, i * pb, out[n * pb + n + i] === 1) : null);
+  return res;
+}
+function toBytesBatch(c, points) {
+  const id = curveId(c), eb = ENC[id];
+  validateMSMPoints(points, c);
+  if (points.length === 0) return [];
+  init();
+  const out = native.encodePoints(id, marshalPoints(c, id, points));
+  const n = points.length;
+  return points.map((_, i) => {
+    if (!out[n * eb + i]) throw new Error('bad point: ZERO');     // weierstrass.ts:545
+    return out.slice(i * eb, (i + 1) * eb);
+  });
+}
+
+// ---- FFT over the bls12-381 scalar field: FFT(roots, Fr).direct / .inverse (fft.ts:518-577) --------
+const FR = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001n;
+function powMod(b, e, m) { let r = 1n; b %= m; while (e > 0n) { if (e & 1n) r = r * b % m; b = b * b % m; e >>= 1n; } return r; }
+function fftFr(values, opts) {                  // opts: { inverse, brpInput, brpOutput, generator = 7n }
+  opts = opts || {};
+  const N = values.length;
+  if (N === 0 || (N & (N - 1)) !== 0) throw new Error('FFT: Polynomial size should be power of two');
+  const bits = 31 - Math.clz32(N);
+  const omega = powMod(opts.generator || 7n, (FR - 1n) >> BigInt(bits), FR);   // rootsOfUnity.omega(bits), fft.ts:238-241
+  const data = new Uint8Array(N * 32), om = new Uint8Array(32);
+  values.forEach((v, i) => {
+    if (typeof v !== 'bigint' || v < 0n || v >= FR) throw new Error('invalid field element: outside of range 0..ORDER');
+    leBytes(v, 32, data, 32 * i);
+  });
+  leBytes(omega, 32, om, 0);
+  init();
+  const out = native.ntt(bits, om, data, (opts.inverse ? 1 : 0) | (opts.brpInput ? 2 : 0) | (opts.brpOutput ? 4 : 0));
+  return values.map((_, i) => leNumber(out, 32 * i, 32));
+}
+
+// ---- hash-to-curve for bls12-381 G1 / G2: createHasher(...).hashToCurve (hash-to-curve.ts:441-548) -
+const BLS_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaabn;
+function expandMessageXmd(msg, dst, len) {      // hash-to-curve.ts:189-228 with SHA-256
+  const sha = (...parts) => { const h = crypto.createHash('sha256'); parts.forEach((p) => h.update(p)); return h.digest(); };
+  if (dst.length > 255) dst = sha(Buffer.from('H2C-OVERSIZE-DST-'), dst);
+  const ell = Math.ceil(len / 32);
+  if (len > 65535 || ell > 255) throw new Error('expand_message_xmd: invalid lenInBytes');
+  const dstPrime = Buffer.concat([dst, Buffer.from([dst.length])]);
+  const b0 = sha(Buffer.alloc(64), msg, Buffer.from([len >> 8, len & 255, 0]), dstPrime);
+  const b = [sha(b0, Buffer.from([1]), dstPrime)];
+  for (let i = 1; i < ell; i++) b.push(sha(Buffer.from(b0.map((x, j) => x ^ b[i - 1][j])), Buffer.from([i + 1]), dstPrime));
+  return Buffer.concat(b).slice(0, len);
+}
+function hashToCurveBatch(c, msgs, DST) {
+  const id = curveId(c);
+  if (id !== CURVE.BLS12_381_G1 && id !== CURVE.BLS12_381_G2) throw new Error('noble-gpu: hashToCurveBatch: bls12-381 G1 / G2 only');
+  const m = id === CURVE.BLS12_381_G2 ? 2 : 1, L = 64, count = 2;
+  const dst = Buffer.from(DST || (m === 2 ? 'BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_' : 'BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_NUL_'));
+  const u = new Uint8Array(msgs.length * count * m * 48);
+  msgs.forEach((msg, i) => {
+    const prb = expandMessageXmd(Buffer.from(msg), dst, count * m * L);       // hash_to_field :312-378
+    for (let e = 0; e < count * m; e++) {
+      let v = 0n;
+      for (let j = 0; j < L; j++) v = (v << 8n) | BigInt(prb[e * L + j]);
+      leBytes(v % BLS_P, 48, u, (i * count * m + e) * 48);
+    }
+  });
+  if (msgs.length === 0) return [];
+  init();
+  const pb = native.pointBytes(id), n = msgs.length;
+  const out = native.mapToCurve(id, count, u);
+  return msgs.map((_, i) => unmarshalPoint(c, id, out, i * pb, out[n * pb + i] === 1));
+}
+
+module.exports = { CURVE, init, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
+                   fromBytesBatch, toBytesBatch, fftFr, hashToCurveBatch, native };

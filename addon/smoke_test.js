@@ -48,5 +48,36 @@ if (haveGpu) {
   const ref = gpu.multiplyBaseBatch(Point, [tot])[0];
   assert.strictEqual(msm.x, ref.x); assert.strictEqual(msm.y, ref.y);
   assert.strictEqual(gpu.pippenger(Point, [Point.BASE, Point.BASE.negate(), Point.ZERO], [5n, 5n, 9n]), Point.ZERO);
+  // codecs: SEC1 round trip of the k*G vectors; ZERO is rejected like the reference
+  const enc = gpu.toBytesBatch(Point, viaBase);
+  enc.forEach((e, i) => { assert.strictEqual(e.length, 33); assert.strictEqual(e[0], 2 + Number(exp[i][1] & 1n)); });
+  gpu.fromBytesBatch(Point, enc).forEach((p, i) => { assert.strictEqual(p.x, exp[i][0]); assert.strictEqual(p.y, exp[i][1]); });
+  const bad = Uint8Array.from(enc[0]); bad[0] = 5;
+  assert.strictEqual(gpu.fromBytesBatch(Point, [bad])[0], null);
+  assert.throws(() => gpu.toBytesBatch(Point, [Point.ZERO]), /bad point: ZERO/);
+  // FFT over Fr: the reference's 'Basic FFT' known answer (test/fft.test.ts:221-251) and round trips
+  const kat = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', 'fft_kat.json')));
+  const fin = kat.basic_input.map(BigInt), fexp = kat.basic_exp.map(BigInt);
+  assert.deepStrictEqual(gpu.fftFr(fin), fexp);
+  assert.deepStrictEqual(gpu.fftFr(gpu.fftFr(fin), { inverse: true }), fin);
+  assert.deepStrictEqual(gpu.fftFr(gpu.fftFr(fin, { brpOutput: true }), { inverse: true, brpInput: true }), fin);
+  assert.throws(() => gpu.fftFr([1n, 2n, 3n]), /FFT: Polynomial size should be power of two/);
+  // hash-to-curve + multiply + encode: the reference's priv:msg:sig vectors (test/bls12-381.test.ts:953-966)
+  const BP = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaabn;
+  const BR = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001n;
+  class G2 {                                    // Fp2 coordinates as { c0, c1 } like the reference (tower.ts)
+    constructor(x, y, inf) { this.x = x; this.y = y; this.inf = !!inf; }
+    static fromAffine(a) { return (a.x.c0 === 0n && a.x.c1 === 0n && a.y.c0 === 0n && a.y.c1 === 0n) ? G2.ZERO : new G2(a.x, a.y); }
+    toAffine() { return this.inf ? { x: { c0: 0n, c1: 0n }, y: { c0: 0n, c1: 0n } } : { x: this.x, y: this.y }; }
+  }
+  G2.ZERO = new G2(null, null, true);
+  G2.Fp = { ORDER: BP * BP, BYTES: 96 };
+  G2.Fn = { ORDER: BR, BYTES: 32 };
+  gpu.register(G2, gpu.CURVE.BLS12_381_G2);
+  const sig = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', 'bls12_381_sig_vectors.json'))).g2.slice(0, 8);
+  const H = gpu.hashToCurveBatch(G2, sig.map((r) => Buffer.from(r.msg, 'hex')));
+  const S = gpu.multiplyUnsafeBatch(G2, H, sig.map((r) => BigInt('0x' + r.priv) % BR));
+  gpu.toBytesBatch(G2, S).forEach((e, i) => assert.strictEqual(Buffer.from(e).toString('hex'), sig[i].sig));
   console.log('GPU smoke OK: multiplyBaseBatch / multiplyUnsafeBatch / pippenger match the reference vectors');
+  console.log('GPU smoke OK: codecs, FFT known answer and hash-to-curve signature vectors');
 }
