@@ -460,8 +460,10 @@ int ncg_map_to_curve_batch_dev(ncg_ctx* ctx, int curve, size_t n, int count, con
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: map_to_curve_batch: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  int rc = ensure_mul_ws(ctx, curve, n, st);  // Jacobian scratch for the batched affine conversion
+  if (rc) return rc;
   NCG_HIP(ctx, ncg::map_to_curve_batch(curve, (const uint32_t*)u_dev, count, (uint32_t*)out_affine_dev, out_is_inf_dev,
-                                       (int)n, st));
+                                       (int)n, (uint32_t*)ctx->mul_ws, st));
   return NCG_OK;
 }
 

@@ -21,6 +21,7 @@
 
 #include "bls_lanes.hpp"
 #include "host_api.hpp"
+#include "mulvar.hpp"
 
 namespace ncg {
 
@@ -39,6 +40,17 @@ template <int N>
 NCG_DI Fe29<3> horner1(const uint32_t (&k)[N][14], const Fe29<2>& x) {
   Fe29<3> acc = fe29_const(k[N - 1]);
   for (int i = N - 2; i >= 0; i--) acc = acc * x + fe29_const(k[i]);
+  return acc;
+}
+// Homogeneous Horner: D^(N-1) * sum_i k[i] (X/D)^i = sum_i k[i] X^i D^(N-1-i), no division
+template <int N>
+NCG_DI Fe29<4> horner1_hom(const uint32_t (&k)[N][14], const Fe29<2>& X, const Fe29<2>& D) {
+  Fe29<4> acc = fe29_const(k[N - 1]);
+  Fe29<2> dpow = D;
+  for (int i = N - 2; i >= 0; i--) {
+    acc = acc * X + fe29_const(k[i]) * dpow;
+    if (i) dpow = dpow * D;
+  }
   return acc;
 }
 template <int N>
@@ -90,14 +102,19 @@ NCG_DI Jac<FeBls> g1_map(const Fe29<2>& u) {
     y = value;
   }
   if (sgn0(u) != sgn0(y)) y = nrm(f_neg(y));                   // 23-24
-  x = x * f_inv(tv4);                                          // 25 (tv4 != 0: A != 0 and Z, -tv2 != 0)
-  // 11-isogeny E' -> E (isogenyMap :381-410), straight into Jacobian coordinates:
-  // Z = xd yd, X = xn yd Z, Y = y yn xd Z^2; a zero denominator is the identity (:404-408)
-  auto xn = horner1(BlsH2c::ISO1_XNUM, x), xd = horner1(BlsH2c::ISO1_XDEN, x);
-  auto yn = horner1(BlsH2c::ISO1_YNUM, x), yd = horner1(BlsH2c::ISO1_YDEN, x);
-  if (f_eqz(xd) || f_eqz(yd)) return Jac<FeBls>::inf();
-  Fe29<2> Zj = xd * yd;
-  return {xn * yd * Zj, y * yn * xd * f_sqr(Zj), Zj};
+  // 25: x = x / tv4 is NOT carried out (tv4 != 0: A != 0 and Z, -tv2 != 0): the 11-isogeny
+  // E' -> E (isogenyMap :381-410) is evaluated homogeneously in (X : D) = (x : tv4) and lands in
+  // Jacobian coordinates without any inversion.  With XN = D^11 xnum(x), XD = D^10 xden(x),
+  // YN = D^15 ynum(x), YD = D^15 yden(x):  x' = XN / (XD D),  y' = y YN / YD, so
+  //   Z = XD D YD,  X = XN (XD D) YD^2,  Y = y YN YD^2 (XD D)^3;
+  // a zero denominator is the identity (:404-408).
+  const Fe29<2> D = tv4;
+  auto XN = horner1_hom(BlsH2c::ISO1_XNUM, x, D), XD = horner1_hom(BlsH2c::ISO1_XDEN, x, D);
+  auto YN = horner1_hom(BlsH2c::ISO1_YNUM, x, D), YD = horner1_hom(BlsH2c::ISO1_YDEN, x, D);
+  if (f_eqz(XD) || f_eqz(YD)) return Jac<FeBls>::inf();
+  Fe29<2> Aq = XD * D, YD2 = f_sqr(YD);
+  Fe29<2> A3 = f_sqr(Aq) * Aq;
+  return {XN * Aq * YD2, y * YN * YD2 * A3, Aq * YD};
 }
 
 NCG_DI Jac<FeBls> g1_clear_cofactor(const Jac<FeBls>& P) {  // bls12-381.ts:578-581: [x]P + P
@@ -171,16 +188,27 @@ NCG_DI Jac<FeBls2> g2_clear_cofactor(const Jac<FeBls2>& P) {  // bls12-381.ts:60
 // ------------------------------------------------------------------------------------- lanes
 // u: count field elements (G1: 12 words each; G2: 24 words, c0 then c1), any value below 2^384 -
 // reduced mod p like Fp.create (bls12-381.ts:854, :860).  out: affine wire; *inf = 1 for ZERO.
+// JAC_OUT: write (X, Y, Z) in storage format (3 x FW words, Z = 0 for ZERO) and leave the inversion
+// to k_jac_batch_affine (one inversion per K points)
+template <bool JAC_OUT = false>
 NCG_DI void g1_map_lane(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out, uint8_t* inf) {
   Jac<FeBls> acc = g1_map(fe29_from_wire(u));
   if (count == 2) acc = jac_add(acc, g1_map(fe29_from_wire(u + 12)));
   Jac<FeBls> R = g1_clear_cofactor(acc);
   const bool z = R.is_inf();
+  if constexpr (JAC_OUT) {
+    if (z) R = Jac<FeBls>::inf();
+    FieldIO<FeBls>::store(out, R.X);
+    FieldIO<FeBls>::store(out + 14, R.Y);
+    FieldIO<FeBls>::store(out + 28, R.Z);
+    return;
+  }
   Affine<FeBls> a = jac_to_affine(R, f_inv(R.Z));
   if (z) a = {FeBls::zero(), FeBls::zero()};
   store_affine_wire<FeBls>(out, a);
   *inf = z ? 1 : 0;
 }
+template <bool JAC_OUT = false>
 NCG_DI void g2_map_lane(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out, uint8_t* inf) {
   Fe29x2<2> u0{fe29_from_wire(u), fe29_from_wire(u + 12)};
   Jac<FeBls2> acc = g2_map(u0);
@@ -190,44 +218,68 @@ NCG_DI void g2_map_lane(const uint32_t* __restrict__ u, int count, uint32_t* __r
   }
   Jac<FeBls2> R = g2_clear_cofactor(acc);
   const bool z = R.is_inf();
+  if constexpr (JAC_OUT) {
+    if (z) R = Jac<FeBls2>::inf();
+    FieldIO<FeBls2>::store(out, R.X);
+    FieldIO<FeBls2>::store(out + 28, R.Y);
+    FieldIO<FeBls2>::store(out + 56, R.Z);
+    return;
+  }
   Affine<FeBls2> a = jac_to_affine(R, f_inv(R.Z));
   if (z) a = {FeBls2::zero(), FeBls2::zero()};
   store_affine_wire<FeBls2>(out, a);
   *inf = z ? 1 : 0;
 }
 
+template <bool JAC_OUT>
 __global__ void __launch_bounds__(128) k_map_to_g1(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out,
                                                    uint8_t* __restrict__ inf, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint8_t f;
-  g1_map_lane(u + (size_t)i * count * 12, count, out + (size_t)i * 24, &f);
-  inf[i] = f;
+  uint8_t f = 0;
+  g1_map_lane<JAC_OUT>(u + (size_t)i * count * 12, count, out + (size_t)i * (JAC_OUT ? 42 : 24), &f);
+  if (!JAC_OUT) inf[i] = f;
 }
+template <bool JAC_OUT>
 __global__ void __launch_bounds__(64) k_map_to_g2(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out,
                                                   uint8_t* __restrict__ inf, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint8_t f;
-  g2_map_lane(u + (size_t)i * count * 24, count, out + (size_t)i * 48, &f);
-  inf[i] = f;
+  uint8_t f = 0;
+  g2_map_lane<JAC_OUT>(u + (size_t)i * count * 24, count, out + (size_t)i * (JAC_OUT ? 84 : 48), &f);
+  if (!JAC_OUT) inf[i] = f;
 }
 
-hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n, hipStream_t st) {
+// jac_tmp: n * 3 * FW words of device scratch (then the affine conversion is batched), or nullptr
+hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n,
+                              uint32_t* jac_tmp, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  if (curve == CURVE_BLS12_381_G1)
-    hipLaunchKernelGGL(k_map_to_g1, dim3((n + 127) / 128), dim3(128), 0, st, u, count, out, inf, n);
-  else if (curve == CURVE_BLS12_381_G2)
-    hipLaunchKernelGGL(k_map_to_g2, dim3((n + 63) / 64), dim3(64), 0, st, u, count, out, inf, n);
-  else
+  if (curve == CURVE_BLS12_381_G1) {
+    if (jac_tmp) {
+      hipLaunchKernelGGL(k_map_to_g1<true>, dim3((n + 127) / 128), dim3(128), 0, st, u, count, jac_tmp, inf, n);
+      hipLaunchKernelGGL((k_jac_batch_affine<CurveG1, 8>), dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, jac_tmp, out,
+                         inf, n);
+    } else {
+      hipLaunchKernelGGL(k_map_to_g1<false>, dim3((n + 127) / 128), dim3(128), 0, st, u, count, out, inf, n);
+    }
+  } else if (curve == CURVE_BLS12_381_G2) {
+    if (jac_tmp) {
+      hipLaunchKernelGGL(k_map_to_g2<true>, dim3((n + 63) / 64), dim3(64), 0, st, u, count, jac_tmp, inf, n);
+      hipLaunchKernelGGL((k_jac_batch_affine<CurveG2P, 4>), dim3(((((n + 3) / 4) << 1) + 255) / 256), dim3(256), 0, st,
+                         jac_tmp, out, inf, n);
+    } else {
+      hipLaunchKernelGGL(k_map_to_g2<false>, dim3((n + 63) / 64), dim3(64), 0, st, u, count, out, inf, n);
+    }
+  } else {
     return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 
 void map_to_curve_host(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n) {
   for (int i = 0; i < n; i++) {
-    if (curve == CURVE_BLS12_381_G1) g1_map_lane(u + (size_t)i * count * 12, count, out + (size_t)i * 24, inf + i);
-    else g2_map_lane(u + (size_t)i * count * 24, count, out + (size_t)i * 48, inf + i);
+    if (curve == CURVE_BLS12_381_G1) g1_map_lane<false>(u + (size_t)i * count * 12, count, out + (size_t)i * 24, inf + i);
+    else g2_map_lane<false>(u + (size_t)i * count * 24, count, out + (size_t)i * 48, inf + i);
   }
 }
 

@@ -30,7 +30,8 @@ void decode_points_host(int curve, const uint8_t* in, int flags, uint32_t* out, 
 
 // batch map-to-curve + cofactor clearing for bls12-381 G1 / G2 (h2c.hip); count = 1 or 2 field
 // elements per output point
-hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n, hipStream_t st);
+hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n,
+                              uint32_t* jac_tmp, hipStream_t st);
 void map_to_curve_host(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n);
 
 // radix-2 NTT over bls12-381 Fr (ntt.hip)
