@@ -151,6 +151,7 @@ struct MsmSeg {
 // traffic in a loop of ~17k instructions per add is cheaper than half the occupancy)
 template <class C> struct AccumMinWaves { static constexpr int value = NCG_ACCUM_MINW; };
 template <> struct AccumMinWaves<CurveG2P> { static constexpr int value = 2; };
+template <> struct AccumMinWaves<CurveG1> { static constexpr int value = 2; };  // 256 VGPRs + 36 B scratch: 2 % faster than 1 wave
 template <class C>
 __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(const uint32_t* __restrict__ pts_mont,
                                                    const uint32_t* __restrict__ sorted,
