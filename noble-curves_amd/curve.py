@@ -325,6 +325,44 @@ def toBytesBatch(c, points, engine=None):
     return [enc[i].tobytes() for i in range(len(points))]
 
 
+def isTorsionFreeBatch(c, points, engine=None):
+    """[p.isTorsionFree() for p in points]: membership in the prime-order subgroup, decided as the
+    reference's generic test does - [n]P == ZERO with n = Fn.ORDER (weierstrass.ts:976-981,
+    edwards.ts:589-591) - one batch multiply by the group order.  (The bls12-381 endomorphism tests of
+    bls12-381.ts:567-577 / :599-601 give the same booleans; the decoders use those.)  secp256k1 has
+    cofactor 1: every curve point qualifies."""
+    validateMSMPoints(points, c)
+    if not points:
+        return []
+    if c.CURVE_ID == SECP256K1:
+        return [True] * len(points)
+    eng = engine or get_engine()
+    n = len(points)
+    _, inf = eng.mul_var_batch(c.CURVE_ID, _points_wire(points, c.POINT_BYTES), _scalars_wire([c.Fn.ORDER] * n))
+    return [bool(f) for f in inf]
+
+
+def clearCofactorBatch(c, points, engine=None):
+    """[p.clearCofactor() for p in points] where that is an integer multiple that fits the batch
+    multiply: ed25519 [8]P (edwards.ts:611-618), bls12-381 G1 [|x| + 1]P = [x]P + P with the
+    reference's positive BLS_X (bls12-381.ts:578-581), secp256k1 the identity map.  (G2's psi-based
+    clearing is part of `h2c.bls12_381_G2_hasher`.)"""
+    validateMSMPoints(points, c)
+    if not points:
+        return []
+    if c.CURVE_ID == SECP256K1:
+        return list(points)
+    if c.CURVE_ID == ED25519:
+        k = 8
+    elif c.CURVE_ID == BLS12_381_G1:
+        k = 0xD201000000010000 + 1
+    else:
+        raise ValueError("noble-gpu: clearCofactorBatch: no integer-multiple form for this curve")
+    eng = engine or get_engine()
+    out, inf = eng.mul_var_batch(c.CURVE_ID, _points_wire(points, c.POINT_BYTES), _scalars_wire([k] * len(points)))
+    return [c._from_wire(out[i], bool(inf[i])) for i in range(len(points))]
+
+
 def sumPoints(c, points, engine=None):
     """Sum of a batch of points - the group operation behind bls.aggregatePublicKeys /
     aggregateSignatures (src/abstract/bls.ts:857-873).  Runs as an MSM with unit

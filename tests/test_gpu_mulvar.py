@@ -273,3 +273,49 @@ def test_ed25519_fixed_base_table_gpu():
     assert (out == out2).all() and (inf == inf2).all()
     got = G.multiplyBaseBatch(G.ed25519_Point, [k for k in ks if k])
     assert all(p.toAffine() == Ed25519.BASE.multiplyUnsafe(k).toAffine() for p, k in zip(got[:20], [k for k in ks if k][:20]))
+
+
+@pytest.mark.gpu
+def test_torsion_and_cofactor_batches_gpu():
+    """isTorsionFree / clearCofactor in batch vs the oracle: ed25519 points with and without a torsion
+    component (test/ed25519.test.ts:355-390 style inputs), bls12-381 G1 points inside and outside the
+    prime-order subgroup."""
+    from noble_curves_amd import curve as G
+    from oracle.curves import BLS_P, BlsG1, Ed25519
+    from oracle.weierstrass import bls_g1_is_torsion_free
+    rng = makeRng(0x7025)
+    # ed25519: prime-order points, small-order points, and sums of both
+    torsion = []
+    for enc in ("0100000000000000000000000000000000000000000000000000000000000000",
+                "ecffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff7f",
+                "0000000000000000000000000000000000000000000000000000000000000080",
+                "26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc05"):
+        torsion.append(Ed25519.fromBytes(bytes.fromhex(enc), True))
+    prime = [Ed25519.BASE.multiplyUnsafe(rng.rndBelow(1 << 200) + 1) for _ in range(6)]
+    mixed = [prime[i].add(torsion[i % len(torsion)]) for i in range(6)]
+    opts = prime + torsion + mixed
+    gpts = [G.ed25519_Point.fromAffine(p.toAffine()) for p in opts]
+    assert G.isTorsionFreeBatch(G.ed25519_Point, gpts) == [p.isTorsionFree() for p in opts]
+    cleared = G.clearCofactorBatch(G.ed25519_Point, gpts)
+    assert [p.toAffine() for p in cleared] == [p.clearCofactor().toAffine() for p in opts]
+    # bls12-381 G1: subgroup points and arbitrary curve points (x from the counter, y = sqrt(x^3 + 4))
+    F = BlsG1.Fp
+    outside = []
+    x = 5
+    while len(outside) < 5:
+        try:
+            y = F.sqrt((pow(x, 3, BLS_P) + 4) % BLS_P)
+            outside.append(BlsG1.fromAffine((x, y)))
+        except ValueError:
+            pass
+        x += 1
+    inside = [BlsG1.BASE.multiplyUnsafe(rng.rndBelow(1 << 128) + 1) for _ in range(5)]
+    opts = inside + outside
+    gpts = [G.bls12_381_G1_Point.fromAffine(p.toAffine()) for p in opts]
+    exp = [bls_g1_is_torsion_free(BlsG1, p) for p in opts]
+    assert exp[:5] == [True] * 5 and not all(exp[5:])
+    assert G.isTorsionFreeBatch(G.bls12_381_G1_Point, gpts) == exp
+    cleared = G.clearCofactorBatch(G.bls12_381_G1_Point, gpts)
+    from oracle.h2c import g1_clear_cofactor
+    assert [p.toAffine() for p in cleared] == [g1_clear_cofactor(p).toAffine() for p in opts]
+    assert all(G.isTorsionFreeBatch(G.bls12_381_G1_Point, cleared))
