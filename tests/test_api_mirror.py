@@ -65,3 +65,29 @@ def test_reference_flow_on_gpu():
     ks = [1, 2, ED25519_L - 1, 0xDEADBEEF]
     assert [p.toAffine() for p in G.multiplyBaseBatch(E, ks)] == [Ed25519.BASE.multiplyUnsafe(k).toAffine() for k in ks]
     assert [p.toAffine() for p in G.multiplyBaseBatch(K1, ks)] == [Secp256k1.BASE.multiplyUnsafe(k).toAffine() for k in ks]
+
+
+def test_h2c_shim_hash_to_field_matches_oracle():
+    """The shim's expand_message_xmd / hash_to_field (hash-to-curve.ts:189-228, :312-378) against the oracle's
+    restatement (pinned by the reference's signature vectors): short / long messages, empty and oversize
+    (> 255 byte) DSTs, both extension degrees; error paths of the reference."""
+    from noble_curves_amd import h2c as G
+    from oracle.curves import BLS_P, makeRng
+    from oracle.h2c import expand_message_xmd, hash_to_field
+    rng = makeRng(0x4D5D)
+    for i in range(24):
+        msg = bytes(rng.rnd64() & 0xFF for _ in range([0, 1, 31, 32, 33, 200][i % 6]))
+        dst = bytes(rng.rnd64() & 0xFF for _ in range([1, 16, 43, 255, 256, 300][(i // 2) % 6]))
+        n = [1, 32, 33, 64, 128, 256][(i // 3) % 6]
+        assert G.expand_message_xmd(msg, dst, n) == expand_message_xmd(msg, dst, n)
+        for m in (1, 2):
+            opts = {"p": BLS_P, "m": m, "k": 128, "DST": dst}
+            assert G.hash_to_field(msg, 2, opts) == hash_to_field(msg, 2, BLS_P, m, 128, dst)
+    with pytest.raises(ValueError, match="invalid lenInBytes"):
+        G.expand_message_xmd(b"", b"d", 65536)
+    with pytest.raises(ValueError, match="expected count >= 1"):
+        G.hash_to_field(b"", 0, {"p": BLS_P, "m": 1, "k": 128, "DST": b"d"})
+    with pytest.raises(ValueError, match="expected m >= 1"):
+        G.hash_to_field(b"", 1, {"p": BLS_P, "m": 0, "k": 128, "DST": b"d"})
+    assert G.bls12_381_G2_hasher.defaults["DST"] == "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_"
+    assert G.bls12_381_G1_hasher.defaults["m"] == 1 and G.bls12_381_G2_hasher.defaults["m"] == 2
