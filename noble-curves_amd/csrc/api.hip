@@ -63,6 +63,34 @@ static int set_err(ncg_ctx* ctx, int code, const char* fmt, ...) {
                      hipGetErrorString(_e), __FILE__, __LINE__);                             \
   } while (0)
 
+// Host <-> device copies of the host-pointer entry points.  Pageable user buffers move at a few
+// GB/s through the runtime's staging path; registering (pinning) a large buffer for the duration of
+// the call lets the DMA engines read/write it directly at PCIe speed.  Everything registered here is
+// released when the object goes out of scope, after the stream has been drained.
+struct PinSet {
+  ncg_ctx* ctx;
+  void* regs[8];
+  int n = 0;
+  explicit PinSet(ncg_ctx* c) : ctx(c) {}
+  void pin(const void* p, size_t bytes) {
+    if (bytes < ((size_t)4 << 20) || n >= 8) return;
+    if (hipHostRegister((void*)p, bytes, hipHostRegisterDefault) == hipSuccess) regs[n++] = (void*)p;
+    else (void)hipGetLastError();  // already pinned by the caller, or not registrable: plain copy
+  }
+  hipError_t h2d(void* dst, const void* src, size_t bytes) {
+    pin(src, bytes);
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+  }
+  hipError_t d2h(void* dst, const void* src, size_t bytes) {
+    pin(dst, bytes);
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  ~PinSet() {
+    if (n) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < n; i++) (void)hipHostUnregister(regs[i]);
+  }
+};
+
 static int ensure_scratch(ncg_ctx* ctx, size_t bytes) {
   if (ctx->scratch_bytes >= bytes) return NCG_OK;
   if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -188,6 +216,7 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
   if (!points_affine || !scalars || !out_affine)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
   size_t pts_b = n * pb, sc_b = n * 32, inf_b = (n + 255) & ~(size_t)255;
   int rc = ensure_scratch(ctx, 2 * pts_b + sc_b + inf_b + 1024);
   if (rc) return rc;
@@ -196,12 +225,12 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
   char* d_out = d_pts + pts_b;
   char* d_sc = d_out + pts_b;
   char* d_inf = d_sc + sc_b;
-  NCG_HIP(ctx, hipMemcpyAsync(d_pts, points_affine, pts_b, hipMemcpyHostToDevice, ctx->stream));
-  NCG_HIP(ctx, hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, pins.h2d(d_pts, points_affine, pts_b));
+  NCG_HIP(ctx, pins.h2d(d_sc, scalars, sc_b));
   rc = ncg_mul_var_batch_dev(ctx, curve, n, d_pts, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, pts_b, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, pins.d2h(out_affine, d_out, pts_b));
+  if (out_is_inf) NCG_HIP(ctx, pins.d2h(out_is_inf, d_inf, n));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }
@@ -260,17 +289,18 @@ int ncg_mul_base_batch(ncg_ctx* ctx, int curve, size_t n, const void* scalars, v
   if (n == 0) return NCG_OK;
   if (!scalars || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_base_batch: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
   size_t pts_b = n * pb, sc_b = n * 32, inf_b = (n + 255) & ~(size_t)255;
   int rc = ensure_scratch(ctx, pts_b + sc_b + inf_b + 1024);
   if (rc) return rc;
   char* d_out = (char*)ctx->scratch;
   char* d_sc = d_out + pts_b;
   char* d_inf = d_sc + sc_b;
-  NCG_HIP(ctx, hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, pins.h2d(d_sc, scalars, sc_b));
   rc = ncg_mul_base_batch_dev(ctx, curve, n, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, pts_b, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, pins.d2h(out_affine, d_out, pts_b));
+  if (out_is_inf) NCG_HIP(ctx, pins.d2h(out_is_inf, d_inf, n));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }
@@ -319,13 +349,14 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
   if (n == 0) return ncg_msm_dev(ctx, curve, 0, nullptr, nullptr, out_affine, out_is_inf, nullptr);
   if (!points_affine || !scalars || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
   size_t pts_b = n * pb, sc_b = n * 32;
   int rc = ensure_scratch(ctx, pts_b + sc_b + 2048);
   if (rc) return rc;
   char* d_pts = (char*)ctx->scratch;
   char* d_sc = d_pts + ((pts_b + 255) & ~(size_t)255);
-  NCG_HIP(ctx, hipMemcpyAsync(d_pts, points_affine, pts_b, hipMemcpyHostToDevice, ctx->stream));
-  NCG_HIP(ctx, hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, pins.h2d(d_pts, points_affine, pts_b));
+  NCG_HIP(ctx, pins.h2d(d_sc, scalars, sc_b));
   return ncg_msm_dev(ctx, curve, n, d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
 }
 
@@ -353,17 +384,18 @@ int ncg_normalize_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_pr
   if (n == 0) return NCG_OK;
   if (!points_proj || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: normalize_batch: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
   size_t in_b = n * (size_t)(pb / 2) * 3, out_b = n * (size_t)pb, inf_b = (n + 255) & ~(size_t)255;
   int rc = ensure_scratch(ctx, in_b + out_b + inf_b + 2048);
   if (rc) return rc;
   char* d_in = (char*)ctx->scratch;
   char* d_out = d_in + ((in_b + 255) & ~(size_t)255);
   char* d_inf = d_out + out_b;
-  NCG_HIP(ctx, hipMemcpyAsync(d_in, points_proj, in_b, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, pins.h2d(d_in, points_proj, in_b));
   rc = ncg_normalize_batch_dev(ctx, curve, n, d_in, d_out, (uint8_t*)d_inf, ctx->stream);
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, pins.d2h(out_affine, d_out, out_b));
+  if (out_is_inf) NCG_HIP(ctx, pins.d2h(out_is_inf, d_inf, n));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }
@@ -393,6 +425,7 @@ int ncg_decode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* encod
   if (!encoded || !out_affine || !out_ok)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: decode_points_batch: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
   size_t in_b = (n * ib + 255) & ~(size_t)255, out_b = n * (size_t)pb, fl_b = (n + 255) & ~(size_t)255;
   int rc = ensure_scratch(ctx, in_b + out_b + 2 * fl_b + 1024);
   if (rc) return rc;
@@ -400,12 +433,12 @@ int ncg_decode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* encod
   char* d_out = d_in + in_b;
   char* d_ok = d_out + out_b;
   char* d_inf = d_ok + fl_b;
-  NCG_HIP(ctx, hipMemcpyAsync(d_in, encoded, n * ib, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, pins.h2d(d_in, encoded, n * ib));
   rc = ncg_decode_points_batch_dev(ctx, curve, n, d_in, flags, d_out, (uint8_t*)d_ok, (uint8_t*)d_inf, ctx->stream);
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
-  NCG_HIP(ctx, hipMemcpyAsync(out_ok, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, pins.d2h(out_affine, d_out, out_b));
+  NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
+  if (out_is_inf) NCG_HIP(ctx, pins.d2h(out_is_inf, d_inf, n));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }
@@ -433,17 +466,18 @@ int ncg_encode_points_batch(ncg_ctx* ctx, int curve, size_t n, const void* affin
   if (!affine || !out_encoded || !out_ok)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: encode_points_batch: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
   size_t in_b = (n * (size_t)pb + 255) & ~(size_t)255, out_b = (n * (size_t)ob + 255) & ~(size_t)255;
   int rc = ensure_scratch(ctx, in_b + out_b + n + 1024);
   if (rc) return rc;
   char* d_in = (char*)ctx->scratch;
   char* d_out = d_in + in_b;
   char* d_ok = d_out + out_b;
-  NCG_HIP(ctx, hipMemcpyAsync(d_in, affine, n * (size_t)pb, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, pins.h2d(d_in, affine, n * (size_t)pb));
   rc = ncg_encode_points_batch_dev(ctx, curve, n, d_in, d_out, (uint8_t*)d_ok, ctx->stream);
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(out_encoded, d_out, n * (size_t)ob, hipMemcpyDeviceToHost, ctx->stream));
-  NCG_HIP(ctx, hipMemcpyAsync(out_ok, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, pins.d2h(out_encoded, d_out, n * (size_t)ob));
+  NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }
@@ -476,6 +510,7 @@ int ncg_map_to_curve_batch(ncg_ctx* ctx, int curve, size_t n, int count, const v
   if (n == 0) return NCG_OK;
   if (!u || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: map_to_curve_batch: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
   const int pb = ncg_point_bytes(curve);
   const size_t in_b = (n * (size_t)count * (pb / 2) + 255) & ~(size_t)255, out_b = n * (size_t)pb;
   int rc = ensure_scratch(ctx, in_b + out_b + n + 1024);
@@ -483,11 +518,11 @@ int ncg_map_to_curve_batch(ncg_ctx* ctx, int curve, size_t n, int count, const v
   char* d_in = (char*)ctx->scratch;
   char* d_out = d_in + in_b;
   char* d_inf = d_out + out_b;
-  NCG_HIP(ctx, hipMemcpyAsync(d_in, u, n * (size_t)count * (pb / 2), hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, pins.h2d(d_in, u, n * (size_t)count * (pb / 2)));
   rc = ncg_map_to_curve_batch_dev(ctx, curve, n, count, d_in, d_out, (uint8_t*)d_inf, ctx->stream);
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(out_affine, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_is_inf) NCG_HIP(ctx, hipMemcpyAsync(out_is_inf, d_inf, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, pins.d2h(out_affine, d_out, out_b));
+  if (out_is_inf) NCG_HIP(ctx, pins.d2h(out_is_inf, d_inf, n));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }
@@ -581,13 +616,14 @@ int ncg_ntt(ncg_ctx* ctx, int field, int log2n, size_t batch, const void* omega,
   if (batch == 0) return NCG_OK;
   if (!omega || !in || !out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
   const size_t bytes = (batch << log2n) * 32;
   int rc = ensure_scratch(ctx, bytes + 1024);
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(ctx->scratch, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, pins.h2d(ctx->scratch, in, bytes));
   rc = ncg_ntt_dev(ctx, field, log2n, batch, omega, ctx->scratch, ctx->scratch, flags, ctx->stream);
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(out, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, pins.d2h(out, ctx->scratch, bytes));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }
@@ -627,6 +663,7 @@ int ncg_ed25519_verify_batch(ncg_ctx* ctx, size_t n, const void* sig64, const vo
   if (!sig64 || !pk32 || !k32 || !out_ok)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ed25519_verify_batch: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
   size_t okb = (n + 255) & ~(size_t)255;
   int rc = ensure_scratch(ctx, n * 128 + okb + 1024);
   if (rc) return rc;
@@ -634,12 +671,12 @@ int ncg_ed25519_verify_batch(ncg_ctx* ctx, size_t n, const void* sig64, const vo
   char* d_pk = d_sig + n * 64;
   char* d_k = d_pk + n * 32;
   char* d_ok = d_k + n * 32;
-  NCG_HIP(ctx, hipMemcpyAsync(d_sig, sig64, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  NCG_HIP(ctx, hipMemcpyAsync(d_pk, pk32, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  NCG_HIP(ctx, hipMemcpyAsync(d_k, k32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, pins.h2d(d_sig, sig64, n * 64));
+  NCG_HIP(ctx, pins.h2d(d_pk, pk32, n * 32));
+  NCG_HIP(ctx, pins.h2d(d_k, k32, n * 32));
   rc = ncg_ed25519_verify_batch_dev(ctx, n, d_sig, d_pk, d_k, zip215, (uint8_t*)d_ok, ctx->stream);
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(out_ok, d_ok, n, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }
