@@ -237,7 +237,13 @@ __global__ void __launch_bounds__(256) k_decode_secp(const uint8_t* __restrict__
   if (i >= n) return;
   ok[i] = secp_decode_lane(in + (size_t)i * 33, out + (size_t)i * 16) ? 1 : 0;
 }
-__global__ void __launch_bounds__(256) k_decode_g1(const uint8_t* __restrict__ in, uint32_t* __restrict__ out,
+#ifndef NCG_DEC_G1_MINW
+#define NCG_DEC_G1_MINW 2
+#endif
+#ifndef NCG_DEC_G2_MINW
+#define NCG_DEC_G2_MINW 2
+#endif
+__global__ void __launch_bounds__(256, NCG_DEC_G1_MINW) k_decode_g1(const uint8_t* __restrict__ in, uint32_t* __restrict__ out,
                                                    uint8_t* __restrict__ ok, uint8_t* __restrict__ inf, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -245,7 +251,7 @@ __global__ void __launch_bounds__(256) k_decode_g1(const uint8_t* __restrict__ i
   ok[i] = g1_decode_lane(in + (size_t)i * 48, out + (size_t)i * 24, &f) ? 1 : 0;
   inf[i] = f;
 }
-__global__ void __launch_bounds__(128) k_decode_g2(const uint8_t* __restrict__ in, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(128, NCG_DEC_G2_MINW) k_decode_g2(const uint8_t* __restrict__ in, uint32_t* __restrict__ out,
                                                    uint8_t* __restrict__ ok, uint8_t* __restrict__ inf, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -231,8 +231,14 @@ NCG_DI void g2_map_lane(const uint32_t* __restrict__ u, int count, uint32_t* __r
   *inf = z ? 1 : 0;
 }
 
+#ifndef NCG_H2C_G1_MINW
+#define NCG_H2C_G1_MINW 2
+#endif
+#ifndef NCG_H2C_G2_MINW
+#define NCG_H2C_G2_MINW 1
+#endif
 template <bool JAC_OUT>
-__global__ void __launch_bounds__(128) k_map_to_g1(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(128, NCG_H2C_G1_MINW) k_map_to_g1(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out,
                                                    uint8_t* __restrict__ inf, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -241,7 +247,7 @@ __global__ void __launch_bounds__(128) k_map_to_g1(const uint32_t* __restrict__ 
   if (!JAC_OUT) inf[i] = f;
 }
 template <bool JAC_OUT>
-__global__ void __launch_bounds__(64) k_map_to_g2(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(64, NCG_H2C_G2_MINW) k_map_to_g2(const uint32_t* __restrict__ u, int count, uint32_t* __restrict__ out,
                                                   uint8_t* __restrict__ inf, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
