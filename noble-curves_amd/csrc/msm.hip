@@ -21,6 +21,11 @@ __global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* __restri
   G::wire_to_storage(pts + (size_t)i * G::WIRE_AFF, out + (size_t)i * G::AFF_WORDS);
 }
 
+// fix-up / fold / grouping kernels: G1 sits 29-43 registers above the 2-waves/SIMD line and is 2-3 %
+// faster when asked to fit; the lane-paired G2 kernels are not (measured)
+template <class C> struct TailMinWaves { static constexpr int value = 1; };
+template <> struct TailMinWaves<CurveG1> { static constexpr int value = 2; };
+
 // ------------------------------------------------------------------ 2. signed digits
 // digits[w*n + i] = ((k_i + H') >> (c w)) & (2^c - 1)) - 2^(c-1)
 __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
@@ -229,7 +234,7 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
 // bucket holding every entry of a window (identical scalars; the short top window) costs
 // ~log2(n/seg) additions of latency instead of n/seg.
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_fixup_pass(uint32_t* __restrict__ part_pts,
+__global__ void __launch_bounds__(256, TailMinWaves<C>::value) k_msm_fixup_pass(uint32_t* __restrict__ part_pts,
                                                         const int* __restrict__ part_meta,
                                                         const uint32_t* __restrict__ bucket_start, MsmPlan pl,
                                                         MsmSeg sg, int d, uint32_t* __restrict__ pass_flags,
@@ -279,7 +284,7 @@ __global__ void __launch_bounds__(256) k_msm_fixup_write(const uint32_t* __restr
 // in:  [narr][nwin][n_in] XYZZ   (array 0 = S, arrays 1.. = pending R sums)
 // out: [narr+1][nwin][n_in/2]    out[a] = pairwise sums (a < narr), out[narr] = odd elements of S
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_reduce_level(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(256, TailMinWaves<C>::value) k_msm_reduce_level(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                           int narr, int nwin, int n_in) {
   using G = MsmGroup<C>;
   constexpr int XW = G::ACC_WORDS;
@@ -308,7 +313,7 @@ __global__ void __launch_bounds__(256) k_msm_reduce_level(const uint32_t* __rest
 // groups in parallel), so the host does one addition per GROUP - its doublings (one per scalar
 // bit) are the part only a latency-optimised core can do quickly.
 template <class C>
-__global__ void __launch_bounds__(256) k_msm_group_pending(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+__global__ void __launch_bounds__(256, TailMinWaves<C>::value) k_msm_group_pending(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                            int narr, int nwin, int g, int ngroups) {
   using G = MsmGroup<C>;
   constexpr int XW = G::ACC_WORDS;
