@@ -13,10 +13,11 @@
 // The map is a function of u alone, so the device is free in HOW it evaluates it:
 //   * the isogeny lands directly in Jacobian coordinates (Z = xd yd), no inversion;
 //   * G1 sqrt_ratio is the reference's 3 mod 4 variant (one power);
-//   * G2 sqrt_ratio(u, v) = sqrt(u / v) or sqrt(Z u / v) through fe29x2_sqrt (bls_lanes.hpp) and
-//     the inverse of tv4 that SWU needs anyway (v = tv4^3) - the reference's generic F.2.1.1
-//     ladder in Fp2 is ~2x the field work.  Either root is fine: SWU fixes the sign of y by
-//     sgn0(u) == sgn0(y) (:707-708).
+//   * G2 sqrt_ratio(u, v) = sqrt(u / v) or sqrt(Z u / v) through the norm-based Fp2 square root
+//     (both candidates share its first power, fe29x2_sqrt_or_zsqrt) and the inverse of tv4 that
+//     SWU needs anyway (v = tv4^3): 3 exponentiations in Fp per map; the reference's generic
+//     F.2.1.1 ladder in Fp2 is several times the field work.  Either root is fine: SWU fixes the
+//     sign of y by sgn0(u) == sgn0(y) (:707-708).
 #include <vector>
 
 #include "bls_lanes.hpp"
@@ -122,6 +123,35 @@ NCG_DI Jac<FeBls> g1_clear_cofactor(const Jac<FeBls>& P) {  // bls12-381.ts:578-
 }
 
 // ------------------------------------------------------------------------------------- G2
+// sqrt_ratio core for Fp2: returns whether w is a square and a square root of w (if it is) or of
+// zw = Z w (if it is not; Z is the non-square SWU constant, so exactly one of the two is a
+// square).  The first power is shared: a1 = norm(w)^((p+1)/4) squares to +-norm(w); "+" means w is
+// a square with sqrt(norm(w)) = a1, "-" means it is not and sqrt(norm(Z w)) = a1 K with
+// K = sqrt(-norm(Z)) - so both cases continue with ONE more power (fe29x2_sqrt, bls_lanes.hpp, is
+// the same algorithm for a single candidate).
+NCG_DI bool fe29x2_sqrt_or_zsqrt(const Fe29x2<2>& w, const Fe29x2<2>& zw, Fe29x2<2>& root) {
+  const Fe29<1> half = fe29_const(ParamsBls29::HALF);
+  Fe29<2> norm = (f_sqr(w.c0) + f_sqr(w.c1)) * Fe29<1>::one();
+  Fe29<2> a1 = fe29_pow_words12(norm, BlsFpConsts::SQRT_EXP_M1) * norm;
+  const bool isQR = f_eq(f_sqr(a1), norm);
+  Fe29<2> aK = a1 * fe29_const(BlsH2c::SWU2_K);
+  const Fe29x2<2> t = isQR ? w : zw;
+  const Fe29<2> a = isQR ? a1 : aK;
+  const bool c1_zero = f_eqz(t.c1);
+  Fe29<2> d = (a + t.c0) * half;
+  if (c1_zero) d = t.c0;
+  Fe29<2> tt = fe29_pow_words12(d, BlsFpConsts::SQRT_EXP_M1);
+  Fe29<2> s = tt * d;
+  const bool residue = f_eq(f_sqr(s), d);
+  Fe29<2> o = t.c1 * half * tt;
+  if (residue) {
+    root = {s, o};
+  } else {
+    root = {f_neg(o) * Fe29<1>::one(), s};
+  }
+  return isQR;
+}
+
 NCG_DI Jac<FeBls2> g2_map(const Fe29x2<2>& u) {  // mapToG2 (bls12-381.ts:859-862)
   const Fe29x2<1> A = fe29x2_const(BlsH2c::SWU2_A), B = fe29x2_const(BlsH2c::SWU2_B), Z = fe29x2_const(BlsH2c::SWU2_Z);
   Fe29x2<2> tv1 = nrm(f_sqr(u) * Z);
@@ -138,11 +168,7 @@ NCG_DI Jac<FeBls2> g2_map(const Fe29x2<2>& u) {  // mapToG2 (bls12-381.ts:859-86
   Fe29x2<2> inv4 = f_inv(tv4);
   Fe29x2<2> w = nrm(gx * (f_sqr(inv4) * inv4));
   Fe29x2<2> value;
-  const bool isQR = fe29x2_sqrt(w, value);
-  if (!isQR) {
-    Fe29x2<2> zw = nrm(w * Z);
-    (void)fe29x2_sqrt(zw, value);  // Z is a non-square, so Z w is a square
-  }
+  const bool isQR = fe29x2_sqrt_or_zsqrt(w, nrm(w * Z), value);  // Z is a non-square: w or Z w is a square
   Fe29x2<2> y = nrm(tv1 * u * value);
   if (isQR) {
     x = tv3;
