@@ -113,6 +113,16 @@ int ncg_decode_points_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* e
                                 void* out_affine_dev, uint8_t* out_ok_dev, uint8_t* out_is_inf_dev,
                                 void* stream);
 
+/* ---- aggregation of encoded points -----------------------------------------------------------
+ * out = sum_i Point.fromBytes(encoded[i]): the group operation of bls.aggregatePublicKeys /
+ * aggregateSignatures on encoded inputs (src/abstract/bls.ts:857-873: normPub / fromBytes +
+ * assertValidity, then the running sum).  Decoding (incl. the subgroup checks) and the sum - an MSM
+ * with unit scalars - run on the device; only the encodings go up.  An entry the reference would
+ * reject makes the call fail with NCG_ERR_INVALID_ARG and *out_bad_index = its position (else -1).
+ * Encodings and `flags` as in ncg_decode_points_batch. */
+int ncg_aggregate_encoded(ncg_ctx* ctx, int curve, size_t n, const void* encoded, int flags,
+                          void* out_affine, uint8_t* out_is_inf, int64_t* out_bad_index);
+
 /* ---- batch point encoding (Point.toBytes, compressed form) -----------------------------------
  * encoded[i] = affine wire point i in the encodings listed above (secp256k1 pointToBytes
  * src/abstract/weierstrass.ts:541-564; bls12-381 coder.encode src/bls12-381.ts:400-410; ed25519

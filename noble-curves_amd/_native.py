@@ -81,6 +81,7 @@ _vp, _sz, _i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 _OPTIONAL_PROTOS = {
     "ncg_decode_points_batch": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp],
     "ncg_decode_points_batch_dev": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp, _vp],
+    "ncg_aggregate_encoded": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp],
     "ncg_encode_points_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
     "ncg_encode_points_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_map_to_curve_batch": [_vp, _i32, _sz, _i32, _vp, _vp, _vp],
@@ -177,6 +178,20 @@ class Engine:
             self._check(self.lib.ncg_decode_points_batch(self.h, curve, n, enc.ctypes.data, 1 if zip215 else 0,
                                                          out.ctypes.data, ok.ctypes.data, inf.ctypes.data))
         return out, ok.astype(bool), inf.astype(bool)
+
+    def aggregate_encoded(self, curve, encoded, zip215=False):
+        """encoded uint8 [n, ENCODED_BYTES] -> (affine [PB], is_inf, bad_index): sum of the decoded points;
+        bad_index >= 0 (and no result) when an entry does not decode."""
+        enc = np.ascontiguousarray(encoded, dtype=np.uint8).reshape(-1, ENCODED_BYTES[curve])
+        out = np.zeros((POINT_BYTES[curve],), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        bad = ctypes.c_int64(-1)
+        rc = self.lib.ncg_aggregate_encoded(self.h, curve, enc.shape[0], enc.ctypes.data, 1 if zip215 else 0,
+                                            out.ctypes.data, ctypes.byref(inf), ctypes.byref(bad))
+        if rc and bad.value >= 0:
+            return None, False, int(bad.value)
+        self._check(rc)
+        return out, bool(inf.value), -1
 
     def encode_points_batch(self, curve, affine):
         """affine uint8 [n, PB] -> (encoded [n, 33|32|48|96], ok [n] bool): compressed Point.toBytes."""

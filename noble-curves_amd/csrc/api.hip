@@ -360,6 +360,48 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
   return ncg_msm_dev(ctx, curve, n, d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
 }
 
+// decode on the device, then sum through the MSM path with unit scalars; nothing but the encodings
+// goes up and one point (plus the verdicts) comes back
+int ncg_aggregate_encoded(ncg_ctx* ctx, int curve, size_t n, const void* encoded, int flags, void* out_affine,
+                          uint8_t* out_is_inf, int64_t* out_bad_index) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  const int ib = ncg::decode_in_bytes(curve), pb = ncg_point_bytes(curve);
+  if (ib == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: aggregate_encoded: unsupported curve %d", curve);
+  if (out_bad_index) *out_bad_index = -1;
+  if (n == 0) return ncg_msm_dev(ctx, curve, 0, nullptr, nullptr, out_affine, out_is_inf, nullptr);
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!encoded || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: aggregate_encoded: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint8_t> ok(n);
+  const size_t in_b = (n * (size_t)ib + 255) & ~(size_t)255, pts_b = (n * (size_t)pb + 255) & ~(size_t)255,
+               sc_b = n * 32, fl_b = (n + 255) & ~(size_t)255;
+  {
+    PinSet pins(ctx);
+    int rc = ensure_scratch(ctx, in_b + pts_b + sc_b + 2 * fl_b + 2048);
+    if (rc) return rc;
+    char* d_in = (char*)ctx->scratch;
+    char* d_pts = d_in + in_b;
+    char* d_sc = d_pts + pts_b;
+    char* d_ok = d_sc + sc_b;
+    char* d_inf = d_ok + fl_b;
+    NCG_HIP(ctx, pins.h2d(d_in, encoded, n * (size_t)ib));
+    rc = ncg_decode_points_batch_dev(ctx, curve, n, d_in, flags, d_pts, (uint8_t*)d_ok, (uint8_t*)d_inf, ctx->stream);
+    if (rc) return rc;
+    NCG_HIP(ctx, hipMemsetAsync(d_sc, 0, sc_b, ctx->stream));
+    NCG_HIP(ctx, hipMemset2DAsync(d_sc, 32, 1, 1, n, ctx->stream));  // scalar 1 in every 32-byte row
+    NCG_HIP(ctx, pins.d2h(ok.data(), d_ok, n));
+    NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  for (size_t i = 0; i < n; i++)
+    if (!ok[i]) {  // the reference throws while decoding (Point.fromBytes / assertValidity)
+      if (out_bad_index) *out_bad_index = (int64_t)i;
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: aggregate_encoded: invalid point encoding at index %zu", i);
+    }
+  char* d_pts = (char*)ctx->scratch + in_b;
+  char* d_sc = d_pts + pts_b;
+  return ncg_msm_dev(ctx, curve, n, d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
+}
+
 int ncg_normalize_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_proj_dev, void* out_affine_dev,
                             uint8_t* out_is_inf_dev, void* stream) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");

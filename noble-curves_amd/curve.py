@@ -325,6 +325,29 @@ def toBytesBatch(c, points, engine=None):
     return [enc[i].tobytes() for i in range(len(points))]
 
 
+def aggregateFromBytes(c, encodings, zip215=False, engine=None):
+    """sum(c.fromBytes(b) for b in encodings) - the group part of bls.aggregatePublicKeys /
+    aggregateSignatures on encoded inputs (src/abstract/bls.ts:857-873).  Decoding, validity and
+    subgroup checks and the sum all run on the device; an entry the reference's fromBytes would
+    reject raises ValueError naming its index.  Empty input gives ZERO."""
+    size = _native.ENCODED_BYTES.get(c.CURVE_ID)
+    if size is None:
+        raise ValueError("noble-gpu: no batch decoder for this curve")
+    rows = []
+    for i, b in enumerate(encodings):
+        b = bytes(b)
+        if len(b) != size:
+            raise ValueError("invalid point encoding at index %d: expected %d bytes" % (i, size))
+        rows.append(np.frombuffer(b, dtype=np.uint8))
+    if not rows:
+        return c.ZERO
+    eng = engine or get_engine()
+    out, inf, bad = eng.aggregate_encoded(c.CURVE_ID, np.array(rows), zip215)
+    if bad >= 0:
+        raise ValueError("invalid point encoding at index %d" % bad)
+    return c._from_wire(out, inf)
+
+
 def isTorsionFreeBatch(c, points, engine=None):
     """[p.isTorsionFree() for p in points]: membership in the prime-order subgroup, decided as the
     reference's generic test does - [n]P == ZERO with n = Fn.ORDER (weierstrass.ts:976-981,

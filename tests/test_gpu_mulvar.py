@@ -319,3 +319,39 @@ def test_torsion_and_cofactor_batches_gpu():
     from oracle.h2c import g1_clear_cofactor
     assert [p.toAffine() for p in cleared] == [g1_clear_cofactor(p).toAffine() for p in opts]
     assert all(G.isTorsionFreeBatch(G.bls12_381_G1_Point, cleared))
+
+
+@pytest.mark.gpu
+def test_aggregate_from_bytes_gpu():
+    """bls.aggregatePublicKeys-style sum of encoded points (src/abstract/bls.ts:857-873): G1 and G2 compressed
+    keys incl. the infinity encoding, secp256k1 and ed25519 encodings; a bad entry is reported by index."""
+    from noble_curves_amd import curve as G
+    from oracle.curves import BlsG1, BlsG2, Ed25519, Secp256k1
+    from oracle.weierstrass import bls_g1_encode_compressed, bls_g2_encode_compressed, sec1_encode
+    rng = makeRng(0xA66)
+    for Pt, O, encf, n in ((G.bls12_381_G1_Point, BlsG1, bls_g1_encode_compressed, 300),
+                           (G.bls12_381_G2_Point, BlsG2, bls_g2_encode_compressed, 70),
+                           (G.secp256k1_Point, Secp256k1, sec1_encode, 200),
+                           (G.ed25519_Point, Ed25519, lambda p: p.toBytes(), 200)):
+        ks = [rng.rndBelow(1 << 64) + 1 for _ in range(n)]
+        base = [O.BASE.multiplyUnsafe(k) for k in ks[:8]]
+        pts = [base[i % 8].add(base[(i * 3 + 1) % 8]) for i in range(n)]
+        encs = [encf(p) for p in pts]
+        if O in (BlsG1, BlsG2):
+            encs.append(encf(O.ZERO))
+        exp = O.ZERO
+        for p in pts:
+            exp = exp.add(p)
+        got = G.aggregateFromBytes(Pt, encs, zip215=True)
+        assert got.toAffine() == exp.toAffine() and got.is0() == exp.is0()
+        assert G.aggregateFromBytes(Pt, []).is0()
+        bad = list(encs)
+        bad[5] = bytes([bad[5][0] ^ 0xFF]) + bad[5][1:] if O is not Ed25519 else bytes([0xEE] * 31 + [0x7F])
+        try:
+            O.fromBytes(bad[5]) if O is Ed25519 else None
+            ed_ok = O is Ed25519
+        except ValueError:
+            ed_ok = False
+        if not ed_ok:
+            with pytest.raises(ValueError, match="invalid point encoding at index 5"):
+                G.aggregateFromBytes(Pt, bad)
