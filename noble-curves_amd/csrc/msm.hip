@@ -505,10 +505,19 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
                      pts_mont, n);
   hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl);
   size_t lds = (size_t)pl.nb * 4;
-  e = hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  {  // opt in to large dynamic LDS once per process and device (c <= 16: at most 128 KB)
+    static bool attr_done[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+      const int max_lds = (1 << 15) * 4;
+      e = hipFuncSetAttribute((const void*)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 16) attr_done[dev] = true;
+    }
+  }
   hipLaunchKernelGGL(k_msm_hist, dim3(pl.Q, pl.nwin), dim3(1024), lds, st, digits, counts, pl);
   hipLaunchKernelGGL(k_msm_bucket_totals, dim3((pl.nb + 255) / 256, pl.nwin), dim3(256), 0, st, counts, bstart, pl);
   hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), 0, st, bstart, pl);
@@ -552,11 +561,25 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  std::vector<uint32_t> fin((size_t)ng * pl.nwin * XW);
-  e = hipMemcpyAsync(fin.data(), cur, fin.size() * 4, hipMemcpyDeviceToHost, st);
+  // the surviving points land in a small pinned buffer (one per thread, reused): a pageable target
+  // would go through the runtime's staging copy
+  const size_t fin_words = (size_t)ng * pl.nwin * XW;
+  static thread_local uint32_t* pinned = nullptr;
+  static thread_local size_t pinned_words = 0;
+  if (pinned_words < fin_words) {
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+    pinned_words = 0;
+    if (hipHostMalloc((void**)&pinned, fin_words * 4, hipHostMallocDefault) == hipSuccess) pinned_words = fin_words;
+    else (void)hipGetLastError();
+  }
+  std::vector<uint32_t> fin(fin_words);
+  uint32_t* land = pinned_words >= fin_words ? pinned : fin.data();
+  e = hipMemcpyAsync(land, cur, fin_words * 4, hipMemcpyDeviceToHost, st);
   if (e != hipSuccess) return e;
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
+  if (land != fin.data()) std::copy(land, land + fin_words, fin.begin());
   static const bool timing = std::getenv("NCG_TIMING") != nullptr;
   auto t0 = std::chrono::steady_clock::now();
   msm_host_finish<C>(fin, pl, out_affine_host, out_inf_host);
