@@ -394,6 +394,8 @@ int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) {
   c = std::max(2, std::min(16, c));
   pl->n = n;
   pl->ls = curve == CURVE_BLS12_381_G2 ? 1 : 0;  // lane-paired kernels: 2 lanes per item
+  // waves/SIMD the accumulate kernel runs at (registers): 4 for the 256-bit fields, 2 for bls12-381
+  pl->accum_waves = (curve == CURVE_SECP256K1 || curve == CURVE_ED25519) ? 4 : 2;
   pl->c = c;
   pl->nb = 1 << (c - 1);
   pl->nwin = plan_windows(c, curve_order(curve), pl->hconst);
@@ -418,13 +420,23 @@ static MsmSeg msm_seg(const MsmPlan& pl) {
   if (env) {
     sg.seg = std::max(1, std::atoi(env));
   } else {
-    // 64 entries per lane at full size; fewer for small MSMs so that ~4 waves/SIMD stay busy
-    // (lanes = nwin*n/seg >= 262144), but never below 16 (every lane costs up to two fix-up adds)
-    long lanes_at_64 = ((long)pl.nwin * pl.n / 64) << pl.ls;
-    sg.seg = 64;
-    while (sg.seg > 16 && lanes_at_64 < 262144) {
-      sg.seg >>= 1;
-      lanes_at_64 <<= 1;
+    // Every lane adds `seg` consecutive sorted entries, and the accumulate kernel keeps
+    // cap = waves/SIMD x 1024 SIMDs x 64 lanes resident, so its time goes like rounds(seg) * seg with
+    // rounds = ceil(lanes / cap), plus ~3 addition-times of fix-up per lane.  Pick the seg that minimises
+    // that (measured on MI355X: G1 2^20 seg 128 = one full round 4.29 ms, 64 = two rounds 4.46, 96 4.90,
+    // 192 5.44; G2 2^18 seg 73 = one round 4.84 ms, 32 5.08, 74 5.14).
+    const long cap = 65536L * pl.accum_waves;
+    double best = 1e300;
+    sg.seg = 16;
+    for (int seg = 16; seg <= 160; seg++) {
+      const long nseg = (pl.n + seg - 1) / seg;
+      const long lanes = ((long)pl.nwin * nseg) << pl.ls;
+      const long rounds = (lanes + cap - 1) / cap;
+      const double cost = (double)rounds * seg + 3.0 * (double)lanes / (double)cap;
+      if (cost < best - 1e-9) {
+        best = cost;
+        sg.seg = seg;
+      }
     }
   }
   sg.nseg = (pl.n + sg.seg - 1) / sg.seg;

@@ -40,6 +40,7 @@ struct MsmPlan {
   int Q = 0;       // sort chunks (blocks per window)
   int chunk = 0;   // points per chunk
   int ls = 0;      // lanes per item = 1 << ls (lane-paired Fp2 kernels)
+  int accum_waves = 2;  // waves/SIMD of the accumulate kernel (sets the resident-lane capacity)
   uint32_t hconst[10];  // H' = sum_w 2^(c-1) * 2^(c w), 10 LE limbs
 };
 
