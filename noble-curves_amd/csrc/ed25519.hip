@@ -9,7 +9,10 @@
 //   strict mode only: A.isSmallOrder() rejects                                     (:980)
 //   accept iff [8](R + [k]A - [s]B) == O                                           (:985-988)
 // The reference computes [s]B with its cached window table (44 adds) and [k]A with a wNAF walk;
-// here both share ONE doubling chain (Straus): signed-odd windows of 2 bits for -A (2-entry
+// here both share ONE doubling chain (Straus).  Default (EdCfgGtab): signed-odd 4-bit windows for
+// -A (8-entry per-lane table of projective Niels points in device memory, 1 KB per item) and 8-bit
+// windows for B (128 precomputed affine Niels multiples shared by every lane): 264 doublings,
+// 66 + 33 additions, 4 waves/SIMD.  Fallback without scratch (EdCfgLds): 2-bit windows for -A (2-entry
 // per-lane table in LDS, projective Niels form: 16 KB per wave, so 8-10 waves fit a CU - a 3-bit
 // window measured 1.7x slower for that reason) and 6 bits for B (32 precomputed affine Niels
 // multiples shared by every lane): 258 doublings, 129 + 43 additions.

@@ -13,9 +13,11 @@
 // as the reference does; bls12-381 G1/G2 get no endomorphism (the reference has none there and
 // inputs may lie outside the prime-order subgroup).
 //
-// Per-lane table of odd multiples [1,3,..,2^W-1]*P lives in LDS (limb-major, lane-minor: bank
-// conflict free for any digit pattern) as *affine* points of an isomorphic curve (shared-Z
-// "effective affine" trick), so every table add is a mixed add.
+// The per-lane table of odd multiples [1,3,..,2^W-1]*P holds *affine* points of an isomorphic
+// curve (shared-Z "effective affine" trick), so every table add is a mixed add.  It lives in
+// device memory (k_mul_var_gtab: item-major, one contiguous 1-3 KB block per lane - no LDS
+// footprint, so wide windows and 3-4 waves/SIMD go together; the default) or in LDS (k_mul_var:
+// limb-major, lane-minor, bank-conflict free for any digit pattern; used when no scratch is given).
 #pragma once
 #include "curves.hpp"
 #include "scalar.hpp"
