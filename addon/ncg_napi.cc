@@ -9,6 +9,7 @@
 //   ed25519VerifyBatch(sigs, pks, ks, zip215: bool)  -> Uint8Array n (0 / 1)
 //   decodePoints(curveId, encoded, zip215: bool)     -> Uint8Array n * (PB + 2)  (points, ok flags, inf flags)
 //   encodePoints(curveId, points)                    -> Uint8Array n * (EB + 1)  (encodings, ok flags)
+//   aggregateEncoded(curveId, encoded, zip215)       -> Uint8Array PB + 1 (flag); throws naming a bad index
 //   ntt(log2n, omega: Uint8Array 32, data, flags)    -> Uint8Array (same length)
 //   mapToCurve(curveId, count, u)                    -> Uint8Array n * (PB + 1)
 //   pointBytes(curveId) / version()
@@ -198,6 +199,33 @@ static napi_value DecodePoints(napi_env env, napi_callback_info info) {
   return res;
 }
 
+static napi_value AggregateEncoded(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t curve;
+  uint8_t *enc, *out;
+  size_t el;
+  bool zip215 = false;
+  if (argc < 2 || napi_get_value_int32(env, argv[0], &curve) != napi_ok || !get_u8(env, argv[1], &enc, &el)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: aggregateEncoded(curveId, Uint8Array, zip215)");
+    return nullptr;
+  }
+  if (argc >= 3) napi_get_value_bool(env, argv[2], &zip215);
+  int eb = encoded_bytes(curve), pb = ncg_point_bytes(curve);
+  if (!eb || el % eb) {
+    napi_throw_error(env, nullptr, "noble-gpu: aggregateEncoded: bad curve or length");
+    return nullptr;
+  }
+  napi_value res = make_u8(env, pb + 1, &out);
+  if (!res) return nullptr;
+  int64_t bad = -1;
+  if (ncg_aggregate_encoded(g_ctx, curve, el / eb, enc, zip215 ? NCG_DECODE_ZIP215 : 0, out, out + pb, &bad) != 0)
+    return throw_native(env);
+  return res;
+}
+
 static napi_value EncodePoints(napi_env env, napi_callback_info info) {
   size_t argc = 2;
   napi_value argv[2];
@@ -297,6 +325,7 @@ NAPI_MODULE_INIT() {
              {"mulVarBatch", MulVarBatch}, {"mulBaseBatch", MulBaseBatch},
              {"ed25519VerifyBatch", Ed25519VerifyBatch}, {"pointBytes", PointBytes},
              {"decodePoints", DecodePoints}, {"encodePoints", EncodePoints},
+             {"aggregateEncoded", AggregateEncoded},
              {"ntt", Ntt},               {"mapToCurve", MapToCurve},
              {"version", Version}};
   for (auto& f : fns) {

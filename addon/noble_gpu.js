@@ -148,6 +148,20 @@ function toBytesBatch(c, points) {
   });
 }
 
+// sum of the decoded points: the group part of bls.aggregatePublicKeys on encoded keys (abstract/bls.ts:857-873)
+function aggregateFromBytes(c, encodings, zip215) {
+  const id = curveId(c), eb = ENC[id], pb = native.pointBytes(id), n = encodings.length;
+  if (n === 0) return c.ZERO;
+  const buf = new Uint8Array(n * eb);
+  encodings.forEach((e, i) => {
+    if (!(e instanceof Uint8Array) || e.length !== eb) throw new Error('invalid point encoding at index ' + i + ': expected ' + eb + ' bytes');
+    buf.set(e, i * eb);
+  });
+  init();
+  const out = native.aggregateEncoded(id, buf, !!zip215);
+  return unmarshalPoint(c, id, out, 0, out[pb] === 1);
+}
+
 // ---- FFT over the bls12-381 scalar field: FFT(roots, Fr).direct / .inverse (fft.ts:518-577) --------
 const FR = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001n;
 function powMod(b, e, m) { let r = 1n; b %= m; while (e > 0n) { if (e & 1n) r = r * b % m; b = b * b % m; e >>= 1n; } return r; }
@@ -203,4 +217,4 @@ function hashToCurveBatch(c, msgs, DST) {
 }
 
 module.exports = { CURVE, init, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
-                   fromBytesBatch, toBytesBatch, fftFr, hashToCurveBatch, native };
+                   fromBytesBatch, toBytesBatch, aggregateFromBytes, fftFr, hashToCurveBatch, native };

@@ -55,6 +55,10 @@ if (haveGpu) {
   const bad = Uint8Array.from(enc[0]); bad[0] = 5;
   assert.strictEqual(gpu.fromBytesBatch(Point, [bad])[0], null);
   assert.throws(() => gpu.toBytesBatch(Point, [Point.ZERO]), /bad point: ZERO/);
+  const agg = gpu.aggregateFromBytes(Point, enc);                 // sum of k_i G == (sum k_i) G
+  const aggRef = gpu.multiplyBaseBatch(Point, [ks.reduce((a, k) => (a + k) % N, 0n)])[0];
+  assert.strictEqual(agg.x, aggRef.x); assert.strictEqual(agg.y, aggRef.y);
+  assert.throws(() => gpu.aggregateFromBytes(Point, [enc[0], bad]), /invalid point encoding at index 1/);
   // FFT over Fr: the reference's 'Basic FFT' known answer (test/fft.test.ts:221-251) and round trips
   const kat = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', 'fft_kat.json')));
   const fin = kat.basic_input.map(BigInt), fexp = kat.basic_exp.map(BigInt);
