@@ -582,7 +582,7 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
     if (pinned) (void)hipHostFree(pinned);
     pinned = nullptr;
     pinned_words = 0;
-    if (hipHostMalloc((void**)&pinned, fin_words * 4, hipHostMallocDefault) == hipSuccess) pinned_words = fin_words;
+    if (hipHostMalloc((void**)&pinned, fin_words * 4, hipHostMallocPortable) == hipSuccess) pinned_words = fin_words;
     else (void)hipGetLastError();
   }
   std::vector<uint32_t> fin(fin_words);
