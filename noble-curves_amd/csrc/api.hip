@@ -184,6 +184,9 @@ static int ensure_mul_ws(ncg_ctx* ctx, int curve, size_t n, hipStream_t st) {
   hipError_t e = hipMalloc(&ctx->mul_ws, need);
   if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
   ctx->mul_ws_bytes = need;
+  // touch the fresh allocation once here, so the first kernel that uses it is not the one paying for
+  // the page mappings of a GB-sized buffer
+  NCG_HIP(ctx, hipMemsetAsync(ctx->mul_ws, 0, need, st));
   return NCG_OK;
 }
 
