@@ -1,0 +1,36 @@
+'use strict';
+// End-to-end timing from the JS side (SURVEY 8d): BigInt marshalling + N-API + H2D/D2H + kernels, next to the
+// native call alone, for pippenger and multiplyUnsafeBatch on secp256k1.  node addon/bench_js.js [log2n]
+const gpu = require('./noble_gpu.js');
+const N = 0xfffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141n;
+const P = 0xfffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2fn;
+class Point {
+  constructor(x, y, inf) { this.x = x; this.y = y; this.inf = !!inf; }
+  static fromAffine(a) { return (a.x === 0n && a.y === 0n) ? Point.ZERO : new Point(a.x, a.y); }
+  toAffine() { return this.inf ? { x: 0n, y: 0n } : { x: this.x, y: this.y }; }
+}
+Point.ZERO = new Point(0n, 0n, true);
+Point.Fp = { ORDER: P, BYTES: 32 };
+Point.Fn = { ORDER: N, BYTES: 32 };
+gpu.register(Point, gpu.CURVE.SECP256K1);
+gpu.init(0);
+const n = 1 << (parseInt(process.argv[2] || '14', 10));
+let s = 0x9e3779b97f4a7c15n;
+const rnd = () => { s ^= s << 13n; s &= (1n << 64n) - 1n; s ^= s >> 7n; s ^= s << 17n; s &= (1n << 64n) - 1n; return s; };
+const ks = [], ss = [];
+for (let i = 0; i < n; i++) { ks.push(((rnd() << 64n) | rnd()) % (N - 1n) + 1n); ss.push(((rnd() << 192n) | (rnd() << 128n) | (rnd() << 64n) | rnd()) % N); }
+const pts = gpu.multiplyBaseBatch(Point, ks);
+const ms = (f) => { const t0 = process.hrtime.bigint(); const r = f(); return [Number(process.hrtime.bigint() - t0) / 1e6, r]; };
+gpu.pippenger(Point, pts.slice(0, 64), ss.slice(0, 64));
+const [tMsm] = ms(() => gpu.pippenger(Point, pts, ss));
+const [tMul] = ms(() => gpu.multiplyUnsafeBatch(Point, pts, ss));
+// native part alone: pre-marshalled buffers
+const pb = new Uint8Array(n * 64), sb = new Uint8Array(n * 32);
+const le = (v, len, out, off) => { for (let i = 0; i < len; i++) { out[off + i] = Number(v & 0xffn); v >>= 8n; } };
+pts.forEach((p, i) => { le(p.x, 32, pb, 64 * i); le(p.y, 32, pb, 64 * i + 32); });
+ss.forEach((v, i) => le(v, 32, sb, 32 * i));
+gpu.native.msm(0, pb, sb);
+const [tMsmN] = ms(() => gpu.native.msm(0, pb, sb));
+const [tMulN] = ms(() => gpu.native.mulVarBatch(0, pb, sb));
+console.log(JSON.stringify({ n, pippenger_js_ms: tMsm, pippenger_native_ms: tMsmN, multiplyUnsafeBatch_js_ms: tMul,
+  multiplyUnsafeBatch_native_ms: tMulN }));

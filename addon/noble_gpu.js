@@ -18,13 +18,17 @@ let inited = false;
 function init(device) { if (!inited) { native.init(device || 0); inited = true; } }
 function register(c, curveId) { registry.set(c, curveId); }
 
-function leBytes(n, len, out, off) {            // utils.ts:498 numberToBytesLE
-  for (let i = 0; i < len; i++) { out[off + i] = Number(n & 0xffn); n >>= 8n; }
+// BigInt <-> little-endian bytes through hex strings (utils.ts:498 numberToBytesLE / :456
+// bytesToNumberLE use the same route): ~15x faster than shifting a BigInt byte by byte, and the
+// marshalling is what an end-to-end call from JS spends its time in (SURVEY 8a gotcha 8).
+function leBytes(n, len, out, off) {
+  const be = Buffer.from(n.toString(16).padStart(2 * len, '0'), 'hex');
+  for (let i = 0; i < len; i++) out[off + i] = be[len - 1 - i];
 }
-function leNumber(buf, off, len) {              // utils.ts:456 bytesToNumberLE
-  let n = 0n;
-  for (let i = len - 1; i >= 0; i--) n = (n << 8n) | BigInt(buf[off + i]);
-  return n;
+function leNumber(buf, off, len) {
+  const be = Buffer.allocUnsafe(len);
+  for (let i = 0; i < len; i++) be[i] = buf[off + len - 1 - i];
+  return BigInt('0x' + be.toString('hex'));
 }
 function coordsOf(aff, isFp2) { return isFp2 ? [aff.x.c0, aff.x.c1, aff.y.c0, aff.y.c1] : [aff.x, aff.y]; }
 
