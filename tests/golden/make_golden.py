@@ -92,6 +92,10 @@ def main():
     })
     dump("ed25519_zip215.json", json.load(open(f"{REF}/ed25519/zip215.json")))
     dump("ed25519_edge_cases.json", json.load(open(f"{REF}/ed25519/edge-cases.json")))
+    # Wycheproof (old format, 145 cases in 51 key groups): pk, msg, sig, expected verdict (test/ed25519.test.ts:420-444)
+    wy = json.load(open(f"{REF}/ed25519/ed25519_test_OLD.json"))
+    dump("ed25519_wycheproof_old.json", [{"pk": g["key"]["pk"], "msg": t["msg"], "sig": t["sig"], "result": t["result"],
+                                          "comment": t["comment"]} for g in wy["testGroups"] for t in g["tests"]])
 
 
 if __name__ == "__main__":

@@ -40,3 +40,17 @@ def test_sign_input_vectors_and_single_verify():
     assert ed.verify_batch([], [], []) == []
     with pytest.raises(ValueError):
         ed.verify(sigs[0][:63], msgs[0], pks[0])
+
+
+@pytest.mark.gpu
+def test_wycheproof_old_vectors_gpu():
+    """test/ed25519.test.ts:420-444 through the batch verifier (signatures of the wrong length never reach the
+    device: the shim rejects them like the reference's abytes check)."""
+    from noble_curves_amd import ed25519 as ed
+    rows = load_golden("ed25519_wycheproof_old.json")
+    good = [r for r in rows if len(r["sig"]) == 128]
+    got = ed.verify_batch([bytes.fromhex(r["sig"]) for r in good], [bytes.fromhex(r["msg"]) for r in good],
+                          [bytes.fromhex(r["pk"]) for r in good])
+    for r, v in zip(good, got):
+        assert v == (r["result"] in ("valid", "acceptable")), r["comment"]
+    assert all(r["result"] == "invalid" for r in rows if len(r["sig"]) != 128)

@@ -331,3 +331,17 @@ def test_hash_to_curve_vectors():
     assert len(expand_message_xmd(b"abc", b"QUUX-V01-CS02-with-expander-SHA256-128", 0x80)) == 0x80
     with pytest.raises(ValueError, match="invalid lenInBytes"):
         expand_message_xmd(b"", b"dst", 65536)
+
+
+def test_ed25519_wycheproof_old():
+    """test/ed25519.test.ts:420-444: valid / acceptable verify, invalid are rejected (malformed sizes count as
+    rejected, like the reference's try/catch)."""
+    rows = load("ed25519_wycheproof_old.json")
+    assert len(rows) == 145
+    for r in rows:
+        pk, msg, sig = bytes.fromhex(r["pk"]), bytes.fromhex(r["msg"]), bytes.fromhex(r["sig"])
+        try:
+            ok = len(sig) == 64 and eddsa_verify(Ed25519, sig, msg, pk)
+        except ValueError:
+            ok = False
+        assert ok == (r["result"] in ("valid", "acceptable")), r["comment"]
