@@ -63,6 +63,12 @@ def main():
         sk_pk, pk, msg, sig_msg = parts[0], parts[1], parts[2], parts[3]
         rows.append({"sk": sk_pk[:64], "pk": pk, "msg": msg, "sig": sig_msg[:128]})
     dump("ed25519_vectors.json", rows)
+    # hash_to_field known answers (expand_message_xmd over SHA-256 into the bls12-381 scalar field,
+    # test/bls12-381.test.ts:1281-1293) and SEC1 pointCompress vectors (test/secp256k1.test.ts:104-113)
+    rows = [l.rstrip("\n").split(":") for l in open(f"{REF}/bls12-381/bls12-381-scalar-xmd-sha256-test-vectors.txt") if ":" in l]
+    dump("bls12_381_scalar_xmd.json", {"DST": "QUUX-V01-CS02-with-BLS12381SCALAR_XMD:SHA-256_SSWU_RO_",
+                                       "vectors": [{"msg": r[0], "expected": r[1]} for r in rows]})
+    dump("secp256k1_point_compress.json", pts["valid"]["pointCompress"])
     # hash-to-curve: EIP-2537 mapToCurve vectors (test/bls12-381.test.ts:1605-1626) and the head of the
     # priv:msg:sig signature vectors that pin hashToCurve end to end (:953-966, :1003-1012)
     dump("bls12_381_eip2537.json", json.load(open(f"{REF}/bls12-381/eip2537.json")))

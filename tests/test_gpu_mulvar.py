@@ -355,3 +355,22 @@ def test_aggregate_from_bytes_gpu():
         if not ed_ok:
             with pytest.raises(ValueError, match="invalid point encoding at index 5"):
                 G.aggregateFromBytes(Pt, bad)
+
+
+@pytest.mark.gpu
+def test_sec1_point_compress_vectors_gpu():
+    """test/secp256k1.test.ts:104-113: the 240 pointCompress vectors through fromBytesBatch / toBytesBatch"""
+    from noble_curves_amd import curve as G
+    rows = [r for r in load_golden("secp256k1_point_compress.json") if r["compress"]]
+    pts = []
+    comp_in = [bytes.fromhex(r["P"]) for r in rows if len(r["P"]) == 66]
+    dec = iter(G.fromBytesBatch(G.secp256k1_Point, comp_in))
+    for r in rows:
+        if len(r["P"]) == 66:
+            pts.append(next(dec))
+        else:
+            b = bytes.fromhex(r["P"])
+            pts.append(G.secp256k1_Point.fromAffine((int.from_bytes(b[1:33], "big"), int.from_bytes(b[33:], "big"))))
+    assert all(p is not None for p in pts)
+    enc = G.toBytesBatch(G.secp256k1_Point, pts)
+    assert [e.hex() for e in enc] == [r["expected"] for r in rows]

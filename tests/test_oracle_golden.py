@@ -345,3 +345,23 @@ def test_ed25519_wycheproof_old():
         except ValueError:
             ok = False
         assert ok == (r["result"] in ("valid", "acceptable")), r["comment"]
+
+
+def test_hash_to_field_scalar_xmd_vectors_and_sec1_compress():
+    """test/bls12-381.test.ts:1281-1293 (hash_to_field, expand 'xmd', p = r, m = 1) pins expand_message_xmd for
+    the oracle AND the product shim; test/secp256k1.test.ts:104-113 pointCompress pins the SEC1 codec."""
+    from noble_curves_amd import h2c as shim
+    from oracle.h2c import hash_to_field
+    from oracle.weierstrass import sec1_decode, sec1_encode
+    kat = load("bls12_381_scalar_xmd.json")
+    dst = kat["DST"].encode()
+    assert len(kat["vectors"]) >= 3
+    for v in kat["vectors"]:
+        exp = int(v["expected"], 16)
+        assert hash_to_field(v["msg"].encode(), 1, BLS_R, 1, 128, dst)[0][0] == exp
+        assert shim.hash_to_field(v["msg"].encode(), 1, {"p": BLS_R, "m": 1, "k": 128, "DST": dst})[0][0] == exp
+    rows = load("secp256k1_point_compress.json")
+    assert len(rows) == 240
+    for r in rows:
+        P = sec1_decode(Secp256k1, bytes.fromhex(r["P"]))
+        assert sec1_encode(P, r["compress"]).hex() == r["expected"]
