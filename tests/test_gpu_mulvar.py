@@ -374,3 +374,45 @@ def test_sec1_point_compress_vectors_gpu():
     assert all(p is not None for p in pts)
     enc = G.toBytesBatch(G.secp256k1_Point, pts)
     assert [e.hex() for e in enc] == [r["expected"] for r in rows]
+
+
+@pytest.mark.gpu
+def test_reference_inline_multiply_kats_gpu():
+    """Inline known answers of the reference's tests: the four Monero scalar -> point vectors
+    (test/ed25519.test.ts:312-333), the bls12-381 MUL_VECTORS / naive double-and-add scalars for G1 and G2
+    (test/bls12-381.test.ts:645-702) through the variable-base AND the fixed-base kernels, n * BASE == O."""
+    from noble_curves_amd import curve as G
+    from oracle.curves import BLS_R, BlsG1, BlsG2
+    xmr = [("090af56259a4b6bfbc4337980d5d75fbe3c074630368ff3804d33028e5dbfa77",
+            "0f3b913371411b27e646b537e888f685bf929ea7aab93c950ed84433f064480d"),
+           ("00364e8711a60780382a5d57b061c126f039940f28a9e91fe039d4d3094d8b88",
+            "ad545340b58610f0cd62f17d55af1ab11ecde9c084d5476865ddb4dbda015349"),
+           ("0b9bf90ff3abec042752cac3a07a62f0c16cfb9d32a3fc2305d676ec2d86e941",
+            "e097c4415fe85724d522b2e449e8fd78dd40d20097bdc9ae36fe8ec6fe12cb8c"),
+           ("069d896f02d79524c9878e080308180e2859d07f9f54454e0800e8db0847a46e",
+            "f12cb7c43b59971395926f278ce7c2eaded9444fbce62ca717564cb508a0db1d")]
+    pts = G.multiplyBaseBatch(G.ed25519_Point, [int(s, 16) for s, _ in xmr])
+    assert [e.hex() for e in G.toBytesBatch(G.ed25519_Point, pts)] == [p for _, p in xmr]
+    mul_vectors = [0x28B90DEAF189015D3A325908C5E0E4BF00F84F7E639B056FF82D7E70B6EEDE4C,
+                   0x13EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+                   0x23EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+                   0x33EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+                   0x43EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+                   0x53EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+                   0x63EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000000]
+    ks = mul_vectors + [1, 2, BLS_R - 1, (1 << 128) + 1, 12345]
+    for Pt, O in ((G.bls12_381_G1_Point, BlsG1), (G.bls12_381_G2_Point, BlsG2)):
+        via_var = G.multiplyBatch(Pt, [Pt.BASE] * len(ks), ks)
+        via_base = G.multiplyBaseBatch(Pt, ks)
+        for k, a, b in zip(ks, via_var, via_base):
+            acc, base, s = O.ZERO, O.BASE, k                  # the reference's naiveMul
+            while s > 0:
+                if s & 1:
+                    acc = acc.add(base)
+                if s > 1:
+                    base = base.double()
+                s >>= 1
+            assert a.toAffine() == acc.toAffine() == b.toAffine(), hex(k)
+        assert G.isTorsionFreeBatch(Pt, [Pt.BASE, via_var[-1]]) == [True, True]   # n * BASE == O
+        fresh = G.multiplyBatch(Pt, [via_var[-1]], [54321])[0]
+        assert fresh.toAffine() == O.BASE.multiplyUnsafe(12345 * 54321 % BLS_R).toAffine()
