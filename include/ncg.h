@@ -113,6 +113,16 @@ int ncg_decode_points_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* e
                                 void* out_affine_dev, uint8_t* out_ok_dev, uint8_t* out_is_inf_dev,
                                 void* stream);
 
+/* ---- pairwise point addition -------------------------------------------------------------------
+ * out[i] = a[i] + b[i] (subtract != 0: a[i] - b[i]) on affine wire points: Point.add / subtract of the
+ * reference for a batch of pairs, incl. P = Q, P = -Q and ZERO operands (src/abstract/weierstrass.ts:
+ * 834-891, src/abstract/edwards.ts:526-545).  With two batch multiplies this is Point.mulAddUnsafe
+ * (a*P + b*Q, weierstrass.ts:937-944 - the ECDSA-verification shape). */
+int ncg_add_pairs_batch(ncg_ctx* ctx, int curve, size_t n, const void* a, const void* b, int subtract,
+                        void* out_affine, uint8_t* out_is_inf);
+int ncg_add_pairs_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* a_dev, const void* b_dev,
+                            int subtract, void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream);
+
 /* ---- aggregation of encoded points -----------------------------------------------------------
  * out = sum_i Point.fromBytes(encoded[i]): the group operation of bls.aggregatePublicKeys /
  * aggregateSignatures on encoded inputs (src/abstract/bls.ts:857-873: normPub / fromBytes +

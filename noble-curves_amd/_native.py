@@ -81,6 +81,8 @@ _vp, _sz, _i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 _OPTIONAL_PROTOS = {
     "ncg_decode_points_batch": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp],
     "ncg_decode_points_batch_dev": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp, _vp],
+    "ncg_add_pairs_batch": [_vp, _i32, _sz, _vp, _vp, _i32, _vp, _vp],
+    "ncg_add_pairs_batch_dev": [_vp, _i32, _sz, _vp, _vp, _i32, _vp, _vp, _vp],
     "ncg_aggregate_encoded": [_vp, _i32, _sz, _vp, _i32, _vp, _vp, _vp],
     "ncg_encode_points_batch": [_vp, _i32, _sz, _vp, _vp, _vp],
     "ncg_encode_points_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
@@ -178,6 +180,20 @@ class Engine:
             self._check(self.lib.ncg_decode_points_batch(self.h, curve, n, enc.ctypes.data, 1 if zip215 else 0,
                                                          out.ctypes.data, ok.ctypes.data, inf.ctypes.data))
         return out, ok.astype(bool), inf.astype(bool)
+
+    def add_pairs_batch(self, curve, a, b, subtract=False):
+        """a, b uint8 [n, PB] affine wire points -> (a[i] + b[i] (or a[i] - b[i]) [n, PB], is_inf [n])."""
+        pb = POINT_BYTES[curve]
+        a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, pb)
+        b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, pb)
+        if a.shape != b.shape:
+            raise ValueError("noble-gpu: add_pairs_batch: operand arrays differ in length")
+        out = np.empty_like(a)
+        inf = np.empty((a.shape[0],), dtype=np.uint8)
+        if a.shape[0]:
+            self._check(self.lib.ncg_add_pairs_batch(self.h, curve, a.shape[0], a.ctypes.data, b.ctypes.data,
+                                                     1 if subtract else 0, out.ctypes.data, inf.ctypes.data))
+        return out, inf
 
     def aggregate_encoded(self, curve, encoded, zip215=False):
         """encoded uint8 [n, ENCODED_BYTES] -> (affine [PB], is_inf, bad_index): sum of the decoded points;

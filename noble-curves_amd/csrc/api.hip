@@ -238,6 +238,50 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
   return NCG_OK;
 }
 
+int ncg_add_pairs_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* a_dev, const void* b_dev, int subtract,
+                            void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve < NCG_SECP256K1 || curve > NCG_BLS12_381_G2)
+    return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: add_pairs_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!a_dev || !b_dev || !out_affine_dev || !out_is_inf_dev)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: add_pairs_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  int rc = ensure_mul_ws(ctx, curve, n, st);
+  if (rc) return rc;
+  NCG_HIP(ctx, ncg::pair_add_batch(curve, (const uint32_t*)a_dev, (const uint32_t*)b_dev, subtract, (uint32_t*)out_affine_dev,
+                                   out_is_inf_dev, (int)n, (uint32_t*)ctx->mul_ws, st));
+  return NCG_OK;
+}
+
+int ncg_add_pairs_batch(ncg_ctx* ctx, int curve, size_t n, const void* a, const void* b, int subtract, void* out_affine,
+                        uint8_t* out_is_inf) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  int pb = ncg_point_bytes(curve);
+  if (pb == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: add_pairs_batch: unsupported curve %d", curve);
+  if (n == 0) return NCG_OK;
+  if (!a || !b || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: add_pairs_batch: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
+  size_t pts_b = n * (size_t)pb, inf_b = (n + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, 3 * pts_b + inf_b + 1024);
+  if (rc) return rc;
+  char* d_a = (char*)ctx->scratch;
+  char* d_b = d_a + pts_b;
+  char* d_out = d_b + pts_b;
+  char* d_inf = d_out + pts_b;
+  NCG_HIP(ctx, pins.h2d(d_a, a, pts_b));
+  NCG_HIP(ctx, pins.h2d(d_b, b, pts_b));
+  rc = ncg_add_pairs_batch_dev(ctx, curve, n, d_a, d_b, subtract, d_out, (uint8_t*)d_inf, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, pins.d2h(out_affine, d_out, pts_b));
+  if (out_is_inf) NCG_HIP(ctx, pins.d2h(out_is_inf, d_inf, n));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
 int ncg_mul_base_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* scalars_dev, void* out_affine_dev,
                            uint8_t* out_is_inf_dev, void* stream) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");

@@ -267,6 +267,13 @@ __global__ void __launch_bounds__(256) k_ed_batch_affine(const uint32_t* __restr
   }
 }
 
+// (X, Y, Z) triples (24 words each, as written by the kernels above) -> affine wire points + identity flags
+hipError_t ed25519_proj_to_affine(const uint32_t* proj, uint32_t* out, uint8_t* out_inf, int n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_ed_batch_affine<8>, dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, proj, out, out_inf, n);
+  return hipGetLastError();
+}
+
 // proj_tmp: ed25519_tmp_words(n) words of device scratch ((X, Y, Z) per item + the per-item window
 // tables), or nullptr (LDS table, per-lane inversion)
 size_t ed25519_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * (24 + EdCfgGtab::TA * 32); }

@@ -13,6 +13,11 @@ size_t mul_var_tmp_bytes(int curve, int n);
 hipError_t normalize_batch(int curve, const uint32_t* proj_wire, uint32_t* out_wire, uint8_t* out_inf, int n,
                            hipStream_t st);
 
+// pairwise A[i] + B[i] (subtract: A[i] - B[i]) on affine wire points; jac_tmp as for mul_var_batch
+hipError_t pair_add_batch(int curve, const uint32_t* a, const uint32_t* b, int subtract, uint32_t* out, uint8_t* out_inf,
+                          int n, uint32_t* jac_tmp, hipStream_t st);
+hipError_t ed25519_proj_to_affine(const uint32_t* proj, uint32_t* out, uint8_t* out_inf, int n, hipStream_t st);
+
 // fixed-base batch multiply (mulbase.hip)
 size_t mul_base_table_bytes(int curve);
 hipError_t mul_base_build_table(int curve, const uint32_t* base_wire_host, uint32_t* d_table, hipStream_t st);

@@ -54,6 +54,69 @@ static hipError_t launch_mul_var_gtab(const uint32_t* pts, const uint32_t* scala
   return hipGetLastError();
 }
 
+// ---- pairwise addition out[i] = A[i] + B[i] (or A[i] - B[i]) ---------------------------------------
+// Point.add / subtract of the reference for a batch of pairs (src/abstract/weierstrass.ts:834-891 incl.
+// the P = Q, P = -Q and ZERO cases; src/abstract/edwards.ts:526-545), and the combining step of
+// Point.mulAddUnsafe (weierstrass.ts:937-944: a*P + b*Q = two batch multiplies + this).
+template <class C>
+__global__ void __launch_bounds__(256) k_pair_add(const uint32_t* __restrict__ a_wire, const uint32_t* __restrict__ b_wire,
+                                                  int subtract, uint32_t* __restrict__ jac_out, int n) {
+  using F = typename C::F;
+  constexpr int FW = FieldIO<F>::WORDS, WW = FieldWire<F>::WORDS;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
+  if (i >= n) return;
+  Affine<F> A = load_affine_wire<F>(a_wire + (size_t)i * 2 * WW);
+  Affine<F> B = load_affine_wire<F>(b_wire + (size_t)i * 2 * WW);
+  if (subtract) B.y = f_neg(B.y);
+  Jac<F> R = jac_madd(jac_from_affine(A), B);
+  if (R.is_inf()) R = Jac<F>::inf();
+  uint32_t* o = jac_out + (size_t)i * 3 * FW;
+  FieldIO<F>::store(o, R.X);
+  FieldIO<F>::store(o + FW, R.Y);
+  FieldIO<F>::store(o + 2 * FW, R.Z);
+}
+__global__ void __launch_bounds__(256) k_pair_add_ed(const uint32_t* __restrict__ a_wire, const uint32_t* __restrict__ b_wire,
+                                                     int subtract, uint32_t* __restrict__ proj_out, int n) {
+  using F = FpEd;
+  using PR = ParamsEdP;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  F ax = FieldWire<F>::load(a_wire + (size_t)i * 16), ay = FieldWire<F>::load(a_wire + (size_t)i * 16 + 8);
+  F bx = FieldWire<F>::load(b_wire + (size_t)i * 16), by = FieldWire<F>::load(b_wire + (size_t)i * 16 + 8);
+  EdExt<F> A{ax, ay, F::one(), ax * ay};
+  EdExt<F> R = ed_madd_niels(A, ed_affine_to_niels(bx, by, EdConsts::d2()), subtract != 0);
+  uint32_t* o = proj_out + (size_t)i * 24;
+  fp_store<PR>(o, R.X);
+  fp_store<PR>(o + 8, R.Y);
+  fp_store<PR>(o + 16, R.Z);
+}
+
+template <class C, int K>
+static hipError_t pair_add_t(const uint32_t* a, const uint32_t* b, int subtract, uint32_t* out, uint8_t* out_inf, int n,
+                             uint32_t* jac_tmp, hipStream_t st) {
+  constexpr int LS = LaneShift<C>::value;
+  hipLaunchKernelGGL(k_pair_add<C>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, a, b, subtract,
+                     jac_tmp, n);
+  int threads = ((n + K - 1) / K) << LS;
+  hipLaunchKernelGGL((k_jac_batch_affine<C, K>), dim3((threads + 255) / 256), dim3(256), 0, st, jac_tmp, out, out_inf, n);
+  return hipGetLastError();
+}
+
+// jac_tmp: mul_var_tmp_bytes(curve, n) bytes of device scratch
+hipError_t pair_add_batch(int curve, const uint32_t* a, const uint32_t* b, int subtract, uint32_t* out, uint8_t* out_inf,
+                          int n, uint32_t* jac_tmp, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  switch (curve) {
+    case CURVE_SECP256K1: return pair_add_t<CurveSecp, 8>(a, b, subtract, out, out_inf, n, jac_tmp, st);
+    case CURVE_BLS12_381_G1: return pair_add_t<CurveG1, 8>(a, b, subtract, out, out_inf, n, jac_tmp, st);
+    case CURVE_BLS12_381_G2: return pair_add_t<CurveG2P, 4>(a, b, subtract, out, out_inf, n, jac_tmp, st);
+    case CURVE_ED25519:
+      hipLaunchKernelGGL(k_pair_add_ed, dim3((n + 255) / 256), dim3(256), 0, st, a, b, subtract, jac_tmp, n);
+      return ed25519_proj_to_affine(jac_tmp, out, out_inf, n, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t normalize_batch(int curve, const uint32_t* proj_wire, uint32_t* out_wire, uint8_t* out_inf, int n,
                            hipStream_t st) {
   if (n <= 0) return hipSuccess;

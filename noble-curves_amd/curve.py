@@ -325,6 +325,35 @@ def toBytesBatch(c, points, engine=None):
     return [enc[i].tobytes() for i in range(len(points))]
 
 
+def addBatch(c, ps, qs, engine=None, _subtract=False):
+    """[p.add(q) for p, q in zip(ps, qs)] (weierstrass.ts:834-880, edwards.ts:526-545) in one launch."""
+    validateMSMPoints(ps, c)
+    validateMSMPoints(qs, c)
+    if len(ps) != len(qs):
+        raise ValueError("arrays of points must have equal length")
+    if not ps:
+        return []
+    eng = engine or get_engine()
+    out, inf = eng.add_pairs_batch(c.CURVE_ID, _points_wire(ps, c.POINT_BYTES), _points_wire(qs, c.POINT_BYTES), _subtract)
+    return [c._from_wire(out[i], bool(inf[i])) for i in range(len(ps))]
+
+
+def subtractBatch(c, ps, qs, engine=None):
+    """[p.subtract(q) ...] (weierstrass.ts:882-885)."""
+    return addBatch(c, ps, qs, engine, _subtract=True)
+
+
+def mulAddUnsafeBatch(c, ps, a_s, qs, b_s, engine=None):
+    """[p.mulAddUnsafe(a, q, b) ...] = a*p + b*q per item (weierstrass.ts:937-944; the u1*G + u2*P of ECDSA
+    verification and public-key recovery, :1403, :1609): two batch multiplies and one pairwise addition,
+    scalars 0 <= k < n like multiplyUnsafe (:915-928)."""
+    if not (len(ps) == len(a_s) == len(qs) == len(b_s)):
+        raise ValueError("arrays of points and scalars must have equal length")
+    A = multiplyUnsafeBatch(c, ps, a_s, engine)
+    B = multiplyUnsafeBatch(c, qs, b_s, engine)
+    return addBatch(c, A, B, engine)
+
+
 def aggregateFromBytes(c, encodings, zip215=False, engine=None):
     """sum(c.fromBytes(b) for b in encodings) - the group part of bls.aggregatePublicKeys /
     aggregateSignatures on encoded inputs (src/abstract/bls.ts:857-873).  Decoding, validity and

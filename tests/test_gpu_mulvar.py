@@ -416,3 +416,50 @@ def test_reference_inline_multiply_kats_gpu():
         assert G.isTorsionFreeBatch(Pt, [Pt.BASE, via_var[-1]]) == [True, True]   # n * BASE == O
         fresh = G.multiplyBatch(Pt, [via_var[-1]], [54321])[0]
         assert fresh.toAffine() == O.BASE.multiplyUnsafe(12345 * 54321 % BLS_R).toAffine()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["secp256k1", "bls12_381_G1", "bls12_381_G2", "ed25519"])
+def test_pairwise_add_subtract_and_mul_add_gpu(name):
+    """Point.add / subtract incl. P = Q, P = -Q and ZERO operands (weierstrass.ts:834-891, edwards.ts:526-545) and
+    Point.mulAddUnsafe a*P + b*Q (weierstrass.ts:937-944) in batch, vs the oracle."""
+    from noble_curves_amd import curve as G
+    from oracle.curves import BlsG1, BlsG2, Ed25519, Secp256k1
+    Pt, O = {"secp256k1": (G.secp256k1_Point, Secp256k1), "bls12_381_G1": (G.bls12_381_G1_Point, BlsG1),
+             "bls12_381_G2": (G.bls12_381_G2_Point, BlsG2), "ed25519": (G.ed25519_Point, Ed25519)}[name]
+    rng = makeRng(0xADD + len(name))
+    n = 24 if name != "bls12_381_G2" else 12
+    ks = [rng.rndBelow(1 << 100) + 1 for _ in range(n)]
+    base = [O.BASE.multiplyUnsafe(k) for k in ks]
+    ps = list(base)
+    qs = [base[(i + 1) % n] for i in range(n)]
+    qs[0] = ps[0]                     # P = Q: doubling
+    qs[1] = ps[1].negate()            # P = -Q: ZERO
+    ps[2] = O.ZERO                    # ZERO + Q
+    qs[3] = O.ZERO                    # P + ZERO
+    ps[4], qs[4] = O.ZERO, O.ZERO
+
+    def g(p):
+        return Pt.ZERO if p.is0() else Pt.fromAffine(p.toAffine())
+    gp, gq = [g(p) for p in ps], [g(q) for q in qs]
+    got = G.addBatch(Pt, gp, gq)
+    for a, p, q in zip(got, ps, qs):
+        e = p.add(q)
+        assert a.toAffine() == e.toAffine() and a.is0() == e.is0()
+    got = G.subtractBatch(Pt, gp, gq)
+    for a, p, q in zip(got, ps, qs):
+        e = p.subtract(q)
+        assert a.toAffine() == e.toAffine() and a.is0() == e.is0()
+    order = Pt.Fn.ORDER
+    a_s = [rng.rndBelow(order) for _ in range(n)]
+    b_s = [rng.rndBelow(order) for _ in range(n)]
+    a_s[5], b_s[6] = 0, 0
+    b_s[7] = (order - a_s[7]) % order
+    qs2 = list(gq)
+    qs2[7] = gp[7]                    # a*P + (n - a)*P = ZERO
+    ops, oqs = [p for p in ps], [q for q in qs]
+    oqs[7] = ops[7]
+    got = G.mulAddUnsafeBatch(Pt, gp, a_s, qs2, b_s)
+    for r, p, a, q, b in zip(got, ops, a_s, oqs, b_s):
+        e = p.multiplyUnsafe(a).add(q.multiplyUnsafe(b))
+        assert r.toAffine() == e.toAffine() and r.is0() == e.is0()
