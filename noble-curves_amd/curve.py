@@ -349,7 +349,13 @@ def mulAddUnsafeBatch(c, ps, a_s, qs, b_s, engine=None):
     scalars 0 <= k < n like multiplyUnsafe (:915-928)."""
     if not (len(ps) == len(a_s) == len(qs) == len(b_s)):
         raise ValueError("arrays of points and scalars must have equal length")
-    A = multiplyUnsafeBatch(c, ps, a_s, engine)
+    if ps and all(p is c.BASE or (not p.is0() and p.toAffine() == c.BASE.toAffine()) for p in ps):
+        for k in a_s:                              # same range rule as multiplyUnsafe
+            if not (isinstance(k, int) and not isinstance(k, bool) and 0 <= k < c.Fn.ORDER):
+                raise ValueError("invalid scalar: out of range")
+        A = multiplyBaseBatch(c, list(a_s), engine, unsafe=True)   # u1*G through the fixed-base table
+    else:
+        A = multiplyUnsafeBatch(c, ps, a_s, engine)
     B = multiplyUnsafeBatch(c, qs, b_s, engine)
     return addBatch(c, A, B, engine)
 

@@ -463,3 +463,8 @@ def test_pairwise_add_subtract_and_mul_add_gpu(name):
     for r, p, a, q, b in zip(got, ops, a_s, oqs, b_s):
         e = p.multiplyUnsafe(a).add(q.multiplyUnsafe(b))
         assert r.toAffine() == e.toAffine() and r.is0() == e.is0()
+    # ECDSA-verification shape u1*G + u2*P: the first term goes through the fixed-base table
+    got = G.mulAddUnsafeBatch(Pt, [Pt.BASE] * n, a_s, qs2, b_s)
+    for r, a, q, b in zip(got, a_s, oqs, b_s):
+        e = O.BASE.multiplyUnsafe(a).add(q.multiplyUnsafe(b))
+        assert r.toAffine() == e.toAffine() and r.is0() == e.is0()
