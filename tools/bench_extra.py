@@ -73,6 +73,16 @@ def main():
     ones = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
     ones[:, 0] = 1
     rate("secp256k1 point sum (MSM, unit scalars)", n, timeit(lambda: eng.msm_dev(SECP256K1, n, P(kpts), P(ones), s)), "points")
+    padd = lambda: eng._check(eng.lib.ncg_add_pairs_batch_dev(eng.h, SECP256K1, n, P(kpts), P(pts), 0, P(dec), P(inf), s))  # noqa: E731
+    rate("secp256k1 pairwise point add", n, timeit(padd), "points")
+    t1 = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    t2 = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+
+    def ecdsa_shape():                                                   # u1*G + u2*P per item (weierstrass.ts:1609)
+        eng.mul_base_batch_dev(SECP256K1, n, P(sc), P(t1), P(inf), s)
+        eng.mul_var_batch_dev(SECP256K1, n, P(kpts), P(sc), P(t2), P(inf), s)
+        eng._check(eng.lib.ncg_add_pairs_batch_dev(eng.h, SECP256K1, n, P(t1), P(t2), 0, P(dec), P(inf), s))
+    rate("secp256k1 u1*G + u2*P (mulAddUnsafe, ECDSA-verify shape)", n, timeit(ecdsa_shape), "double-mults")
     proj = torch.cat([kpts, torch.zeros((n, 32), dtype=torch.uint8, device=dev)], dim=1)
     proj[:, 64] = 1                                                        # Z = 1
     fn = lambda: eng._check(eng.lib.ncg_normalize_batch_dev(eng.h, SECP256K1, n, P(proj), P(dec), P(inf), s))  # noqa: E731
