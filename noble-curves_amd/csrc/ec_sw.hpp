@@ -47,9 +47,18 @@ NCG_DI Jac<F> jac_neg(const Jac<F>& p) {
   return {p.X, f_neg(p.Y), p.Z};
 }
 
+// Fields whose products of a literal zero are literal zeros again (so "Z = 0 stays Z = 0" through
+// a doubling for free).  False for the unpaired Fp2 over Fe29, whose Karatsuba subtractions turn
+// 0 into a non-literal multiple of p: there the doubling returns infinity explicitly.
+template <class F> struct KeepsLiteralZero { static constexpr bool value = true; };
+template <int B> struct KeepsLiteralZero<Fe29x2<B>> { static constexpr bool value = false; };
+
 // dbl-2009-l (a = 0): 2M + 5S.  Z = 0 stays Z = 0; no point of order 2 exists on these curves.
 template <class F>
 NCG_DI Jac<F> jac_dbl(const Jac<F>& p) {
+  if constexpr (!KeepsLiteralZero<F>::value) {
+    if (p.is_inf()) return Jac<F>::inf();
+  }
   auto A = f_sqr(p.X);
   auto B = f_sqr(p.Y);
   auto C = f_sqr(B);

@@ -24,15 +24,20 @@
 
 namespace ncg {
 
-// madd that also returns the Z ratio (Z3 = Z1 * zr); used only while building the table, where
-// exceptional cases cannot occur for points of prime order.
+// madd that also returns the Z ratio (Z3 = Z1 * zr); used only while building the table.  The
+// formula is incomplete: it is wrong when p = +-q (H = 0), which happens while building
+// [1,3,..]P exactly when P has small order (j*P = +-2P for some odd j < 2^W) - possible for any
+// input the reference accepts on bls12-381 G1/G2 (cofactor > 1; Point.fromAffine does not
+// subgroup-check, src/abstract/weierstrass.ts:710-718).  `degenerate` records that case; the
+// caller then recomputes the lane with the complete ladder mul_var_slow below.
 template <class F>
-NCG_DI Jac<F> jac_madd_zr(const Jac<F>& p, const Affine<F>& q, F& zr) {
+NCG_DI Jac<F> jac_madd_zr(const Jac<F>& p, const Affine<F>& q, F& zr, bool& degenerate) {
   auto Z1Z1 = f_sqr(p.Z);
   auto U2 = q.x * Z1Z1;
   auto S2 = q.y * p.Z * Z1Z1;
   auto H = U2 - p.X;
   auto R = S2 - p.Y;
+  degenerate = degenerate || f_eqz(H);
   auto HH = f_sqr(H);
   auto HHH = H * HH;
   auto V = p.X * HH;
@@ -40,6 +45,26 @@ NCG_DI Jac<F> jac_madd_zr(const Jac<F>& p, const Affine<F>& q, F& zr) {
   auto Y3 = R * (V - X3) - p.Y * HHH;
   zr = H * F::one();  // stored: bring the bound back under the storage bound
   return {X3, Y3, p.Z * H};
+}
+
+// Complete (every exceptional case handled by jac_madd / jac_dbl) MSB-first double-and-add over the
+// whole 256-bit scalar: the value of the reference's multiplyUnsafe for ANY curve point
+// (src/abstract/weierstrass.ts:915-928 on the complete formulas :793-880).  Only lanes whose
+// window table degenerated (small-order P) come here, so its cost (256 dbl + ~128 madd) is
+// irrelevant; P and k are re-read from memory so nothing stays live across the main ladder.
+template <class C>
+NCG_DI Jac<typename C::F> mul_var_slow(const uint32_t* __restrict__ pt_wire, const uint32_t* __restrict__ k_wire) {
+  using F = typename C::F;
+  const Affine<F> P = load_affine_wire<F>(pt_wire);
+  Jac<F> R = Jac<F>::inf();
+  for (int w = 7; w >= 0; w--) {
+    const uint32_t word = k_wire[w];
+    for (int bit = 31; bit >= 0; bit--) {
+      R = jac_dbl(R);
+      if ((word >> bit) & 1u) R = jac_madd(R, P);
+    }
+  }
+  return R;
 }
 
 template <class C, int W>
@@ -79,6 +104,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
   // ---- table of odd multiples on the isomorphic curve ------------------------------------
   // entry e, word w at tab[(e*2*FW + w)*stride]
   F Zg;
+  bool degenerate = false;
   {
     Jac<F> D = jac_dbl(Jac<F>{P.x, P.y, F::one()});
     auto dz2 = f_sqr(D.Z);
@@ -99,7 +125,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
 #pragma unroll
     for (int j = 1; j < TS; j++) {
       F zj;
-      T = jac_madd_zr(T, Dp, zj);
+      T = jac_madd_zr(T, Dp, zj, degenerate);
       zr_put(j, zj);
       FieldIO<F>::store_strided(tab + (j * 2 * TW) * stride, stride, T.X);
       FieldIO<F>::store_strided(tab + (j * 2 * TW + TW) * stride, stride, T.Y);
@@ -179,7 +205,10 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     }
   }
   // back from the isomorphic curve, then to affine (weierstrass.ts:951-969 toAffine)
+  const bool ladder_inf = R.is_inf();  // tested before the product: not every field keeps 0 * Zg literal
   R.Z = R.Z * Zg;
+  if (ladder_inf) R = Jac<F>::inf();
+  if (degenerate) R = mul_var_slow<C>(pt_wire, k_wire);  // small-order P: complete ladder instead
   bool inf = trivial_zero || R.is_inf();
   if constexpr (JAC_OUT) {
     if (inf) R = Jac<F>::inf();

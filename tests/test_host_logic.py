@@ -386,3 +386,26 @@ def test_map_to_curve_lanes_match_oracle():
                 pts = [hasher.map(r[j * m:(j + 1) * m]) for j in range(count)]
                 exp = hasher.clear(pts[0] if count == 1 else pts[0].add(pts[1]))
                 assert wire_to_affine(curve, out[i]) == exp.toAffine() and inf[i] == exp.is0(), (curve, count, i)
+
+
+@pytest.mark.parametrize("curve,name", [(BLS12_381_G1, "g1"), (BLS12_381_G2, "g2")])
+def test_lane_ladder_small_order_points(curve, name):
+    """Inputs are arbitrary curve points (SURVEY 8a gotcha 1; weierstrass.ts:696-718, :915-928):
+    points of order 3 / 11 (G1) and 13 / 23 (G2), alone and mixed with a subgroup component, through
+    the per-lane ladder vs k*P by double-and-add on the oracle's complete formulas."""
+    import smallorder
+    cases = smallorder.small_order_cases(name)
+    ks = smallorder.small_order_scalars(3)
+    if name == "g2":
+        ks = ks[:14] + ks[-3:]
+    pts, scal, exp = [], [], []
+    for P, _ in cases:
+        for k in ks:
+            pts.append(P)
+            scal.append(k)
+            exp.append(smallorder.naive_mul(P, k).toAffine())
+    out, inf = hosttest.mul_var(curve, points_to_wire(curve, pts), scalars_to_wire(scal))
+    zero = ORACLE_CURVE[curve].ZERO.toAffine()
+    for i, e in enumerate(exp):
+        assert wire_to_affine(curve, out[i]) == e, (i, hex(scal[i]))
+        assert bool(inf[i]) == (e == zero), (i, hex(scal[i]))
