@@ -8,10 +8,10 @@ namespace ncg {
 enum CurveId : int { CURVE_SECP256K1 = 0, CURVE_ED25519 = 1, CURVE_BLS12_381_G1 = 2, CURVE_BLS12_381_G2 = 3 };
 
 struct CurveSecp {  // src/secp256k1.ts:48-64
-  using F = FpSecp;
+  using F = FeSecp;  // radix-2^29 lazy form (fe9.hpp)
   static constexpr bool GLV = true;  // h = 1: endomorphism split is always exact
   static constexpr int SCALAR_BITS = 256;
-  static NCG_DI F beta() { return F::from_const(ParamsSecpP::BETA); }
+  static NCG_DI Fe9<Fe9SecpPR, 1> beta() { return Fe9<Fe9SecpPR, 1>::from_limbs(Fe9SecpPR::BETA); }
 };
 struct CurveG1 {  // src/bls12-381.ts:134-148; no endomorphism in the reference (and inputs are
   using F = FeBls;  // not subgroup-checked), so none here either (SURVEY 8a gotcha 1)

@@ -73,14 +73,20 @@ NCG_DI Jac<F> jac_dbl(const Jac<F>& p) {
   return {X3, Y3, Z3};
 }
 
-// Jacobian + affine (madd-2007-bl without the 2x scaling): 8M + 3S, exceptional cases explicit.
-template <class F>
-NCG_DI Jac<F> jac_madd(const Jac<F>& p, const Affine<F>& q) {
-  if (q.is_inf()) return p;
-  if (p.is_inf()) return {q.x, q.y, F::one()};
+// conditional negation; the result type is f_neg's (lazy fields widen their bound there)
+template <class T>
+NCG_DI auto f_cneg(const T& a, bool c) -> decltype(f_neg(a)) {
+  using R = decltype(f_neg(a));
+  return c ? f_neg(a) : R(a);
+}
+
+// Jacobian + affine (x, y) (madd-2007-bl without the 2x scaling): 8M + 3S, P = +-Q explicit.  x and y
+// may be of a wider-bound type than the stored coordinates (a conditionally negated table entry).
+template <class F, class FX, class FY>
+NCG_DI Jac<F> jac_madd_xy(const Jac<F>& p, const FX& qx, const FY& qy) {
   auto Z1Z1 = f_sqr(p.Z);
-  auto U2 = q.x * Z1Z1;
-  auto S2 = q.y * p.Z * Z1Z1;
+  auto U2 = qx * Z1Z1;
+  auto S2 = qy * p.Z * Z1Z1;
   auto H = U2 - p.X;
   auto R = S2 - p.Y;
   if (f_eqz(H)) {
@@ -94,6 +100,17 @@ NCG_DI Jac<F> jac_madd(const Jac<F>& p, const Affine<F>& q) {
   auto Y3 = R * (V - X3) - p.Y * HHH;
   auto Z3 = p.Z * H;
   return {X3, Y3, Z3};
+}
+// the same with the infinity cases of either operand (affine infinity = literal (0, 0))
+template <class F, class FX, class FY>
+NCG_DI Jac<F> jac_madd_q(const Jac<F>& p, const FX& qx, const FY& qy) {
+  if (qx.is_zero() && qy.is_zero()) return p;
+  if (p.is_inf()) return {qx, qy, F::one()};
+  return jac_madd_xy(p, qx, qy);
+}
+template <class F>
+NCG_DI Jac<F> jac_madd(const Jac<F>& p, const Affine<F>& q) {
+  return jac_madd_q(p, q.x, q.y);
 }
 
 // Jacobian + Jacobian: 12M + 4S, exceptional cases explicit.
@@ -128,6 +145,76 @@ NCG_DI Affine<F> jac_to_affine(const Jac<F>& p, const ZI& zinv) {
   if (p.is_inf()) return {F::zero(), F::zero()};
   auto zi2 = f_sqr(zinv);
   return {p.X * zi2, p.Y * zi2 * zinv};
+}
+
+// ----------------------------------------------------------------- Jacobian over Fe9 (secp256k1)
+// Same formulas with the bookkeeping of the lazy limb bounds made explicit (fe9.hpp): a product wants
+// bound(a)*bound(b) <= 7 and a stored coordinate bound <= 2, so the few differences that feed a product
+// or a store are weakly normalised (`fe9_norm`, 3 plain ops per limb), and the doubling uses 4XB = 4*X*Y^2
+// directly instead of the (X+B)^2 - A - C squaring trick (a multiply is cheaper than a square plus two
+// normalised subtractions here).  Overloads: picked for F = Fe9<PR, B> by partial ordering.
+template <class PR, int B>
+NCG_DI Jac<Fe9<PR, B>> jac_dbl(const Jac<Fe9<PR, B>>& p) {
+  auto A = f_sqr(p.X);
+  auto Bq = f_sqr(p.Y);
+  auto C8 = f_dbl(f_sqr(f_dbl(Bq)));                 // 8 Y^4, bound 2
+  auto D = fe9_norm(f_dbl(f_dbl(p.X * Bq)));         // 4 X Y^2
+  auto E = fe9_norm(A + A + A);
+  auto X3 = f_sqr(E) - f_dbl(D);                     // bound 4
+  auto Y3 = E * (D - X3) - C8;                       // (bound 6) * 1, then 1 - 2 -> 4
+  auto Z3 = f_dbl(p.Y * p.Z);
+  return {X3, Y3, Z3};
+}
+
+// Jacobian + affine (x, y) with y possibly a (conditionally) negated table entry of a wider bound.
+template <class PR, int B, int BX, int BY>
+NCG_DI Jac<Fe9<PR, B>> jac_madd_xy(const Jac<Fe9<PR, B>>& p, const Fe9<PR, BX>& qx, const Fe9<PR, BY>& qy) {
+  using F = Fe9<PR, B>;
+  auto Z1Z1 = f_sqr(p.Z);
+  auto U2 = qx * Z1Z1;
+  auto S2 = qy * (p.Z * Z1Z1);
+  auto Hw = U2 - p.X;
+  auto Rw = S2 - p.Y;
+  if (f_eqz(Hw)) {
+    if (f_eqz(Rw)) return jac_dbl(p);  // P == Q
+    return Jac<F>::inf();              // P == -Q
+  }
+  auto H = fe9_norm(Hw);
+  auto R = fe9_norm(Rw);
+  auto HH = f_sqr(H);
+  auto HHH = H * HH;
+  auto V = p.X * HH;
+  auto X3 = fe9_norm(f_sqr(R) - HHH - f_dbl(V));
+  auto Y3 = R * (V - X3) - p.Y * HHH;
+  auto Z3 = p.Z * H;
+  return {X3, Y3, Z3};
+}
+template <class PR, int B>
+NCG_DI Jac<Fe9<PR, B>> jac_add(const Jac<Fe9<PR, B>>& p, const Jac<Fe9<PR, B>>& q) {
+  using F = Fe9<PR, B>;
+  if (q.is_inf()) return p;
+  if (p.is_inf()) return q;
+  auto Z1Z1 = f_sqr(p.Z);
+  auto Z2Z2 = f_sqr(q.Z);
+  auto U1 = p.X * Z2Z2;
+  auto U2 = q.X * Z1Z1;
+  auto S1 = p.Y * (q.Z * Z2Z2);
+  auto S2 = q.Y * (p.Z * Z1Z1);
+  auto Hw = U2 - U1;
+  auto Rw = S2 - S1;
+  if (f_eqz(Hw)) {
+    if (f_eqz(Rw)) return jac_dbl(p);
+    return Jac<F>::inf();
+  }
+  auto H = fe9_norm(Hw);
+  auto R = fe9_norm(Rw);
+  auto HH = f_sqr(H);
+  auto HHH = H * HH;
+  auto V = U1 * HH;
+  auto X3 = fe9_norm(f_sqr(R) - HHH - f_dbl(V));
+  auto Y3 = R * (V - X3) - S1 * HHH;
+  auto Z3 = (p.Z * q.Z) * H;
+  return {X3, Y3, Z3};
 }
 
 // ----------------------------------------------------------------- XYZZ
@@ -210,6 +297,80 @@ NCG_DI Xyzz<F> xyzz_add(const Xyzz<F>& p, const Xyzz<F>& q) {
   auto X3 = f_sqr(R) - PPP - f_dbl(Q);
   auto Y3 = R * (Q - X3) - S1 * PPP;
   return {X3, Y3, p.ZZ * q.ZZ * PP, p.ZZZ * q.ZZZ * PPP};
+}
+
+// ----------------------------------------------------------------- XYZZ over Fe9
+template <class PR, int B>
+NCG_DI Xyzz<Fe9<PR, B>> xyzz_mdbl(const Affine<Fe9<PR, B>>& p) {
+  auto U = f_dbl(p.y);                                // bound 4
+  auto V = f_sqr(U);
+  auto W = U * V;
+  auto S = p.x * V;
+  auto xx = f_sqr(p.x);
+  auto M = fe9_norm(xx + xx + xx);
+  auto X3 = fe9_norm(f_sqr(M) - f_dbl(S));
+  auto Y3 = M * (S - X3) - W * p.y;
+  return {X3, Y3, V, W};
+}
+template <class PR, int B>
+NCG_DI Xyzz<Fe9<PR, B>> xyzz_dbl(const Xyzz<Fe9<PR, B>>& p) {
+  if (p.is_inf()) return p;
+  auto U = f_dbl(p.Y);
+  auto V = f_sqr(U);
+  auto W = U * V;
+  auto S = p.X * V;
+  auto xx = f_sqr(p.X);
+  auto M = fe9_norm(xx + xx + xx);
+  auto X3 = fe9_norm(f_sqr(M) - f_dbl(S));
+  auto Y3 = M * (S - X3) - W * p.Y;
+  return {X3, Y3, V * p.ZZ, W * p.ZZZ};
+}
+template <class PR, int B>
+NCG_DI Xyzz<Fe9<PR, B>> xyzz_madd(const Xyzz<Fe9<PR, B>>& p, const Affine<Fe9<PR, B>>& q_in, bool neg = false) {
+  using F = Fe9<PR, B>;
+  if (q_in.is_inf()) return p;
+  const Fe9<PR, B + 1> qy = neg ? f_neg(q_in.y) : Fe9<PR, B + 1>(q_in.y);
+  if (p.is_inf()) return {q_in.x, qy, F::one(), F::one()};
+  auto U2 = q_in.x * p.ZZ;
+  auto S2 = qy * p.ZZZ;
+  auto Pw = U2 - p.X;
+  auto Rw = S2 - p.Y;
+  if (f_eqz(Pw)) {
+    if (f_eqz(Rw)) return xyzz_mdbl(Affine<F>{q_in.x, qy});
+    return Xyzz<F>::inf();
+  }
+  auto Pq = fe9_norm(Pw);
+  auto R = fe9_norm(Rw);
+  auto PP = f_sqr(Pq);
+  auto PPP = Pq * PP;
+  auto Q = p.X * PP;
+  auto X3 = fe9_norm(f_sqr(R) - PPP - f_dbl(Q));
+  auto Y3 = R * (Q - X3) - p.Y * PPP;
+  return {X3, Y3, p.ZZ * PP, p.ZZZ * PPP};
+}
+template <class PR, int B>
+NCG_DI Xyzz<Fe9<PR, B>> xyzz_add(const Xyzz<Fe9<PR, B>>& p, const Xyzz<Fe9<PR, B>>& q) {
+  using F = Fe9<PR, B>;
+  if (q.is_inf()) return p;
+  if (p.is_inf()) return q;
+  auto U1 = p.X * q.ZZ;
+  auto U2 = q.X * p.ZZ;
+  auto S1 = p.Y * q.ZZZ;
+  auto S2 = q.Y * p.ZZZ;
+  auto Pw = U2 - U1;
+  auto Rw = S2 - S1;
+  if (f_eqz(Pw)) {
+    if (f_eqz(Rw)) return xyzz_dbl(p);
+    return Xyzz<F>::inf();
+  }
+  auto Pq = fe9_norm(Pw);
+  auto R = fe9_norm(Rw);
+  auto PP = f_sqr(Pq);
+  auto PPP = Pq * PP;
+  auto Q = U1 * PP;
+  auto X3 = fe9_norm(f_sqr(R) - PPP - f_dbl(Q));
+  auto Y3 = R * (Q - X3) - S1 * PPP;
+  return {X3, Y3, (p.ZZ * q.ZZ) * PP, (p.ZZZ * q.ZZZ) * PPP};
 }
 
 }  // namespace ncg

@@ -3,6 +3,7 @@
 // mul = 3 Fp.mul Karatsuba (:420-431), sqr = 2 Fp.mul (:432-438).
 #pragma once
 #include "fe29.hpp"
+#include "fe9.hpp"
 #include "fp.hpp"
 
 namespace ncg {
@@ -120,6 +121,39 @@ struct FieldWire<Fp2T<PR>> {
     FieldWire<Fp<PR>>::store(p, a.c0);
     FieldWire<Fp<PR>>::store(p + PR::N, a.c1);
   }
+};
+
+// ---- Fe9 adapters: 9 stored words (29-bit limbs), 8 wire words
+template <class PR, int B>
+struct FieldIO<Fe9<PR, B>> {
+  static constexpr int WORDS = 9;
+  static constexpr int LANE_WORDS = WORDS;
+  static NCG_DI Fe9<PR, B> load(const uint32_t* p) {
+    Fe9<PR, B> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = p[i];
+    return r;
+  }
+  static NCG_DI void store(uint32_t* p, const Fe9<PR, B>& a) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) p[i] = a.v[i];
+  }
+  template <class PTR> static NCG_DI Fe9<PR, B> load_strided(PTR p, int stride) {
+    Fe9<PR, B> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = p[i * stride];
+    return r;
+  }
+  template <class PTR> static NCG_DI void store_strided(PTR p, int stride, const Fe9<PR, B>& a) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) p[i * stride] = a.v[i];
+  }
+};
+template <class PR, int B>
+struct FieldWire<Fe9<PR, B>> {
+  static constexpr int WORDS = 8;
+  static NCG_DI Fe9<PR, B> load(const uint32_t* p) { return fe9_from_wire<PR>(p); }
+  static NCG_DI void store(uint32_t* p, const Fe9<PR, B>& a) { fe9_to_wire(p, a); }
 };
 
 // ---- Fe29 / Fe29x2 adapters

@@ -36,7 +36,69 @@ static void ht_field_t(int op, const uint32_t* a, const uint32_t* b, uint32_t* r
   fp_store<PR>(r, fp_from_mont<PR>(z));
 }
 
+// Fe9 ops on RAW limb arrays (so tests can feed the loosest limbs each bound type admits).
+// variant picks the operand bounds (A, B); the result is written as the canonical wire value.
+template <class PR, int A, int B>
+static void ht_fe9_ab(int op, const uint32_t* a, const uint32_t* b, uint32_t* r) {
+  Fe9<PR, A> x;
+  Fe9<PR, B> y;
+  for (int i = 0; i < 9; i++) {
+    x.v[i] = a[i];
+    y.v[i] = b[i];
+  }
+  switch (op) {
+    case 0: fe9_to_wire(r, x * y); break;
+    case 1: if constexpr (A <= 2) fe9_to_wire(r, f_sqr(x)); else fe9_to_wire(r, f_sqr(fe9_norm(x))); break;
+    case 2: if constexpr (A + B <= 7) fe9_to_wire(r, x + y); break;
+    case 3: if constexpr (A + B + 1 <= 7) fe9_to_wire(r, x - y); break;
+    case 4: if constexpr (A + 1 <= 7) fe9_to_wire(r, f_neg(x)); break;
+    case 5: fe9_to_wire(r, f_inv(x)); break;
+    case 6: fe9_to_wire(r, fe9_norm(x)); break;
+    case 7: r[0] = f_eqz(x) ? 1u : 0u; break;
+    case 8: {  // norm must leave limbs below U
+      auto n = fe9_norm(x);
+      uint32_t mx = 0;
+      for (int i = 0; i < 9; i++) mx = n.v[i] > mx ? n.v[i] : mx;
+      r[0] = mx;
+      break;
+    }
+    case 9: {  // product limbs (raw), to check the output bound
+      auto n = x * y;
+      for (int i = 0; i < 8; i++) r[i] = 0;
+      uint32_t mx = 0;
+      for (int i = 0; i < 9; i++) mx = n.v[i] > mx ? n.v[i] : mx;
+      r[0] = mx;
+      break;
+    }
+    case 10: if constexpr (2 * A <= 7) fe9_to_wire(r, f_dbl(x)); break;
+  }
+}
+template <class PR>
+static int ht_fe9_t(int op, int variant, const uint32_t* a, const uint32_t* b, uint32_t* r) {
+  switch (variant) {
+    case 11: ht_fe9_ab<PR, 1, 1>(op, a, b, r); return 0;
+    case 12: ht_fe9_ab<PR, 1, 2>(op, a, b, r); return 0;
+    case 17: ht_fe9_ab<PR, 1, 7>(op, a, b, r); return 0;
+    case 71: ht_fe9_ab<PR, 7, 1>(op, a, b, r); return 0;
+    case 23: ht_fe9_ab<PR, 2, 3>(op, a, b, r); return 0;
+    case 32: ht_fe9_ab<PR, 3, 2>(op, a, b, r); return 0;
+    case 22: ht_fe9_ab<PR, 2, 2>(op, a, b, r); return 0;
+    case 15: ht_fe9_ab<PR, 1, 5>(op, a, b, r); return 0;
+    case 33: ht_fe9_ab<PR, 3, 3>(op, a, b, r); return 0;
+    case 77: ht_fe9_ab<PR, 7, 7>(op, a, b, r); return 0;
+    case 46: ht_fe9_ab<PR, 4, 6>(op, a, b, r); return 0;
+  }
+  return -1;
+}
+
 extern "C" {
+
+// field: 0 secp256k1 p, 1 ed25519 p (radix-2^29 lazy form, fe9.hpp); a, b: 9 raw limbs; r: 8 wire words
+int ht_fe9_op(int field, int op, int variant, const uint32_t* a, const uint32_t* b, uint32_t* r) {
+  if (field == 0) return ht_fe9_t<Fe9SecpPR>(op, variant, a, b, r);
+  if (field == 1) return ht_fe9_t<Fe9EdPR>(op, variant, a, b, r);
+  return -1;
+}
 
 int ht_mul_var(int curve, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n) {
   switch (curve) {

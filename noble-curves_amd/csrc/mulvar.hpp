@@ -46,6 +46,24 @@ NCG_DI Jac<F> jac_madd_zr(const Jac<F>& p, const Affine<F>& q, F& zr, bool& dege
   zr = H * F::one();  // stored: bring the bound back under the storage bound
   return {X3, Y3, p.Z * H};
 }
+template <class PR, int B>
+NCG_DI Jac<Fe9<PR, B>> jac_madd_zr(const Jac<Fe9<PR, B>>& p, const Affine<Fe9<PR, B>>& q, Fe9<PR, B>& zr,
+                                   bool& degenerate) {
+  auto Z1Z1 = f_sqr(p.Z);
+  auto U2 = q.x * Z1Z1;
+  auto S2 = q.y * (p.Z * Z1Z1);
+  auto Hw = U2 - p.X;
+  degenerate = degenerate || f_eqz(Hw);
+  auto H = fe9_norm(Hw);
+  auto R = fe9_norm(S2 - p.Y);
+  auto HH = f_sqr(H);
+  auto HHH = H * HH;
+  auto V = p.X * HH;
+  auto X3 = fe9_norm(f_sqr(R) - HHH - f_dbl(V));
+  auto Y3 = R * (V - X3) - p.Y * HHH;
+  zr = H;
+  return {X3, Y3, p.Z * H};
+}
 
 // Complete (every exceptional case handled by jac_madd / jac_dbl) MSB-first double-and-add over the
 // whole 256-bit scalar: the value of the reference's multiplyUnsafe for ANY curve point
@@ -158,7 +176,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
   } else {
     w1.template init<8>(k);
   }
-  const F beta = C::beta();
+  const auto beta = C::beta();
 
   // ---- ladder -------------------------------------------------------------------------------
   Jac<F> R = Jac<F>::inf();
@@ -170,38 +188,25 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     {
       int d1 = w1.pop();
       int e = ((d1 < 0 ? -d1 : d1) - 1) >> 1;
-      Affine<F> q;
-      q.x = FieldIO<F>::load_strided(tab + (e * 2 * TW) * stride, stride);
-      q.y = FieldIO<F>::load_strided(tab + (e * 2 * TW + TW) * stride, stride);
-      if ((d1 < 0) != neg1) q.y = f_neg(q.y);
-      R = jac_madd(R, q);
+      const F qx = FieldIO<F>::load_strided(tab + (e * 2 * TW) * stride, stride);
+      const F qy = FieldIO<F>::load_strided(tab + (e * 2 * TW + TW) * stride, stride);
+      R = jac_madd_q(R, qx, f_cneg(qy, (d1 < 0) != neg1));
     }
     if constexpr (C::GLV) {
       int d2 = w2.pop();
       int e = ((d2 < 0 ? -d2 : d2) - 1) >> 1;
-      Affine<F> q;
-      q.x = FieldIO<F>::load_strided(tab + (e * 2 * TW) * stride, stride) * beta;
-      q.y = FieldIO<F>::load_strided(tab + (e * 2 * TW + TW) * stride, stride);
-      if ((d2 < 0) != neg2) q.y = f_neg(q.y);
-      R = jac_madd(R, q);
+      const auto qx = FieldIO<F>::load_strided(tab + (e * 2 * TW) * stride, stride) * beta;
+      const F qy = FieldIO<F>::load_strided(tab + (e * 2 * TW + TW) * stride, stride);
+      R = jac_madd_q(R, qx, f_cneg(qy, (d2 < 0) != neg2));
     }
   }
   // even scalars were bumped by one: take the extra point back out
   {
-    Affine<F> q;
-    q.x = FieldIO<F>::load_strided(tab, stride);
-    q.y = FieldIO<F>::load_strided(tab + TW * stride, stride);
-    if (w1.was_even) {
-      Affine<F> m = q;
-      if (!neg1) m.y = f_neg(m.y);
-      R = jac_madd(R, m);
-    }
+    const F qx = FieldIO<F>::load_strided(tab, stride);
+    const F qy = FieldIO<F>::load_strided(tab + TW * stride, stride);
+    if (w1.was_even) R = jac_madd_q(R, qx, f_cneg(qy, !neg1));
     if constexpr (C::GLV) {
-      if (w2.was_even) {
-        Affine<F> m{q.x * beta, q.y};
-        if (!neg2) m.y = f_neg(m.y);
-        R = jac_madd(R, m);
-      }
+      if (w2.was_even) R = jac_madd_q(R, qx * beta, f_cneg(qy, !neg2));
     }
   }
   // back from the isomorphic curve, then to affine (weierstrass.ts:951-969 toAffine)

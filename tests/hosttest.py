@@ -29,6 +29,7 @@ def lib():
         _lib.ht_map_to_curve.argtypes = [i32, vp, i32, vp, vp, i32]
         _lib.ht_ntt.argtypes = [i32, vp, vp, vp, i32]
         _lib.ht_ntt_plan.argtypes = [i32, vp]
+        _lib.ht_fe9_op.argtypes = [i32, i32, i32, vp, vp, vp]
     return _lib
 
 
@@ -129,3 +130,15 @@ def map_to_curve(curve, u, count, point_bytes):
     inf = np.zeros((n,), dtype=np.uint8)
     assert lib().ht_map_to_curve(curve, uu.ctypes.data, count, out.ctypes.data, inf.ctypes.data, n) == 0
     return out, inf.astype(bool)
+
+
+def fe9_op(field, op, variant, a_limbs, b_limbs):
+    """Fe9 (radix-2^29 lazy field) op on raw 9-limb operands; returns the canonical integer result
+    (ops 0-6, 10) or the raw word 0 (ops 7-9)."""
+    A = np.array(a_limbs, dtype=np.uint32)
+    B = np.array(b_limbs, dtype=np.uint32)
+    R = np.zeros(8, dtype=np.uint32)
+    assert lib().ht_fe9_op(field, op, variant, A.ctypes.data, B.ctypes.data, R.ctypes.data) == 0
+    if op in (7, 8, 9):
+        return int(R[0])
+    return sum(int(R[i]) << (32 * i) for i in range(8))

@@ -409,3 +409,65 @@ def test_lane_ladder_small_order_points(curve, name):
     for i, e in enumerate(exp):
         assert wire_to_affine(curve, out[i]) == e, (i, hex(scal[i]))
         assert bool(inf[i]) == (e == zero), (i, hex(scal[i]))
+
+
+@pytest.mark.parametrize("fid,p", [(0, SECP256K1_P), (1, ED25519_P)])
+def test_fe9_lazy_field_ops_at_their_bounds(fid, p):
+    """fe9.hpp (radix 2^29, lazy limb bounds) against big-int arithmetic, with operands whose limbs sit
+    at the top of what each bound type admits (limbs < B*U, U = 2^29 + 2^19): no 64-bit column may
+    overflow, outputs must come back below U, every value must match mod p (modular.ts:940-982)."""
+    U = (1 << 29) + (1 << 19)
+    rng = makeRng(0xFE9 + fid)
+
+    def val(l):
+        return sum(x << (29 * i) for i, x in enumerate(l))
+
+    def limbs_of(x):
+        return [(x >> (29 * i)) & ((1 << 29) - 1) for i in range(9)]
+
+    def operand(B, kind):
+        if kind == 0:
+            return [B * U - 1] * 9
+        if kind == 1:
+            return [0] * 8 + [B * U - 1]
+        if kind == 2:
+            return [B * U - 1] + [0] * 8
+        return [rng.rndBelow(B * U) if rng.rnd64() % 4 else B * U - 1 for _ in range(9)]
+
+    for variant in (11, 12, 17, 71, 23, 32, 22, 15, 33, 77, 46):
+        A, B = variant // 10, variant % 10
+        for kind in range(12):
+            a, b = operand(A, min(kind, 3)), operand(B, min((kind * 7 + 1) % 5, 3))
+            va, vb = val(a), val(b)
+            assert hosttest.fe9_op(fid, 0, variant, a, b) == va * vb % p
+            assert hosttest.fe9_op(fid, 9, variant, a, b) < U
+            assert hosttest.fe9_op(fid, 1, variant, a, b) == va * va % p
+            if A + B <= 7:
+                assert hosttest.fe9_op(fid, 2, variant, a, b) == (va + vb) % p
+            if A + B + 1 <= 7:
+                assert hosttest.fe9_op(fid, 3, variant, a, b) == (va - vb) % p
+            if A + 1 <= 7:
+                assert hosttest.fe9_op(fid, 4, variant, a, b) == (-va) % p
+            if 2 * A <= 7:
+                assert hosttest.fe9_op(fid, 10, variant, a, b) == 2 * va % p
+            assert hosttest.fe9_op(fid, 6, variant, a, b) == va % p
+            assert hosttest.fe9_op(fid, 8, variant, a, b) < U
+            assert hosttest.fe9_op(fid, 7, variant, a, b) == (1 if va % p == 0 else 0)
+    # zero tests on exact multiples of p, written with loose limbs; and literal zero
+    for j in (0, 1, 2, 5, 31, 33, 64, 100, 200):
+        l = limbs_of(j * p) if j * p < (1 << 261) else None
+        if l is None:
+            hi = (j * p) >> (29 * 8)
+            if hi >= 7 * U:
+                continue
+            l = limbs_of(j * p)[:8] + [hi]
+        assert val(l) == j * p
+        assert hosttest.fe9_op(fid, 7, 71, l, [0] * 9) == 1
+        l2 = list(l)
+        l2[3] ^= 1
+        assert hosttest.fe9_op(fid, 7, 71, l2, [0] * 9) == 0
+    # canonicalisation edge values and inversion
+    for x in (0, 1, 2, p - 1, p, p + 1, 2 * p - 1, 2 * p, (1 << 256) - 1, (1 << 256), (1 << 261) - 1):
+        assert hosttest.fe9_op(fid, 6, 11, limbs_of(x), [0] * 9) == x % p
+    for x in (1, 2, 3, p - 1, p - 2, rng.rndBelow(p), rng.rndBelow(p), 0):
+        assert hosttest.fe9_op(fid, 5, 11, limbs_of(x), [0] * 9) == (pow(x, -1, p) if x else 0)

@@ -76,6 +76,35 @@ def field29(name, p, n, extra=None):
     return s
 
 
+def field9(name, p, extra=None):
+    """Constants of the carry-free radix-2^29 form of a 256-bit special prime (fe9.hpp): 9 limbs, plain
+    residues, 2^261 folded as C = C0 + C1*2^29; BIAS[K] = a multiple of p whose limbs are all >= K*U
+    (U = 2^29 + 2^19, the limb unit of the bound types) for subtraction without borrows."""
+    M = (1 << 29) - 1
+    U = (1 << 29) + (1 << 19)
+    C = (1 << 261) % p
+    c0, c1 = C & M, C >> 29
+    assert c0 < (1 << 15) and c1 < (1 << 10)
+    s = "struct %s {\n" % name
+    s += arr29("P", p, 9)
+    s += "  static constexpr uint32_t C0 = %du, C1 = %du;  // 2^261 mod p = C0 + C1 * 2^29\n" % (c0, c1)
+    s += "  static constexpr uint32_t PINV = 0x%08xu;  // p^-1 mod 2^29\n" % pow(p, -1, 1 << 29)
+    s += "  static constexpr int JMAX = %d;  // a value with limbs < B*U is below JMAX*B*p\n" % (
+        (U * sum(1 << (29 * i) for i in range(9)) + p - 1) // p)
+    s += "  static constexpr uint32_t BIAS[8][9] = {\n"
+    for k in range(8):
+        base = sum((k * U) << (29 * i) for i in range(9))
+        t = (-base) % p
+        lim = [k * U + ((t >> (29 * i)) & M) for i in range(9)]
+        assert sum(l << (29 * i) for i, l in enumerate(lim)) % p == 0 and all(k * U <= l < (k + 1) * U for l in lim)
+        s += "    {%s},\n" % ", ".join("0x%08xu" % l for l in lim)
+    s += "  };\n"
+    for k, v in (extra or {}).items():
+        s += arr29(k, v % p, 9)
+    s += "};\n\n"
+    return s
+
+
 def main():
     kp = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F
     kn = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
@@ -88,6 +117,8 @@ def main():
     out += field("ParamsSecpP", kp, 8, {"BETA": beta, "B3": 21}, fold=(977, 1, 1))
     out += field("ParamsEdP", ep, 8, {"D": ed, "D2": 2 * ed % ep, "SQRT_M1": sqrtm1}, fold=(38, 0, 2))
     out += field("ParamsBlsP", bp, 12, {})
+    out += field9("Fe9SecpPR", kp, {"BETA": beta})
+    out += field9("Fe9EdPR", ep, {"D": ed, "D2": 2 * ed % ep, "SQRT_M1": sqrtm1})
     g1_beta = 0x5F19672FDF76CE51BA69C6076A0F77EADDB3A93BE6F89688DE17D813620A00022E01FFFFFFFEFFFE
     # G2 psi endomorphism coefficients (src/abstract/tower.ts:240-241 with base 1/(u+1),
     # src/bls12-381.ts:283): PSI_X = base^((p-1)/3), PSI_Y = base^((p-1)/2) in Fp2 = Fp[u]/(u^2+1)
