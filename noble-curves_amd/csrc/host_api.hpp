@@ -9,6 +9,9 @@ namespace ncg {
 hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
                          int n, uint32_t* jac_tmp, hipStream_t st);
 size_t mul_var_tmp_bytes(int curve, int n);
+// A/B variant of the secp256k1 kernel with the field multiply inlined (mulvar_inl.hip); minw = waves/SIMD requested
+hipError_t mul_var_secp_inline(int minw, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
+                               uint32_t* jac_tmp, hipStream_t st);
 // projective (X, Y, Z) wire points -> affine wire points, x = X/Z, y = Y/Z (normalizeZ)
 hipError_t normalize_batch(int curve, const uint32_t* proj_wire, uint32_t* out_wire, uint8_t* out_inf, int n,
                            hipStream_t st);

@@ -33,27 +33,6 @@ static hipError_t launch_mul_var(const uint32_t* pts, const uint32_t* scalars, u
   return hipGetLastError();
 }
 
-// Table in device memory (k_mul_var_gtab): the table lives behind the Jacobian scratch in `jac_tmp`
-// (mul_var_tmp_bytes accounts for both).
-template <class C, int W>
-static size_t gtab_words_per_item() { return (size_t)MulVarCfg<C, W>::TS * 3 * MulVarCfg<C, W>::TW; }
-static size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
-
-template <class C, int W, int MINW, int K = 8>
-static hipError_t launch_mul_var_gtab(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
-                                      int n, uint32_t* jac_tmp, hipStream_t st) {
-  if (n <= 0) return hipSuccess;
-  using Cfg = MulVarCfg<C, W>;
-  constexpr int LS = LaneShift<C>::value;
-  uint32_t* gtab = jac_tmp + pad64(n) * 3 * Cfg::FW;
-  const unsigned blocks = (unsigned)((((size_t)n << LS) + 63) / 64);
-  hipLaunchKernelGGL((k_mul_var_gtab<C, W, MINW, true>), dim3(blocks), dim3(64), 0, st, pts, scalars, jac_tmp, out_inf,
-                     gtab, n);
-  int threads = ((n + K - 1) / K) << LS;
-  hipLaunchKernelGGL((k_jac_batch_affine<C, K>), dim3((threads + 255) / 256), dim3(256), 0, st, jac_tmp, out, out_inf, n);
-  return hipGetLastError();
-}
-
 // ---- pairwise addition out[i] = A[i] + B[i] (or A[i] - B[i]) ---------------------------------------
 // Point.add / subtract of the reference for a batch of pairs (src/abstract/weierstrass.ts:834-891 incl.
 // the P = Q, P = -Q and ZERO cases; src/abstract/edwards.ts:526-545), and the combining step of
@@ -160,8 +139,12 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
     // NCG_SECP_W / NCG_G1_W / NCG_G2_W select the alternatives: 1WM = table in device memory with
     // W-bit windows and M waves/SIMD requested, WM = table in LDS).
     case CURVE_SECP256K1: {
-      static const int w = [] { const char* e = std::getenv("NCG_SECP_W"); return e ? std::atoi(e) : 154; }();
+      static const int w = [] { const char* e = std::getenv("NCG_SECP_W"); return e ? std::atoi(e) : 243; }();
       if (jac_tmp && w == 154) return launch_mul_var_gtab<CurveSecp, 5, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (jac_tmp && w == 153) return launch_mul_var_gtab<CurveSecp, 5, 3>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (jac_tmp && w == 152) return launch_mul_var_gtab<CurveSecp, 5, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (jac_tmp && w >= 252 && w <= 254) return mul_var_secp_inline(w - 250, pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (jac_tmp && w >= 243 && w <= 244) return mul_var_secp_inline(w - 230, pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 144) return launch_mul_var_gtab<CurveSecp, 4, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 133) return launch_mul_var_gtab<CurveSecp, 3, 3>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (w == 42) return launch_mul_var<CurveSecp, 4, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);

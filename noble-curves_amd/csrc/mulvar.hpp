@@ -140,7 +140,9 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     };
     FieldIO<F>::store_strided(tab, stride, T.X);
     FieldIO<F>::store_strided(tab + TW * stride, stride, T.Y);
-#pragma unroll
+    // with the Z-ratios in memory nothing here indexes a register array: keep the loops rolled (the
+    // unrolled build is 15 mixed additions of straight-line code in front of the ladder)
+#pragma unroll(ZR_IN_TAB ? 1 : TS)
     for (int j = 1; j < TS; j++) {
       F zj;
       T = jac_madd_zr(T, Dp, zj, degenerate);
@@ -150,7 +152,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     }
     // bring every entry to the last entry's Z
     F s = F::one();
-#pragma unroll
+#pragma unroll(ZR_IN_TAB ? 1 : TS)
     for (int j = TS - 2; j >= 0; j--) {
       if (j == TS - 2) s = zr_get(j + 1);
       else s = s * zr_get(j + 1);
@@ -182,7 +184,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
   Jac<F> R = Jac<F>::inf();
   for (int i = 0; i < M; i++) {
     if (i > 0) {
-#pragma unroll
+#pragma unroll(NCG_MUL_INLINE ? 1 : W)
       for (int d = 0; d < W; d++) R = jac_dbl(R);
     }
     {
@@ -348,6 +350,28 @@ k_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ scalars
   const int src = active ? idx : n - 1;  // idle lanes redo the last item, stores masked
   mul_var_lane<C, W, JAC_OUT>(pts + (size_t)src * 2 * WW, scalars + (size_t)src * 8, out + (size_t)src * OUTW,
                               out_inf + src, active, lds + lane, 64);
+}
+
+// ---- launchers shared by the translation units that instantiate these kernels (host side)
+// Table in device memory (k_mul_var_gtab): the table lives behind the Jacobian scratch in `jac_tmp`
+// (mul_var_tmp_bytes accounts for both).
+template <class C, int W>
+inline size_t gtab_words_per_item() { return (size_t)MulVarCfg<C, W>::TS * 3 * MulVarCfg<C, W>::TW; }
+inline size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
+
+template <class C, int W, int MINW, int K = 8>
+inline hipError_t launch_mul_var_gtab(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf,
+                                      int n, uint32_t* jac_tmp, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  using Cfg = MulVarCfg<C, W>;
+  constexpr int LS = LaneShift<C>::value;
+  uint32_t* gtab = jac_tmp + pad64(n) * 3 * Cfg::FW;
+  const unsigned blocks = (unsigned)((((size_t)n << LS) + 63) / 64);
+  hipLaunchKernelGGL((k_mul_var_gtab<C, W, MINW, true>), dim3(blocks), dim3(64), 0, st, pts, scalars, jac_tmp, out_inf,
+                     gtab, n);
+  int threads = ((n + K - 1) / K) << LS;
+  hipLaunchKernelGGL((k_jac_batch_affine<C, K>), dim3((threads + 255) / 256), dim3(256), 0, st, jac_tmp, out, out_inf, n);
+  return hipGetLastError();
 }
 
 }  // namespace ncg
