@@ -54,12 +54,13 @@ enum ncg_status {
   NCG_ERR_HIP = -2,
   NCG_ERR_NO_DEVICE = -3,
   NCG_ERR_UNSUPPORTED = -4,
-  NCG_ERR_NOMEM = -5
+  NCG_ERR_NOMEM = -5,
+  NCG_ERR_RCCL = -6
 };
 
 /* ---- context ------------------------------------------------------------------------- */
-/* One context per process per GPU (one process per GPU is the deployment model; multi-GPU
- * composition is done by the host layer over RCCL, see noble-curves_amd/distributed.py). */
+/* One context per GPU.  Multi-GPU: see the "multi-GPU MSM" section below (per-process
+ * communicators for one-process-per-GPU launches, ncg_multi for one process driving several GPUs). */
 int ncg_init(int device_id, ncg_ctx** out_ctx);
 void ncg_destroy(ncg_ctx* ctx);
 const char* ncg_last_error(ncg_ctx* ctx); /* ctx may be NULL: last process-wide error */
@@ -194,6 +195,47 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
             void* out_affine, uint8_t* out_is_inf);
 int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev,
                 const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream);
+
+/* ---- multi-GPU MSM ---------------------------------------------------------------------
+ * pippenger is a sum over points (src/abstract/curve.ts:863-905; its last step is the chain
+ * `sum = sum.add(resI)` :895-902), so the points are sharded: each GPU runs the single-GPU pipeline on
+ * its slice up to the grouped window sums (~18 KB for G1), ONE ncclAllGather over xGMI exchanges those,
+ * a one-wave kernel adds the G arrays (G - 1 additions per lane) and the usual finish follows.  No
+ * bucket-sized data moves and nothing but the final point reaches the host.  All four curves
+ * (BASELINE configs[3] G1 and configs[4] G2).  SURVEY 8(b): "one RCCL communicator for the device
+ * set, all hidden behind the call"; RCCL (librccl.so) is loaded on first use.
+ *
+ * (1) One process per GPU (torch.distributed, MPI, bench.py): rank 0 calls ncg_comm_unique_id and
+ *     ships the 128 bytes to the other ranks by any means; every rank calls ncg_comm_init on its own
+ *     context (collective).  ncg_msm_sharded_dev is then a collective: every rank passes ITS points
+ *     (n_local of them, device memory) and n_max = the largest n_local of any rank (it fixes the
+ *     window plan, which must agree on all ranks; pass 0 if all ranks hold n_local points); every
+ *     rank receives the same sum in host memory.  Without a communicator it is ncg_msm_dev. */
+#define NCG_COMM_ID_BYTES 128
+int ncg_comm_unique_id(uint8_t* out_id128);
+int ncg_comm_init(ncg_ctx* ctx, int nranks, int rank, const uint8_t* id128);
+int ncg_comm_destroy(ncg_ctx* ctx); /* also done by ncg_destroy */
+int ncg_comm_size(ncg_ctx* ctx);
+int ncg_comm_rank(ncg_ctx* ctx);
+int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max,
+                        const void* points_affine_dev, const void* scalars_dev, void* out_affine,
+                        uint8_t* out_is_inf, void* stream);
+/* The sharded pipeline on ONE GPU (self-check, shard-plan A/B): the points are cut into `parts` slices,
+ * each runs the per-shard phase in turn, the slices' window sums go through the multi-GPU combine kernel
+ * and finish - everything of ncg_msm_sharded_dev except the all-gather. */
+int ncg_msm_split_dev(ncg_ctx* ctx, int curve, size_t n, int parts, const void* points_affine_dev,
+                      const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream);
+/* (2) One process, several GPUs (the shape of the N-API addon: Node runs one thread).  ncg_multi_init
+ *     opens a context per device and one communicator over the set (ncclCommInitAll); ncg_msm_multi
+ *     takes HOST arrays like ncg_msm, uploads slice g to device g, and returns the sum. */
+typedef struct ncg_multi ncg_multi;
+int ncg_multi_init(const int* device_ids, int n_dev, ncg_multi** out);
+void ncg_multi_destroy(ncg_multi* m);
+int ncg_multi_devices(ncg_multi* m);
+ncg_ctx* ncg_multi_ctx(ncg_multi* m, int i); /* context of device i (for the single-GPU entry points) */
+const char* ncg_multi_last_error(ncg_multi* m);
+int ncg_msm_multi(ncg_multi* m, int curve, size_t n, const void* points_affine, const void* scalars,
+                  void* out_affine, uint8_t* out_is_inf);
 
 /* ---- ed25519 batch signature verification -------------------------------------------------
  * out_ok[i] = eddsa.verify(sig[i], msg[i], pk[i], {zip215}) of the reference

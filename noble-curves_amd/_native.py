@@ -73,6 +73,12 @@ def load_library():
             if fn is not None:
                 fn.argtypes = args
                 fn.restype = i32
+        lib.ncg_multi_destroy.argtypes = [vp]
+        lib.ncg_multi_destroy.restype = None
+        lib.ncg_multi_ctx.argtypes = [vp, i32]
+        lib.ncg_multi_ctx.restype = vp
+        lib.ncg_multi_last_error.argtypes = [vp]
+        lib.ncg_multi_last_error.restype = ctypes.c_char_p
         _lib = lib
         return lib
 
@@ -98,7 +104,18 @@ _OPTIONAL_PROTOS = {
     "ncg_mul_base_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_ed25519_verify_batch": [_vp, _sz, _vp, _vp, _vp, _i32, _vp],
     "ncg_ed25519_verify_batch_dev": [_vp, _sz, _vp, _vp, _vp, _i32, _vp, _vp],
+    "ncg_comm_unique_id": [_vp],
+    "ncg_comm_init": [_vp, _i32, _i32, _vp],
+    "ncg_comm_destroy": [_vp],
+    "ncg_comm_size": [_vp],
+    "ncg_comm_rank": [_vp],
+    "ncg_msm_sharded_dev": [_vp, _i32, _sz, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
+    "ncg_msm_split_dev": [_vp, _i32, _sz, _i32, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
+    "ncg_multi_init": [ctypes.POINTER(_i32), _i32, ctypes.POINTER(_vp)],
+    "ncg_multi_devices": [_vp],
+    "ncg_msm_multi": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
 }
+COMM_ID_BYTES = 128
 
 
 # ---------------------------------------------------------------- wire helpers (numpy, no torch)
@@ -275,6 +292,45 @@ class Engine:
                                          stream))
         return out, bool(inf.value)
 
+    # ---- multi-GPU MSM, one process per GPU (include/ncg.h "multi-GPU MSM" (1)) ------------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL unique id (rank 0 creates it and ships it to the other ranks)."""
+        lib = load_library()
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+        rc = lib.ncg_comm_unique_id(buf)
+        if rc != 0:
+            raise NativeError((lib.ncg_last_error(None) or b"").decode() or "noble-gpu: ncg_comm_unique_id failed")
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        """Collective: joins this context to the communicator named by `unique_id`."""
+        uid = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._check(self.lib.ncg_comm_init(self.h, nranks, rank, uid))
+
+    def comm_size(self):
+        return self.lib.ncg_comm_size(self.h)
+
+    def msm_sharded_dev(self, curve, n_local, d_points, d_scalars, stream=None, n_max=0):
+        """Collective MSM over the union of all ranks' device-resident shards (RCCL all-gather of the
+        grouped window sums + on-device add); every rank gets (affine wire bytes [PB], is_inf)."""
+        pb = POINT_BYTES[curve]
+        out = np.zeros((pb,), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self._check(self.lib.ncg_msm_sharded_dev(self.h, curve, n_local, n_max, d_points, d_scalars, out.ctypes.data,
+                                                 ctypes.byref(inf), stream))
+        return out, bool(inf.value)
+
+    def msm_split_dev(self, curve, n, parts, d_points, d_scalars, stream=None):
+        """The sharded pipeline on this one GPU: `parts` slices, per-shard phase each, multi-GPU combine
+        kernel, finish (ncg_msm_split_dev)."""
+        pb = POINT_BYTES[curve]
+        out = np.zeros((pb,), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self._check(self.lib.ncg_msm_split_dev(self.h, curve, n, parts, d_points, d_scalars, out.ctypes.data,
+                                               ctypes.byref(inf), stream))
+        return out, bool(inf.value)
+
     # ---- ed25519 batch verify --------------------------------------------------------------------
     def ed25519_verify_batch(self, sigs, pks, ks, zip215=True):
         """sigs uint8 [n,64], pks [n,32], ks [n,32] (challenge scalars, LE) -> bool array [n]."""
@@ -338,6 +394,49 @@ class Engine:
         ms = ctypes.c_float()
         self._check(self.lib.ncg_ubench(self.h, kind, blocks, threads, iters, ctypes.byref(ms)))
         return ms.value
+
+
+class MultiEngine:
+    """One process driving several GPUs (include/ncg.h "multi-GPU MSM" (2)): a context per device and one
+    RCCL communicator over the set; `msm` shards host arrays over the devices."""
+
+    def __init__(self, device_ids):
+        self.lib = load_library()
+        ids = (ctypes.c_int * len(device_ids))(*device_ids)
+        h = ctypes.c_void_p()
+        rc = self.lib.ncg_multi_init(ids, len(device_ids), ctypes.byref(h))
+        if rc != 0:
+            raise NativeError((self.lib.ncg_last_error(None) or b"").decode() or "noble-gpu: ncg_multi_init failed (%d)" % rc)
+        self.h = h
+
+    def devices(self):
+        return self.lib.ncg_multi_devices(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ncg_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def msm(self, curve, points, scalars):
+        pb = POINT_BYTES[curve]
+        points = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, pb)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        n = points.shape[0]
+        if scalars.shape[0] != n:
+            raise ValueError("arrays of points and scalars must have equal length")
+        out = np.zeros((pb,), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        rc = self.lib.ncg_msm_multi(self.h, curve, n, points.ctypes.data if n else None,
+                                    scalars.ctypes.data if n else None, out.ctypes.data, ctypes.byref(inf))
+        if rc != 0:
+            raise NativeError((self.lib.ncg_multi_last_error(self.h) or b"").decode() or "noble-gpu: msm_multi failed")
+        return out, bool(inf.value)
 
 
 _engines = {}

@@ -18,30 +18,9 @@ std::mutex g_err_mu;
 std::string g_last_error;
 }  // namespace
 
-struct ncg_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::string last_error;
-  // reusable device scratch for the host-pointer entry points
-  void* scratch = nullptr;
-  size_t scratch_bytes = 0;
-  void* mul_ws = nullptr;  // batch-multiply Jacobian scratch (device)
-  size_t mul_ws_bytes = 0;
-  void* msm_ws = nullptr;  // MSM workspace (device)
-  size_t msm_ws_bytes = 0;
-  uint32_t* ed_btab = nullptr;  // ed25519 base-point table (device)
-  uint32_t* base_tab[4] = {nullptr, nullptr, nullptr, nullptr};  // fixed-base tables per curve (device)
-  uint32_t* ub_in = nullptr;
-  uint32_t* ub_out = nullptr;
-  size_t ub_out_words = 0;
-  // NTT: one twiddle table per transform size (device), keyed by the root it was built from
-  uint32_t* ntt_tab[NCG_NTT_MAX_LOG2N + 1] = {};
-  uint32_t ntt_omega[NCG_NTT_MAX_LOG2N + 1][8] = {};
-  void* ntt_ws = nullptr;
-  size_t ntt_ws_bytes = 0;
-};
+#include "ctx.hpp"
 
-static int set_err(ncg_ctx* ctx, int code, const char* fmt, ...) {
+int ncg_set_err(ncg_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -54,14 +33,6 @@ static int set_err(ncg_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) ctx->last_error = buf;
   return code;
 }
-
-#define NCG_HIP(ctx, expr)                                                                   \
-  do {                                                                                       \
-    hipError_t _e = (expr);                                                                  \
-    if (_e != hipSuccess)                                                                    \
-      return set_err(ctx, NCG_ERR_HIP, "noble-gpu: HIP error %d (%s) at %s:%d", (int)_e,    \
-                     hipGetErrorString(_e), __FILE__, __LINE__);                             \
-  } while (0)
 
 // Host <-> device copies of the host-pointer entry points.  Pageable user buffers move at a few
 // GB/s through the runtime's staging path; registering (pinning) a large buffer for the duration of
@@ -100,6 +71,23 @@ static int ensure_scratch(ncg_ctx* ctx, size_t bytes) {
   hipError_t e = hipMalloc(&ctx->scratch, want);
   if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
   ctx->scratch_bytes = want;
+  return NCG_OK;
+}
+
+// window plan for an n-point MSM (c_override > 0 fixes the window width) and a workspace big enough for it
+int ncg_msm_plan_ws(ncg_ctx* ctx, int curve, size_t n, int c_override, ncg::MsmPlan* pl) {
+  if (ncg::msm_make_plan(curve, (int)n, c_override, pl) != 0)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+  size_t need = ncg::msm_workspace_bytes(curve, *pl);
+  if (ctx->msm_ws_bytes < need) {
+    if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
+    ctx->msm_ws = nullptr;
+    ctx->msm_ws_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->msm_ws, need);
+    if (e != hipSuccess)
+      return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: msm workspace hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    ctx->msm_ws_bytes = need;
+  }
   return NCG_OK;
 }
 
@@ -156,6 +144,8 @@ void ncg_destroy(ncg_ctx* ctx) {
   for (int i = 0; i <= NCG_NTT_MAX_LOG2N; i++)
     if (ctx->ntt_tab[i]) (void)hipFree(ctx->ntt_tab[i]);
   if (ctx->ntt_ws) (void)hipFree(ctx->ntt_ws);
+  (void)ncg_comm_destroy(ctx);
+  if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -369,18 +359,8 @@ int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev
   if (!points_affine_dev || !scalars_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   ncg::MsmPlan pl;
-  if (ncg::msm_make_plan(curve, (int)n, 0, &pl) != 0)
-    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
-  size_t need = ncg::msm_workspace_bytes(curve, pl);
-  if (ctx->msm_ws_bytes < need) {
-    if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
-    ctx->msm_ws = nullptr;
-    ctx->msm_ws_bytes = 0;
-    hipError_t e = hipMalloc(&ctx->msm_ws, need);
-    if (e != hipSuccess)
-      return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: msm workspace hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
-    ctx->msm_ws_bytes = need;
-  }
+  int prc = ncg_msm_plan_ws(ctx, curve, n, 0, &pl);
+  if (prc) return prc;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   NCG_HIP(ctx, ncg::msm_run(curve, pl, (const uint32_t*)points_affine_dev, (const uint32_t*)scalars_dev, ctx->msm_ws,
                             (uint32_t*)out_affine, &inf_local, st));

@@ -57,6 +57,19 @@ size_t msm_workspace_bytes(int curve, const MsmPlan& pl);
 hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
                    uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st);
 
+// The same in two phases, for the multi-GPU path: msm_device_phase leaves the grouped window sums
+// (msm_fin_words(curve, pl) words = npoints accumulators of msm_acc_words(curve) words) in the workspace
+// and returns their device address; msm_sum_partials adds nparts such arrays element by element;
+// msm_finish brings one array to the host and finishes (synchronises `st`).
+hipError_t msm_device_phase(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
+                            const uint32_t** d_fin, hipStream_t st);
+hipError_t msm_finish(int curve, const MsmPlan& pl, const uint32_t* d_fin, uint32_t* out_affine_host,
+                      uint8_t* out_inf_host, hipStream_t st);
+hipError_t msm_sum_partials(int curve, const uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
+                            hipStream_t st);
+size_t msm_fin_words(int curve, const MsmPlan& pl);
+size_t msm_acc_words(int curve);
+
 // ed25519 batch verify (ed25519.hip).  btab: device copy of the table built by ed25519_build_base_table.
 constexpr int ED25519_BTAB_WORDS = 128 * 24;  // [1,3,..,255]B, affine Niels
 void ed25519_build_base_table(uint32_t* out_words);

@@ -333,6 +333,23 @@ __global__ void __launch_bounds__(256, TailMinWaves<C>::value) k_msm_group_pendi
   G::acc_store(out + ((size_t)j * nwin + w) * XW, acc);
 }
 
+// ------------------------------------------------------------------ 5c. multi-GPU combine
+// in: [nparts][npoints] accumulators (the grouped window sums of nparts GPUs, all-gathered);
+// out[t] = sum_r in[r][t] - the reference's final `sum.add(resI)` chain over disjoint point ranges
+// (src/abstract/curve.ts:895-902 is linear in the points, so partial MSMs add up term by term).
+template <class C>
+__global__ void __launch_bounds__(64, TailMinWaves<C>::value) k_msm_sum_partials(const uint32_t* __restrict__ in,
+                                                                                 uint32_t* __restrict__ out, int nparts,
+                                                                                 int npoints) {
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
+  if (t >= npoints) return;
+  typename G::Acc acc = G::acc_load(in + (size_t)t * XW);
+  for (int r = 1; r < nparts; r++) acc = G::add(acc, G::acc_load(in + ((size_t)r * npoints + t) * XW));
+  G::acc_store(out + (size_t)t * XW, acc);
+}
+
 // ------------------------------------------------------------------ planning
 static void mp_set_bit(uint32_t* a, int bit) { a[bit >> 5] |= 1u << (bit & 31); }
 
@@ -494,9 +511,11 @@ static void msm_host_finish(const std::vector<uint32_t>& fin, const MsmPlan& pl,
   G::to_affine_wire(acc, out_affine, out_inf);
 }
 
+// Device phase: everything up to the grouped window sums (ng x nwin accumulators, device memory,
+// inside the workspace).  Asynchronous on `st`.
 template <class C>
-static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                            uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st) {
+static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
+                               const uint32_t** d_fin, hipStream_t st) {
   using G = MsmGroup<C>;
   using D = typename DeviceCurve<C>::type;  // kernels: lane-paired form for G2
   constexpr int LS = LaneShift<D>::value;
@@ -571,8 +590,24 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
                        narr, pl.nwin, MSM_GROUP, ng);
     cur = red[flip];
   }
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  *d_fin = cur;
+  return hipGetLastError();
+}
+
+template <class C>
+static size_t msm_fin_words_t(const MsmPlan& pl) {
+  return (size_t)msm_ngroups(pl.c) * pl.nwin * MsmGroup<C>::ACC_WORDS;
+}
+
+// Finish: the grouped window sums come to the host (one small copy), Horner, canonical affine output.
+// Synchronises `st`.
+template <class C>
+static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t* out_affine_host, uint8_t* out_inf_host,
+                               hipStream_t st) {
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
+  const int ng = msm_ngroups(pl.c);
+  hipError_t e;
   // the surviving points land in a small pinned buffer (one per thread, reused): a pageable target
   // would go through the runtime's staging copy
   const size_t fin_words = (size_t)ng * pl.nwin * XW;
@@ -601,6 +636,71 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
             std::chrono::duration<double, std::micro>(t1 - t0).count(), pl.c, pl.nwin);
   }
   return hipSuccess;
+}
+
+template <class C>
+static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
+                            uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st) {
+  const uint32_t* d_fin = nullptr;
+  hipError_t e = msm_device_t<C>(pl, d_pts, d_scalars, ws, &d_fin, st);
+  if (e != hipSuccess) return e;
+  return msm_finish_t<C>(pl, d_fin, out_affine_host, out_inf_host, st);
+}
+
+template <class C>
+static hipError_t msm_sum_partials_t(const uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
+                                     hipStream_t st) {
+  using D = typename DeviceCurve<C>::type;
+  constexpr int LS = LaneShift<D>::value;
+  hipLaunchKernelGGL(k_msm_sum_partials<D>, dim3((unsigned)(((npoints << LS) + 63) / 64)), dim3(64), 0, st, d_gathered,
+                     d_out, nparts, (int)npoints);
+  return hipGetLastError();
+}
+
+#define NCG_MSM_DISPATCH(curve, CALL)                       \
+  switch (curve) {                                          \
+    case CURVE_SECP256K1: return CALL(CurveSecp);           \
+    case CURVE_BLS12_381_G1: return CALL(CurveG1);          \
+    case CURVE_BLS12_381_G2: return CALL(CurveG2);          \
+    case CURVE_ED25519: return CALL(CurveEd);               \
+    default: return hipErrorInvalidValue;                   \
+  }
+
+hipError_t msm_device_phase(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
+                            const uint32_t** d_fin, hipStream_t st) {
+#define CALL(C) msm_device_t<C>(pl, d_pts, d_scalars, ws, d_fin, st)
+  NCG_MSM_DISPATCH(curve, CALL)
+#undef CALL
+}
+hipError_t msm_finish(int curve, const MsmPlan& pl, const uint32_t* d_fin, uint32_t* out_affine_host,
+                      uint8_t* out_inf_host, hipStream_t st) {
+#define CALL(C) msm_finish_t<C>(pl, d_fin, out_affine_host, out_inf_host, st)
+  NCG_MSM_DISPATCH(curve, CALL)
+#undef CALL
+}
+hipError_t msm_sum_partials(int curve, const uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
+                            hipStream_t st) {
+#define CALL(C) msm_sum_partials_t<C>(d_gathered, nparts, npoints, d_out, st)
+  NCG_MSM_DISPATCH(curve, CALL)
+#undef CALL
+}
+size_t msm_fin_words(int curve, const MsmPlan& pl) {
+  switch (curve) {
+    case CURVE_SECP256K1: return msm_fin_words_t<CurveSecp>(pl);
+    case CURVE_BLS12_381_G1: return msm_fin_words_t<CurveG1>(pl);
+    case CURVE_BLS12_381_G2: return msm_fin_words_t<CurveG2>(pl);
+    case CURVE_ED25519: return msm_fin_words_t<CurveEd>(pl);
+    default: return 0;
+  }
+}
+size_t msm_acc_words(int curve) {
+  switch (curve) {
+    case CURVE_SECP256K1: return MsmGroup<CurveSecp>::ACC_WORDS;
+    case CURVE_BLS12_381_G1: return MsmGroup<CurveG1>::ACC_WORDS;
+    case CURVE_BLS12_381_G2: return MsmGroup<CurveG2>::ACC_WORDS;
+    case CURVE_ED25519: return MsmGroup<CurveEd>::ACC_WORDS;
+    default: return 0;
+  }
 }
 
 size_t msm_workspace_bytes(int curve, const MsmPlan& pl) {

@@ -1,14 +1,16 @@
-"""Multi-GPU composition of the hot path: one process per GPU, torch.distributed (backend
-"nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU unit tests).
+"""Multi-GPU composition of the hot path: one process per GPU, launched by torch.distributed.
 
 * Batch scalar multiplication / batch verification are embarrassingly parallel: shard by index
   (`shard_range`), no data-path collective.
-* MSM is a sum of independent terms: every rank runs the full single-GPU pipeline
-  on its shard of (points, scalars), then ONE all-gather of the per-rank partial sums
-  (one affine point + infinity flag: 97-193 bytes per rank) and a combine step - the
-  partials are summed by the same MSM path with unit scalars, so the combine also runs in the
-  HIP kernels.  RCCL cannot reduce with a group law, hence all-gather + local add rather than
-  all-reduce.  The exchange is latency-bound (KBs over xGMI); no bucket-sized traffic moves.
+* MSM is a sum over points (src/abstract/curve.ts:863-905): every rank runs the single-GPU
+  pipeline on its shard up to the grouped window sums; the exchange and the combine happen INSIDE the
+  C ABI (`ncg_msm_sharded_dev`, csrc/comm.hip): one ncclAllGather of ~18 KB per rank on device buffers
+  over xGMI, a one-wave kernel adding the per-rank arrays, one finish.  RCCL cannot reduce with a group
+  law, hence all-gather + local add.  This module only boot-straps the communicator: rank 0 makes the
+  RCCL unique id and torch.distributed broadcasts its 128 bytes.
+* Dry runs without RCCL (backend "gloo": CPU unit tests, or several ranks sharing one GPU): the same
+  per-rank pipeline, then torch.distributed all-gathers the per-rank partial POINTS and the engine adds
+  them pairwise (`add_pairs_batch`).
 """
 import numpy as np
 
@@ -27,8 +29,26 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
+def init_comm(engine, device=None):
+    """Collective: give `engine` an RCCL communicator spanning the torch.distributed world (backend nccl).
+    Returns True if the native multi-GPU path is active, False for single-rank / gloo dry runs."""
+    import torch
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1 or dist.get_backend() != "nccl":
+        return False
+    if engine.comm_size() == dist.get_world_size():
+        return True
+    rank, world = dist.get_rank(), dist.get_world_size()
+    uid = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).to(device)
+    dist.broadcast(uid, 0)
+    engine.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+    return True
+
+
 def all_gather_partials(partial_wire, is_inf, device=None):
-    """All-gather one (affine point bytes, infinity flag) per rank -> uint8 array [world, PB+1]."""
+    """(dry-run path) all-gather one (affine point bytes, infinity flag) per rank -> uint8 [world, PB+1]."""
     import torch
     dist = _dist()
     pb = partial_wire.shape[0]
@@ -46,27 +66,35 @@ def all_gather_partials(partial_wire, is_inf, device=None):
 
 
 def combine_partials(engine, curve, gathered):
-    """Sum of the per-rank partial points, through the engine's MSM with unit scalars."""
+    """(dry-run path) sum of the per-rank partial points by pairwise additions on the engine."""
     pb = POINT_BYTES[curve]
     pts = np.ascontiguousarray(gathered[:, :pb])
-    ones = np.zeros((pts.shape[0], 32), dtype=np.uint8)
-    ones[:, 0] = 1
-    return engine.msm(curve, pts, ones)
+    while pts.shape[0] > 1:
+        half = pts.shape[0] // 2
+        summed, _ = engine.add_pairs_batch(curve, pts[:half], pts[half:2 * half])
+        pts = np.concatenate([summed, pts[2 * half:]], axis=0)
+    out = np.ascontiguousarray(pts[0])
+    ident = np.zeros((pb,), np.uint8)
+    if pb == 64 and curve == 1:          # Edwards identity is (0, 1)
+        ident[32] = 1
+    return out, bool((out == ident).all())
 
 
-def msm_sharded(engine, curve, n_local, d_points, d_scalars, stream=None, device=None):
-    """MSM over the union of all ranks' shards.  `d_points` / `d_scalars` are this rank's
-    device-resident shard (raw pointers).  Every rank returns the same (affine bytes, is_inf)."""
-    part, part_inf = engine.msm_dev(curve, n_local, d_points, d_scalars, stream)
+def msm_sharded(engine, curve, n_local, d_points, d_scalars, stream=None, device=None, n_max=0):
+    """MSM over the union of all ranks' shards.  `d_points` / `d_scalars` are this rank's device-resident
+    shard (raw pointers).  Every rank returns the same (affine bytes, is_inf)."""
     dist = _dist()
     if dist is None or dist.get_world_size() == 1:
-        return part, part_inf
-    gathered = all_gather_partials(part, part_inf, device)
-    return combine_partials(engine, curve, gathered)
+        return engine.msm_dev(curve, n_local, d_points, d_scalars, stream)
+    if init_comm(engine, device):
+        return engine.msm_sharded_dev(curve, n_local, d_points, d_scalars, stream, n_max)
+    part, part_inf = engine.msm_dev(curve, n_local, d_points, d_scalars, stream)
+    return combine_partials(engine, curve, all_gather_partials(part, part_inf, device))
 
 
 def msm_sharded_host(engine, curve, points_wire, scalars_wire, device=None):
-    """Host-buffer variant: every rank holds the full arrays and takes its index shard."""
+    """Host-buffer variant: every rank holds the full arrays and takes its index shard (dry-run path:
+    partial points exchanged by torch.distributed)."""
     dist = _dist()
     world = dist.get_world_size() if dist else 1
     rank = dist.get_rank() if dist else 0
@@ -74,5 +102,4 @@ def msm_sharded_host(engine, curve, points_wire, scalars_wire, device=None):
     part, part_inf = engine.msm(curve, points_wire[lo:hi], scalars_wire[lo:hi])
     if world == 1:
         return part, part_inf
-    gathered = all_gather_partials(part, part_inf, device)
-    return combine_partials(engine, curve, gathered)
+    return combine_partials(engine, curve, all_gather_partials(part, part_inf, device))

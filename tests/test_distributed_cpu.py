@@ -1,7 +1,9 @@
-"""world_size-2 gloo test of the multi-GPU MSM composition (shard -> local MSM -> all-gather of
-partial sums -> combine).  The native engine needs a GPU, so the per-rank MSM is played by an
-oracle-backed stand-in with the same `msm` signature: this checks the sharding / collective /
-combine logic that the driver's 8-GPU run relies on, not the kernels."""
+"""world_size-2 gloo test of the multi-rank MSM glue (shard -> local MSM -> exchange -> combine) that runs
+without a GPU.  The native engine needs a GPU, so here the per-rank engine is an oracle-backed stand-in
+with the same `msm` / `add_pairs_batch` signatures: this checks shard_range, the collective and the
+combine order.  The NATIVE multi-rank paths are covered on the GPU box by tests/test_gpu_multi.py
+(2 ranks sharing the GPU over gloo with the real engine; the RCCL communicator path with one rank; the
+per-shard phase + combine kernel with 2-8 shards on one GPU)."""
 import os
 import socket
 import sys
@@ -25,6 +27,18 @@ class OracleEngine:
         r = C.pippenger(Pt, pts, sc)
         aff = r.toAffine()
         return np.frombuffer(affine_to_wire(curve, aff), dtype=np.uint8).copy(), r.is0()
+
+    def add_pairs_batch(self, curve, a, b, subtract=False):
+        from helpers import ORACLE_CURVE, affine_to_wire, wire_to_affine
+        Pt = ORACLE_CURVE[curve]
+        out = np.zeros_like(a)
+        inf = np.zeros((a.shape[0],), np.uint8)
+        for i in range(a.shape[0]):
+            p, q = Pt.fromAffine(wire_to_affine(curve, a[i])), Pt.fromAffine(wire_to_affine(curve, b[i]))
+            r = p.subtract(q) if subtract else p.add(q)
+            out[i] = np.frombuffer(affine_to_wire(curve, r.toAffine()), dtype=np.uint8)
+            inf[i] = r.is0()
+        return out, inf
 
 
 def _worker(rank, world, port, n, q):
