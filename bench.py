@@ -5,56 +5,186 @@
 
 Primary line (`value`): configs[1] - secp256k1 batch variable-base scalar multiplication
 (Point.multiplyUnsafe semantics, GLV), 2^20 (P_i, k_i) pairs per GPU, inputs resident in HBM.
-`extra.msm_g1`: configs[3] - bls12-381 G1 Pippenger MSM, 2^20 points per GPU (weak) with an
-RCCL all-gather of the per-GPU partial sums + a combine MSM; `extra.msm_g1_strong` (N > 1) is
-the same 2^20-point MSM split across the N GPUs.
+`extra.msm_g1`: configs[3] - bls12-381 G1 Pippenger MSM, 2^20 points per GPU (weak); for N > 1 the points
+are sharded and combined inside the C ABI (`ncg_msm_sharded_dev`: one RCCL all-gather of the grouped
+window sums + an on-device add); `extra.msm_g1_strong` is ONE 2^20-point MSM split over the N GPUs;
+`extra.msm_g2` / `msm_g2_strong` the same for configs[4] (G2, 2^18); `extra.ed25519_verify` configs[2]
+with the challenge hash on the device (and the kernel-only rate beside it); `extra.ntt_fr` SURVEY 8f row 3.
 
-A "step" is one pass of the hot path over the whole synthetic batch.  Every result is verified
-before any throughput is printed: sampled outputs against the CPU oracle's C restatement, plus
-full-size identities (sum of all outputs == (sum k_i (a+i b)) G through the MSM path; MSM ==
-(sum (a+i b) s_i) G, the construction of the reference's test/slow-curves.test.ts:185-252).
+A "step" is one pass of the hot path over the whole synthetic batch.  Every result is verified before
+any throughput is printed: sampled outputs against the CPU oracle's C restatement, plus full-size
+identities (sum of all outputs == (sum k_i (a+i b)) G through the MSM path; MSM == (sum (a+i b) s_i) G,
+the construction of the reference's test/slow-curves.test.ts:185-252).
+
+Roofline fields: `roofline.achieved/frac` = algorithmic bytes / event-timed kernel
+time vs 8 TB/s (the contract's definition; this path is bound by integer VALU issue, not HBM, so the
+fraction is small by nature - SURVEY 8d); `roofline.traffic` = HBM bytes per launch from rocprofv3 PMC
+passes, measured live in this run when rocprofv3 is usable (`traffic_source: "live"`), else read from the
+committed profile of the same command; `roofline.valu` = executed VALU work: wave-instructions from the
+SQ_INSTS_VALU counter and statically counted v_mad_u64_u32 per item, against the measured issue ceilings.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
-INT_MAC_PEAK = 256 * 4 * 16 * 2.4e9   # v_mad_u64_u32: 16 lanes/clk/SIMD (measured, profiles/r01_ubench*)
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 16 lanes/clk/SIMD at the nominal 2.4 GHz = 3.93e13 lane-ops/s
+MAD_PEAK = 3.08e13                         # v_mad_u64_u32 ceiling measured on MI355X (profiles/r01_ubench_instr_rates.json,
+                                           # profiles/r02_valu_rates.jsonl: ~2x the issue time of a plain 32-bit VALU op)
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+# FETCH_SIZE / WRITE_SIZE -> bytes, calibrated per access pattern with tools/pmc_calib on known byte counts
+# (profiles/r02_pmc.json "calibration"): item-major 64 B gathers count at face value, 16 B/lane coalesced
+# streams at half (MI355X_MICROARCH.md, HBM), writes at face value.
+FETCH_FACTOR = {"gather": 1.0, "stream": 2.0}
+KERNELS = {   # workload -> (kernel-name prefix in rocprofv3 output, FETCH access pattern)
+    "secp256k1": ("ncg::k_mul_var_gtab<ncg::CurveSecp", "gather"),
+    "msm_g1": ("ncg::k_msm_accum<ncg::CurveG1", "gather"),
+    "msm_g2": ("ncg::k_msm_accum<ncg::CurveG2P", "gather"),
+    "ed25519": ("ncg::k_ed25519_verify", "gather"),
+    "ntt": ("ncg::k_ntt_pass", "stream"),
+}
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE passes, gfx950 correction applied: profiles/r01_pmc_traffic.json), or None."""
+# ---------------------------------------------------------------------------- PMC (rocprofv3) plumbing
+def _pmc_committed():
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            ks = json.load(f)["kernels"]
-        for name, v in ks.items():
-            if name.startswith(kernel_prefix):
-                return v["hbm_bytes_per_launch_corrected"]
+        with open(PMC_PROFILE) as f:
+            return json.load(f)["kernels"]
     except (OSError, KeyError, ValueError):
-        pass
+        return {}
+
+
+def _pmc_lookup(kernels, prefix):
+    for name, v in kernels.items():
+        if name.startswith(prefix):
+            return v
     return None
 
 
-def pmc_traffic_ntt(bits):
-    """HBM bytes per 2^bits transform: sum over its k_ntt_pass launches (grid sizes of the pass plan)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            bg = json.load(f)["kernels"]["ncg::k_ntt_pass"]["by_grid"]
-        n = 1 << bits
-        grids = [n >> 1, n >> 1, n >> 2] if bits == 22 else None   # 6 + 6 stages on 2^T x 4 tiles (256 thr), 10 on 2^10
-        return sum(bg[str(g)]["hbm_bytes_per_launch_corrected"] for g in grids) if grids else None
-    except (OSError, KeyError, ValueError, TypeError):
+def pmc_live(workload, log2n, budget_s=420.0):
+    """Three rocprofv3 counter passes over a short child run of this script (counters alone with
+    --kernel-trace, as MI355X_MICROARCH.md prescribes).  Returns {kernel: {counter: avg per launch}} or None."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
         return None
+    try:
+        import pmc_summary
+    except ImportError:
+        return None
+    passes = [["SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]]
+    out = {}
+    t0 = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="ncg_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, ctrs in enumerate(passes):
+            left = budget_s - (time.perf_counter() - t0)
+            if left < 30:
+                return None
+            d = os.path.join(tmp, "p%d" % i)
+            cmd = [exe, "--pmc"] + ctrs + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                                          os.path.abspath(__file__), "--workload", workload, "--log2n", str(log2n), "--steps", "3",
+                                          "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc", "--quick-verify"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left)
+            if r.returncode != 0:
+                return None
+            counters, durs = pmc_summary.read_pass(d)
+            for k, cs in counters.items():
+                e = out.setdefault(k, {})
+                for c, vals in cs.items():
+                    e[c] = sum(vals) / len(vals)
+                if durs.get(k) and "SQ_INSTS_VALU" in cs:
+                    e["avg_ms_valu_pass"] = sum(durs[k]) / len(durs[k]) / 1e6
+        return out
+    except (subprocess.SubprocessError, OSError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+class Pmc:
+    """HBM traffic and executed-VALU figures per kernel: live counters if this run collected them, else the
+    committed profile (profiles/r02_pmc.json, same command, earlier box)."""
+
+    def __init__(self, live):
+        self.live = live
+        self.committed = _pmc_committed()
+
+    def _get(self, prefix):
+        if self.live:
+            v = _pmc_lookup(self.live, prefix)
+            if v:
+                return v, "live"
+        v = _pmc_lookup(self.committed, prefix)
+        return (v, "profiles/r02_pmc.json") if v else (None, None)
+
+    def traffic(self, workload, launches_per_unit=1):
+        prefix, pattern = KERNELS[workload]
+        v, src = self._get(prefix)
+        if not v or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            return None, None
+        b = (v["FETCH_SIZE"] * FETCH_FACTOR[pattern] + v["WRITE_SIZE"]) * 1024.0 * launches_per_unit
+        return int(b), src
+
+    def valu_insts(self, workload):
+        prefix, _ = KERNELS[workload]
+        v, src = self._get(prefix)
+        if not v or "SQ_INSTS_VALU" not in v:
+            return None, None
+        return v["SQ_INSTS_VALU"], src
+
+
+def valu_block(pmc, workload, kern_s, ref_mac, exec_mads, launches=1):
+    """roofline.valu: reference-equivalent work, executed multiplier work and executed VALU instructions."""
+    blk = {"ref_equiv_mac_per_s": ref_mac / kern_s, "ref_equiv_note": "limb-MACs of the reference's op sequence (SURVEY 8d), "
+           "not executed work", "executed_mad_per_s": exec_mads / kern_s, "mad_peak_per_s": MAD_PEAK,
+           "mad_frac": exec_mads / kern_s / MAD_PEAK,
+           "executed_mad_note": "v_mad_u64_u32 per item counted from the kernel's operation sequence (DESIGN.md section 5) "
+                                "x items; peak = measured v_mad_u64_u32 ceiling"}
+    insts, src = pmc.valu_insts(workload)
+    if insts:
+        lane_ops = insts * 64.0 * launches / kern_s
+        blk.update({"executed_valu_lane_ops_per_s": lane_ops, "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                    "valu_issue_frac": lane_ops / VALU_PEAK_LANE_OPS, "sq_insts_valu_per_launch": insts,
+                    "valu_source": src,
+                    "valu_issue_note": "SQ_INSTS_VALU x 64 lanes / kernel time vs 16 lanes/clk/SIMD at 2.4 GHz; plain 32-bit "
+                                       "ops issue faster than that (frac can pass 1), multiplies slower"})
+    return blk
+
+
+# ---- statically counted multiplier work (v_mad_u64_u32 per item); see DESIGN.md section 5 for the derivations
+FE9_M, FE9_S = 106, 70          # secp256k1 fe9.hpp: 81 products + 18 fold + 7 tail; 45 + 18 + 7
+FE29_M, FE29_S = 392, 301       # bls12-381 fp29.hpp: 196 + 196 Montgomery; 105 + 196
+
+
+def secp_mads_per_mult(W=4, K=16):
+    wins = (129 + W - 1) // W                                 # windows per 128-bit half
+    dbl, madd = (wins - 1) * W, 2 * wins + 1                   # +1: one parity fix-up on average
+    ts = 1 << (W - 1)
+    m = dbl * 3 + madd * 8 + (ts - 1) * 8 + (ts - 1) * 4 + wins + 6   # table build, rescale, beta, set-up
+    s = dbl * 4 + madd * 3 + (ts - 1) * 3 + (ts - 1) * 1 + 2
+    m += 6 + 15.0 / K                                          # batched affine conversion: chain + share of the inversion
+    s += 1 + 255.0 / K
+    return m * FE9_M + s * FE9_S
+
+
+def g1_msm_mads_per_point(nwin, n, nb):
+    accum = nwin * (8 * FE29_M + 2 * FE29_S)                   # one XYZZ mixed add per (point, window)
+    fold = nwin * 3.0 * nb * (12 * FE29_M + 2 * FE29_S) / n    # fix-up + log-depth fold, ~3 full adds per bucket
+    return accum + fold
 
 
 def ints_to_le_bytes(vals, nbytes=32):
@@ -136,6 +266,75 @@ def max_over_ranks(x, dist_on, device):
     return float(t.item())
 
 
+def sum_over_ranks_bigint(v, order, dist_on, device):
+    """(sum over ranks of a big integer) mod order, moved as 62-bit chunks."""
+    if not dist_on:
+        return v % order
+    import torch.distributed as dist
+    t = torch.tensor([v >> (62 * j) & ((1 << 62) - 1) for j in range(5)], dtype=torch.int64,
+                     device=device if dist.get_backend() == "nccl" else "cpu")
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return sum(sum(int(x) << (62 * j) for j, x in enumerate(p.tolist())) for p in parts) % order
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    node = None
+    try:
+        node = subprocess.run(["node", "--version"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return {"cpu_model": model, "logical_cores": os.cpu_count(), "node_version": node,
+            "reference_runnable": False,
+            "reference_note": "the TypeScript reference needs Node >= 20.19 with type stripping and @noble/hashes (SURVEY 8c); "
+                              "the CPU figures are the oracle's C restatement of the same algorithm (kind: port)"}
+
+
+def cpu_baseline_rates(work, total_items, chunk, seconds, check=None):
+    """Times `work(lo, hi)` (a ctypes call into oracle/c that releases the GIL) on one thread and on all
+    hardware threads, each for about `seconds`; returns (rate_1, done_1, rate_all, done_all, threads)."""
+    from concurrent.futures import ThreadPoolExecutor
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds and done + chunk <= total_items:
+        r = work(done, done + chunk)
+        if check:
+            check(done, done + chunk, r)
+        done += chunk
+    r1, d1 = done / (time.perf_counter() - t0), done
+    threads = os.cpu_count() or 1
+    if threads == 1 or done + chunk * threads > total_items:
+        return r1, d1, None, 0, threads
+    start = done
+    per_thread = max(1, int(r1 * seconds / chunk))              # chunks each thread should take
+    per_thread = min(per_thread, (total_items - start) // (chunk * threads))
+    if per_thread < 1:
+        return r1, d1, None, 0, threads
+
+    span = per_thread * chunk                                   # ONE call per thread: the whole slice runs outside the GIL
+    results = [None] * threads
+
+    def run(t):
+        lo = start + t * span
+        results[t] = work(lo, lo + span)
+        return span
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        dall = sum(ex.map(run, range(threads)))
+    dt = time.perf_counter() - t0
+    if check:
+        for t in range(threads):
+            check(start + t * span, start + (t + 1) * span, results[t])
+    return r1, d1, dall / dt, dall, threads
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,7 +343,9 @@ def main():
     ap.add_argument("--log2n", type=int, default=20, help="items per GPU (2^log2n)")
     ap.add_argument("--workload", default="all", choices=["all", "secp256k1", "msm_g1", "msm_g2", "ed25519", "ntt"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="per CPU-baseline leg (1 thread, then all threads)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 counter passes in this run")
+    ap.add_argument("--quick-verify", action="store_true", help="(PMC child runs) skip the slow host-side cross-checks")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     args = ap.parse_args()
@@ -167,11 +368,11 @@ def main():
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
 
     from noble_curves_amd import get_engine
-    from noble_curves_amd._native import BLS12_381_G1, SECP256K1
-    from noble_curves_amd.distributed import msm_sharded
+    from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, ED25519, SECP256K1
+    from noble_curves_amd.distributed import init_comm, msm_sharded
     from helpers import wire_to_affine
     from oracle import cport
-    from oracle.curves import BLS_R, BlsG1, SECP256K1_N, Secp256k1, makeRng
+    from oracle.curves import BLS_R, BlsG1, BlsG2, SECP256K1_N, Secp256k1, makeRng
 
     eng = get_engine(dev_index)
     # a real (non-null) stream: kernels, copies and the timing events all go on it
@@ -181,8 +382,22 @@ def main():
     assert stream != 0
     n = 1 << args.log2n
     K, W = args.steps, args.warmup
+    cpu_leg = rank == 0 and world == 1 and not args.no_cpu_baseline
+    live = None
+    if rank == 0 and world == 1 and not args.no_live_pmc and not args.quick_verify:
+        live = pmc_live(args.workload, args.log2n)
+    pmc = Pmc(live)
+    native_multi = init_comm(eng, device) if dist_on else False
     result = {}
     extra = {}
+    host = cpu_info() if rank == 0 else {}
+
+    def baseline_entry(r1, d1, rall, dall, threads, unit, sample):
+        e = {"value": r1, "unit": unit, "cores": 1, "kind": "port", "sample": sample % d1,
+             "cpu_model": host.get("cpu_model"), "logical_cores": host.get("logical_cores")}
+        if rall:
+            e["all_threads"] = {"value": rall, "cores": threads, "items": dall}
+        return e
 
     # ------------------------------------------------------------------ secp256k1 batch multiply
     if args.workload in ("all", "secp256k1"):
@@ -214,7 +429,7 @@ def main():
         kern_ms = ev_ms / K
         rate = world * n * K / wall
         alg_bytes = 160.0 * n          # 64 B point + 32 B scalar in, 64 B out
-        alg_mac = 3.4e5 * n            # reference-equivalent limb-MACs per scalar-mult
+        traffic, tsrc = pmc.traffic("secp256k1") if args.log2n == 20 else (None, None)
         result = {
             "metric": "secp256k1_scalar_mults_per_sec", "value": rate, "unit": "scalar-mults/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3,
@@ -224,98 +439,97 @@ def main():
                        % args.log2n, "items_per_gpu": n, "parallelism": "shard-by-index x%d" % world},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("ncg::k_mul_var_gtab<ncg::CurveSecp") if args.log2n == 20 else None,
-                         "kernel": "k_mul_var_gtab<CurveSecp,5> (+ k_jac_batch_affine); traffic includes the per-item window tables kept in device memory", "kernel_ms": kern_ms,
-                         "valu": {"achieved_mac_per_s": alg_mac / (kern_ms * 1e-3), "peak_mac_per_s": INT_MAC_PEAK,
-                                  "frac": alg_mac / (kern_ms * 1e-3) / INT_MAC_PEAK,
-                                  "note": "reference-equivalent limb-MACs (SURVEY 8d) / v_mad_u64_u32 peak"}},
+                         "traffic": traffic, "traffic_source": tsrc,
+                         "kernel": "k_mul_var_gtab<CurveSecpI,4,3> (+ k_jac_batch_affine<16>, included in kernel_ms); "
+                                   "traffic = the dominant kernel's, incl. its per-item window table in device memory",
+                         "kernel_ms": kern_ms,
+                         "valu": valu_block(pmc, "secp256k1", kern_ms * 1e-3, 3.4e5 * n, secp_mads_per_mult() * n)},
         }
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            done, t0 = 0, time.perf_counter()
-            pts_h, sc_h = pts.cpu().numpy(), sc.cpu().numpy()
-            while time.perf_counter() - t0 < args.cpu_seconds and done + 1000 <= n:
-                o_c, _ = cport.multiply_unsafe("secp256k1", pts_h[done:done + 1000], sc_h[done:done + 1000])
-                assert np.array_equal(o_c, out[done:done + 1000].cpu().numpy())
-                done += 1000
-            dt = time.perf_counter() - t0
-            result["cpu_baseline"] = {"value": done / dt, "unit": "scalar-mults/s", "cores": 1, "kind": "port",
-                                      "sample": "first %d pairs of the same batch, oracle/c (RCB + GLV wNAF-4), "
-                                                "outputs compared bit-exactly with the GPU's" % done}
+        if cpu_leg:
+            pts_h, sc_h, out_h = pts.cpu().numpy(), sc.cpu().numpy(), out.cpu().numpy()
 
-    # ------------------------------------------------------------------ bls12-381 G1 MSM
-    if args.workload in ("all", "msm_g1"):
-        rng = makeRng(0x6D736D0000000003 + rank)
+            def work(lo, hi):
+                return cport.multiply_unsafe("secp256k1", pts_h[lo:hi], sc_h[lo:hi])[0]
+
+            def check(lo, hi, r):
+                assert np.array_equal(r, out_h[lo:hi]), "CPU baseline output differs from the GPU's"
+            r1, d1, rall, dall, thr = cpu_baseline_rates(work, n, 500, args.cpu_seconds, check)
+            result["cpu_baseline"] = baseline_entry(r1, d1, rall, dall, thr, "scalar-mults/s",
+                                                    "first %d pairs of the same batch through oracle/c (RCB + GLV wNAF-4), outputs "
+                                                    "compared bit-exactly with the GPU's; all_threads: the next pairs, one chunk stream per thread")
+
+    # ------------------------------------------------------------------ bls12-381 G1 / G2 MSM
+    def msm_workload(curve, Pt, cname, nn, seed, alg_b, ref_mac_pt, key):
+        rng = makeRng(seed + rank)
         a, b = rng.rndBelow(BLS_R - 1) + 1, rng.rndBelow(BLS_R - 1) + 1
-        pts, pks = gen_points(eng, BLS12_381_G1, BlsG1, n, a, b, device, stream)
-        sc = gen_scalars(n, 254, 777 + rank, device)
+        pts, pks = gen_points(eng, curve, Pt, nn, a, b, device, stream)
+        sc = gen_scalars(nn, 254, 777 + seed % 1000 + rank, device)
         sc[::17] = 0                                         # test/slow-curves.test.ts:215
         ks = scalars_to_ints(sc)
         local_expect = sum(k * p for k, p in zip(ks, pks)) % BLS_R
         holder = {}
 
         def step():
-            holder["r"] = msm_sharded(eng, BLS12_381_G1, n, dev_ptr(pts), dev_ptr(sc), stream, device)
+            holder["r"] = msm_sharded(eng, curve, nn, dev_ptr(pts), dev_ptr(sc), stream, device)
 
         wall, ev_ms = time_steps(step, K, W, dist_on)
         wall = max_over_ranks(wall, dist_on, device)
-        if dist_on:
-            import torch.distributed as dist
-            t = torch.tensor([local_expect & ((1 << 62) - 1), local_expect >> 62 & ((1 << 62) - 1),
-                              local_expect >> 124 & ((1 << 62) - 1), local_expect >> 186 & ((1 << 62) - 1),
-                              local_expect >> 248], dtype=torch.int64,
-                             device=device if dist.get_backend() == "nccl" else "cpu")
-            parts = [torch.zeros_like(t) for _ in range(world)]
-            dist.all_gather(parts, t)
-            tot = 0
-            for p in parts:
-                v = [int(x) for x in p.tolist()]
-                tot += v[0] + (v[1] << 62) + (v[2] << 124) + (v[3] << 186) + (v[4] << 248)
-            expect = tot % BLS_R
-        else:
-            expect = local_expect
+        expect = sum_over_ranks_bigint(local_expect, BLS_R, dist_on, device)
         got, got_inf = holder["r"]
-        assert wire_to_affine(BLS12_381_G1, got) == BlsG1.BASE.multiplyUnsafe(expect).toAffine(), "MSM mismatch"
-        msm_rate = world * n * K / wall
-        alg_bytes = 128.0 * n
-        alg_mac = 9.45e4 * n
-        msm = {"metric": "bls12_381_g1_msm_points_per_sec", "value": msm_rate, "unit": "points/s",
-               "ms_per_msm": wall / K * 1e3, "points_per_gpu": n, "total_points": world * n, "scaling": "weak",
-               "roofline": {"bound": "hbm", "achieved": alg_bytes / (wall / K) / 1e9, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": alg_bytes / (wall / K) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": pmc_traffic("ncg::k_msm_accum<ncg::CurveG1") if args.log2n == 20 else None,
-                            "kernel": "k_msm_accum<CurveG1> (dominant; the figure is for the whole MSM)",
-                            "valu": {"achieved_mac_per_s": alg_mac / (wall / K), "peak_mac_per_s": INT_MAC_PEAK,
-                                     "frac": alg_mac / (wall / K) / INT_MAC_PEAK}}}
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            m = min(n, 1 << 18)
+        assert wire_to_affine(curve, got) == Pt.BASE.multiplyUnsafe(expect).toAffine(), "MSM mismatch"
+        c = max(2, min(16, (nn.bit_length() - 1) - (3 if curve == BLS12_381_G2 else 4)))
+        nwin = -(-(255 + 1) // c)
+        traffic, tsrc = pmc.traffic(key) if (curve == BLS12_381_G1 and args.log2n == 20) or (curve == BLS12_381_G2 and args.log2n == 20) else (None, None)
+        entry = {"metric": "bls12_381_%s_msm_points_per_sec" % cname, "value": world * nn * K / wall, "unit": "points/s",
+                 "ms_per_msm": wall / K * 1e3, "points_per_gpu": nn, "total_points": world * nn, "scaling": "weak",
+                 "multi_gpu": ("ncg_msm_sharded_dev: RCCL all-gather of grouped window sums + on-device add" if native_multi
+                               else ("gloo dry run: partial points exchanged by torch.distributed" if dist_on else "single GPU")),
+                 "roofline": {"bound": "hbm", "achieved": alg_b * nn / (wall / K) / 1e9, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": alg_b * nn / (wall / K) / 1e9 / HBM_PEAK_GBS,
+                              "traffic": traffic, "traffic_source": tsrc,
+                              "kernel": "k_msm_accum (dominant; achieved is for the whole MSM incl. the host finish, traffic for that kernel)",
+                              "valu": valu_block(pmc, key, wall / K, ref_mac_pt * nn,
+                                                 (g1_msm_mads_per_point(nwin, nn, 1 << (c - 1)) * (3 if curve == BLS12_381_G2 else 1)) * nn)}}
+        sub = {"pts": pts, "sc": sc, "ks": ks, "pks": pks}
+        return entry, sub
+
+    if args.workload in ("all", "msm_g1"):
+        msm, sub = msm_workload(BLS12_381_G1, BlsG1, "g1", n, 0x6D736D0000000003, 128.0, 9.45e4, "msm_g1")
+        if cpu_leg:
+            pts_h, sc_h = sub["pts"].cpu().numpy(), sub["sc"].cpu().numpy()
+            m = min(n, 1 << 17)
             t0 = time.perf_counter()
-            o_c, i_c = cport.pippenger("bls12_381_g1", pts[:m].cpu().numpy(), sc[:m].cpu().numpy())
+            o_c, i_c = cport.pippenger("bls12_381_g1", pts_h[:m], sc_h[:m])
             dt = time.perf_counter() - t0
-            g_s, _ = eng.msm_dev(BLS12_381_G1, m, dev_ptr(pts), dev_ptr(sc), stream)
+            g_s, _ = eng.msm_dev(BLS12_381_G1, m, dev_ptr(sub["pts"]), dev_ptr(sub["sc"]), stream)
             assert np.array_equal(o_c, g_s), "MSM sample mismatch vs oracle pippenger"
-            msm["cpu_baseline"] = {"value": m / dt, "unit": "points/s", "cores": 1, "kind": "port",
-                                   "sample": "first 2^%d points of the same MSM through oracle/c pippenger "
-                                             "(curve.ts:863-905 restated), result compared bit-exactly with the "
-                                             "GPU MSM on the same subset" % (m.bit_length() - 1)}
+            thr = os.cpu_count() or 1
+            rall = None
+            if thr > 1 and n >= m * 2:
+                from concurrent.futures import ThreadPoolExecutor
+                mm = min(m, n // thr)
+                t0 = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=thr) as ex:
+                    list(ex.map(lambda t: cport.pippenger("bls12_381_g1", pts_h[t * mm:(t + 1) * mm], sc_h[t * mm:(t + 1) * mm]), range(thr)))
+                rall = thr * mm / (time.perf_counter() - t0)
+            msm["cpu_baseline"] = baseline_entry(m / dt, m, rall, thr * (min(m, n // thr)) if rall else 0, thr, "points/s",
+                                                 "first %d points of the same MSM through oracle/c pippenger (curve.ts:863-905 "
+                                                 "restated), result compared bit-exactly with the GPU MSM on the same subset; "
+                                                 "all_threads: one independent MSM of n/threads points per thread (points/s summed)")
         extra["msm_g1"] = msm
         if dist_on:
             # strong scaling (configs[3] as written): ONE 2^log2n-point MSM whose points are split
-            # across the ranks (n/world each), one all-gather of the partial sums, one combine
+            # across the ranks (n/world each), combined inside the C ABI
             ns = n // world
-            sub_expect = sum(k * p for k, p in zip(ks[:ns], pks[:ns])) % BLS_R
+            sub_expect = sum(k * p for k, p in zip(sub["ks"][:ns], sub["pks"][:ns])) % BLS_R
             hs = {}
 
             def step_strong():
-                hs["r"] = msm_sharded(eng, BLS12_381_G1, ns, dev_ptr(pts), dev_ptr(sc), stream, device)
+                hs["r"] = msm_sharded(eng, BLS12_381_G1, ns, dev_ptr(sub["pts"]), dev_ptr(sub["sc"]), stream, device)
 
             wall_s, _ = time_steps(step_strong, K, W, dist_on)
             wall_s = max_over_ranks(wall_s, dist_on, device)
-            import torch.distributed as dist
-            tt = torch.tensor([sub_expect >> (62 * j) & ((1 << 62) - 1) for j in range(5)], dtype=torch.int64,
-                              device=device if dist.get_backend() == "nccl" else "cpu")
-            parts = [torch.zeros_like(tt) for _ in range(world)]
-            dist.all_gather(parts, tt)
-            tot = sum(sum(int(x) << (62 * j) for j, x in enumerate(p.tolist())) for p in parts) % BLS_R
+            tot = sum_over_ranks_bigint(sub_expect, BLS_R, dist_on, device)
             got_s, _ = hs["r"]
             assert wire_to_affine(BLS12_381_G1, got_s) == BlsG1.BASE.multiplyUnsafe(tot).toAffine(), "strong MSM mismatch"
             extra["msm_g1_strong"] = {"metric": "bls12_381_g1_msm_points_per_sec", "value": ns * world * K / wall_s,
@@ -323,108 +537,169 @@ def main():
                                       "points_per_gpu": ns, "scaling": "strong"}
         if not result:
             result = dict(msm)
-            result.update({"n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3,
+            result.update({"n_gpus": world, "steps": K, "warmup": W, "ms_per_step": msm["ms_per_msm"],
                            "higher_is_better": True, "vs_baseline": None, "dtype": "u32",
                            "data": "synthetic: P_i=(a+i*b)G1, s_i uniform in [0,2^254), every 17th zero",
                            "config": {"workload": "bls12-381 G1 Pippenger MSM, 2^%d points per GPU" % args.log2n}})
             extra.pop("msm_g1", None)
 
-    # ------------------------------------------------------------------ bls12-381 G2 MSM (configs[4])
     if args.workload in ("all", "msm_g2"):
-        from noble_curves_amd._native import BLS12_381_G2
-        from oracle.curves import BlsG2
-        n2 = max(1, n >> 2)                                   # 2^18 at the default size
-        rng = makeRng(0x6D736D0000000004 + rank)
-        a, b = rng.rndBelow(BLS_R - 1) + 1, rng.rndBelow(BLS_R - 1) + 1
-        pts2, pks2 = gen_points(eng, BLS12_381_G2, BlsG2, n2, a, b, device, stream)
-        sc2 = gen_scalars(n2, 254, 999 + rank, device)
-        sc2[::17] = 0
-        ks2 = scalars_to_ints(sc2)
-        local_expect = sum(k * p for k, p in zip(ks2, pks2)) % BLS_R
-        holder2 = {}
+        n2 = max(1, n >> 2)                                   # 2^18 at the default size (configs[4])
+        msm2, sub2 = msm_workload(BLS12_381_G2, BlsG2, "g2", n2, 0x6D736D0000000004, 224.0, 3.0e5, "msm_g2")
+        extra["msm_g2"] = msm2
+        if dist_on:
+            ns = n2 // world
+            sub_expect = sum(k * p for k, p in zip(sub2["ks"][:ns], sub2["pks"][:ns])) % BLS_R
+            hs2 = {}
 
-        def step_g2():
-            holder2["r"] = eng.msm_dev(BLS12_381_G2, n2, dev_ptr(pts2), dev_ptr(sc2), stream)
+            def step_strong2():
+                hs2["r"] = msm_sharded(eng, BLS12_381_G2, ns, dev_ptr(sub2["pts"]), dev_ptr(sub2["sc"]), stream, device)
 
-        wall, _ = time_steps(step_g2, K, W, dist_on)
-        wall = max_over_ranks(wall, dist_on, device)
-        got, _ = holder2["r"]
-        assert wire_to_affine(BLS12_381_G2, got) == BlsG2.BASE.multiplyUnsafe(local_expect).toAffine(), "G2 MSM mismatch"
-        extra["msm_g2"] = {"metric": "bls12_381_g2_msm_points_per_sec", "value": world * n2 * K / wall,
-                           "unit": "points/s", "ms_per_msm": wall / K * 1e3, "points_per_gpu": n2,
-                           "note": "independent 2^%d-point MSM per GPU (replicas)" % (n2.bit_length() - 1),
-                           "roofline": {"bound": "hbm", "achieved": 224.0 * n2 / (wall / K) / 1e9,
-                                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": 224.0 * n2 / (wall / K) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                        "valu": {"achieved_mac_per_s": 3.0e5 * n2 / (wall / K),
-                                                 "peak_mac_per_s": INT_MAC_PEAK,
-                                                 "frac": 3.0e5 * n2 / (wall / K) / INT_MAC_PEAK}}}
+            wall_s, _ = time_steps(step_strong2, K, W, dist_on)
+            wall_s = max_over_ranks(wall_s, dist_on, device)
+            tot = sum_over_ranks_bigint(sub_expect, BLS_R, dist_on, device)
+            got_s, _ = hs2["r"]
+            assert wire_to_affine(BLS12_381_G2, got_s) == BlsG2.BASE.multiplyUnsafe(tot).toAffine(), "strong G2 MSM mismatch"
+            extra["msm_g2_strong"] = {"metric": "bls12_381_g2_msm_points_per_sec", "value": ns * world * K / wall_s,
+                                      "unit": "points/s", "ms_per_msm": wall_s / K * 1e3, "total_points": ns * world,
+                                      "points_per_gpu": ns, "scaling": "strong"}
+        if not result:
+            result = dict(msm2)
+            result.update({"n_gpus": world, "steps": K, "warmup": W, "ms_per_step": msm2["ms_per_msm"],
+                           "higher_is_better": True, "vs_baseline": None, "dtype": "u32",
+                           "data": "synthetic: P_i=(a+i*b)G2, s_i uniform in [0,2^254), every 17th zero",
+                           "config": {"workload": "bls12-381 G2 Pippenger MSM, 2^%d points per GPU" % (args.log2n - 2)}})
+            extra.pop("msm_g2", None)
 
     # ------------------------------------------------------------------ ed25519 batch verify (configs[2])
     if args.workload in ("all", "ed25519"):
         import hashlib
+        from helpers import load_golden
         from oracle.curves import ED25519_L, Ed25519
         from oracle.edwards import eddsa_verify
         nv = max(64, n >> 2)                                  # 2^18 at the default size
         rng = makeRng(0x6E6F626C6503 + rank)
-        POOL = 32
-        a_s = [rng.rndBelow(ED25519_L - 1) + 1 for _ in range(POOL)]
-        r_s = [rng.rndBelow(ED25519_L - 1) + 1 for _ in range(POOL)]
-        A_b = [Ed25519.BASE.multiply(x).toBytes() for x in a_s]
-        R_b = [Ed25519.BASE.multiply(x).toBytes() for x in r_s]
+        g = torch.Generator(device="cpu")
+        g.manual_seed(0x6E6F626C6503 + rank)
+        # every signature has its own key pair and nonce: A_i = a_i B, R_i = r_i B on the GPU (fixed-base batch
+        # multiply + batch encoding), messages = 32 random bytes
+        a_sc = gen_scalars(nv, 252, 31 + rank, device)
+        r_sc = gen_scalars(nv, 252, 32 + rank, device)
+        a_int, r_int = scalars_to_ints(a_sc), scalars_to_ints(r_sc)
+        aff = torch.empty((nv, 64), dtype=torch.uint8, device=device)
+        inf_t = torch.empty((nv,), dtype=torch.uint8, device=device)
+        eng.mul_base_batch_dev(ED25519, nv, dev_ptr(a_sc), dev_ptr(aff), dev_ptr(inf_t), stream)
+        torch.cuda.synchronize()
+        A_b, okA = eng.encode_points_batch(ED25519, aff.cpu().numpy())
+        eng.mul_base_batch_dev(ED25519, nv, dev_ptr(r_sc), dev_ptr(aff), dev_ptr(inf_t), stream)
+        torch.cuda.synchronize()
+        R_b, okR = eng.encode_points_batch(ED25519, aff.cpu().numpy())
+        assert okA.all() and okR.all()
+        msgs = torch.randint(0, 256, (nv, 32), dtype=torch.uint8, generator=g).numpy()
+        # k_i = SHA-512(R || A || M) mod L on the device (sampled against hashlib below), s_i = r_i + k_i a_i
         sig_np = np.zeros((nv, 64), np.uint8)
-        pk_np = np.zeros((nv, 32), np.uint8)
-        k_np = np.zeros((nv, 32), np.uint8)
+        sig_np[:, :32] = R_b
+        d_sig0, d_pk, d_msg = (torch.from_numpy(x).to(device) for x in (sig_np, A_b, msgs.reshape(-1)))
+        off = torch.arange(0, 32 * (nv + 1), 32, dtype=torch.int64, device=device)
+        d_k = torch.empty((nv, 32), dtype=torch.uint8, device=device)
+        eng.ed25519_challenge_batch_dev(nv, dev_ptr(d_sig0), dev_ptr(d_pk), dev_ptr(d_msg), dev_ptr(off), dev_ptr(d_k), stream)
+        torch.cuda.synchronize()
+        k_np = d_k.cpu().numpy()
+        k_int = [int.from_bytes(k_np[i].tobytes(), "little") for i in range(nv)]
+        for i in list(range(0, 64)) + list(range(64, nv, max(1, nv // 512))):
+            assert k_int[i] == int.from_bytes(hashlib.sha512(R_b[i].tobytes() + A_b[i].tobytes() + msgs[i].tobytes()).digest(), "little") % ED25519_L, \
+                "device SHA-512 challenge differs from hashlib"
+        s_int = [(r + k * a) % ED25519_L for r, k, a in zip(r_int, k_int, a_int)]
+        sig_np[:, 32:] = ints_to_le_bytes(s_int)
         expect = np.ones((nv,), bool)
-        msgs = []
-        for i in range(nv):
-            ia, ir = i % POOL, (i // POOL) % POOL
-            msg = i.to_bytes(8, "little") + bytes([rank]) * 24
-            kk = int.from_bytes(hashlib.sha512(R_b[ir] + A_b[ia] + msg).digest(), "little") % ED25519_L
-            s_ = (r_s[ir] + kk * a_s[ia]) % ED25519_L
-            sig = bytearray(R_b[ir] + s_.to_bytes(32, "little"))
-            if i % 64 == 63:                                   # 1/64 corrupted
-                sig[33 + (i >> 6) % 20] ^= 1 << (i % 7)
-                expect[i] = False
-            sig_np[i] = np.frombuffer(bytes(sig), np.uint8)
-            pk_np[i] = np.frombuffer(A_b[ia], np.uint8)
-            k_np[i] = np.frombuffer(kk.to_bytes(32, "little"), np.uint8)
-            msgs.append(msg)
-        d_sig, d_pk, d_k = (torch.from_numpy(x).to(device) for x in (sig_np, pk_np, k_np))
+        for i in range(63, nv, 64):                            # 1/64 corrupted: a bit flip in R, s or the message
+            kind = (i >> 6) % 3
+            if kind == 0:
+                sig_np[i, (i >> 8) % 31] ^= 1 << (i % 7)
+            elif kind == 1:
+                sig_np[i, 33 + (i >> 8) % 20] ^= 1 << (i % 7)
+            else:
+                msgs[i, (i >> 8) % 32] ^= 1 << (i % 7)
+            expect[i] = False
+        # the 196 ZIP-215 cases of the reference (small-order / non-canonical encodings) ride along at the end
+        zv = load_golden("ed25519_zip215.json")
+        nz = len(zv) if nv >= 1024 else 0
+        tail = nv - nz
+        pk_np = A_b.copy()
+        msg_list = [msgs[i].tobytes() for i in range(tail)]
+        for j in range(nz):
+            sig_np[tail + j] = np.frombuffer(bytes.fromhex(zv[j]["sig_bytes"]), np.uint8)
+            pk_np[tail + j] = np.frombuffer(bytes.fromhex(zv[j]["vk_bytes"]), np.uint8)
+            msg_list.append(b"Zcash")
+            expect[tail + j] = zv[j]["valid_zip215"]
+        blob = np.frombuffer(b"".join(msg_list), np.uint8)
+        offs = np.zeros((nv + 1,), np.int64)
+        offs[1:] = np.cumsum([len(m) for m in msg_list])
+        d_sig, d_pk, d_blob, d_off = (torch.from_numpy(x.copy()).to(device) for x in (sig_np, pk_np, blob, offs))
         d_ok = torch.empty((nv,), dtype=torch.uint8, device=device)
+        d_k2 = torch.empty((nv, 32), dtype=torch.uint8, device=device)
 
-        def step_ed():
-            eng.ed25519_verify_batch_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_k), True, dev_ptr(d_ok), stream)
+        def step_ed():     # hash on the device + verify: the reference's verify() from (sig, msg, pk)
+            eng.ed25519_verify_batch_msgs_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_blob), dev_ptr(d_off), True, dev_ptr(d_ok), stream)
 
         wall, ev_ms = time_steps(step_ed, K, W, dist_on)
         wall = max_over_ranks(wall, dist_on, device)
         got = d_ok.cpu().numpy().astype(bool)
-        assert np.array_equal(got, expect), "ed25519 verdict mismatch vs construction"
-        for i in list(range(0, 40)) + list(range(63, nv, max(64, nv // 16 // 64 * 64))):
-            assert got[i] == eddsa_verify(Ed25519, sig_np[i].tobytes(), msgs[i], pk_np[i].tobytes(), zip215=True)
+        assert np.array_equal(got, expect), "ed25519 verdict mismatch vs construction / zip215.json"
+        # kernel-only rate (pre-hashed challenges, the r01 figure) on the same batch
+        eng.ed25519_challenge_batch_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_blob), dev_ptr(d_off), dev_ptr(d_k2), stream)
+
+        def step_ed_k():
+            eng.ed25519_verify_batch_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_k2), True, dev_ptr(d_ok), stream)
+
+        wall_k, ev_ms_k = time_steps(step_ed_k, K, W, dist_on)
+        wall_k = max_over_ranks(wall_k, dist_on, device)
+        assert np.array_equal(d_ok.cpu().numpy().astype(bool), expect)
+        # strict (RFC 8032) mode once, untimed: construction for the synthetic part, the oracle for the 196 cases
+        eng.ed25519_verify_batch_msgs_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_blob), dev_ptr(d_off), False, dev_ptr(d_ok), stream)
+        torch.cuda.synchronize()
+        got_strict = d_ok.cpu().numpy().astype(bool)
+        assert np.array_equal(got_strict[:tail], expect[:tail]), "ed25519 strict-mode verdict mismatch"
+        if not args.quick_verify:
+            for j in range(nz):
+                assert got_strict[tail + j] == eddsa_verify(Ed25519, sig_np[tail + j].tobytes(), b"Zcash", pk_np[tail + j].tobytes(), zip215=False), \
+                    "strict-mode verdict differs from the oracle on zip215.json case %d" % j
+            for i in list(range(0, 24)) + list(range(63, tail, max(64, tail // 16 // 64 * 64))):
+                assert got[i] == eddsa_verify(Ed25519, sig_np[i].tobytes(), msg_list[i], pk_np[i].tobytes(), zip215=True)
         ed_cpu = None
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            done, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < args.cpu_seconds and done + 500 <= nv:
-                o_c = cport.ed25519_verify_batch(sig_np[done:done + 500], pk_np[done:done + 500], k_np[done:done + 500], True)
-                assert np.array_equal(o_c, got[done:done + 500]), "ed25519 sample mismatch vs oracle/c"
-                done += 500
-            dt = time.perf_counter() - t0
-            ed_cpu = {"value": done / dt, "unit": "verifies/s", "cores": 1, "kind": "port",
-                      "sample": "first %d signatures of the same batch through oracle/c (edwards.ts:942-989 restated, "
-                                "challenge pre-hashed), verdicts compared with the GPU's" % done}
+        if cpu_leg:
+            k2_np = d_k2.cpu().numpy()
+
+            def work(lo, hi):
+                for i in range(lo, hi):                        # the reference's verify hashes too
+                    hashlib.sha512(sig_np[i, :32].tobytes() + pk_np[i].tobytes() + msg_list[i]).digest()
+                return cport.ed25519_verify_batch(sig_np[lo:hi], pk_np[lo:hi], k2_np[lo:hi], True)
+
+            def check(lo, hi, r):
+                assert np.array_equal(r, got[lo:hi]), "ed25519 sample mismatch vs oracle/c"
+            r1, d1, rall, dall, thr = cpu_baseline_rates(work, nv, 250, args.cpu_seconds, check)
+            ed_cpu = baseline_entry(r1, d1, rall, dall, thr, "verifies/s",
+                                    "first %d signatures of the same batch through oracle/c (edwards.ts:942-989 restated) plus "
+                                    "hashlib SHA-512 per item, verdicts compared with the GPU's")
+        kern_s = ev_ms_k / K * 1e-3
+        traffic, tsrc = pmc.traffic("ed25519") if nv == 1 << 18 else (None, None)
         extra["ed25519_verify"] = {"metric": "ed25519_verifies_per_sec", "value": world * nv * K / wall,
                                    "unit": "verifies/s", "ms_per_batch": wall / K * 1e3, "sigs_per_gpu": nv,
-                                   "note": "challenge k = SHA-512(R||A||M) mod L computed by the host shim (untimed); "
-                                           "1/64 of the signatures corrupted; verdicts checked against the oracle",
-                                   "roofline": {"bound": "hbm", "achieved": 129.0 * nv / (ev_ms / K * 1e-3) / 1e9,
+                                   "kernel_only": {"value": world * nv * K / wall_k, "ms_per_batch": wall_k / K * 1e3,
+                                                   "note": "pre-hashed challenges (ncg_ed25519_verify_batch_dev)"},
+                                   "note": "verify from (sig, msg, pk): SHA-512(R||A||M) mod L and the curve arithmetic both on the device "
+                                           "(ncg_ed25519_verify_batch_msgs_dev); %d distinct key pairs, 32-byte messages, 1/64 corrupted "
+                                           "(R, s or message), the reference's %d zip215.json cases appended; zip215 = true timed, "
+                                           "strict mode verified once" % (tail, nz),
+                                   "roofline": {"bound": "hbm", "achieved": 161.0 * nv / (ev_ms / K * 1e-3) / 1e9,
                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": 129.0 * nv / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                "traffic": pmc_traffic("ncg::k_ed25519_verify") if nv == 1 << 18 else None,
-                                                "kernel": "k_ed25519_verify", "kernel_ms": ev_ms / K,
-                                                "valu": {"achieved_mac_per_s": 4.9e5 * nv / (ev_ms / K * 1e-3),
-                                                         "peak_mac_per_s": INT_MAC_PEAK,
-                                                         "frac": 4.9e5 * nv / (ev_ms / K * 1e-3) / INT_MAC_PEAK}}}
+                                                "frac": 161.0 * nv / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "traffic": traffic, "traffic_source": tsrc,
+                                                "kernel": "k_ed25519_verify (+ k_ed25519_challenge in the hash-inclusive figure)",
+                                                "kernel_ms": ev_ms / K, "kernel_only_ms": ev_ms_k / K,
+                                                "valu": valu_block(pmc, "ed25519", kern_s, 4.9e5 * nv, 0.0)}}
+        extra["ed25519_verify"]["roofline"]["valu"].pop("executed_mad_per_s", None)
+        extra["ed25519_verify"]["roofline"]["valu"].pop("mad_frac", None)
         if ed_cpu:
             extra["ed25519_verify"]["cpu_baseline"] = ed_cpu
 
@@ -447,21 +722,18 @@ def main():
 
         wall, ev_ms = time_steps(step_ntt, K, W, dist_on)
         wall = max_over_ranks(wall, dist_on, device)
-        # checks: inverse(direct(x)) == x on the device; y[0] = sum x_i and a 2^12-point prefix transform
-        # against the oracle's C restatement of the reference loop
         eng.ntt_dev(bits, 1, om, dev_ptr(y), dev_ptr(z), stream, inverse=True)
         torch.cuda.synchronize()
         assert bool((z == x).all().item()), "NTT: inverse(direct(x)) != x"
         xs = x.cpu().numpy()
-        from oracle.curves import BLS_R as _R
         le = xs.view("<u8").reshape(nn, 4).astype(object)
-        acc = (int(le[:, 0].sum()) + (int(le[:, 1].sum()) << 64) + (int(le[:, 2].sum()) << 128) + (int(le[:, 3].sum()) << 192)) % _R
+        acc = (int(le[:, 0].sum()) + (int(le[:, 1].sum()) << 64) + (int(le[:, 2].sum()) << 128) + (int(le[:, 3].sum()) << 192)) % BLS_R
         assert int.from_bytes(y[0].cpu().numpy().tobytes(), "little") == acc, "NTT: y[0] != sum of inputs"
         sb = 12
         ys = eng.ntt(sb, xs[:1 << sb], roots.omega(sb))
         assert np.array_equal(ys, cport.fft_fr(sb, xs[:1 << sb], roots.omega(sb))), "NTT sample mismatch vs oracle/c"
         ntt_cpu = None
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if cpu_leg:
             cb = 18
             t0 = time.perf_counter()
             reps = 0
@@ -470,27 +742,31 @@ def main():
                 reps += 1
             dt = time.perf_counter() - t0
             assert np.array_equal(yc, eng.ntt(cb, xs[:1 << cb], roots.omega(cb))), "NTT 2^18 mismatch vs oracle/c"
-            ntt_cpu = {"value": reps * (1 << cb) / dt, "unit": "elements/s", "cores": 1, "kind": "port",
-                       "sample": "%d transforms of 2^%d of the same coefficients through oracle/c (fft.ts:422-480 loop "
-                                 "restated; includes its roots-table build), output compared with the GPU's" % (reps, cb)}
+            ntt_cpu = baseline_entry(reps * (1 << cb) / dt, reps, None, 0, 1, "elements/s",
+                                     "%%d transforms of 2^%d of the same coefficients through oracle/c (fft.ts:422-480 loop "
+                                     "restated; includes its roots-table build), output compared with the GPU's" % cb)
+        npass = 3 if bits == 22 else None
+        traffic, tsrc = pmc.traffic("ntt", npass) if npass else (None, None)
         extra["ntt_fr"] = {"metric": "bls12_381_fr_ntt_elements_per_sec", "value": world * nn * K / wall,
                            "unit": "elements/s", "ms_per_transform": wall / K * 1e3, "log2n": bits,
                            "note": "FFT(roots, Fr).direct, natural in / natural out, one 2^%d transform per GPU" % bits,
                            "roofline": {"bound": "hbm", "achieved": 64.0 * nn / (ev_ms / K * 1e-3) / 1e9,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": 64.0 * nn / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "traffic": pmc_traffic_ntt(bits),
-                                        "kernel": "k_ntt_pass (3 launches per 2^22 transform; achieved and traffic are per transform)",
+                                        "traffic": traffic, "traffic_source": tsrc,
+                                        "kernel": "k_ntt_pass (3 launches per 2^22 transform; achieved and traffic are per transform: "
+                                                  "3 x the average launch)",
                                         "kernel_ms": ev_ms / K,
-                                        "valu": {"achieved_mac_per_s": 136.0 * (nn / 2 * bits) / (ev_ms / K * 1e-3),
-                                                 "peak_mac_per_s": INT_MAC_PEAK,
-                                                 "frac": 136.0 * (nn / 2 * bits) / (ev_ms / K * 1e-3) / INT_MAC_PEAK}}}
+                                        "valu": valu_block(pmc, "ntt", ev_ms / K * 1e-3, 136.0 * (nn / 2 * bits), 136.0 * (nn / 2 * bits),
+                                                           launches=npass or 1)}}
         if ntt_cpu:
             extra["ntt_fr"]["cpu_baseline"] = ntt_cpu
 
     if extra:
         result["extra"] = extra
     if rank == 0:
+        result["host"] = host
+        result["pmc"] = "live rocprofv3 passes in this run" if live else "committed profile profiles/r02_pmc.json"
         print(json.dumps(result))
         if args.out:
             with open(args.out, "w") as f:

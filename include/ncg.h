@@ -251,6 +251,20 @@ int ncg_ed25519_verify_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev,
                                  const void* pk32_dev, const void* k32_dev, int zip215,
                                  uint8_t* out_ok_dev, void* stream);
 
+/* The same from the MESSAGES: the challenge k = SHA-512(R || A || M) mod L (edwards.ts:984, :900-906,
+ * modN_LE :866-868; SHA-512 is @noble/hashes in the reference) is computed on the device, one lane per
+ * signature, so nothing but (signature, key, message) crosses - SURVEY 8(b) `k32* | (msgs*, msg_off*)`.
+ * msgs: the messages back to back; msg_off: n + 1 byte offsets, message i = msgs[msg_off[i] .. msg_off[i+1]).
+ * ncg_ed25519_challenge_batch_dev exposes the hash step alone (out: n x 32 bytes LE). */
+int ncg_ed25519_verify_batch_msgs(ncg_ctx* ctx, size_t n, const void* sig64, const void* pk32,
+                                  const void* msgs, const uint64_t* msg_off, int zip215, uint8_t* out_ok);
+int ncg_ed25519_verify_batch_msgs_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* pk32_dev,
+                                      const void* msgs_dev, const uint64_t* msg_off_dev, int zip215,
+                                      uint8_t* out_ok_dev, void* stream);
+int ncg_ed25519_challenge_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* pk32_dev,
+                                    const void* msgs_dev, const uint64_t* msg_off_dev, void* out_k32_dev,
+                                    void* stream);
+
 /* ---- measurement helpers (not on the product path) ------------------------------------ */
 /* Runs instruction-rate / field-multiply micro-benchmark `kind` (see csrc/ubench.hip) and
  * returns the kernel time in milliseconds. */

@@ -104,6 +104,9 @@ _OPTIONAL_PROTOS = {
     "ncg_mul_base_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_ed25519_verify_batch": [_vp, _sz, _vp, _vp, _vp, _i32, _vp],
     "ncg_ed25519_verify_batch_dev": [_vp, _sz, _vp, _vp, _vp, _i32, _vp, _vp],
+    "ncg_ed25519_verify_batch_msgs": [_vp, _sz, _vp, _vp, _vp, _vp, _i32, _vp],
+    "ncg_ed25519_verify_batch_msgs_dev": [_vp, _sz, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
+    "ncg_ed25519_challenge_batch_dev": [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp],
     "ncg_comm_unique_id": [_vp],
     "ncg_comm_init": [_vp, _i32, _i32, _vp],
     "ncg_comm_destroy": [_vp],
@@ -345,6 +348,30 @@ class Engine:
             self._check(self.lib.ncg_ed25519_verify_batch(self.h, n, sigs.ctypes.data, pks.ctypes.data,
                                                           ks.ctypes.data, 1 if zip215 else 0, ok.ctypes.data))
         return ok.astype(bool)
+
+    def ed25519_verify_batch_msgs(self, sigs, pks, msgs_blob, msg_off, zip215=True):
+        """sigs uint8 [n,64], pks [n,32], msgs_blob uint8 [total], msg_off uint64 [n+1] -> bool array [n];
+        the challenge hash SHA-512(R || A || M) mod L runs on the device."""
+        sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 64)
+        pks = np.ascontiguousarray(pks, dtype=np.uint8).reshape(-1, 32)
+        blob = np.ascontiguousarray(msgs_blob, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(msg_off, dtype=np.uint64).reshape(-1)
+        n = sigs.shape[0]
+        if pks.shape[0] != n or off.shape[0] != n + 1:
+            raise ValueError("arrays of signatures, public keys and message offsets must have matching lengths")
+        ok = np.zeros((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_ed25519_verify_batch_msgs(self.h, n, sigs.ctypes.data, pks.ctypes.data,
+                                                               blob.ctypes.data if blob.size else None, off.ctypes.data,
+                                                               1 if zip215 else 0, ok.ctypes.data))
+        return ok.astype(bool)
+
+    def ed25519_verify_batch_msgs_dev(self, n, d_sigs, d_pks, d_msgs, d_off, zip215, d_ok, stream=None):
+        self._check(self.lib.ncg_ed25519_verify_batch_msgs_dev(self.h, n, d_sigs, d_pks, d_msgs, d_off,
+                                                               1 if zip215 else 0, d_ok, stream))
+
+    def ed25519_challenge_batch_dev(self, n, d_sigs, d_pks, d_msgs, d_off, d_ks, stream=None):
+        self._check(self.lib.ncg_ed25519_challenge_batch_dev(self.h, n, d_sigs, d_pks, d_msgs, d_off, d_ks, stream))
 
     def ed25519_verify_batch_dev(self, n, d_sigs, d_pks, d_ks, zip215, d_ok, stream=None):
         self._check(self.lib.ncg_ed25519_verify_batch_dev(self.h, n, d_sigs, d_pks, d_ks, 1 if zip215 else 0,

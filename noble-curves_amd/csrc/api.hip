@@ -137,6 +137,7 @@ void ncg_destroy(ncg_ctx* ctx) {
   if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
   if (ctx->mul_ws) (void)hipFree(ctx->mul_ws);
   if (ctx->ed_btab) (void)hipFree(ctx->ed_btab);
+  if (ctx->ed_ks) (void)hipFree(ctx->ed_ks);
   for (int i = 0; i < 4; i++)
     if (ctx->base_tab[i]) (void)hipFree(ctx->base_tab[i]);
   if (ctx->ub_in) (void)hipFree(ctx->ub_in);
@@ -744,6 +745,85 @@ int ncg_ed25519_verify_batch(ncg_ctx* ctx, size_t n, const void* sig64, const vo
   NCG_HIP(ctx, pins.h2d(d_pk, pk32, n * 32));
   NCG_HIP(ctx, pins.h2d(d_k, k32, n * 32));
   rc = ncg_ed25519_verify_batch_dev(ctx, n, d_sig, d_pk, d_k, zip215, (uint8_t*)d_ok, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
+// ---- ed25519 verify from messages: the challenge hash runs on the device too
+static int ensure_ed_ks(ncg_ctx* ctx, size_t n, hipStream_t st) {
+  const size_t need = n * 32;
+  if (ctx->ed_ks_bytes >= need) return NCG_OK;
+  NCG_HIP(ctx, hipStreamSynchronize(st));
+  if (ctx->ed_ks) (void)hipFree(ctx->ed_ks);
+  ctx->ed_ks = nullptr;
+  ctx->ed_ks_bytes = 0;
+  hipError_t e = hipMalloc(&ctx->ed_ks, need + (need >> 2));
+  if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+  ctx->ed_ks_bytes = need + (need >> 2);
+  return NCG_OK;
+}
+
+int ncg_ed25519_challenge_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* pk32_dev, const void* msgs_dev,
+                                    const uint64_t* msg_off_dev, void* out_k32_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64_dev || !pk32_dev || !msg_off_dev || !out_k32_dev)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ed25519_challenge: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  NCG_HIP(ctx, ncg::ed25519_challenge_batch((const uint8_t*)sig64_dev, (const uint8_t*)pk32_dev, (const uint8_t*)msgs_dev,
+                                            msg_off_dev, (uint32_t*)out_k32_dev, (int)n, st));
+  return NCG_OK;
+}
+
+int ncg_ed25519_verify_batch_msgs_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* pk32_dev,
+                                      const void* msgs_dev, const uint64_t* msg_off_dev, int zip215, uint8_t* out_ok_dev,
+                                      void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!out_ok_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ed25519_verify_msgs: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  int rc = ensure_ed_ks(ctx, n, st);
+  if (rc) return rc;
+  rc = ncg_ed25519_challenge_batch_dev(ctx, n, sig64_dev, pk32_dev, msgs_dev, msg_off_dev, ctx->ed_ks, st);
+  if (rc) return rc;
+  return ncg_ed25519_verify_batch_dev(ctx, n, sig64_dev, pk32_dev, ctx->ed_ks, zip215, out_ok_dev, st);
+}
+
+int ncg_ed25519_verify_batch_msgs(ncg_ctx* ctx, size_t n, const void* sig64, const void* pk32, const void* msgs,
+                                  const uint64_t* msg_off, int zip215, uint8_t* out_ok) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64 || !pk32 || !msg_off || !out_ok) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ed25519_verify_msgs: NULL buffer");
+  for (size_t i = 0; i < n; i++)
+    if (msg_off[i + 1] < msg_off[i]) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ed25519_verify_msgs: offsets must not decrease (index %zu)", i);
+  const size_t mbytes = (size_t)(msg_off[n] - msg_off[0]);
+  if (mbytes && !msgs) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ed25519_verify_msgs: NULL message buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
+  const size_t sig_b = n * 64, pk_b = n * 32, off_b = (n + 1) * 8;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  int rc = ensure_scratch(ctx, al(sig_b) + al(pk_b) + al(off_b) + al(mbytes + 8) + al(n) + 1024);
+  if (rc) return rc;
+  char* d_sig = (char*)ctx->scratch;
+  char* d_pk = d_sig + al(sig_b);
+  char* d_off = d_pk + al(pk_b);
+  char* d_msg = d_off + al(off_b);
+  char* d_ok = d_msg + al(mbytes + 8);
+  NCG_HIP(ctx, pins.h2d(d_sig, sig64, sig_b));
+  NCG_HIP(ctx, pins.h2d(d_pk, pk32, pk_b));
+  std::vector<uint64_t> rel(n + 1);  // offsets relative to the first message
+  for (size_t i = 0; i <= n; i++) rel[i] = msg_off[i] - msg_off[0];
+  NCG_HIP(ctx, hipMemcpyAsync(d_off, rel.data(), off_b, hipMemcpyHostToDevice, ctx->stream));
+  if (mbytes) NCG_HIP(ctx, pins.h2d(d_msg, (const char*)msgs + msg_off[0], mbytes));
+  rc = ncg_ed25519_verify_batch_msgs_dev(ctx, n, d_sig, d_pk, d_msg, (const uint64_t*)d_off, zip215, (uint8_t*)d_ok,
+                                         ctx->stream);
   if (rc) return rc;
   NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -19,6 +19,8 @@ struct ncg_ctx {
   void* msm_ws = nullptr;  // MSM workspace (device)
   size_t msm_ws_bytes = 0;
   uint32_t* ed_btab = nullptr;  // ed25519 base-point table (device)
+  void* ed_ks = nullptr;        // ed25519 challenge scalars of the message-taking verify (device)
+  size_t ed_ks_bytes = 0;
   uint32_t* base_tab[4] = {nullptr, nullptr, nullptr, nullptr};  // fixed-base tables per curve (device)
   uint32_t* ub_in = nullptr;
   uint32_t* ub_out = nullptr;

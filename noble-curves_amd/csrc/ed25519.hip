@@ -23,6 +23,7 @@
 #include "ec_te.hpp"
 #include "host_api.hpp"
 #include "scalar.hpp"
+#include "sha512.hpp"
 
 namespace ncg {
 
@@ -434,6 +435,36 @@ hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, st, sigs, pks, ks, btab, zip215, out_ok, (uint32_t*)nullptr, n);
   return hipGetLastError();
+}
+
+// ---- challenge scalars k = SHA-512(R || A || M) mod L for a batch (sha512.hpp), one lane per signature.
+// msgs: all messages back to back; msg_off: n + 1 byte offsets into it (message i = [off[i], off[i+1])).
+__global__ void __launch_bounds__(256) k_ed25519_challenge(const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ pks,
+                                                           const uint8_t* __restrict__ msgs,
+                                                           const uint64_t* __restrict__ msg_off, uint32_t* __restrict__ ks,
+                                                           int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t lo = msg_off[i], hi = msg_off[i + 1];
+  uint64_t h[8];
+  sha512_ram(h, sigs + (size_t)i * 64, pks + (size_t)i * 32, msgs + lo, hi - lo);
+  uint32_t k[8];
+  sha512_digest_mod_l(k, h);
+#pragma unroll
+  for (int j = 0; j < 8; j++) ks[(size_t)i * 8 + j] = k[j];
+}
+hipError_t ed25519_challenge_batch(const uint8_t* sigs, const uint8_t* pks, const uint8_t* msgs, const uint64_t* msg_off,
+                                   uint32_t* ks, int n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_ed25519_challenge, dim3((n + 255) / 256), dim3(256), 0, st, sigs, pks, msgs, msg_off, ks, n);
+  return hipGetLastError();
+}
+void ed25519_challenge_host(const uint8_t* sig, const uint8_t* pk, const uint8_t* msg, uint64_t len, uint32_t* k_out) {
+  uint64_t h[8];
+  sha512_ram(h, sig, pk, msg, len);
+  uint32_t k[8];
+  sha512_digest_mod_l(k, h);
+  for (int j = 0; j < 8; j++) k_out[j] = k[j];
 }
 
 // host-only: run the lane function on the CPU (unit tests through hosttest.hip)

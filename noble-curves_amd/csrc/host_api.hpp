@@ -77,6 +77,10 @@ size_t ed25519_verify_tmp_words(int n);
 size_t ed25519_tmp_words(int n);
 hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
                                 int zip215, uint8_t* out_ok, int n, uint32_t* gtab, hipStream_t st);
+// challenge scalars k[i] = SHA-512(R_i || A_i || M_i) mod L (edwards.ts:984, :900-906) for a batch; ks: n x 8 words
+hipError_t ed25519_challenge_batch(const uint8_t* sigs, const uint8_t* pks, const uint8_t* msgs, const uint64_t* msg_off,
+                                   uint32_t* ks, int n, hipStream_t st);
+void ed25519_challenge_host(const uint8_t* sig, const uint8_t* pk, const uint8_t* msg, uint64_t len, uint32_t* k_out);
 hipError_t ed25519_mul_var_batch(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
                                  uint32_t* proj_tmp, hipStream_t st);
 // fixed-base multiply: table of ed25519_fixed_table_words() words built by ed25519_build_fixed_table (host)

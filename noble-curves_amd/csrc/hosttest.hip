@@ -178,6 +178,12 @@ int ht_ntt_plan(int n, int* out) {
   return np;
 }
 
+// challenge scalar k = SHA-512(R || A || M) mod L through the device code (sha512.hpp); out: 8 words
+int ht_ed25519_challenge(const uint8_t* sig, const uint8_t* pk, const uint8_t* msg, uint64_t len, uint32_t* out) {
+  ed25519_challenge_host(sig, pk, msg, len, out);
+  return 0;
+}
+
 // ed25519 verify of one item on the CPU through the kernel's lane function
 int ht_ed25519_verify(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, int zip215) {
   static uint32_t btab[ED25519_BTAB_WORDS];

@@ -30,6 +30,7 @@ def lib():
         _lib.ht_ntt.argtypes = [i32, vp, vp, vp, i32]
         _lib.ht_ntt_plan.argtypes = [i32, vp]
         _lib.ht_fe9_op.argtypes = [i32, i32, i32, vp, vp, vp]
+        _lib.ht_ed25519_challenge.argtypes = [vp, vp, vp, ctypes.c_uint64, vp]
     return _lib
 
 
@@ -142,3 +143,13 @@ def fe9_op(field, op, variant, a_limbs, b_limbs):
     if op in (7, 8, 9):
         return int(R[0])
     return sum(int(R[i]) << (32 * i) for i in range(8))
+
+
+def ed25519_challenge(sig, pk, msg):
+    """k = SHA-512(R || A || M) mod L through the device code (csrc/sha512.hpp) on the CPU."""
+    S = np.frombuffer(bytes(sig), dtype=np.uint8).copy()
+    P = np.frombuffer(bytes(pk), dtype=np.uint8).copy()
+    M = np.frombuffer(bytes(msg) + b"\0", dtype=np.uint8).copy()
+    out = np.zeros(8, dtype=np.uint32)
+    assert lib().ht_ed25519_challenge(S.ctypes.data, P.ctypes.data, M.ctypes.data, len(msg), out.ctypes.data) == 0
+    return sum(int(out[i]) << (32 * i) for i in range(8))

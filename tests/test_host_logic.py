@@ -471,3 +471,17 @@ def test_fe9_lazy_field_ops_at_their_bounds(fid, p):
         assert hosttest.fe9_op(fid, 6, 11, limbs_of(x), [0] * 9) == x % p
     for x in (1, 2, 3, p - 1, p - 2, rng.rndBelow(p), rng.rndBelow(p), 0):
         assert hosttest.fe9_op(fid, 5, 11, limbs_of(x), [0] * 9) == (pow(x, -1, p) if x else 0)
+
+
+def test_sha512_challenge_matches_hashlib():
+    """csrc/sha512.hpp (SHA-512 of R || A || M, then LE mod L) vs hashlib for every padding / block-count
+    boundary (total = 64 + len: one block up to len 47, two up to 175, ...) and extreme digests."""
+    import hashlib
+    from oracle.curves import ED25519_L
+    rng = makeRng(0x5A512)
+    for ln in list(range(0, 6)) + [46, 47, 48, 49, 63, 64, 111, 112, 113, 174, 175, 176, 177, 255, 256, 300, 1023, 2000]:
+        sig = bytes(rng.rnd64() & 0xFF for _ in range(64))
+        pk = bytes(rng.rnd64() & 0xFF for _ in range(32))
+        msg = bytes(rng.rnd64() & 0xFF for _ in range(ln))
+        exp = int.from_bytes(hashlib.sha512(sig[:32] + pk + msg).digest(), "little") % ED25519_L
+        assert hosttest.ed25519_challenge(sig, pk, msg) == exp, ln
