@@ -18,6 +18,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "../include/ncg.h"
 
@@ -167,6 +168,165 @@ static napi_value Ed25519VerifyBatch(napi_env env, napi_callback_info info) {
   napi_value res = make_u8(env, n, &out);
   if (!res) return nullptr;
   if (n && ncg_ed25519_verify_batch(g_ctx, n, sig, pk, k, zip215 ? 1 : 0, out) != 0) return throw_native(env);
+  return res;
+}
+
+// eddsa.verify from (sig, msg, pk): the challenge hash runs on the device too.  msgs = all messages back to
+// back, offs = Float64Array / BigUint64Array-free: a Uint8Array holding n + 1 little-endian uint64 offsets.
+static napi_value Ed25519VerifyMsgs(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  uint8_t *sig, *pk, *msgs, *offs, *out;
+  size_t sgl, pkl, ml, ol;
+  bool zip215 = true;
+  if (argc < 4 || !get_u8(env, argv[0], &sig, &sgl) || !get_u8(env, argv[1], &pk, &pkl) || !get_u8(env, argv[2], &msgs, &ml) ||
+      !get_u8(env, argv[3], &offs, &ol)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: ed25519VerifyMsgs(sigs, pks, msgs, offsets, zip215)");
+    return nullptr;
+  }
+  if (argc >= 5) napi_get_value_bool(env, argv[4], &zip215);
+  const size_t n = sgl / 64;
+  if (sgl % 64 || pkl != n * 32 || ol != (n + 1) * 8) {
+    napi_throw_error(env, nullptr, "arrays of signatures, public keys and message offsets must have matching lengths");
+    return nullptr;
+  }
+  std::vector<uint64_t> off(n + 1);
+  memcpy(off.data(), offs, ol);
+  if (off[n] > ml) {
+    napi_throw_error(env, nullptr, "noble-gpu: message offsets run past the message buffer");
+    return nullptr;
+  }
+  napi_value res = make_u8(env, n, &out);
+  if (!res) return nullptr;
+  if (n && ncg_ed25519_verify_batch_msgs(g_ctx, n, sig, pk, msgs, off.data(), zip215 ? 1 : 0, out) != 0) return throw_native(env);
+  return res;
+}
+
+static int encoded_bytes(int curve);
+// ---- resident point sets: upload once (affine wire points or compressed encodings), then MSMs / batch
+// multiplies with only the scalars crossing.  Handles are small integers; `scalars` may be a Uint8Array
+// of packed 32-byte LE values (no marshalling at all) or an Array of BigInt (read with
+// napi_get_value_bigint_words - no hex strings).
+static std::vector<ncg_points*> g_sets;
+
+static bool get_scalars(napi_env env, napi_value v, size_t n, std::vector<uint8_t>& store, uint8_t** data) {
+  size_t len = 0;
+  if (get_u8(env, v, data, &len)) return len == n * 32;
+  bool is_arr = false;
+  if (napi_is_array(env, v, &is_arr) != napi_ok || !is_arr) return false;
+  uint32_t m = 0;
+  if (napi_get_array_length(env, v, &m) != napi_ok || m != n) return false;
+  store.assign(n * 32, 0);
+  for (uint32_t i = 0; i < m; i++) {
+    napi_value e;
+    if (napi_get_element(env, v, i, &e) != napi_ok) return false;
+    int sign = 0;
+    size_t words = 4;
+    uint64_t w[4] = {0, 0, 0, 0};
+    if (napi_get_value_bigint_words(env, e, &sign, &words, w) != napi_ok || sign != 0 || words > 4) return false;
+    memcpy(store.data() + (size_t)i * 32, w, 32);  // little-endian host
+  }
+  *data = store.data();
+  return true;
+}
+
+static napi_value UploadPoints(napi_env env, napi_callback_info info) {  // (curveId, Uint8Array affine | encoded, encoded?, zip215?)
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t curve;
+  uint8_t* buf;
+  size_t len;
+  bool encoded = false, zip215 = false;
+  if (argc < 2 || napi_get_value_int32(env, argv[0], &curve) != napi_ok || !get_u8(env, argv[1], &buf, &len)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: uploadPoints(curveId, Uint8Array, encoded, zip215)");
+    return nullptr;
+  }
+  if (argc >= 3) napi_get_value_bool(env, argv[2], &encoded);
+  if (argc >= 4) napi_get_value_bool(env, argv[3], &zip215);
+  const int unit = encoded ? encoded_bytes(curve) : ncg_point_bytes(curve);
+  if (unit == 0 || len % unit) {
+    napi_throw_error(env, nullptr, "noble-gpu: uploadPoints: buffer is not a whole number of points");
+    return nullptr;
+  }
+  ncg_points* h = nullptr;
+  int64_t bad = -1;
+  int rc = encoded ? ncg_points_from_encoded(g_ctx, curve, len / unit, buf, zip215 ? 1 : 0, &h, &bad)
+                   : ncg_points_upload(g_ctx, curve, len / unit, buf, &h);
+  if (rc != 0) return throw_native(env);
+  size_t slot = g_sets.size();
+  for (size_t i = 0; i < g_sets.size(); i++)
+    if (!g_sets[i]) { slot = i; break; }
+  if (slot == g_sets.size()) g_sets.push_back(nullptr);
+  g_sets[slot] = h;
+  napi_value r;
+  napi_create_uint32(env, (uint32_t)slot, &r);
+  return r;
+}
+
+static ncg_points* get_set(napi_env env, napi_value v) {
+  uint32_t id = 0;
+  if (napi_get_value_uint32(env, v, &id) != napi_ok || id >= g_sets.size() || !g_sets[id]) {
+    napi_throw_error(env, nullptr, "noble-gpu: unknown point-set handle");
+    return nullptr;
+  }
+  return g_sets[id];
+}
+
+static napi_value FreePoints(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  uint32_t id = 0;
+  if (argc >= 1 && napi_get_value_uint32(env, argv[0], &id) == napi_ok && id < g_sets.size() && g_sets[id]) {
+    ncg_points_free(g_sets[id]);
+    g_sets[id] = nullptr;
+  }
+  return nullptr;
+}
+
+static napi_value MsmResident(napi_env env, napi_callback_info info) {  // (handle, scalars) -> affine || inf
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  ncg_points* h = argc >= 1 ? get_set(env, argv[0]) : nullptr;
+  if (!h) return nullptr;
+  const size_t n = ncg_points_count(h);
+  std::vector<uint8_t> store;
+  uint8_t *sc = nullptr, *out;
+  if (argc < 2 || !get_scalars(env, argv[1], n, store, &sc)) {
+    napi_throw_error(env, nullptr, "arrays of points and scalars must have equal length");
+    return nullptr;
+  }
+  const int pb = ncg_point_bytes(ncg_points_curve(h));
+  napi_value res = make_u8(env, pb + 1, &out);
+  if (!res) return nullptr;
+  if (ncg_msm_resident(g_ctx, h, sc, out, out + pb) != 0) return throw_native(env);
+  return res;
+}
+
+static napi_value MulVarResident(napi_env env, napi_callback_info info) {  // (handle, scalars) -> n x (affine) || n x inf
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  ncg_points* h = argc >= 1 ? get_set(env, argv[0]) : nullptr;
+  if (!h) return nullptr;
+  const size_t n = ncg_points_count(h);
+  std::vector<uint8_t> store;
+  uint8_t *sc = nullptr, *out;
+  if (argc < 2 || !get_scalars(env, argv[1], n, store, &sc)) {
+    napi_throw_error(env, nullptr, "arrays of points and scalars must have equal length");
+    return nullptr;
+  }
+  const int pb = ncg_point_bytes(ncg_points_curve(h));
+  napi_value res = make_u8(env, n * (pb + 1), &out);
+  if (!res) return nullptr;
+  if (n && ncg_mul_var_batch_resident(g_ctx, h, sc, out, out + n * pb) != 0) return throw_native(env);
   return res;
 }
 
@@ -327,6 +487,9 @@ NAPI_MODULE_INIT() {
              {"decodePoints", DecodePoints}, {"encodePoints", EncodePoints},
              {"aggregateEncoded", AggregateEncoded},
              {"ntt", Ntt},               {"mapToCurve", MapToCurve},
+             {"uploadPoints", UploadPoints}, {"freePoints", FreePoints},
+             {"msmResident", MsmResident}, {"mulVarResident", MulVarResident},
+             {"ed25519VerifyMsgs", Ed25519VerifyMsgs},
              {"version", Version}};
   for (auto& f : fns) {
     napi_value v;

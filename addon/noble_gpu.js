@@ -78,6 +78,71 @@ function pippenger(c, points, scalars) {
   const out = native.msm(id, marshalPoints(c, id, points), marshalScalars(scalars));
   return unmarshalPoint(c, id, out, 0, out[out.length - 1] === 1);
 }
+// ---- resident point sets (interleavedMSMUnsafe's pattern, curve.ts:907-959): upload once, then only the
+// scalars cross per call.  `scalars` may be a BigInt[] (validated like the reference, read natively as
+// 64-bit words) or a Uint8Array of packed 32-byte little-endian values (no marshalling at all).
+class PointSet {
+  constructor(c, id, handle, length) { this.c = c; this.id = id; this.handle = handle; this.length = length; }
+  free() { if (this.handle !== null) { native.freePoints(this.handle); this.handle = null; } }
+}
+function uploadPoints(c, points) {
+  const id = curveId(c);
+  validateMSMPoints(points, c);
+  init();
+  return new PointSet(c, id, native.uploadPoints(id, marshalPoints(c, id, points), false, false), points.length);
+}
+function uploadEncoded(c, bytes, zip215) {      // concatenated compressed encodings; decoded + validated on the device
+  const id = curveId(c);
+  init();
+  const eb = { 0: 33, 1: 32, 2: 48, 3: 96 }[id];
+  if (!(bytes instanceof Uint8Array) || bytes.length % eb) throw new Error('noble-gpu: expected a Uint8Array of ' + eb + '-byte encodings');
+  return new PointSet(c, id, native.uploadPoints(id, bytes, true, !!zip215), bytes.length / eb);
+}
+function residentScalars(set, scalars) {
+  if (scalars instanceof Uint8Array) {
+    if (scalars.length !== 32 * set.length) throw new Error('arrays of points and scalars must have equal length');
+    return scalars;
+  }
+  validateMSMScalars(scalars, set.c.Fn);
+  if (scalars.length !== set.length) throw new Error('arrays of points and scalars must have equal length');
+  return scalars;
+}
+function pippengerResident(set, scalars) {
+  const sc = residentScalars(set, scalars);
+  if (set.length === 0) return set.c.ZERO;
+  const out = native.msmResident(set.handle, sc);
+  return unmarshalPoint(set.c, set.id, out, 0, out[out.length - 1] === 1);
+}
+function multiplyUnsafeBatchResident(set, scalars) {
+  const sc = residentScalars(set, scalars);
+  if (set.length === 0) return [];
+  const n = set.length, pb = native.pointBytes(set.id);
+  const out = native.mulVarResident(set.handle, sc);
+  const res = new Array(n);
+  for (let i = 0; i < n; i++) res[i] = unmarshalPoint(set.c, set.id, out, i * pb, out[n * pb + i] === 1);
+  return res;
+}
+// eddsa.verify for a batch from (sig, msg, publicKey): the SHA-512 challenge is computed on the device
+function ed25519VerifyBatchDevice(items, zip215) {
+  const n = items.length;
+  if (n === 0) return [];
+  let total = 0;
+  items.forEach((it) => { total += it.msg.length; });
+  const sig = new Uint8Array(64 * n), pk = new Uint8Array(32 * n), msgs = new Uint8Array(total), offs = new Uint8Array(8 * (n + 1));
+  const dv = new DataView(offs.buffer);
+  let pos = 0;
+  items.forEach((it, i) => {
+    if (it.sig.length !== 64) throw new Error('"signature" expected Uint8Array of length 64');
+    if (it.publicKey.length !== 32) throw new Error('"publicKey" expected Uint8Array of length 32');
+    sig.set(it.sig, 64 * i); pk.set(it.publicKey, 32 * i); msgs.set(it.msg, pos);
+    dv.setUint32(8 * i, pos % 4294967296, true); dv.setUint32(8 * i + 4, Math.floor(pos / 4294967296), true);
+    pos += it.msg.length;
+  });
+  dv.setUint32(8 * n, pos % 4294967296, true); dv.setUint32(8 * n + 4, Math.floor(pos / 4294967296), true);
+  init();
+  return Array.from(native.ed25519VerifyMsgs(sig, pk, msgs, offs, zip215 !== false)).map((x) => x === 1);
+}
+
 function multiplyUnsafeBatch(c, points, scalars) {
   const id = curveId(c);
   validateMSMPoints(points, c);
@@ -221,4 +286,5 @@ function hashToCurveBatch(c, msgs, DST) {
 }
 
 module.exports = { CURVE, init, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
+                   PointSet, uploadPoints, uploadEncoded, pippengerResident, multiplyUnsafeBatchResident, ed25519VerifyBatchDevice,
                    fromBytesBatch, toBytesBatch, aggregateFromBytes, fftFr, hashToCurveBatch, native };

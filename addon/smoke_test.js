@@ -82,6 +82,52 @@ if (haveGpu) {
   const H = gpu.hashToCurveBatch(G2, sig.map((r) => Buffer.from(r.msg, 'hex')));
   const S = gpu.multiplyUnsafeBatch(G2, H, sig.map((r) => BigInt('0x' + r.priv) % BR));
   gpu.toBytesBatch(G2, S).forEach((e, i) => assert.strictEqual(Buffer.from(e).toString('hex'), sig[i].sig));
+  // resident point sets: upload once (points, or their encodings decoded on the device), then MSMs with only
+  // the scalars crossing - as BigInt[] (validated) or as packed bytes
+  const set = gpu.uploadPoints(Point, viaBase);
+  const setEnc = gpu.uploadEncoded(Point, Uint8Array.from([].concat(...enc.map((e) => Array.from(e)))));
+  for (const st of [set, setEnc]) {
+    const r1 = gpu.pippengerResident(st, ss);
+    assert.strictEqual(r1.x, ref.x); assert.strictEqual(r1.y, ref.y);
+    const packed = new Uint8Array(32 * ss.length);
+    ss.forEach((v, i) => { let t = v; for (let j = 0; j < 32; j++) { packed[32 * i + j] = Number(t & 0xffn); t >>= 8n; } });
+    const r2 = gpu.pippengerResident(st, packed);
+    assert.strictEqual(r2.x, ref.x); assert.strictEqual(r2.y, ref.y);
+    const mv = gpu.multiplyUnsafeBatchResident(st, ss);
+    const mvRef = gpu.multiplyUnsafeBatch(Point, viaBase, ss);
+    mv.forEach((p, i) => { assert.strictEqual(p.x, mvRef[i].x); assert.strictEqual(p.y, mvRef[i].y); });
+  }
+  assert.throws(() => gpu.pippengerResident(set, ss.slice(1)), /arrays of points and scalars must have equal length/);
+  assert.throws(() => gpu.pippengerResident(set, ss.map(() => N)), /invalid scalar at index 0/);
+  assert.throws(() => gpu.uploadEncoded(Point, Uint8Array.from(Array.from(enc[0]).concat(Array.from(bad)))), /invalid point encoding at index 1/);
+  set.free(); setEnc.free();
+  // timing of the resident path at 2^16 (SURVEY 8a gotcha 8: marshalling is the end-to-end cost)
+  {
+    const n = 1 << 16;
+    const big = gpu.multiplyBaseBatch(Point, Array.from({ length: 64 }, (_, i) => BigInt(i + 1)));
+    const pts = Array.from({ length: n }, (_, i) => big[i % 64]);
+    const bs = gpu.uploadPoints(Point, pts);
+    const scB = new Uint8Array(32 * n);
+    for (let i = 0; i < n; i++) for (let j = 0; j < 31; j++) scB[32 * i + j] = (i * 131 + j * 17 + 7) & 0xff;
+    gpu.pippengerResident(bs, scB);
+    const t0 = process.hrtime.bigint();
+    const reps = 5;
+    for (let r = 0; r < reps; r++) gpu.pippengerResident(bs, scB);
+    const ms = Number(process.hrtime.bigint() - t0) / 1e6 / reps;
+    console.log('resident pippenger 2^16 (packed scalars): ' + ms.toFixed(2) + ' ms per call');
+    bs.free();
+  }
+  // ed25519 from messages (hash on the device): RFC 8032 test 2 and a corrupted copy
+  {
+    const hex = (h) => Uint8Array.from(Buffer.from(h, 'hex'));
+    const pk = hex('3d4017c3e843895a92b70aa74d1b7ebc9c982ccf2ec4968cc0cd55f12af4660c');
+    const msg = hex('72');
+    const sg = hex('92a009a9f0d4cab8720e820b5f642540a2b27b5416503f8fb3762223ebdb69da085ac1e43e15996e458f3613d0f11d8c387b2eaeb4302aeeb00d291612bb0c00');
+    const badSg = Uint8Array.from(sg); badSg[40] ^= 1;
+    assert.deepStrictEqual(gpu.ed25519VerifyBatchDevice([{ sig: sg, msg, publicKey: pk }, { sig: badSg, msg, publicKey: pk },
+                                                         { sig: sg, msg: hex('73'), publicKey: pk }]), [true, false, false]);
+    assert.deepStrictEqual(gpu.ed25519VerifyBatch([{ sig: sg, msg, publicKey: pk }]), [true]);
+  }
   console.log('GPU smoke OK: multiplyBaseBatch / multiplyUnsafeBatch / pippenger match the reference vectors');
   console.log('GPU smoke OK: codecs, FFT known answer and hash-to-curve signature vectors');
 }

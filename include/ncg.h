@@ -196,6 +196,28 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
 int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev,
                 const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream);
 
+/* ---- resident point sets --------------------------------------------------------------------
+ * Upload a point set once, multiply many times with only the scalars crossing - the usage pattern of
+ * the reference's interleavedMSMUnsafe closure (src/abstract/curve.ts:907-959: precompute for a fixed
+ * point set, call with scalars), and the answer to SURVEY 8a gotcha 8 (marshalling dominates an
+ * end-to-end call).  ncg_points_from_encoded takes the points in their compressed wire encodings
+ * (sizes as for ncg_decode_points_batch) and decodes / validates them on the device; an entry the
+ * reference's fromBytes would reject fails the call and is named in *out_bad_index.  A handle
+ * belongs to the context it was made on; free it before the context. */
+typedef struct ncg_points ncg_points;
+int ncg_points_upload(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, ncg_points** out);
+int ncg_points_from_encoded(ncg_ctx* ctx, int curve, size_t n, const void* encoded, int flags,
+                            ncg_points** out, int64_t* out_bad_index);
+void ncg_points_free(ncg_points* pts);
+size_t ncg_points_count(const ncg_points* pts);
+int ncg_points_curve(const ncg_points* pts);
+const void* ncg_points_dev(const ncg_points* pts); /* device address of the affine wire points */
+/* pippenger(c, <resident points>, scalars) and the batch multiplyUnsafe on them; scalars: host */
+int ncg_msm_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine,
+                     uint8_t* out_is_inf);
+int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars,
+                               void* out_affine, uint8_t* out_is_inf);
+
 /* ---- multi-GPU MSM ---------------------------------------------------------------------
  * pippenger is a sum over points (src/abstract/curve.ts:863-905; its last step is the chain
  * `sum = sum.add(resI)` :895-902), so the points are sharded: each GPU runs the single-GPU pipeline on

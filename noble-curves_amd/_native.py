@@ -73,6 +73,12 @@ def load_library():
             if fn is not None:
                 fn.argtypes = args
                 fn.restype = i32
+        lib.ncg_points_free.argtypes = [vp]
+        lib.ncg_points_free.restype = None
+        lib.ncg_points_count.argtypes = [vp]
+        lib.ncg_points_count.restype = sz
+        lib.ncg_points_dev.argtypes = [vp]
+        lib.ncg_points_dev.restype = vp
         lib.ncg_multi_destroy.argtypes = [vp]
         lib.ncg_multi_destroy.restype = None
         lib.ncg_multi_ctx.argtypes = [vp, i32]
@@ -107,6 +113,11 @@ _OPTIONAL_PROTOS = {
     "ncg_ed25519_verify_batch_msgs": [_vp, _sz, _vp, _vp, _vp, _vp, _i32, _vp],
     "ncg_ed25519_verify_batch_msgs_dev": [_vp, _sz, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "ncg_ed25519_challenge_batch_dev": [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ncg_points_upload": [_vp, _i32, _sz, _vp, ctypes.POINTER(_vp)],
+    "ncg_points_from_encoded": [_vp, _i32, _sz, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int64)],
+    "ncg_points_curve": [_vp],
+    "ncg_msm_resident": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
+    "ncg_mul_var_batch_resident": [_vp, _vp, _vp, _vp, _vp],
     "ncg_comm_unique_id": [_vp],
     "ncg_comm_init": [_vp, _i32, _i32, _vp],
     "ncg_comm_destroy": [_vp],
@@ -295,6 +306,28 @@ class Engine:
                                          stream))
         return out, bool(inf.value)
 
+    # ---- resident point sets (include/ncg.h "resident point sets") -------------------------------
+    def upload_points(self, curve, points):
+        """points uint8 [n, PB] -> ResidentPoints (device-resident until .free() / garbage collection)."""
+        pb = POINT_BYTES[curve]
+        points = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, pb)
+        h = ctypes.c_void_p()
+        self._check(self.lib.ncg_points_upload(self.h, curve, points.shape[0], points.ctypes.data if points.size else None,
+                                               ctypes.byref(h)))
+        return ResidentPoints(self, h, curve)
+
+    def upload_encoded(self, curve, encoded, zip215=False):
+        """encoded uint8 [n, ENCODED_BYTES] -> (ResidentPoints | None, bad_index): decoded and validated on the device."""
+        enc = np.ascontiguousarray(encoded, dtype=np.uint8).reshape(-1, ENCODED_BYTES[curve])
+        h = ctypes.c_void_p()
+        bad = ctypes.c_int64(-1)
+        rc = self.lib.ncg_points_from_encoded(self.h, curve, enc.shape[0], enc.ctypes.data if enc.size else None,
+                                              1 if zip215 else 0, ctypes.byref(h), ctypes.byref(bad))
+        if rc and bad.value >= 0:
+            return None, int(bad.value)
+        self._check(rc)
+        return ResidentPoints(self, h, curve), -1
+
     # ---- multi-GPU MSM, one process per GPU (include/ncg.h "multi-GPU MSM" (1)) ------------------
     @staticmethod
     def comm_unique_id():
@@ -421,6 +454,54 @@ class Engine:
         ms = ctypes.c_float()
         self._check(self.lib.ncg_ubench(self.h, kind, blocks, threads, iters, ctypes.byref(ms)))
         return ms.value
+
+
+class ResidentPoints:
+    """A point set kept in device memory (ncg_points): run MSMs / batch multiplies against it with only
+    the scalars crossing."""
+
+    def __init__(self, engine, handle, curve):
+        self.engine, self.h, self.curve = engine, handle, curve
+
+    def __len__(self):
+        return int(self.engine.lib.ncg_points_count(self.h)) if self.h else 0
+
+    def dev_ptr(self):
+        return self.engine.lib.ncg_points_dev(self.h)
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.engine.lib.ncg_points_free(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if getattr(self.engine, "h", None):
+                self.free()
+        except Exception:
+            pass
+
+    def msm(self, scalars):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        if scalars.shape[0] != len(self):
+            raise ValueError("arrays of points and scalars must have equal length")
+        out = np.zeros((POINT_BYTES[self.curve],), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self.engine._check(self.engine.lib.ncg_msm_resident(self.engine.h, self.h, scalars.ctypes.data if scalars.size else None,
+                                                            out.ctypes.data, ctypes.byref(inf)))
+        return out, bool(inf.value)
+
+    def mul_var_batch(self, scalars):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        n = len(self)
+        if scalars.shape[0] != n:
+            raise ValueError("arrays of points and scalars must have equal length")
+        out = np.empty((n, POINT_BYTES[self.curve]), dtype=np.uint8)
+        inf = np.empty((n,), dtype=np.uint8)
+        if n:
+            self.engine._check(self.engine.lib.ncg_mul_var_batch_resident(self.engine.h, self.h, scalars.ctypes.data,
+                                                                          out.ctypes.data, inf.ctypes.data))
+        return out, inf
 
 
 class MultiEngine:

@@ -388,6 +388,155 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
   return ncg_msm_dev(ctx, curve, n, d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
 }
 
+// ---- resident point sets: upload once, multiply many (interleavedMSMUnsafe's usage pattern,
+// src/abstract/curve.ts:907-959; SURVEY 8a gotcha 8: marshalling dominates an end-to-end call)
+struct ncg_points {
+  ncg_ctx* ctx;
+  int curve;
+  size_t n;
+  void* d_pts;
+};
+
+int ncg_points_upload(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, ncg_points** out) {
+  if (!ctx || !out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_upload: NULL argument");
+  *out = nullptr;
+  const int pb = ncg_point_bytes(curve);
+  if (pb == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: points_upload: unsupported curve %d", curve);
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (n && !points_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_upload: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  ncg_points* h = new ncg_points{ctx, curve, n, nullptr};
+  if (n) {
+    hipError_t e = hipMalloc(&h->d_pts, n * (size_t)pb);
+    if (e != hipSuccess) {
+      delete h;
+      return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", n * (size_t)pb, hipGetErrorString(e));
+    }
+    PinSet pins(ctx);
+    e = pins.h2d(h->d_pts, points_affine, n * (size_t)pb);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(h->d_pts);
+      delete h;
+      return set_err(ctx, NCG_ERR_HIP, "noble-gpu: points_upload: copy failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = h;
+  return NCG_OK;
+}
+
+int ncg_points_from_encoded(ncg_ctx* ctx, int curve, size_t n, const void* encoded, int flags, ncg_points** out,
+                            int64_t* out_bad_index) {
+  if (!ctx || !out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_from_encoded: NULL argument");
+  *out = nullptr;
+  if (out_bad_index) *out_bad_index = -1;
+  const int ib = ncg::decode_in_bytes(curve), pb = ncg_point_bytes(curve);
+  if (ib == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: points_from_encoded: unsupported curve %d", curve);
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (n && !encoded) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_from_encoded: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  ncg_points* h = new ncg_points{ctx, curve, n, nullptr};
+  if (n) {
+    hipError_t e = hipMalloc(&h->d_pts, n * (size_t)pb);
+    if (e != hipSuccess) {
+      delete h;
+      return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", n * (size_t)pb, hipGetErrorString(e));
+    }
+    std::vector<uint8_t> ok(n);
+    const size_t in_b = (n * (size_t)ib + 255) & ~(size_t)255, fl_b = (n + 255) & ~(size_t)255;
+    int rc = ensure_scratch(ctx, in_b + 2 * fl_b + 1024);
+    if (rc == NCG_OK) {
+      PinSet pins(ctx);
+      char* d_in = (char*)ctx->scratch;
+      char* d_ok = d_in + in_b;
+      char* d_inf = d_ok + fl_b;
+      hipError_t e2 = pins.h2d(d_in, encoded, n * (size_t)ib);
+      if (e2 == hipSuccess)
+        rc = ncg_decode_points_batch_dev(ctx, curve, n, d_in, flags, h->d_pts, (uint8_t*)d_ok, (uint8_t*)d_inf, ctx->stream);
+      if (e2 == hipSuccess && rc == NCG_OK) e2 = pins.d2h(ok.data(), d_ok, n);
+      if (e2 == hipSuccess && rc == NCG_OK) e2 = hipStreamSynchronize(ctx->stream);
+      if (e2 != hipSuccess) rc = set_err(ctx, NCG_ERR_HIP, "noble-gpu: points_from_encoded: %s", hipGetErrorString(e2));
+    }
+    if (rc == NCG_OK)
+      for (size_t i = 0; i < n; i++)
+        if (!ok[i]) {  // the reference throws while decoding (Point.fromBytes / assertValidity)
+          if (out_bad_index) *out_bad_index = (int64_t)i;
+          rc = set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_from_encoded: invalid point encoding at index %zu", i);
+          break;
+        }
+    if (rc != NCG_OK) {
+      (void)hipFree(h->d_pts);
+      delete h;
+      return rc;
+    }
+  }
+  *out = h;
+  return NCG_OK;
+}
+
+void ncg_points_free(ncg_points* h) {
+  if (!h) return;
+  if (h->d_pts) {
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipFree(h->d_pts);
+  }
+  delete h;
+}
+size_t ncg_points_count(const ncg_points* h) { return h ? h->n : 0; }
+int ncg_points_curve(const ncg_points* h) { return h ? h->curve : -1; }
+const void* ncg_points_dev(const ncg_points* h) { return h ? h->d_pts : nullptr; }
+
+// scalars -> the tail of the scratch buffer; returns the device address
+static int upload_scalars(ncg_ctx* ctx, PinSet& pins, size_t n, const void* scalars, char** d_sc) {
+  int rc = ensure_scratch(ctx, n * 32 + 512);
+  if (rc) return rc;
+  *d_sc = (char*)ctx->scratch;
+  NCG_HIP(ctx, pins.h2d(*d_sc, scalars, n * 32));
+  return NCG_OK;
+}
+
+int ncg_msm_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine, uint8_t* out_is_inf) {
+  if (!ctx || !pts || pts->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_resident: handle does not belong to this context");
+  if (pts->n == 0) return ncg_msm_dev(ctx, pts->curve, 0, nullptr, nullptr, out_affine, out_is_inf, nullptr);
+  if (!scalars || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_resident: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
+  char* d_sc = nullptr;
+  int rc = upload_scalars(ctx, pins, pts->n, scalars, &d_sc);
+  if (rc) return rc;
+  return ncg_msm_dev(ctx, pts->curve, pts->n, pts->d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
+}
+
+int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine,
+                               uint8_t* out_is_inf) {
+  if (!ctx || !pts || pts->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch_resident: handle does not belong to this context");
+  const size_t n = pts->n;
+  if (n == 0) return NCG_OK;
+  if (!scalars || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch_resident: NULL buffer");
+  const int pb = ncg_point_bytes(pts->curve);
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
+  const size_t sc_b = (n * 32 + 255) & ~(size_t)255, out_b = (n * (size_t)pb + 255) & ~(size_t)255;
+  int rc = ensure_scratch(ctx, sc_b + out_b + n + 1024);
+  if (rc) return rc;
+  char* d_sc = (char*)ctx->scratch;
+  char* d_out = d_sc + sc_b;
+  char* d_inf = d_out + out_b;
+  NCG_HIP(ctx, pins.h2d(d_sc, scalars, n * 32));
+  rc = ncg_mul_var_batch_dev(ctx, pts->curve, n, pts->d_pts, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, pins.d2h(out_affine, d_out, n * (size_t)pb));
+  std::vector<uint8_t> inf_tmp;
+  uint8_t* inf_dst = out_is_inf;
+  if (!inf_dst) {
+    inf_tmp.resize(n);
+    inf_dst = inf_tmp.data();
+  }
+  NCG_HIP(ctx, pins.d2h(inf_dst, d_inf, n));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
 // decode on the device, then sum through the MSM path with unit scalars; nothing but the encodings
 // goes up and one point (plus the verdicts) comes back
 int ncg_aggregate_encoded(ncg_ctx* ctx, int curve, size_t n, const void* encoded, int flags, void* out_affine,

@@ -42,7 +42,7 @@ template <class C> struct DeviceCurve { using type = C; };
 template <> struct DeviceCurve<CurveG2> { using type = CurveG2P; };
 
 struct CurveEd {  // src/ed25519.ts:57-65 (twisted Edwards a = -1; cofactor 8: no subgroup tricks)
-  using F = FpEd;
+  using F = FEd;  // radix-2^29 lazy form (fe9.hpp)
   static constexpr bool GLV = false;
   static constexpr int SCALAR_BITS = 253;
 };

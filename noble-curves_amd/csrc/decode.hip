@@ -219,14 +219,14 @@ NCG_DI bool ed_decode_lane(const uint8_t* __restrict__ in, bool zip215, uint32_t
     const uint8_t* b = in + 4 * i;
     w[i] = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
   }
-  FpEd x, y;
+  FEd x, y;
   bool ok = ed_decompress(w, zip215, x, y);
   if (!ok) {
-    x = FpEd::zero();
-    y = FpEd::zero();
+    x = FEd::zero();
+    y = FEd::zero();
   }
-  FieldWire<FpEd>::store(out, x);
-  FieldWire<FpEd>::store(out + 8, y);
+  FieldWire<FEd>::store(out, x);
+  FieldWire<FEd>::store(out + 8, y);
   return ok;
 }
 

@@ -73,13 +73,6 @@ NCG_DI Jac<F> jac_dbl(const Jac<F>& p) {
   return {X3, Y3, Z3};
 }
 
-// conditional negation; the result type is f_neg's (lazy fields widen their bound there)
-template <class T>
-NCG_DI auto f_cneg(const T& a, bool c) -> decltype(f_neg(a)) {
-  using R = decltype(f_neg(a));
-  return c ? f_neg(a) : R(a);
-}
-
 // Jacobian + affine (x, y) (madd-2007-bl without the 2x scaling): 8M + 3S, P = +-Q explicit.  x and y
 // may be of a wider-bound type than the stored coordinates (a conditionally negated table entry).
 template <class F, class FX, class FY>

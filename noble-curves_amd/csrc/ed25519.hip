@@ -32,12 +32,18 @@ namespace ncg {
 // of 128 entries, the first TB = 2^(WB-1) are used).  WA * MA = WB * MB = BITS >= 254.
 //   EdCfgLds  (2, 6): 258 bits - per-lane table in LDS (16 KB per wave)
 //   EdCfgGtab (4, 8): 264 bits - per-lane table in device memory (1 KB per item), half the additions
+constexpr int ED_FW = FieldIO<FEd>::WORDS;        // stored words per field element (9)
+constexpr int ED_NIELS_WORDS = 4 * ED_FW;          // projective Niels entry (Y+X, Y-X, Z, 2dT)
+constexpr int ED_AFF_NIELS_WORDS = 3 * ED_FW;      // affine Niels entry (y+x, y-x, 2dxy)
+constexpr int ED_PROJ_WORDS = 3 * ED_FW;           // (X, Y, Z) hand-off to the batched inversion
+static_assert(ED25519_BTAB_WORDS == 128 * ED_AFF_NIELS_WORDS, "base table size in host_api.hpp");
+
 template <int WA_, int WB_, int BITS_>
 struct EdCfg {
   static constexpr int WA = WA_, WB = WB_, BITS = BITS_;
   static constexpr int MA = BITS / WA, MB = BITS / WB;
   static constexpr int TA = 1 << (WA - 1), TB = 1 << (WB - 1);
-  static constexpr int LDS_WORDS = TA * 32 * 64;
+  static constexpr int LDS_WORDS = TA * ED_NIELS_WORDS * 64;
   static_assert(WA * MA == BITS && WB * MB == BITS && WB % WA == 0 && BITS >= 254 && TB <= 128, "window tiling");
 };
 using EdCfgLds = EdCfg<2, 6, 258>;
@@ -51,19 +57,37 @@ NCG_DI bool ed_scalar_lt_L(const uint32_t (&s)[8]) {
 }
 
 template <class PTR>
-NCG_DI void ed_store_niels(PTR tab, int stride, int e, const EdNielsProj<FpEd>& q) {
-  using IO = FieldIO<FpEd>;
-  IO::store_strided(tab + (e * 32 + 0) * stride, stride, q.yplusx);
-  IO::store_strided(tab + (e * 32 + 8) * stride, stride, q.yminusx);
-  IO::store_strided(tab + (e * 32 + 16) * stride, stride, q.Z);
-  IO::store_strided(tab + (e * 32 + 24) * stride, stride, q.t2d);
+NCG_DI void ed_store_niels(PTR tab, int stride, int e, const EdNielsProj<FEd>& q) {
+  using IO = FieldIO<FEd>;
+  constexpr int NW = ED_NIELS_WORDS, FW = ED_FW;
+  IO::store_strided(tab + (e * NW + 0) * stride, stride, q.yplusx);
+  IO::store_strided(tab + (e * NW + FW) * stride, stride, q.yminusx);
+  IO::store_strided(tab + (e * NW + 2 * FW) * stride, stride, q.Z);
+  IO::store_strided(tab + (e * NW + 3 * FW) * stride, stride, q.t2d);
 }
 template <class PTR>
-NCG_DI EdNielsProj<FpEd> ed_load_niels(PTR tab, int stride, int e) {
-  using IO = FieldIO<FpEd>;
-  return {IO::load_strided(tab + (e * 32 + 0) * stride, stride), IO::load_strided(tab + (e * 32 + 8) * stride, stride),
-          IO::load_strided(tab + (e * 32 + 16) * stride, stride),
-          IO::load_strided(tab + (e * 32 + 24) * stride, stride)};
+NCG_DI EdNielsProj<FEd> ed_load_niels(PTR tab, int stride, int e) {
+  using IO = FieldIO<FEd>;
+  constexpr int NW = ED_NIELS_WORDS, FW = ED_FW;
+  return {IO::load_strided(tab + (e * NW + 0) * stride, stride), IO::load_strided(tab + (e * NW + FW) * stride, stride),
+          IO::load_strided(tab + (e * NW + 2 * FW) * stride, stride),
+          IO::load_strided(tab + (e * NW + 3 * FW) * stride, stride)};
+}
+NCG_DI EdNielsAff<FEd> ed_load_aff_niels(const uint32_t* __restrict__ e) {
+  using IO = FieldIO<FEd>;
+  return {IO::load(e), IO::load(e + ED_FW), IO::load(e + 2 * ED_FW)};
+}
+NCG_DI void ed_store_aff_niels(uint32_t* __restrict__ e, const EdNielsAff<FEd>& q) {
+  using IO = FieldIO<FEd>;
+  IO::store(e, q.yplusx);
+  IO::store(e + ED_FW, q.yminusx);
+  IO::store(e + 2 * ED_FW, q.t2d);
+}
+NCG_DI void ed_store_proj(uint32_t* __restrict__ o, const EdExt<FEd>& p) {
+  using IO = FieldIO<FEd>;
+  IO::store(o, p.X);
+  IO::store(o + ED_FW, p.Y);
+  IO::store(o + 2 * ED_FW, p.Z);
 }
 
 // Per-lane verification; `tab`/`stride` as in mul_var_lane.  btab: 128 affine Niels entries
@@ -72,8 +96,7 @@ template <class CFG, class TABPTR>
 NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t* __restrict__ pk,
                                 const uint32_t* __restrict__ kscal, const uint32_t* __restrict__ btab, bool zip215,
                                 TABPTR tab, const int stride) {
-  using F = FpEd;
-  using PR = ParamsEdP;
+  using F = FEd;
   uint32_t aw[8], rw[8], s[8], k[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -89,7 +112,7 @@ NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t
   const F d2 = EdConsts::d2();
 
   // -A in extended coordinates, its double, and the table [1,3,5,7](-A) in Niels form
-  EdExt<F> nA{fp_neg<PR>(ax), ay, F::one(), fp_neg<PR>(ax * ay)};
+  EdExt<F> nA{f_neg(ax), ay, F::one(), f_neg(ax * ay)};
   if (!zip215) {  // strict: reject small-order A  (isSmallOrder: [8]A == O)
     EdExt<F> t = ed_dbl(ed_dbl(ed_dbl(nA)));
     if (ed_is_identity(t)) ok = false;
@@ -112,7 +135,7 @@ NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t
   EdExt<F> acc = EdExt<F>::identity();
   for (int i = CFG::MA - 1; i >= 0; i--) {
     if (i != CFG::MA - 1) {
-#pragma unroll
+#pragma unroll(NCG_MUL_INLINE ? 1 : CFG::WA)
       for (int d = 0; d < CFG::WA - 1; d++) acc = ed_dbl_no_t(acc);
       acc = ed_dbl(acc);
     }
@@ -120,16 +143,11 @@ NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t
     acc = ed_add_niels(acc, ed_load_niels(tab, stride, ((dA < 0 ? -dA : dA) - 1) >> 1), dA < 0);
     if (i % (CFG::WB / CFG::WA) == 0) {
       int dB = ws.pop();
-      const uint32_t* bp = btab + (((dB < 0 ? -dB : dB) - 1) >> 1) * 24;
-      EdNielsAff<F> q{fp_load<PR>(bp), fp_load<PR>(bp + 8), fp_load<PR>(bp + 16)};
-      acc = ed_madd_niels(acc, q, dB < 0);
+      acc = ed_madd_niels(acc, ed_load_aff_niels(btab + (((dB < 0 ? -dB : dB) - 1) >> 1) * ED_AFF_NIELS_WORDS), dB < 0);
     }
   }
   if (wk.was_even) acc = ed_add_niels(acc, ed_load_niels(tab, stride, 0), true);
-  if (ws.was_even) {
-    EdNielsAff<F> q{fp_load<PR>(btab), fp_load<PR>(btab + 8), fp_load<PR>(btab + 16)};
-    acc = ed_madd_niels(acc, q, true);
-  }
+  if (ws.was_even) acc = ed_madd_niels(acc, ed_load_aff_niels(btab), true);
   // acc = [s]B - [k]A ; subtract R, clear the cofactor, compare with the identity
   acc = ed_madd_niels(acc, ed_affine_to_niels(rx, ry, d2), true);
   acc = ed_dbl(ed_dbl(ed_dbl(acc)));
@@ -149,7 +167,7 @@ k_ed25519_verify(const uint32_t* __restrict__ sigs, const uint32_t* __restrict__
   bool ok;
   if constexpr (GTAB)
     ok = ed25519_verify_lane<CFG>(sigs + (size_t)src * 16, pks + (size_t)src * 8, ks + (size_t)src * 8, btab, zip215 != 0,
-                                  gtab + (size_t)idx * (CFG::TA * 32), 1);
+                                  gtab + (size_t)idx * (CFG::TA * ED_NIELS_WORDS), 1);
   else
     ok = ed25519_verify_lane<CFG>(sigs + (size_t)src * 16, pks + (size_t)src * 8, ks + (size_t)src * 8, btab, zip215 != 0,
                                   lds + lane, 64);
@@ -167,8 +185,7 @@ template <class CFG, bool PROJ_OUT = false, class TABPTR>
 NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* __restrict__ k_wire,
                                  uint32_t* __restrict__ out_wire, uint8_t* __restrict__ out_inf, bool active,
                                  TABPTR tab, const int stride) {
-  using F = FpEd;
-  using PR = ParamsEdP;
+  using F = FEd;
   F x = FieldWire<F>::load(pt_wire), y = FieldWire<F>::load(pt_wire + 8);
   uint32_t k[8];
 #pragma unroll
@@ -201,19 +218,15 @@ NCG_DI void ed25519_mul_var_lane(const uint32_t* __restrict__ pt_wire, const uin
   if (wk.was_even) acc = ed_add_niels(acc, ed_load_niels(tab, stride, 0), true);
   if (kzero) acc = EdExt<F>::identity();
   if constexpr (PROJ_OUT) {
-    if (active) {
-      fp_store<PR>(out_wire, acc.X);
-      fp_store<PR>(out_wire + 8, acc.Y);
-      fp_store<PR>(out_wire + 16, acc.Z);
-    }
+    if (active) ed_store_proj(out_wire, acc);
     return;
   }
-  F zi = fp_inv<PR>(acc.Z);
+  F zi = f_inv(acc.Z);
   F ox = acc.X * zi, oy = acc.Y * zi;
   if (active) {
     FieldWire<F>::store(out_wire, ox);
     FieldWire<F>::store(out_wire + 8, oy);
-    *out_inf = (ox.is_zero() && oy == F::one()) ? 1 : 0;
+    *out_inf = (f_eqz(ox) && f_eq(oy, F::one())) ? 1 : 0;
   }
 }
 
@@ -228,11 +241,11 @@ k_ed25519_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__
   const int src = active ? idx : n - 1;
   if constexpr (GTAB)
     ed25519_mul_var_lane<CFG, PROJ_OUT>(pts + (size_t)src * 16, scalars + (size_t)src * 8,
-                                        out + (size_t)src * (PROJ_OUT ? 24 : 16), out_inf + src, active,
-                                        gtab + (size_t)idx * (CFG::TA * 32), 1);
+                                        out + (size_t)src * (PROJ_OUT ? ED_PROJ_WORDS : 16), out_inf + src, active,
+                                        gtab + (size_t)idx * (CFG::TA * ED_NIELS_WORDS), 1);
   else
     ed25519_mul_var_lane<CFG, PROJ_OUT>(pts + (size_t)src * 16, scalars + (size_t)src * 8,
-                                        out + (size_t)src * (PROJ_OUT ? 24 : 16), out_inf + src, active, lds + lane, 64);
+                                        out + (size_t)src * (PROJ_OUT ? ED_PROJ_WORDS : 16), out_inf + src, active, lds + lane, 64);
 }
 
 // (X, Y, Z) -> affine wire (x, y) = (X/Z, Y/Z) with Montgomery's trick over K consecutive points
@@ -240,8 +253,8 @@ k_ed25519_mul_var(const uint32_t* __restrict__ pts, const uint32_t* __restrict__
 template <int K>
 __global__ void __launch_bounds__(256) k_ed_batch_affine(const uint32_t* __restrict__ proj, uint32_t* __restrict__ out_wire,
                                                          uint8_t* __restrict__ out_inf, int n) {
-  using F = FpEd;
-  using PR = ParamsEdP;
+  using F = FEd;
+  using IO = FieldIO<F>;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i0 = t * K;
   if (i0 >= n) return;
@@ -250,25 +263,25 @@ __global__ void __launch_bounds__(256) k_ed_batch_affine(const uint32_t* __restr
 #pragma unroll
   for (int j = 0; j < K; j++) {
     pre[j] = acc;
-    if (i0 + j < n) acc = acc * fp_load<PR>(proj + ((size_t)(i0 + j) * 3 + 2) * 8);  // Z != 0 on Edwards curves
+    if (i0 + j < n) acc = acc * IO::load(proj + (size_t)(i0 + j) * ED_PROJ_WORDS + 2 * ED_FW);  // Z != 0 on Edwards curves
   }
-  F inv = fp_inv<PR>(acc);
+  F inv = f_inv(acc);
 #pragma unroll
   for (int j = K - 1; j >= 0; j--) {
     if (i0 + j < n) {
-      const uint32_t* p = proj + (size_t)(i0 + j) * 24;
-      F z = fp_load<PR>(p + 16);
+      const uint32_t* p = proj + (size_t)(i0 + j) * ED_PROJ_WORDS;
+      F z = IO::load(p + 2 * ED_FW);
       F zi = inv * pre[j];
       inv = inv * z;
-      F x = fp_load<PR>(p) * zi, y = fp_load<PR>(p + 8) * zi;
+      F x = IO::load(p) * zi, y = IO::load(p + ED_FW) * zi;
       FieldWire<F>::store(out_wire + (size_t)(i0 + j) * 16, x);
       FieldWire<F>::store(out_wire + (size_t)(i0 + j) * 16 + 8, y);
-      out_inf[i0 + j] = (x.is_zero() && y == F::one()) ? 1 : 0;
+      out_inf[i0 + j] = (f_eqz(x) && f_eq(y, F::one())) ? 1 : 0;
     }
   }
 }
 
-// (X, Y, Z) triples (24 words each, as written by the kernels above) -> affine wire points + identity flags
+// (X, Y, Z) triples (ED_PROJ_WORDS words each, as written by the kernels above) -> affine wire points + identity flags
 hipError_t ed25519_proj_to_affine(const uint32_t* proj, uint32_t* out, uint8_t* out_inf, int n, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_ed_batch_affine<8>, dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, proj, out, out_inf, n);
@@ -277,12 +290,12 @@ hipError_t ed25519_proj_to_affine(const uint32_t* proj, uint32_t* out, uint8_t* 
 
 // proj_tmp: ed25519_tmp_words(n) words of device scratch ((X, Y, Z) per item + the per-item window
 // tables), or nullptr (LDS table, per-lane inversion)
-size_t ed25519_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * (24 + EdCfgGtab::TA * 32); }
+size_t ed25519_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * (ED_PROJ_WORDS + EdCfgGtab::TA * ED_NIELS_WORDS); }
 hipError_t ed25519_mul_var_batch(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
                                  uint32_t* proj_tmp, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   if (proj_tmp) {
-    uint32_t* gtab = proj_tmp + ((size_t)n + 63) / 64 * 64 * 24;
+    uint32_t* gtab = proj_tmp + ((size_t)n + 63) / 64 * 64 * ED_PROJ_WORDS;
     hipLaunchKernelGGL((k_ed25519_mul_var<EdCfgGtab, true, true, 4>), dim3((n + 63) / 64), dim3(64), 0, st, pts, scalars,
                        proj_tmp, out_inf, gtab, n);
     hipLaunchKernelGGL(k_ed_batch_affine<8>, dim3(((n + 7) / 8 + 255) / 256), dim3(256), 0, st, proj_tmp, out, out_inf, n);
@@ -304,8 +317,7 @@ hipError_t ed25519_mul_var_batch(const uint32_t* pts, const uint32_t* scalars, u
 constexpr int ED_FB_W = 8, ED_FB_M = 33, ED_FB_T = 1 << (ED_FB_W - 1);
 __global__ void __launch_bounds__(256) k_ed_mul_base(const uint32_t* __restrict__ table, const uint32_t* __restrict__ scalars,
                                                      uint32_t* __restrict__ proj_out, int n) {
-  using F = FpEd;
-  using PR = ParamsEdP;
+  using F = FEd;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t k[8];
@@ -317,19 +329,12 @@ __global__ void __launch_bounds__(256) k_ed_mul_base(const uint32_t* __restrict_
   EdExt<F> acc = EdExt<F>::identity();
   for (int w = ED_FB_M - 1; w >= 0; w--) {
     const int d = win.pop();
-    const uint32_t* e = table + ((size_t)w * ED_FB_T + (((d < 0 ? -d : d) - 1) >> 1)) * 24;
-    EdNielsAff<F> q{fp_load<PR>(e), fp_load<PR>(e + 8), fp_load<PR>(e + 16)};
-    acc = ed_madd_niels(acc, q, d < 0);
+    const uint32_t* e = table + ((size_t)w * ED_FB_T + (((d < 0 ? -d : d) - 1) >> 1)) * ED_AFF_NIELS_WORDS;
+    acc = ed_madd_niels(acc, ed_load_aff_niels(e), d < 0);
   }
-  if (win.was_even) {  // the scalar was bumped by one: take BASE back out
-    EdNielsAff<F> q{fp_load<PR>(table), fp_load<PR>(table + 8), fp_load<PR>(table + 16)};
-    acc = ed_madd_niels(acc, q, true);
-  }
+  if (win.was_even) acc = ed_madd_niels(acc, ed_load_aff_niels(table), true);  // the scalar was bumped by one: take BASE back out
   if (zero) acc = EdExt<F>::identity();
-  uint32_t* o = proj_out + (size_t)i * 24;
-  fp_store<PR>(o, acc.X);
-  fp_store<PR>(o + 8, acc.Y);
-  fp_store<PR>(o + 16, acc.Z);
+  ed_store_proj(proj_out + (size_t)i * ED_PROJ_WORDS, acc);
 }
 
 hipError_t ed25519_mul_base_batch(const uint32_t* table, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
@@ -341,26 +346,24 @@ hipError_t ed25519_mul_base_batch(const uint32_t* table, const uint32_t* scalars
 }
 
 void ed25519_mul_var_host(const uint32_t* pt, const uint32_t* k, uint32_t* out, uint8_t* out_inf) {
-  std::vector<uint32_t> tab(EdCfgGtab::TA * 32);
+  std::vector<uint32_t> tab(EdCfgGtab::TA * ED_NIELS_WORDS);
   ed25519_mul_var_lane<EdCfgGtab, false>(pt, k, out, out_inf, true, tab.data(), 1);
 }
 
-static EdExt<FpEd> ed_base_point() {  // src/ed25519.ts:57-65 Gx, Gy
-  using PR = ParamsEdP;
+static EdExt<FEd> ed_base_point() {  // src/ed25519.ts:57-65 Gx, Gy
   static const uint32_t GX[8] = {0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u,
                                  0xcd6e53feu, 0x216936d3u};
   static const uint32_t GY[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u,
                                  0x66666666u, 0x66666666u};
-  FpEd gx = fp_to_mont<PR>(fp_load<PR>(GX)), gy = fp_to_mont<PR>(fp_load<PR>(GY));
-  return {gx, gy, FpEd::one(), gx * gy};
+  FEd gx = FieldWire<FEd>::load(GX), gy = FieldWire<FEd>::load(GY);
+  return {gx, gy, FEd::one(), gx * gy};
 }
 
 // fixed-base table for k_ed_mul_base, computed on the host with the same templates: 33 x 128
 // entries of 24 words, entry [w][j] = (2j+1) 2^(8w) B; one batched inversion for all 4224 points
-size_t ed25519_fixed_table_words() { return (size_t)ED_FB_M * ED_FB_T * 24; }
+size_t ed25519_fixed_table_words() { return (size_t)ED_FB_M * ED_FB_T * ED_AFF_NIELS_WORDS; }
 void ed25519_build_fixed_table(uint32_t* out) {
-  using F = FpEd;
-  using PR = ParamsEdP;
+  using F = FEd;
   const F d2 = EdConsts::d2();
   const int NT = ED_FB_M * ED_FB_T;
   std::vector<EdExt<F>> pts(NT);
@@ -380,43 +383,36 @@ void ed25519_build_fixed_table(uint32_t* out) {
     pre[i] = acc;
     acc = acc * pts[i].Z;
   }
-  F inv = fp_inv<PR>(acc);
+  F inv = f_inv(acc);
   for (int i = NT - 1; i >= 0; i--) {
     F zi = inv * pre[i];
     inv = inv * pts[i].Z;
     F x = pts[i].X * zi, y = pts[i].Y * zi;
-    EdNielsAff<F> q = ed_affine_to_niels(x, y, d2);
-    fp_store<PR>(out + (size_t)i * 24, q.yplusx);
-    fp_store<PR>(out + (size_t)i * 24 + 8, q.yminusx);
-    fp_store<PR>(out + (size_t)i * 24 + 16, q.t2d);
+    ed_store_aff_niels(out + (size_t)i * ED_AFF_NIELS_WORDS, ed_affine_to_niels(x, y, d2));
   }
 }
 
 // ---- base-point table [1,3,..,63]*B in affine Niels form (host-computed with the same templates)
-void ed25519_build_base_table(uint32_t* out /* 128 * 24 words */) {
-  using F = FpEd;
-  using PR = ParamsEdP;
+void ed25519_build_base_table(uint32_t* out /* ED25519_BTAB_WORDS */) {
+  using F = FEd;
   const F d2 = EdConsts::d2();
   EdExt<F> B = ed_base_point();
   EdNielsProj<F> n2 = ed_to_niels(ed_dbl(B), d2);
   EdExt<F> cur = B;
   for (int j = 0; j < 128; j++) {
     if (j > 0) cur = ed_add_niels(cur, n2, false);
-    F zi = fp_inv<PR>(cur.Z);
+    F zi = f_inv(cur.Z);
     F x = cur.X * zi, y = cur.Y * zi;
-    EdNielsAff<F> q = ed_affine_to_niels(x, y, d2);
-    fp_store<PR>(out + j * 24, q.yplusx);
-    fp_store<PR>(out + j * 24 + 8, q.yminusx);
-    fp_store<PR>(out + j * 24 + 16, q.t2d);
+    ed_store_aff_niels(out + j * ED_AFF_NIELS_WORDS, ed_affine_to_niels(x, y, d2));
   }
 }
 
 // gtab: n_pad * TA * 32 words of device scratch for the per-item tables, or nullptr (LDS variant)
-size_t ed25519_verify_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * EdCfgGtab::TA * 32; }
+size_t ed25519_verify_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * EdCfgGtab::TA * ED_NIELS_WORDS; }
 hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
                                 int zip215, uint8_t* out_ok, int n, uint32_t* gtab, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  static const int variant = [] { const char* e = std::getenv("NCG_ED_VARIANT"); return e ? std::atoi(e) : 4; }();
+  static const int variant = [] { const char* e = std::getenv("NCG_ED_VARIANT"); return e ? std::atoi(e) : 3; }();
   if (gtab && variant > 0) {
     if (variant == 2)
       hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 2>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
@@ -469,7 +465,7 @@ void ed25519_challenge_host(const uint8_t* sig, const uint8_t* pk, const uint8_t
 
 // host-only: run the lane function on the CPU (unit tests through hosttest.hip)
 bool ed25519_verify_host(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, const uint32_t* btab, bool zip215) {
-  std::vector<uint32_t> tab(EdCfgGtab::TA * 32);
+  std::vector<uint32_t> tab(EdCfgGtab::TA * ED_NIELS_WORDS);
   return ed25519_verify_lane<EdCfgGtab>(sig, pk, k, btab, zip215, tab.data(), 1);
 }
 

@@ -238,4 +238,11 @@ struct FieldWire<Fe29x2<B>> {
   }
 };
 
+// conditional negation; the result type is f_neg's (lazy fields widen their bound there)
+template <class T>
+NCG_DI auto f_cneg(const T& a, bool c) -> decltype(f_neg(a)) {
+  using R = decltype(f_neg(a));
+  return c ? f_neg(a) : R(a);
+}
+
 }  // namespace ncg

@@ -71,7 +71,7 @@ size_t msm_fin_words(int curve, const MsmPlan& pl);
 size_t msm_acc_words(int curve);
 
 // ed25519 batch verify (ed25519.hip).  btab: device copy of the table built by ed25519_build_base_table.
-constexpr int ED25519_BTAB_WORDS = 128 * 24;  // [1,3,..,255]B, affine Niels
+constexpr int ED25519_BTAB_WORDS = 128 * 27;  // [1,3,..,255]B, affine Niels, 3 x 9 stored words each
 void ed25519_build_base_table(uint32_t* out_words);
 size_t ed25519_verify_tmp_words(int n);
 size_t ed25519_tmp_words(int n);

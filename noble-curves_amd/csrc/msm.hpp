@@ -95,45 +95,45 @@ struct MsmGroup {
 // case; an all-zero stored accumulator (memset) decodes as the identity.
 template <>
 struct MsmGroup<CurveEd> {
-  using F = FpEd;
+  using F = FEd;
   using Acc = EdExt<F>;
   using Aff = EdNielsAff<F>;
-  static constexpr int FW = 8;
+  static constexpr int FW = FieldIO<F>::WORDS;
   static constexpr int WIRE_AFF = 16;
-  static constexpr int AFF_WORDS = 24;
-  static constexpr int ACC_WORDS = 32;
+  static constexpr int AFF_WORDS = 3 * FW;
+  static constexpr int ACC_WORDS = 4 * FW;
   static NCG_DI void wire_to_storage(const uint32_t* wire, uint32_t* out) {
     F x = FieldWire<F>::load(wire), y = FieldWire<F>::load(wire + 8);
     Aff q = ed_affine_to_niels(x, y, EdConsts::d2());
     FieldIO<F>::store(out, q.yplusx);
-    FieldIO<F>::store(out + 8, q.yminusx);
-    FieldIO<F>::store(out + 16, q.t2d);
+    FieldIO<F>::store(out + FW, q.yminusx);
+    FieldIO<F>::store(out + 2 * FW, q.t2d);
   }
   static NCG_DI Aff aff_load(const uint32_t* p) {
-    return {FieldIO<F>::load(p), FieldIO<F>::load(p + 8), FieldIO<F>::load(p + 16)};
+    return {FieldIO<F>::load(p), FieldIO<F>::load(p + FW), FieldIO<F>::load(p + 2 * FW)};
   }
   static NCG_DI Acc identity() { return EdExt<F>::identity(); }
   static NCG_DI Acc acc_load(const uint32_t* p) {
-    Acc a{FieldIO<F>::load(p), FieldIO<F>::load(p + 8), FieldIO<F>::load(p + 16), FieldIO<F>::load(p + 24)};
-    if (a.Z.is_zero()) a = EdExt<F>::identity();
+    Acc a{FieldIO<F>::load(p), FieldIO<F>::load(p + FW), FieldIO<F>::load(p + 2 * FW), FieldIO<F>::load(p + 3 * FW)};
+    if (a.Z.is_zero()) a = EdExt<F>::identity();  // literal zeros = a memset slot
     return a;
   }
   static NCG_DI void acc_store(uint32_t* p, const Acc& a) {
     FieldIO<F>::store(p, a.X);
-    FieldIO<F>::store(p + 8, a.Y);
-    FieldIO<F>::store(p + 16, a.Z);
-    FieldIO<F>::store(p + 24, a.T);
+    FieldIO<F>::store(p + FW, a.Y);
+    FieldIO<F>::store(p + 2 * FW, a.Z);
+    FieldIO<F>::store(p + 3 * FW, a.T);
   }
   static NCG_DI Acc madd(const Acc& a, const Aff& q, bool neg) { return ed_madd_niels(a, q, neg); }
   static NCG_DI Acc add(const Acc& a, const Acc& b) { return ed_add_niels(a, ed_to_niels(b, EdConsts::d2()), false); }
   static NCG_DI Acc dbl(const Acc& a) { return ed_dbl(a); }
   // affine (x, y) = (X/Z, Y/Z); the identity is (0, 1) on Edwards curves (edwards.ts:606)
   static NCG_DI void to_affine_wire(const Acc& acc, uint32_t* out, uint8_t* out_inf) {
-    F zi = fp_inv<ParamsEdP>(acc.Z);
+    F zi = f_inv(acc.Z);
     F x = acc.X * zi, y = acc.Y * zi;
     FieldWire<F>::store(out, x);
     FieldWire<F>::store(out + 8, y);
-    *out_inf = (x.is_zero() && y == F::one()) ? 1 : 0;
+    *out_inf = (f_eqz(x) && f_eq(y, F::one())) ? 1 : 0;
   }
 };
 

@@ -56,18 +56,18 @@ __global__ void __launch_bounds__(256) k_pair_add(const uint32_t* __restrict__ a
 }
 __global__ void __launch_bounds__(256) k_pair_add_ed(const uint32_t* __restrict__ a_wire, const uint32_t* __restrict__ b_wire,
                                                      int subtract, uint32_t* __restrict__ proj_out, int n) {
-  using F = FpEd;
-  using PR = ParamsEdP;
+  using F = FEd;
+  constexpr int FW = FieldIO<F>::WORDS;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   F ax = FieldWire<F>::load(a_wire + (size_t)i * 16), ay = FieldWire<F>::load(a_wire + (size_t)i * 16 + 8);
   F bx = FieldWire<F>::load(b_wire + (size_t)i * 16), by = FieldWire<F>::load(b_wire + (size_t)i * 16 + 8);
   EdExt<F> A{ax, ay, F::one(), ax * ay};
   EdExt<F> R = ed_madd_niels(A, ed_affine_to_niels(bx, by, EdConsts::d2()), subtract != 0);
-  uint32_t* o = proj_out + (size_t)i * 24;
-  fp_store<PR>(o, R.X);
-  fp_store<PR>(o + 8, R.Y);
-  fp_store<PR>(o + 16, R.Z);
+  uint32_t* o = proj_out + (size_t)i * 3 * FW;
+  FieldIO<F>::store(o, R.X);
+  FieldIO<F>::store(o + FW, R.Y);
+  FieldIO<F>::store(o + 2 * FW, R.Z);
 }
 
 template <class C, int K>

@@ -258,6 +258,16 @@ def _scalars_wire(scalars):
 def pippenger(c, points, scalars, engine=None):
     """MSM sum_i scalars[i]*points[i] (curve.ts:863-905): same validation order and messages;
     empty input returns ZERO (:878); zero scalars and ZERO points are allowed."""
+    if isinstance(points, PointSet):               # resident set: validated at upload, only scalars cross
+        if points.c is not c:
+            raise ValueError("invalid point at index 0")
+        validateMSMScalars(scalars, c.Fn)
+        if len(points) != len(scalars):
+            raise ValueError("arrays of points and scalars must have equal length")
+        if len(points) == 0:
+            return c.ZERO
+        out, inf = points.resident.msm(_scalars_wire(scalars))
+        return c._from_wire(out, inf)
     validateMSMPoints(points, c)
     validateMSMScalars(scalars, c.Fn)
     if len(points) != len(scalars):
@@ -269,19 +279,69 @@ def pippenger(c, points, scalars, engine=None):
     return c._from_wire(out, inf)
 
 
+class PointSet:
+    """A validated point set resident on the GPU: `uploadPoints` / `uploadEncoded` make one, `pippenger`
+    and `multiplyUnsafeBatch` accept it in place of the point list - only the scalars cross per call.
+    The reference's counterpart is the closure of interleavedMSMUnsafe (curve.ts:907-959): precompute
+    for a fixed point set once, then call with scalars."""
+
+    def __init__(self, c, resident):
+        self.c, self.resident = c, resident
+
+    def __len__(self):
+        return len(self.resident)
+
+    def free(self):
+        self.resident.free()
+
+
+def uploadPoints(c, points, engine=None):
+    """Validate like pippenger (curve.ts:390-395) and keep the points on the device."""
+    validateMSMPoints(points, c)
+    eng = engine or get_engine()
+    return PointSet(c, eng.upload_points(c.CURVE_ID, _points_wire(points, c.POINT_BYTES)))
+
+
+def uploadEncoded(c, encodings, zip215=False, engine=None):
+    """Point set from compressed encodings (c.fromBytes(b) for each b), decoded and validated on the
+    device; an entry the reference would reject raises ValueError naming its index."""
+    size = _native.ENCODED_BYTES.get(c.CURVE_ID)
+    if size is None:
+        raise ValueError("noble-gpu: no batch decoder for this curve")
+    if isinstance(encodings, np.ndarray):
+        rows = np.ascontiguousarray(encodings, dtype=np.uint8).reshape(-1, size)
+    else:
+        for i, b in enumerate(encodings):
+            if len(bytes(b)) != size:
+                raise ValueError("invalid point encoding at index %d: expected %d bytes" % (i, size))
+        rows = np.frombuffer(b"".join(bytes(b) for b in encodings), dtype=np.uint8).reshape(-1, size)
+    eng = engine or get_engine()
+    res, bad = eng.upload_encoded(c.CURVE_ID, rows, zip215)
+    if res is None:
+        raise ValueError("invalid point encoding at index %d" % bad)
+    return PointSet(c, res)
+
+
 def multiplyUnsafeBatch(c, points, scalars, engine=None, _err="invalid scalar: out of range"):
     """[p.multiplyUnsafe(k) for p, k in zip(points, scalars)] in one launch
     (weierstrass.ts:915-928: 0 <= k < n else RangeError('invalid scalar: out of range'))."""
-    validateMSMPoints(points, c)
+    resident = points if isinstance(points, PointSet) else None
+    if resident is None:
+        validateMSMPoints(points, c)
+    elif resident.c is not c:
+        raise ValueError("invalid point at index 0")
     if len(points) != len(scalars):
         raise ValueError("arrays of points and scalars must have equal length")
     for k in scalars:
         if not (isinstance(k, int) and not isinstance(k, bool) and 0 <= k < c.Fn.ORDER):
             raise ValueError(_err)
-    if not points:
+    if len(points) == 0:
         return []
-    eng = engine or get_engine()
-    out, inf = eng.mul_var_batch(c.CURVE_ID, _points_wire(points, c.POINT_BYTES), _scalars_wire(scalars))
+    if resident is not None:
+        out, inf = resident.resident.mul_var_batch(_scalars_wire(scalars))
+    else:
+        eng = engine or get_engine()
+        out, inf = eng.mul_var_batch(c.CURVE_ID, _points_wire(points, c.POINT_BYTES), _scalars_wire(scalars))
     return [c._from_wire(out[i], bool(inf[i])) for i in range(len(points))]
 
 
