@@ -220,7 +220,7 @@ function toBytesBatch(c, points) {
 // sum of the decoded points: the group part of bls.aggregatePublicKeys on encoded keys (abstract/bls.ts:857-873)
 function aggregateFromBytes(c, encodings, zip215) {
   const id = curveId(c), eb = ENC[id], pb = native.pointBytes(id), n = encodings.length;
-  if (n === 0) return c.ZERO;
+  if (!Array.isArray(encodings) || n === 0) throw new Error('expected non-empty array');   // bls.ts:426-431 aNonEmpty
   const buf = new Uint8Array(n * eb);
   encodings.forEach((e, i) => {
     if (!(e instanceof Uint8Array) || e.length !== eb) throw new Error('invalid point encoding at index ' + i + ': expected ' + eb + ' bytes');

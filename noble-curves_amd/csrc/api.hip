@@ -309,6 +309,7 @@ int ncg_mul_base_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* scalar
     uint32_t* tab = nullptr;
     NCG_HIP(ctx, hipMalloc((void**)&tab, ncg::mul_base_table_bytes(curve)));
     hipError_t e = ncg::mul_base_build_table(curve, base, tab, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // cache the table only once the build is known to have completed
     if (e != hipSuccess) {
       (void)hipFree(tab);
       return set_err(ctx, NCG_ERR_HIP, "noble-gpu: building the fixed-base table failed: %s", hipGetErrorString(e));
@@ -363,8 +364,11 @@ int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev
   int prc = ncg_msm_plan_ws(ctx, curve, n, 0, &pl);
   if (prc) return prc;
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  uint32_t bad = 0xFFFFFFFFu;
   NCG_HIP(ctx, ncg::msm_run(curve, pl, (const uint32_t*)points_affine_dev, (const uint32_t*)scalars_dev, ctx->msm_ws,
-                            (uint32_t*)out_affine, &inf_local, st));
+                            (uint32_t*)out_affine, &inf_local, st, &bad));
+  if (bad != 0xFFFFFFFFu)  // validateMSMScalars (curve.ts:398-404): scalars must be below the group order
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
   if (out_is_inf) *out_is_inf = inf_local;
   return NCG_OK;
 }
@@ -832,11 +836,13 @@ int ncg_ntt(ncg_ctx* ctx, int field, int log2n, size_t batch, const void* omega,
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
   if (log2n < 0 || log2n > NCG_NTT_MAX_LOG2N)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: log2n %d out of range 0..%d", log2n, NCG_NTT_MAX_LOG2N);
+  if (field != NCG_FIELD_BLS12_381_FR) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ntt: unsupported field %d", field);
   if (batch == 0) return NCG_OK;
+  if (batch > 65535) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: batch %zu too large (max 65535)", batch);
   if (!omega || !in || !out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   PinSet pins(ctx);
-  const size_t bytes = (batch << log2n) * 32;
+  const size_t bytes = (batch << log2n) * 32;  // batch <= 2^16, log2n <= 28: below 2^49
   int rc = ensure_scratch(ctx, bytes + 1024);
   if (rc) return rc;
   NCG_HIP(ctx, pins.h2d(ctx->scratch, in, bytes));

@@ -96,7 +96,8 @@ struct FinHeader {  // first 16 bytes of every rank's contribution: the plans mu
 
 // this rank's contribution = header + grouped window sums, written at comm_buf + rank * stride
 int local_phase(ncg_ctx* ctx, int curve, size_t n_local, size_t n_plan, const void* d_pts, const void* d_sc, int slot,
-                int nslots, ncg::MsmPlan* pl_out, size_t* stride_out, hipStream_t st) {
+                int nslots, ncg::MsmPlan* pl_out, size_t* stride_out, hipStream_t st, const uint32_t** d_bad_out = nullptr) {
+  if (d_bad_out) *d_bad_out = nullptr;
   ncg::MsmPlan pl;
   int rc = ncg_msm_plan_ws(ctx, curve, n_plan, 0, &pl);
   if (rc) return rc;
@@ -115,8 +116,9 @@ int local_phase(ncg_ctx* ctx, int curve, size_t n_local, size_t n_plan, const vo
   if (n_local == 0) {  // an empty shard contributes identities (all-zero accumulators decode as such)
     NCG_HIP(ctx, hipMemsetAsync(mine + sizeof h, 0, fin_bytes, st));
   } else {
-    const uint32_t* d_fin = nullptr;
-    NCG_HIP(ctx, ncg::msm_device_phase(curve, pl, (const uint32_t*)d_pts, (const uint32_t*)d_sc, ctx->msm_ws, &d_fin, st));
+    const uint32_t *d_fin = nullptr, *d_bad = nullptr;
+    NCG_HIP(ctx, ncg::msm_device_phase(curve, pl, (const uint32_t*)d_pts, (const uint32_t*)d_sc, ctx->msm_ws, &d_fin, st, &d_bad));
+    if (d_bad_out) *d_bad_out = d_bad;
     NCG_HIP(ctx, hipMemcpyAsync(mine + sizeof h, d_fin, fin_bytes, hipMemcpyDeviceToDevice, st));
   }
   *pl_out = pl;
@@ -246,7 +248,9 @@ int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max, c
     int rc = ensure_comm_buf(ctx, comm_buf_need(sd, fw, G));
     if (rc) return rc;
   }
-  int rc = local_phase(ctx, curve, n_local, n_max, points_affine_dev, scalars_dev, ctx->comm ? ctx->comm_rank : 0, G, &pl, &stride, st);
+  const uint32_t* d_bad = nullptr;
+  int rc = local_phase(ctx, curve, n_local, n_max, points_affine_dev, scalars_dev, ctx->comm ? ctx->comm_rank : 0, G, &pl, &stride, st,
+                       &d_bad);
   if (rc) return rc;
   if (ctx->comm && G > 1) {
     const Rccl* r = rccl();
@@ -255,7 +259,13 @@ int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max, c
     // in place: rank r's slot already sits at offset r * stride of the receive buffer
     NCG_NCCL(ctx, r, r->AllGather(base + stride * (size_t)ctx->comm_rank, base, stride, ncclUint8, (ncclComm_t)ctx->comm, st));
   }
-  return combine_and_finish(ctx, curve, pl, stride, G, out_affine, out_is_inf, st);
+  uint32_t bad = 0xFFFFFFFFu;  // this rank's scalar-range verdict (validateMSMScalars, curve.ts:398-404); read in stream order
+  if (d_bad) NCG_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+  rc = combine_and_finish(ctx, curve, pl, stride, G, out_affine, out_is_inf, st);
+  if (rc) return rc;
+  if (bad != 0xFFFFFFFFu)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: invalid scalar at index %u of this rank's shard (not below the group order)", bad);
+  return NCG_OK;
 }
 
 // The sharded pipeline on ONE GPU (self-check and A/B of the shard-size plan): the point set is cut into
@@ -283,10 +293,18 @@ int ncg_msm_split_dev(ncg_ctx* ctx, int curve, size_t n, int parts, const void* 
   for (int g = 0; g < parts; g++) {
     const size_t lo = std::min(n, per * (size_t)g), cnt = std::min(n, lo + per) - lo;
     ncg::MsmPlan plg;
+    const uint32_t* d_bad = nullptr;
     rc = local_phase(ctx, curve, cnt, per, (const char*)points_affine_dev + lo * (size_t)pb, (const char*)scalars_dev + lo * 32, g,
-                     parts, &plg, &stride, st);
+                     parts, &plg, &stride, st, &d_bad);
     if (rc) return rc;
     if (g == 0) pl = plg;
+    if (d_bad) {  // the workspace (and its flag) is reused by the next slice: read it now
+      uint32_t bad = 0xFFFFFFFFu;
+      NCG_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+      NCG_HIP(ctx, hipStreamSynchronize(st));
+      if (bad != 0xFFFFFFFFu)
+        return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: invalid scalar at index %zu (not below the group order)", lo + bad);
+    }
   }
   return combine_and_finish(ctx, curve, pl, stride, parts, out_affine, out_is_inf, st);
 }
@@ -356,6 +374,8 @@ int ncg_msm_multi(ncg_multi* m, int curve, size_t n, const void* points_affine, 
   size_t stride = 0;
   const Rccl* r = G > 1 ? rccl() : nullptr;
   if (G > 1 && !r) return fail(set_err(nullptr, NCG_ERR_UNSUPPORTED, "noble-gpu: librccl.so not found"));
+  std::vector<const uint32_t*> d_bads(G, nullptr);
+  std::vector<uint32_t> bads(G, 0xFFFFFFFFu);
   // 1. every device: upload its slice and run the device phase (all asynchronous, one host thread)
   for (int g = 0; g < G; g++) {
     ncg_ctx* ctx = m->ctx[g];
@@ -385,7 +405,7 @@ int ncg_msm_multi(ncg_multi* m, int curve, size_t n, const void* points_affine, 
         return fail(set_err(ctx, NCG_ERR_HIP, "noble-gpu: msm_multi: upload failed on device %d", ctx->device));
     }
     ncg::MsmPlan plg;
-    rc = local_phase(ctx, curve, cnt, per, d_pts, d_sc, g, G, &plg, &stride, ctx->stream);
+    rc = local_phase(ctx, curve, cnt, per, d_pts, d_sc, g, G, &plg, &stride, ctx->stream, &d_bads[g]);
     if (rc) return fail(rc);
     if (g == 0) pl = plg;
   }
@@ -405,12 +425,18 @@ int ncg_msm_multi(ncg_multi* m, int curve, size_t n, const void* points_affine, 
   // 3. device 0 adds the partial arrays and finishes; the others only drain their streams
   if (hipSetDevice(m->ctx[0]->device) != hipSuccess) return fail(set_err(m->ctx[0], NCG_ERR_HIP, "noble-gpu: hipSetDevice failed"));
   int rc = combine_and_finish(m->ctx[0], curve, pl, stride, G, out_affine, out_is_inf, m->ctx[0]->stream);
-  for (int g = 1; g < G; g++) {
+  for (int g = 0; g < G; g++) {
     (void)hipSetDevice(m->ctx[g]->device);
+    if (d_bads[g]) (void)hipMemcpyAsync(&bads[g], d_bads[g], 4, hipMemcpyDeviceToHost, m->ctx[g]->stream);
     (void)hipStreamSynchronize(m->ctx[g]->stream);
   }
   (void)hipSetDevice(m->ctx[0]->device);
-  return rc ? fail(rc) : NCG_OK;
+  if (rc) return fail(rc);
+  for (int g = 0; g < G; g++)
+    if (bads[g] != 0xFFFFFFFFu)
+      return fail(set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: msm_multi: invalid scalar at index %zu (not below the group order)",
+                          per * (size_t)g + bads[g]));
+  return NCG_OK;
 }
 
 }  // extern "C"

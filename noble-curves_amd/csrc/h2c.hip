@@ -18,6 +18,7 @@
 //     SWU needs anyway (v = tv4^3): 3 exponentiations in Fp per map; the reference's generic
 //     F.2.1.1 ladder in Fp2 is several times the field work.  Either root is fine: SWU fixes the
 //     sign of y by sgn0(u) == sgn0(y) (:707-708).
+#include <cstdlib>
 #include <vector>
 
 #include "bls_lanes.hpp"
@@ -211,6 +212,38 @@ NCG_DI Jac<FeBls2> g2_clear_cofactor(const Jac<FeBls2>& P) {  // bls12-381.ts:60
   return jac_add(t3, jac_neg(P));
 }
 
+// ---- lane-paired G2 tail (CurveG2P: one Fp2 element per lane pair, fe29.hpp): the point addition and the
+// cofactor clearing of the split G2 pipeline below run in this form - half the registers per lane, so
+// the kernel keeps 2 waves/SIMD instead of spilling ~1900 registers at 1 wave.
+NCG_DI Fe29x2P<1> p2_const(const uint32_t (&c0)[14], const uint32_t (&c1)[14]) {
+  return Fe29x2P<1>(fe29_select(pair_odd(), fe29_const(c1), fe29_const(c0)));
+}
+NCG_DI FeBls2P p2_conj(const FeBls2P& a) {  // c0 - c1 u: the odd lane negates its half
+  return FeBls2P(fe29_select(pair_odd(), f_neg(a.h), a.h));
+}
+NCG_DI Jac<FeBls2P> g2p_psi(const Jac<FeBls2P>& P) {
+  if (P.is_inf()) return P;
+  const Fe29x2P<1> psx = p2_const(ParamsBls29::PSI_X_C0, ParamsBls29::PSI_X_C1);
+  const Fe29x2P<1> psy = p2_const(ParamsBls29::PSI_Y_C0, ParamsBls29::PSI_Y_C1);
+  return {p2_conj(P.X) * psx, p2_conj(P.Y) * psy, p2_conj(P.Z)};
+}
+NCG_DI Jac<FeBls2P> g2p_psi2(const Jac<FeBls2P>& P) {
+  if (P.is_inf()) return P;
+  const Fe29<1> k = fe29_const(BlsH2c::PSI2_X);
+  return {Fe29x2P<2>(P.X.h * k), f_neg(P.Y), P.Z};
+}
+NCG_DI Jac<FeBls2P> g2p_clear_cofactor(const Jac<FeBls2P>& P) {  // bls12-381.ts:604-618, as g2_clear_cofactor
+  Jac<FeBls2P> t1 = jac_neg(bls_mul_by_x(P));
+  Jac<FeBls2P> t2 = g2p_psi(P);
+  Jac<FeBls2P> t3 = g2p_psi2(jac_dbl(P));
+  t3 = jac_add(t3, jac_neg(t2));
+  t2 = jac_add(t1, t2);
+  t2 = jac_neg(bls_mul_by_x(t2));
+  t3 = jac_add(t3, t2);
+  t3 = jac_add(t3, jac_neg(t1));
+  return jac_add(t3, jac_neg(P));
+}
+
 // ------------------------------------------------------------------------------------- lanes
 // u: count field elements (G1: 12 words each; G2: 24 words, c0 then c1), any value below 2^384 -
 // reduced mod p like Fp.create (bls12-381.ts:854, :860).  out: affine wire; *inf = 1 for ZERO.
@@ -282,6 +315,45 @@ __global__ void __launch_bounds__(64, NCG_H2C_G2_MINW) k_map_to_g2(const uint32_
   if (!JAC_OUT) inf[i] = f;
 }
 
+// ---- split G2 pipeline (the default when scratch is given): stage 1 maps every field element to a Jacobian
+// point of E' (one lane per u_j: twice the lanes of the fused kernel for hashToCurve, unpaired Fp2 - its
+// three Fp exponentiations dominate and are light on registers); stage 2 adds the `count` points of an
+// item and clears the cofactor in the lane-paired form; the affine conversion is the shared batched
+// inversion.  Hand-off: Jacobian (X, Y, Z) in storage format, 84 words per point.
+#ifndef NCG_H2C_G2_STAGE1_MINW
+#define NCG_H2C_G2_STAGE1_MINW 1
+#endif
+__global__ void __launch_bounds__(64, NCG_H2C_G2_STAGE1_MINW) k_g2_map_stage1(const uint32_t* __restrict__ u, uint32_t* __restrict__ jac,
+                                                                              int total) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  Fe29x2<2> uu{fe29_from_wire(u + (size_t)t * 24), fe29_from_wire(u + (size_t)t * 24 + 12)};
+  Jac<FeBls2> Q = g2_map(uu);
+  if (Q.is_inf()) Q = Jac<FeBls2>::inf();
+  uint32_t* o = jac + (size_t)t * 84;
+  FieldIO<FeBls2>::store(o, Q.X);
+  FieldIO<FeBls2>::store(o + 28, Q.Y);
+  FieldIO<FeBls2>::store(o + 56, Q.Z);
+}
+__global__ void __launch_bounds__(64, 2) k_g2_map_stage2(const uint32_t* __restrict__ jac_in, int count, uint32_t* __restrict__ jac_out,
+                                                         int n) {
+  using F = FeBls2P;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;  // two lanes per item
+  if (i >= n) return;
+  auto load = [&](size_t idx) -> Jac<F> {
+    const uint32_t* p = jac_in + idx * 84;
+    return {FieldIO<F>::load(p), FieldIO<F>::load(p + 28), FieldIO<F>::load(p + 56)};
+  };
+  Jac<F> acc = load((size_t)i * count);
+  if (count == 2) acc = jac_add(acc, load((size_t)i * 2 + 1));
+  Jac<F> R = g2p_clear_cofactor(acc);
+  if (R.is_inf()) R = Jac<F>::inf();
+  uint32_t* o = jac_out + (size_t)i * 84;
+  FieldIO<F>::store(o, R.X);
+  FieldIO<F>::store(o + 28, R.Y);
+  FieldIO<F>::store(o + 56, R.Z);
+}
+
 // jac_tmp: n * 3 * FW words of device scratch (then the affine conversion is batched), or nullptr
 hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t* out, uint8_t* inf, int n,
                               uint32_t* jac_tmp, hipStream_t st) {
@@ -295,7 +367,16 @@ hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t*
       hipLaunchKernelGGL(k_map_to_g1<false>, dim3((n + 127) / 128), dim3(128), 0, st, u, count, out, inf, n);
     }
   } else if (curve == CURVE_BLS12_381_G2) {
-    if (jac_tmp) {
+    static const int fused = [] { const char* e = std::getenv("NCG_H2C_G2_FUSED"); return e ? std::atoi(e) : 0; }();
+    if (jac_tmp && !fused) {
+      // scratch layout: [n] output Jacobians, then [n * count] stage-1 Jacobians (map_to_curve_tmp_words)
+      uint32_t* stage1 = jac_tmp + (size_t)n * 84;
+      const int total = n * count;
+      hipLaunchKernelGGL(k_g2_map_stage1, dim3((total + 63) / 64), dim3(64), 0, st, u, stage1, total);
+      hipLaunchKernelGGL(k_g2_map_stage2, dim3((unsigned)(((size_t)n * 2 + 63) / 64)), dim3(64), 0, st, stage1, count, jac_tmp, n);
+      hipLaunchKernelGGL((k_jac_batch_affine<CurveG2P, 4>), dim3(((((n + 3) / 4) << 1) + 255) / 256), dim3(256), 0, st,
+                         jac_tmp, out, inf, n);
+    } else if (jac_tmp) {
       hipLaunchKernelGGL(k_map_to_g2<true>, dim3((n + 63) / 64), dim3(64), 0, st, u, count, jac_tmp, inf, n);
       hipLaunchKernelGGL((k_jac_batch_affine<CurveG2P, 4>), dim3(((((n + 3) / 4) << 1) + 255) / 256), dim3(256), 0, st,
                          jac_tmp, out, inf, n);

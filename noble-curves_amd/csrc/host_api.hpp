@@ -54,15 +54,17 @@ struct MsmPlan;
 int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl);
 size_t msm_workspace_bytes(int curve, const MsmPlan& pl);
 // d_pts / d_scalars: device; out_*: host.  Synchronises `st` (host-side Horner finish).
+// *bad_index (optional): smallest index of a scalar >= the group order, 0xFFFFFFFF if none (the result is
+// then meaningless: the caller fails the call like the reference's validateMSMScalars, curve.ts:398-404)
 hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st);
+                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index = nullptr);
 
 // The same in two phases, for the multi-GPU path: msm_device_phase leaves the grouped window sums
 // (msm_fin_words(curve, pl) words = npoints accumulators of msm_acc_words(curve) words) in the workspace
 // and returns their device address; msm_sum_partials adds nparts such arrays element by element;
 // msm_finish brings one array to the host and finishes (synchronises `st`).
 hipError_t msm_device_phase(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                            const uint32_t** d_fin, hipStream_t st);
+                            const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad = nullptr);
 hipError_t msm_finish(int curve, const MsmPlan& pl, const uint32_t* d_fin, uint32_t* out_affine_host,
                       uint8_t* out_inf_host, hipStream_t st);
 hipError_t msm_sum_partials(int curve, const uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,

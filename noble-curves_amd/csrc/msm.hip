@@ -28,12 +28,21 @@ template <> struct TailMinWaves<CurveG1> { static constexpr int value = 2; };
 
 // ------------------------------------------------------------------ 2. signed digits
 // digits[w*n + i] = ((k_i + H') >> (c w)) & (2^c - 1)) - 2^(c-1)
+// A scalar >= the group order is outside the reference's contract (validateMSMScalars, curve.ts:398-404:
+// 'invalid scalar at index i') and outside the window plan: it is reported through *bad_index (smallest
+// offending index) and the call fails.
 __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
-                                                    MsmPlan pl) {
+                                                    MsmPlan pl, uint32_t* __restrict__ bad_index) {
   __shared__ uint32_t sh[256 * 11];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t* my = sh + threadIdx.x * 11;
   if (i < pl.n) {
+    {
+      uint32_t bw = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) (void)__builtin_subc(scalars[(size_t)i * 8 + j], pl.order[j], bw, &bw);
+      if (bw == 0) atomicMin(bad_index, (uint32_t)i);  // scalar >= order
+    }
     uint32_t cy = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) my[j] = __builtin_addc(scalars[(size_t)i * 8 + j], pl.hconst[j], cy, &cy);
@@ -417,6 +426,7 @@ int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) {
   pl->nb = 1 << (c - 1);
   pl->nwin = plan_windows(c, curve_order(curve), pl->hconst);
   if (pl->nwin < 0) return -1;
+  for (int i = 0; i < 8; i++) pl->order[i] = curve_order(curve)[i];
   // sort chunks: aim for ~1024 blocks in flight, at least 4096 points per chunk
   int Q = std::max(1, 1024 / pl->nwin);
   Q = std::min(Q, std::max(1, n / 4096));
@@ -428,7 +438,7 @@ int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) {
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct MsmLayout {
-  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, part_pts, part_meta, pass_flags, red0, red1, total;
+  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, part_pts, part_meta, pass_flags, bad, red0, red1, total;
 };
 
 static MsmSeg msm_seg(const MsmPlan& pl) {
@@ -479,6 +489,7 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
   L.part_pts = take((size_t)pl.nwin * sg.nseg * 2 * MsmGroup<C>::ACC_WORDS * 4);
   L.part_meta = take((size_t)pl.nwin * sg.nseg * 4 * 4);
   L.pass_flags = take(64 * 4);
+  L.bad = take(64);
   // fold ping-pong: level l output holds (l+1) * nwin * nb/2^l points <= nwin*nb (l = 1, 2)
   size_t red = (size_t)pl.nwin * std::max(pl.nb, pl.c) * MsmGroup<C>::ACC_WORDS * 4;
   L.red0 = take(red);
@@ -515,7 +526,7 @@ static void msm_host_finish(const std::vector<uint32_t>& fin, const MsmPlan& pl,
 // inside the workspace).  Asynchronous on `st`.
 template <class C>
 static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                               const uint32_t** d_fin, hipStream_t st) {
+                               const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad = nullptr) {
   using G = MsmGroup<C>;
   using D = typename DeviceCurve<C>::type;  // kernels: lane-paired form for G2
   constexpr int LS = LaneShift<D>::value;
@@ -534,7 +545,10 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
 
   hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts,
                      pts_mont, n);
-  hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl);
+  uint32_t* bad = (uint32_t*)(base + L.bad);
+  e = hipMemsetAsync(bad, 0xFF, 4, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl, bad);
   size_t lds = (size_t)pl.nb * 4;
   {  // opt in to large dynamic LDS once per process and device (c <= 16: at most 128 KB)
     static bool attr_done[16] = {};
@@ -591,6 +605,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     cur = red[flip];
   }
   *d_fin = cur;
+  if (d_bad) *d_bad = bad;
   return hipGetLastError();
 }
 
@@ -603,7 +618,7 @@ static size_t msm_fin_words_t(const MsmPlan& pl) {
 // Synchronises `st`.
 template <class C>
 static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t* out_affine_host, uint8_t* out_inf_host,
-                               hipStream_t st) {
+                               hipStream_t st, const uint32_t* d_bad = nullptr, uint32_t* bad_host = nullptr) {
   using G = MsmGroup<C>;
   constexpr int XW = G::ACC_WORDS;
   const int ng = msm_ngroups(pl.c);
@@ -624,6 +639,10 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
   uint32_t* land = pinned_words >= fin_words ? pinned : fin.data();
   e = hipMemcpyAsync(land, cur, fin_words * 4, hipMemcpyDeviceToHost, st);
   if (e != hipSuccess) return e;
+  if (d_bad && bad_host) {
+    e = hipMemcpyAsync(bad_host, d_bad, 4, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+  }
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
   if (land != fin.data()) std::copy(land, land + fin_words, fin.begin());
@@ -640,11 +659,11 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
 
 template <class C>
 static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                            uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st) {
-  const uint32_t* d_fin = nullptr;
-  hipError_t e = msm_device_t<C>(pl, d_pts, d_scalars, ws, &d_fin, st);
+                            uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index) {
+  const uint32_t *d_fin = nullptr, *d_bad = nullptr;
+  hipError_t e = msm_device_t<C>(pl, d_pts, d_scalars, ws, &d_fin, st, &d_bad);
   if (e != hipSuccess) return e;
-  return msm_finish_t<C>(pl, d_fin, out_affine_host, out_inf_host, st);
+  return msm_finish_t<C>(pl, d_fin, out_affine_host, out_inf_host, st, d_bad, bad_index);
 }
 
 template <class C>
@@ -667,8 +686,8 @@ static hipError_t msm_sum_partials_t(const uint32_t* d_gathered, int nparts, siz
   }
 
 hipError_t msm_device_phase(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                            const uint32_t** d_fin, hipStream_t st) {
-#define CALL(C) msm_device_t<C>(pl, d_pts, d_scalars, ws, d_fin, st)
+                            const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad) {
+#define CALL(C) msm_device_t<C>(pl, d_pts, d_scalars, ws, d_fin, st, d_bad)
   NCG_MSM_DISPATCH(curve, CALL)
 #undef CALL
 }
@@ -714,12 +733,15 @@ size_t msm_workspace_bytes(int curve, const MsmPlan& pl) {
 }
 
 hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st) {
+                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index) {
+  uint32_t dummy = 0xFFFFFFFFu;
+  if (!bad_index) bad_index = &dummy;
+  *bad_index = 0xFFFFFFFFu;
   switch (curve) {
-    case CURVE_SECP256K1: return msm_run_t<CurveSecp>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
-    case CURVE_BLS12_381_G1: return msm_run_t<CurveG1>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
-    case CURVE_BLS12_381_G2: return msm_run_t<CurveG2>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
-    case CURVE_ED25519: return msm_run_t<CurveEd>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st);
+    case CURVE_SECP256K1: return msm_run_t<CurveSecp>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index);
+    case CURVE_BLS12_381_G1: return msm_run_t<CurveG1>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index);
+    case CURVE_BLS12_381_G2: return msm_run_t<CurveG2>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index);
+    case CURVE_ED25519: return msm_run_t<CurveEd>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index);
     default: return hipErrorInvalidValue;
   }
 }

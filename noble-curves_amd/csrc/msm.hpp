@@ -42,6 +42,7 @@ struct MsmPlan {
   int ls = 0;      // lanes per item = 1 << ls (lane-paired Fp2 kernels)
   int accum_waves = 2;  // waves/SIMD of the accumulate kernel (sets the resident-lane capacity)
   uint32_t hconst[10];  // H' = sum_w 2^(c-1) * 2^(c w), 10 LE limbs
+  uint32_t order[8];    // group order: scalars must be below it (the window plan covers (order-1) + H')
 };
 
 // Group policy of the MSM kernels: how an input point is stored, what the bucket accumulator

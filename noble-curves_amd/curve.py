@@ -424,7 +424,8 @@ def aggregateFromBytes(c, encodings, zip215=False, engine=None):
     """sum(c.fromBytes(b) for b in encodings) - the group part of bls.aggregatePublicKeys /
     aggregateSignatures on encoded inputs (src/abstract/bls.ts:857-873).  Decoding, validity and
     subgroup checks and the sum all run on the device; an entry the reference's fromBytes would
-    reject raises ValueError naming its index.  Empty input gives ZERO."""
+    reject raises ValueError naming its index.  Empty input raises like the reference's aNonEmpty guard
+    (bls.ts:426-431 'expected non-empty array')."""
     size = _native.ENCODED_BYTES.get(c.CURVE_ID)
     if size is None:
         raise ValueError("noble-gpu: no batch decoder for this curve")
@@ -435,7 +436,7 @@ def aggregateFromBytes(c, encodings, zip215=False, engine=None):
             raise ValueError("invalid point encoding at index %d: expected %d bytes" % (i, size))
         rows.append(np.frombuffer(b, dtype=np.uint8))
     if not rows:
-        return c.ZERO
+        raise ValueError("expected non-empty array")
     eng = engine or get_engine()
     out, inf, bad = eng.aggregate_encoded(c.CURVE_ID, np.array(rows), zip215)
     if bad >= 0:

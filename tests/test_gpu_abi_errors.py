@@ -57,3 +57,24 @@ def test_status_codes_and_messages():
     k[0, 0] = 1
     o, f = eng.mul_base_batch(SECP256K1, k)
     assert int.from_bytes(o[0, :32].tobytes(), "little") == 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798 and not f[0]
+
+
+def test_msm_rejects_scalars_not_below_the_group_order():
+    """validateMSMScalars (curve.ts:398-404): the window plan covers scalars below the order only, so the
+    C ABI refuses anything else instead of returning a wrong sum (the shims reject earlier, with the
+    reference's message)."""
+    import numpy as np
+    from helpers import points_to_wire, scalars_to_wire
+    from noble_curves_amd import get_engine
+    from noble_curves_amd._native import BLS12_381_G1, NativeError
+    from oracle.curves import BLS_R, BlsG1
+    eng = get_engine()
+    pts = points_to_wire(BLS12_381_G1, [BlsG1.BASE.multiplyUnsafe(i + 1) for i in range(40)])
+    ok = scalars_to_wire([(i * 7919 + 3) % BLS_R for i in range(40)])
+    eng.msm(BLS12_381_G1, pts, ok)
+    for bad_k in (BLS_R, BLS_R + 5, (1 << 256) - 1):
+        sc = ok.copy()
+        sc[17] = np.frombuffer(int(bad_k).to_bytes(32, "little"), np.uint8)
+        with pytest.raises(NativeError, match="invalid scalar at index 17"):
+            eng.msm(BLS12_381_G1, pts, sc)
+    eng.msm(BLS12_381_G1, pts, ok)          # the context survives

@@ -344,7 +344,8 @@ def test_aggregate_from_bytes_gpu():
             exp = exp.add(p)
         got = G.aggregateFromBytes(Pt, encs, zip215=True)
         assert got.toAffine() == exp.toAffine() and got.is0() == exp.is0()
-        assert G.aggregateFromBytes(Pt, []).is0()
+        with pytest.raises(ValueError, match="expected non-empty array"):   # bls.ts:426-431 aNonEmpty
+            G.aggregateFromBytes(Pt, [])
         bad = list(encs)
         bad[5] = bytes([bad[5][0] ^ 0xFF]) + bad[5][1:] if O is not Ed25519 else bytes([0xEE] * 31 + [0x7F])
         try:
