@@ -32,5 +32,11 @@ ss.forEach((v, i) => le(v, 32, sb, 32 * i));
 gpu.native.msm(0, pb, sb);
 const [tMsmN] = ms(() => gpu.native.msm(0, pb, sb));
 const [tMulN] = ms(() => gpu.native.mulVarBatch(0, pb, sb));
-console.log(JSON.stringify({ n, pippenger_js_ms: tMsm, pippenger_native_ms: tMsmN, multiplyUnsafeBatch_js_ms: tMul,
+// resident point set (uploadPoints once): only scalars cross - as BigInt[] (native 64-bit-word reads) and as packed bytes
+const set = gpu.uploadPoints(Point, pts);
+gpu.pippengerResident(set, ss);
+const [tResBig] = ms(() => gpu.pippengerResident(set, ss));
+const [tResBytes] = ms(() => gpu.pippengerResident(set, sb));
+set.free();
+console.log(JSON.stringify({ n, pippenger_resident_bigint_ms: tResBig, pippenger_resident_bytes_ms: tResBytes, pippenger_js_ms: tMsm, pippenger_native_ms: tMsmN, multiplyUnsafeBatch_js_ms: tMul,
   multiplyUnsafeBatch_native_ms: tMulN }));

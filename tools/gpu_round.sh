@@ -8,7 +8,7 @@ STAGES=${*:-test bench stats valu fetch write calib}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH_ARGS="--steps 4 --warmup 1 --no-cpu-baseline"
+BENCH_ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-live-pmc --quick-verify"
 for s in $STAGES; do
   case $s in
     test)  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/summary.txt; tail -3 $OUT/pytest.log ;;
