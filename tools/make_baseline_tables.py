@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Rewrites section 5 of BASELINE.md from the committed round profiles (profiles/r02_*), so the tables are
+transcriptions of measured files, not hand-typed numbers.  python tools/make_baseline_tables.py"""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = lambda *a: os.path.join(ROOT, "profiles", *a)  # noqa: E731
+
+
+def load(name):
+    with open(P(name)) as f:
+        return json.load(f)
+
+
+def main():
+    b = load("r02_bench_line.json")
+    b1 = load("r01_bench_line.json")
+    ex, ex1 = load("r02_bench_extra.json"), load("r01_bench_extra.json")
+    e = b["extra"]
+    host = b.get("host", {})
+    out = []
+    out.append("## 5. Results table (round 2, one MI355X, `profiles/r02_bench_line.json`, `profiles/r02_bench_kernel_stats.csv`, `profiles/r02_pmc.json`)\n")
+    out.append("Throughput with inputs resident in HBM, one run of `python bench.py` (box-to-box variation of the pool: up to ~7 %% on the "
+               "long kernels, more on the MSM lines whose ≈45 launches + host finish are sensitive to the host).  Every result is verified "
+               "bit-exactly before it is printed (sample vs the CPU oracle's C restatement, full-size checksum / progression identity, "
+               "ed25519 verdicts by construction + the reference's 196 zip215.json cases).  `hbm_frac` = algorithmic bytes ÷ 8 TB/s (the "
+               "contract's figure; the path is VALU-bound, §2 caveat); `mad_frac` = executed `v_mad_u64_u32` (counted from the kernel's "
+               "operation sequence) ÷ the measured multiplier ceiling 3.08×10¹³/s; `valu_issue` = SQ_INSTS_VALU × 64 ÷ kernel time ÷ "
+               "3.93×10¹³ lane-ops/s (rocprofv3 PMC, live in the bench run); `traffic` = HBM bytes per launch of the dominant kernel "
+               "(FETCH_SIZE/WRITE_SIZE with the per-pattern calibration of `tools/pmc_calib`).  CPU baseline = `oracle/c` restatement of "
+               "the reference algorithm on the GPU box's host (%s, %s logical cores; Node %s cannot run the TypeScript reference).\n"
+               % (host.get("cpu_model"), host.get("logical_cores"), host.get("node_version")))
+    out.append("| config | N | time (r01 → r02) | throughput | hbm_frac | mad_frac | valu_issue | traffic / algorithmic | CPU port 1 thread / all threads | bit-exact |")
+    out.append("|---|---|---|---|---|---|---|---|---|---|")
+
+    def row(name, n, t1, t2, unit, entry, alg_bytes):
+        rf = entry["roofline"]
+        v = rf["valu"]
+        cb = entry.get("cpu_baseline", {})
+        at = cb.get("all_threads", {})
+        tr = rf.get("traffic")
+        out.append("| %s | %s | %s → **%.2f ms** | **%.3g %s** | %.2f %% | %s | %s | %s | %s / %s | yes |" % (
+            name, n, ("%.2f ms" % t1) if t1 else "—", t2, entry["value"], unit, 100 * rf["frac"],
+            ("%.0f %%" % (100 * v["mad_frac"])) if "mad_frac" in v else "—",
+            ("%.0f %%" % (100 * v["valu_issue_frac"])) if "valu_issue_frac" in v else "—",
+            ("%.2f GB / %.0f MB = %.0f×" % (tr / 1e9, alg_bytes / 1e6, tr / alg_bytes)) if tr else "—",
+            ("%.3g /s" % cb["value"]) if cb else "—", ("%.3g /s (%d thr)" % (at["value"], at["cores"])) if at else "—"))
+
+    e1 = b1["extra"]
+    row("secp256k1 `multiplyUnsafe` batch (GLV)", "2²⁰", b1["ms_per_step"], b["ms_per_step"], "scalar-mults/s", b, 160.0 * (1 << 20))
+    row("ed25519 verify batch (ZIP-215, SHA-512 on the device)", "2¹⁸", e1["ed25519_verify"]["ms_per_batch"], e["ed25519_verify"]["ms_per_batch"],
+        "verifies/s", e["ed25519_verify"], 161.0 * (1 << 18))
+    row("bls12-381 G1 MSM", "2²⁰", e1["msm_g1"]["ms_per_msm"], e["msm_g1"]["ms_per_msm"], "points/s", e["msm_g1"], 128.0 * (1 << 20))
+    row("bls12-381 G2 MSM", "2¹⁸", e1["msm_g2"]["ms_per_msm"], e["msm_g2"]["ms_per_msm"], "points/s", e["msm_g2"], 224.0 * (1 << 18))
+    row("bls12-381 Fr NTT (natural→natural)", "2²²", e1["ntt_fr"]["ms_per_transform"], e["ntt_fr"]["ms_per_transform"], "elements/s", e["ntt_fr"],
+        64.0 * (1 << 22))
+    ko = e["ed25519_verify"]["kernel_only"]
+    out.append("\ned25519 kernel-only (pre-hashed challenges, the r01 figure): %.2f ms → **%.2f ms** (%.3g verifies/s); the device hash adds "
+               "%.2f ms per 2¹⁸ signatures.  Multi-GPU (2/4/8): measured by the driver's scaling run - `bench.py --gpus N` reports weak "
+               "scaling per line, `extra.msm_g1_strong` / `msm_g2_strong` = one 2²⁰ / 2¹⁸-point MSM split over the N GPUs through "
+               "`ncg_msm_sharded_dev` (RCCL all-gather of ~18 KB per rank).\n"
+               % (e1["ed25519_verify"]["ms_per_batch"], ko["ms_per_batch"], ko["value"], e["ed25519_verify"]["ms_per_batch"] - ko["ms_per_batch"]))
+    out.append("Targets: ≥10⁷ secp256k1 scalar-mults/s per MI355X — met (%.1f×); \"≥40 %% HBM roofline\" for the 2²⁰ G1 MSM is not physically "
+               "meaningful (§2 caveat): its dominant kernel runs at %.0f %% of the measured multiplier ceiling in EXECUTED multiplies.\n"
+               % (b["value"] / 1e7, 100 * e["msm_g1"]["roofline"]["valu"]["mad_frac"]))
+    out.append("### Other entry points (one MI355X, `tools/bench_extra.py`, `profiles/r02_bench_extra.json`; r01 beside it)\n")
+    out.append("| entry point | N | r01 | r02 | throughput |")
+    out.append("|---|---|---|---|---|")
+    for k, v in ex.items():
+        o = ex1.get(k)
+        out.append("| %s | 2^%d | %s | %.2f ms | %.3g %s/s |" % (k, v["n"].bit_length() - 1, ("%.2f ms" % o["ms"]) if o else "—", v["ms"], v["per_s"], v["unit"]))
+    out.append("\n### End to end from JavaScript (`addon/bench_js.js`, Node 12 on the GPU box, secp256k1, `profiles/r02_js_bench.jsonl`)\n")
+    out.append("BigInt marshalling + N-API + H2D/D2H + kernels.  `resident` = the point set was uploaded once (`uploadPoints`), only the scalars "
+               "cross per call - as `BigInt[]` read natively as 64-bit words, or as packed bytes (SURVEY 8a gotcha 8).\n")
+    out.append("| N | `pippenger` from JS | resident, BigInt[] scalars | resident, packed scalars | native call alone | `multiplyUnsafeBatch` from JS | native |")
+    out.append("|---|---|---|---|---|---|---|")
+    for line in open(P("r02_js_bench.jsonl")):
+        line = line.strip()
+        if not line.startswith("{"):
+            continue
+        j = json.loads(line)
+        out.append("| 2^%d | %.1f ms | %.2f ms | %.2f ms | %.2f ms | %.1f ms | %.2f ms |" % (
+            j["n"].bit_length() - 1, j["pippenger_js_ms"], j["pippenger_resident_bigint_ms"], j["pippenger_resident_bytes_ms"],
+            j["pippenger_native_ms"], j["multiplyUnsafeBatch_js_ms"], j["multiplyUnsafeBatch_native_ms"]))
+    text = "\n".join(out) + "\n"
+    path = os.path.join(ROOT, "BASELINE.md")
+    s = open(path).read()
+    i = s.index("## 5. Results table")
+    j = s.index("### NTT over bls12-381 Fr")
+    k = s.index("### End to end from JavaScript")
+    # keep the r01 NTT and host-buffer sub-sections (unchanged kernels), replace the rest
+    s2 = s[:i] + text.split("### End to end from JavaScript")[0] + s[j:k] + "### End to end from JavaScript" + text.split("### End to end from JavaScript")[1]
+    open(path, "w").write(s2)
+    print("BASELINE.md section 5 rewritten")
+
+
+if __name__ == "__main__":
+    main()
