@@ -187,6 +187,78 @@ def g1_msm_mads_per_point(nwin, n, nb):
     return accum + fold
 
 
+def make_ed25519_batch(eng, nv, rank, device, stream):
+    """configs[2] input: nv (signature, message, public key) triples, every one with its own
+    key pair and nonce (A_i = a_i B, R_i = r_i B by the fixed-base batch multiply + batch encoding), 32 random
+    message bytes, k_i hashed ON THE DEVICE (sampled against hashlib), s_i = r_i + k_i a_i; 1/64 corrupted (a bit
+    of R, of s or of the message); the reference's 196 zip215.json cases replace the tail.  Returns a dict of
+    host arrays, device tensors and the expected ZIP-215 verdicts."""
+    import hashlib
+    from helpers import load_golden
+    from noble_curves_amd._native import ED25519
+    from oracle.curves import ED25519_L, makeRng
+    rng = makeRng(0x6E6F626C6503 + rank)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(0x6E6F626C6503 + rank)
+    # every signature has its own key pair and nonce: A_i = a_i B, R_i = r_i B on the GPU (fixed-base batch
+    # multiply + batch encoding), messages = 32 random bytes (SURVEY 8d table)
+    a_sc = gen_scalars(nv, 252, 31 + rank, device)
+    r_sc = gen_scalars(nv, 252, 32 + rank, device)
+    a_int, r_int = scalars_to_ints(a_sc), scalars_to_ints(r_sc)
+    aff = torch.empty((nv, 64), dtype=torch.uint8, device=device)
+    inf_t = torch.empty((nv,), dtype=torch.uint8, device=device)
+    eng.mul_base_batch_dev(ED25519, nv, dev_ptr(a_sc), dev_ptr(aff), dev_ptr(inf_t), stream)
+    torch.cuda.synchronize()
+    A_b, okA = eng.encode_points_batch(ED25519, aff.cpu().numpy())
+    eng.mul_base_batch_dev(ED25519, nv, dev_ptr(r_sc), dev_ptr(aff), dev_ptr(inf_t), stream)
+    torch.cuda.synchronize()
+    R_b, okR = eng.encode_points_batch(ED25519, aff.cpu().numpy())
+    assert okA.all() and okR.all()
+    msgs = torch.randint(0, 256, (nv, 32), dtype=torch.uint8, generator=g).numpy()
+    # k_i = SHA-512(R || A || M) mod L on the device (sampled against hashlib below), s_i = r_i + k_i a_i
+    sig_np = np.zeros((nv, 64), np.uint8)
+    sig_np[:, :32] = R_b
+    d_sig0, d_pk, d_msg = (torch.from_numpy(x).to(device) for x in (sig_np, A_b, msgs.reshape(-1)))
+    off = torch.arange(0, 32 * (nv + 1), 32, dtype=torch.int64, device=device)
+    d_k = torch.empty((nv, 32), dtype=torch.uint8, device=device)
+    eng.ed25519_challenge_batch_dev(nv, dev_ptr(d_sig0), dev_ptr(d_pk), dev_ptr(d_msg), dev_ptr(off), dev_ptr(d_k), stream)
+    torch.cuda.synchronize()
+    k_np = d_k.cpu().numpy()
+    k_int = [int.from_bytes(k_np[i].tobytes(), "little") for i in range(nv)]
+    for i in list(range(0, 64)) + list(range(64, nv, max(1, nv // 512))):
+        assert k_int[i] == int.from_bytes(hashlib.sha512(R_b[i].tobytes() + A_b[i].tobytes() + msgs[i].tobytes()).digest(), "little") % ED25519_L, \
+            "device SHA-512 challenge differs from hashlib"
+    s_int = [(r + k * a) % ED25519_L for r, k, a in zip(r_int, k_int, a_int)]
+    sig_np[:, 32:] = ints_to_le_bytes(s_int)
+    expect = np.ones((nv,), bool)
+    for i in range(63, nv, 64):                            # 1/64 corrupted: a bit flip in R, s or the message
+        kind = (i >> 6) % 3
+        if kind == 0:
+            sig_np[i, (i >> 8) % 31] ^= 1 << (i % 7)
+        elif kind == 1:
+            sig_np[i, 33 + (i >> 8) % 20] ^= 1 << (i % 7)
+        else:
+            msgs[i, (i >> 8) % 32] ^= 1 << (i % 7)
+        expect[i] = False
+    # the 196 ZIP-215 cases of the reference (small-order / non-canonical encodings) ride along at the end
+    zv = load_golden("ed25519_zip215.json")
+    nz = len(zv) if nv >= 1024 else 0
+    tail = nv - nz
+    pk_np = A_b.copy()
+    msg_list = [msgs[i].tobytes() for i in range(tail)]
+    for j in range(nz):
+        sig_np[tail + j] = np.frombuffer(bytes.fromhex(zv[j]["sig_bytes"]), np.uint8)
+        pk_np[tail + j] = np.frombuffer(bytes.fromhex(zv[j]["vk_bytes"]), np.uint8)
+        msg_list.append(b"Zcash")
+        expect[tail + j] = zv[j]["valid_zip215"]
+    blob = np.frombuffer(b"".join(msg_list), np.uint8)
+    offs = np.zeros((nv + 1,), np.int64)
+    offs[1:] = np.cumsum([len(m) for m in msg_list])
+    d_sig, d_pk, d_blob, d_off = (torch.from_numpy(x.copy()).to(device) for x in (sig_np, pk_np, blob, offs))
+    return {"sig": sig_np, "pk": pk_np, "msgs": msg_list, "expect": expect, "tail": tail, "nz": nz,
+            "d_sig": d_sig, "d_pk": d_pk, "d_blob": d_blob, "d_off": d_off}
+
+
 def ints_to_le_bytes(vals, nbytes=32):
     return np.frombuffer(b"".join(int(v).to_bytes(nbytes, "little") for v in vals), dtype=np.uint8).reshape(-1, nbytes)
 
@@ -578,64 +650,9 @@ def main():
         from oracle.curves import ED25519_L, Ed25519
         from oracle.edwards import eddsa_verify
         nv = max(64, n >> 2)                                  # 2^18 at the default size
-        rng = makeRng(0x6E6F626C6503 + rank)
-        g = torch.Generator(device="cpu")
-        g.manual_seed(0x6E6F626C6503 + rank)
-        # every signature has its own key pair and nonce: A_i = a_i B, R_i = r_i B on the GPU (fixed-base batch
-        # multiply + batch encoding), messages = 32 random bytes
-        a_sc = gen_scalars(nv, 252, 31 + rank, device)
-        r_sc = gen_scalars(nv, 252, 32 + rank, device)
-        a_int, r_int = scalars_to_ints(a_sc), scalars_to_ints(r_sc)
-        aff = torch.empty((nv, 64), dtype=torch.uint8, device=device)
-        inf_t = torch.empty((nv,), dtype=torch.uint8, device=device)
-        eng.mul_base_batch_dev(ED25519, nv, dev_ptr(a_sc), dev_ptr(aff), dev_ptr(inf_t), stream)
-        torch.cuda.synchronize()
-        A_b, okA = eng.encode_points_batch(ED25519, aff.cpu().numpy())
-        eng.mul_base_batch_dev(ED25519, nv, dev_ptr(r_sc), dev_ptr(aff), dev_ptr(inf_t), stream)
-        torch.cuda.synchronize()
-        R_b, okR = eng.encode_points_batch(ED25519, aff.cpu().numpy())
-        assert okA.all() and okR.all()
-        msgs = torch.randint(0, 256, (nv, 32), dtype=torch.uint8, generator=g).numpy()
-        # k_i = SHA-512(R || A || M) mod L on the device (sampled against hashlib below), s_i = r_i + k_i a_i
-        sig_np = np.zeros((nv, 64), np.uint8)
-        sig_np[:, :32] = R_b
-        d_sig0, d_pk, d_msg = (torch.from_numpy(x).to(device) for x in (sig_np, A_b, msgs.reshape(-1)))
-        off = torch.arange(0, 32 * (nv + 1), 32, dtype=torch.int64, device=device)
-        d_k = torch.empty((nv, 32), dtype=torch.uint8, device=device)
-        eng.ed25519_challenge_batch_dev(nv, dev_ptr(d_sig0), dev_ptr(d_pk), dev_ptr(d_msg), dev_ptr(off), dev_ptr(d_k), stream)
-        torch.cuda.synchronize()
-        k_np = d_k.cpu().numpy()
-        k_int = [int.from_bytes(k_np[i].tobytes(), "little") for i in range(nv)]
-        for i in list(range(0, 64)) + list(range(64, nv, max(1, nv // 512))):
-            assert k_int[i] == int.from_bytes(hashlib.sha512(R_b[i].tobytes() + A_b[i].tobytes() + msgs[i].tobytes()).digest(), "little") % ED25519_L, \
-                "device SHA-512 challenge differs from hashlib"
-        s_int = [(r + k * a) % ED25519_L for r, k, a in zip(r_int, k_int, a_int)]
-        sig_np[:, 32:] = ints_to_le_bytes(s_int)
-        expect = np.ones((nv,), bool)
-        for i in range(63, nv, 64):                            # 1/64 corrupted: a bit flip in R, s or the message
-            kind = (i >> 6) % 3
-            if kind == 0:
-                sig_np[i, (i >> 8) % 31] ^= 1 << (i % 7)
-            elif kind == 1:
-                sig_np[i, 33 + (i >> 8) % 20] ^= 1 << (i % 7)
-            else:
-                msgs[i, (i >> 8) % 32] ^= 1 << (i % 7)
-            expect[i] = False
-        # the 196 ZIP-215 cases of the reference (small-order / non-canonical encodings) ride along at the end
-        zv = load_golden("ed25519_zip215.json")
-        nz = len(zv) if nv >= 1024 else 0
-        tail = nv - nz
-        pk_np = A_b.copy()
-        msg_list = [msgs[i].tobytes() for i in range(tail)]
-        for j in range(nz):
-            sig_np[tail + j] = np.frombuffer(bytes.fromhex(zv[j]["sig_bytes"]), np.uint8)
-            pk_np[tail + j] = np.frombuffer(bytes.fromhex(zv[j]["vk_bytes"]), np.uint8)
-            msg_list.append(b"Zcash")
-            expect[tail + j] = zv[j]["valid_zip215"]
-        blob = np.frombuffer(b"".join(msg_list), np.uint8)
-        offs = np.zeros((nv + 1,), np.int64)
-        offs[1:] = np.cumsum([len(m) for m in msg_list])
-        d_sig, d_pk, d_blob, d_off = (torch.from_numpy(x.copy()).to(device) for x in (sig_np, pk_np, blob, offs))
+        eb = make_ed25519_batch(eng, nv, rank, device, stream)
+        sig_np, pk_np, msg_list, expect, tail, nz = eb["sig"], eb["pk"], eb["msgs"], eb["expect"], eb["tail"], eb["nz"]
+        d_sig, d_pk, d_blob, d_off = eb["d_sig"], eb["d_pk"], eb["d_blob"], eb["d_off"]
         d_ok = torch.empty((nv,), dtype=torch.uint8, device=device)
         d_k2 = torch.empty((nv, 32), dtype=torch.uint8, device=device)
 

@@ -76,3 +76,39 @@ def test_bls_msm_fullsize_progression(curve, Pt, log2n):
     kk = 0x1D + (0x03 << 40)
     got, _ = eng.msm_dev(curve, n, pts.data_ptr(), same.data_ptr(), stream)
     assert wire_to_affine(curve, got) == Pt.BASE.multiplyUnsafe(sum(pks) * kk % BLS_R).toAffine()
+
+
+def test_ed25519_verify_full_size_both_modes():
+    """configs[2] as SURVEY 8d specifies it: 2^18 (signature, message, public key) triples with distinct keys,
+    1/64 corrupted (R, s or message), the reference's 196 zip215.json cases appended; verified from the
+    MESSAGES (SHA-512 on the device) in ZIP-215 and strict mode.  Verdicts: by construction for the synthetic
+    part in both modes, zip215.json's `valid_zip215` for the appended cases, the oracle for their strict-mode
+    verdicts and for a sample of the synthetic ones."""
+    from oracle.curves import Ed25519
+    from oracle.edwards import eddsa_verify
+    eng, dev, st = _setup()
+    nv = 1 << 18
+    eb = bench.make_ed25519_batch(eng, nv, 0, dev, st)
+    d_ok = torch.empty((nv,), dtype=torch.uint8, device=dev)
+    P = lambda t: t.data_ptr()  # noqa: E731
+    eng.ed25519_verify_batch_msgs_dev(nv, P(eb["d_sig"]), P(eb["d_pk"]), P(eb["d_blob"]), P(eb["d_off"]), True, P(d_ok), st)
+    torch.cuda.synchronize()
+    got = d_ok.cpu().numpy().astype(bool)
+    assert np.array_equal(got, eb["expect"])
+    assert int((~got[:eb["tail"]]).sum()) == eb["tail"] // 64        # exactly the corrupted ones fail
+    eng.ed25519_verify_batch_msgs_dev(nv, P(eb["d_sig"]), P(eb["d_pk"]), P(eb["d_blob"]), P(eb["d_off"]), False, P(d_ok), st)
+    torch.cuda.synchronize()
+    strict = d_ok.cpu().numpy().astype(bool)
+    tail = eb["tail"]
+    assert np.array_equal(strict[:tail], eb["expect"][:tail])
+    for j in range(eb["nz"]):
+        i = tail + j
+        assert strict[i] == eddsa_verify(Ed25519, eb["sig"][i].tobytes(), b"Zcash", eb["pk"][i].tobytes(), zip215=False), j
+    for i in list(range(0, 12)) + [63, 127, 191, tail - 1]:
+        assert got[i] == eddsa_verify(Ed25519, eb["sig"][i].tobytes(), eb["msgs"][i], eb["pk"][i].tobytes(), zip215=True)
+    # the pre-hashed entry point agrees (challenges from the device hash)
+    d_k = torch.empty((nv, 32), dtype=torch.uint8, device=dev)
+    eng.ed25519_challenge_batch_dev(nv, P(eb["d_sig"]), P(eb["d_pk"]), P(eb["d_blob"]), P(eb["d_off"]), P(d_k), st)
+    eng.ed25519_verify_batch_dev(nv, P(eb["d_sig"]), P(eb["d_pk"]), P(d_k), True, P(d_ok), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ok.cpu().numpy().astype(bool), eb["expect"])
