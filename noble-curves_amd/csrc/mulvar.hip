@@ -125,7 +125,7 @@ size_t mul_var_tmp_bytes(int curve, int n) {
   switch (curve) {
     // Jacobian scratch + the per-item window table of the widest variant (k_mul_var_gtab)
     case CURVE_SECP256K1: return pad64(n) * (3 * FieldIO<CurveSecp::F>::WORDS + gtab_words_per_item<CurveSecp, 5>()) * 4;
-    case CURVE_BLS12_381_G1: return pad64(n) * (3 * FieldIO<CurveG1::F>::WORDS + gtab_words_per_item<CurveG1, 4>()) * 4;
+    case CURVE_BLS12_381_G1: return pad64(n) * (3 * FieldIO<CurveG1::F>::WORDS + gtab_words_per_item<CurveG1, 5>()) * 4;
     case CURVE_BLS12_381_G2: return pad64(n) * (3 * FieldIO<CurveG2::F>::WORDS + 2 * gtab_words_per_item<CurveG2P, 4>()) * 4;
     case CURVE_ED25519: return ed25519_tmp_words(n) * 4;  // (X, Y, Z) + per-item window tables
     default: return 0;
@@ -152,8 +152,11 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
     }
     case CURVE_ED25519: return ed25519_mul_var_batch(pts, scalars, out, out_inf, n, jac_tmp, st);
     case CURVE_BLS12_381_G1: {
-      static const int w = [] { const char* e = std::getenv("NCG_G1_W"); return e ? std::atoi(e) : 141; }();
+      static const int w = [] { const char* e = std::getenv("NCG_G1_W"); return e ? std::atoi(e) : 142; }();
       if (jac_tmp && w == 141) return launch_mul_var_gtab<CurveG1, 4, 1>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (jac_tmp && w == 142) return launch_mul_var_gtab<CurveG1, 4, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (jac_tmp && w == 152) return launch_mul_var_gtab<CurveG1, 5, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (jac_tmp && w == 151) return launch_mul_var_gtab<CurveG1, 5, 1>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 132) return launch_mul_var_gtab<CurveG1, 3, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
       return launch_mul_var<CurveG1, 3, 1, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);
     }
