@@ -291,6 +291,12 @@ int ncg_ed25519_challenge_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_de
 /* Runs instruction-rate / field-multiply micro-benchmark `kind` (see csrc/ubench.hip) and
  * returns the kernel time in milliseconds. */
 int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float* out_ms);
+/* Field-level self-check: out[i] = op(a[i], b[i]) computed by the device field code, one lane per element
+ * (host buffers).  field 0 / 1 = secp256k1 / ed25519 base field in the radix-2^29 lazy form (fe9.hpp): a, b
+ * are 9 RAW 32-bit limbs per element, `variant` = 10 A + B names the operand bound types; out = 8 canonical
+ * LE words.  field 2 = bls12-381 Fp: 12-word canonical operands and results.  op: 0 mul, 1 sqr, 2 add, 3 sub,
+ * 4 neg, 5 inv, 6 normalise, 7 is-zero-mod-p, 9 largest output limb of the product. */
+int ncg_field_check(ncg_ctx* ctx, int field, int op, int variant, size_t n, const void* a, const void* b, void* out);
 
 #ifdef __cplusplus
 }

@@ -118,6 +118,7 @@ _OPTIONAL_PROTOS = {
     "ncg_points_curve": [_vp],
     "ncg_msm_resident": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
     "ncg_mul_var_batch_resident": [_vp, _vp, _vp, _vp, _vp],
+    "ncg_field_check": [_vp, _i32, _i32, _i32, _sz, _vp, _vp, _vp],
     "ncg_comm_unique_id": [_vp],
     "ncg_comm_init": [_vp, _i32, _i32, _vp],
     "ncg_comm_destroy": [_vp],
@@ -449,6 +450,17 @@ class Engine:
         om = np.frombuffer(int(omega).to_bytes(32, "little"), dtype=np.uint8).copy()
         self._check(self.lib.ncg_ntt_dev(self.h, FIELD_BLS12_381_FR, log2n, batch, om.ctypes.data, d_in, d_out,
                                          self._ntt_flags(inverse, brp_input, brp_output), stream))
+
+    def field_check(self, field, op, variant, a_words, b_words):
+        """Device field code on raw operands (ncg_field_check): a_words, b_words uint32 [n, 9] (fields 0/1) or
+        [n, 12] (field 2) -> uint32 [n, 8 | 12]."""
+        a = np.ascontiguousarray(a_words, dtype=np.uint32)
+        b = np.ascontiguousarray(b_words, dtype=np.uint32)
+        n = a.shape[0]
+        out = np.zeros((n, 12 if field == 2 else 8), dtype=np.uint32)
+        if n:
+            self._check(self.lib.ncg_field_check(self.h, field, op, variant, n, a.ctypes.data, b.ctypes.data, out.ctypes.data))
+        return out
 
     def ubench(self, kind, blocks, threads, iters):
         ms = ctypes.c_float()

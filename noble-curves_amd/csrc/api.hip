@@ -985,6 +985,28 @@ int ncg_ed25519_verify_batch_msgs(ncg_ctx* ctx, size_t n, const void* sig64, con
   return NCG_OK;
 }
 
+int ncg_field_check(ncg_ctx* ctx, int field, int op, int variant, size_t n, const void* a, const void* b, void* out) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (field < 0 || field > 2) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: field_check: unknown field %d", field);
+  if (n == 0) return NCG_OK;
+  if (n > (1u << 24) || !a || !b || !out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: field_check: bad arguments");
+  const size_t in_w = field == 2 ? 12 : 9, out_w = field == 2 ? 12 : 8;
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t in_b = (n * in_w * 4 + 255) & ~(size_t)255, out_b = n * out_w * 4;
+  int rc = ensure_scratch(ctx, 2 * in_b + out_b + 1024);
+  if (rc) return rc;
+  char* d_a = (char*)ctx->scratch;
+  char* d_b = d_a + in_b;
+  char* d_o = d_b + in_b;
+  NCG_HIP(ctx, hipMemcpyAsync(d_a, a, n * in_w * 4, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, hipMemcpyAsync(d_b, b, n * in_w * 4, hipMemcpyHostToDevice, ctx->stream));
+  NCG_HIP(ctx, hipMemsetAsync(d_o, 0, out_b, ctx->stream));
+  NCG_HIP(ctx, ncg::field_check_run(field, op, variant, (const uint32_t*)d_a, (const uint32_t*)d_b, (uint32_t*)d_o, (int)n, ctx->stream));
+  NCG_HIP(ctx, hipMemcpyAsync(out, d_o, out_b, hipMemcpyDeviceToHost, ctx->stream));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
 int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float* out_ms) {
   if (!ctx || !out_ms) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ubench: NULL arg");
   if (blocks <= 0 || threads <= 0 || threads > 256 || iters <= 0)

@@ -93,6 +93,9 @@ hipError_t ed25519_mul_base_batch(const uint32_t* table, const uint32_t* scalars
 void ed25519_mul_var_host(const uint32_t* pt, const uint32_t* k, uint32_t* out, uint8_t* out_inf);
 bool ed25519_verify_host(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, const uint32_t* btab, bool zip215);
 
+// field-level self-check (ubench.hip): out[i] = op(a[i], b[i]) on the device field code
+hipError_t field_check_run(int field, int op, int variant, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, int n,
+                           hipStream_t st);
 hipError_t ubench_run(int kind, int blocks, int threads, int iters, uint32_t* d_out, const uint32_t* d_in,
                       hipStream_t st, float* ms);
 

@@ -151,6 +151,90 @@ __global__ void __launch_bounds__(256) k_ub_field29(uint32_t* out, const uint32_
   out[t] = s;
 }
 
+// ---- field-level self-check on the device: out[i] = op(a[i], b[i]) for the field code the kernels use,
+// one lane per element (tests/test_gpu_field.py compares with big-int arithmetic, so the inline-asm
+// multiply-add chains and the bound-typed lazy reduction are pinned directly, not only through point
+// operations).  field 0 / 1: fe9.hpp (secp256k1 / ed25519 p), operands as 9 RAW limbs each (the tests feed
+// limbs at the top of what a bound type admits), `variant` = 10 A + B picks the operand bound types;
+// field 2: bls12-381 Fe29 (canonical 12-word operands).  Results: canonical wire words (8 or 12) per element.
+template <class PR, int A, int B>
+__device__ void field_check_fe9(int op, const uint32_t* a, const uint32_t* b, uint32_t* r) {
+  Fe9<PR, A> x;
+  Fe9<PR, B> y;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    x.v[i] = a[i];
+    y.v[i] = b[i];
+  }
+  switch (op) {
+    case 0: fe9_to_wire(r, x * y); break;
+    case 1: fe9_to_wire(r, f_sqr(x)); break;
+    case 2: if constexpr (A + B <= 7) fe9_to_wire(r, x + y); break;
+    case 3: if constexpr (A + B + 1 <= 7) fe9_to_wire(r, x - y); break;
+    case 4: if constexpr (A + 1 <= 7) fe9_to_wire(r, f_neg(x)); break;
+    case 5: fe9_to_wire(r, f_inv(x)); break;
+    case 6: fe9_to_wire(r, fe9_norm(x)); break;
+    case 7: {
+      for (int i = 0; i < 8; i++) r[i] = 0;
+      r[0] = f_eqz(x) ? 1u : 0u;
+      break;
+    }
+    case 9: {  // largest limb of the raw product (output-bound check)
+      auto n = x * y;
+      uint32_t mx = 0;
+      for (int i = 0; i < 9; i++) mx = n.v[i] > mx ? n.v[i] : mx;
+      for (int i = 0; i < 8; i++) r[i] = 0;
+      r[0] = mx;
+      break;
+    }
+  }
+}
+template <class PR>
+__global__ void __launch_bounds__(64) k_field_check_fe9(int op, int variant, const uint32_t* __restrict__ a,
+                                                        const uint32_t* __restrict__ b, uint32_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t *pa = a + (size_t)i * 9, *pb = b + (size_t)i * 9;
+  uint32_t* r = out + (size_t)i * 8;
+  switch (variant) {
+    case 11: field_check_fe9<PR, 1, 1>(op, pa, pb, r); break;
+    case 12: field_check_fe9<PR, 1, 2>(op, pa, pb, r); break;
+    case 17: field_check_fe9<PR, 1, 7>(op, pa, pb, r); break;
+    case 71: field_check_fe9<PR, 7, 1>(op, pa, pb, r); break;
+    case 23: field_check_fe9<PR, 2, 3>(op, pa, pb, r); break;
+    case 22: field_check_fe9<PR, 2, 2>(op, pa, pb, r); break;
+    case 33: field_check_fe9<PR, 3, 3>(op, pa, pb, r); break;
+    case 77: field_check_fe9<PR, 7, 7>(op, pa, pb, r); break;
+    default: break;
+  }
+}
+__global__ void __launch_bounds__(64) k_field_check_fe29(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                         uint32_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fe29<2> x = fe29_from_wire(a + (size_t)i * 12), y = fe29_from_wire(b + (size_t)i * 12);
+  uint32_t* r = out + (size_t)i * 12;
+  switch (op) {
+    case 0: fe29_to_wire(r, x * y); break;
+    case 1: fe29_to_wire(r, f_sqr(x)); break;
+    case 2: fe29_to_wire(r, x + y); break;
+    case 3: fe29_to_wire(r, x - y); break;
+    case 4: fe29_to_wire(r, f_neg(x)); break;
+    case 5: fe29_to_wire(r, f_inv(x)); break;
+    default: break;
+  }
+}
+hipError_t field_check_run(int field, int op, int variant, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, int n,
+                           hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  const dim3 grid((n + 63) / 64), block(64);
+  if (field == 0) hipLaunchKernelGGL(k_field_check_fe9<Fe9SecpPR>, grid, block, 0, st, op, variant, d_a, d_b, d_out, n);
+  else if (field == 1) hipLaunchKernelGGL(k_field_check_fe9<Fe9EdPR>, grid, block, 0, st, op, variant, d_a, d_b, d_out, n);
+  else if (field == 2) hipLaunchKernelGGL(k_field_check_fe29, grid, block, 0, st, op, d_a, d_b, d_out, n);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 // Returns milliseconds for one launch of `kind` with the given geometry (after one warm-up).
 hipError_t ubench_run(int kind, int blocks, int threads, int iters, uint32_t* d_out, const uint32_t* d_in,
                       hipStream_t st, float* ms) {
