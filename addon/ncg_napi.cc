@@ -72,6 +72,44 @@ static napi_value Init(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// initMulti([deviceIds]): one process, several GPUs (include/ncg.h "multi-GPU MSM" (2)).  The context of the
+// first device serves the single-GPU entry points; msm() shards over the whole set.
+static ncg_multi* g_multi = nullptr;
+static napi_value InitMulti(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  bool is_arr = false;
+  uint32_t n = 0;
+  if (argc < 1 || napi_is_array(env, argv[0], &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, argv[0], &n) != napi_ok ||
+      n == 0 || n > 64) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: initMulti([deviceId, ...])");
+    return nullptr;
+  }
+  if (g_ctx || g_multi) {
+    napi_throw_error(env, nullptr, "noble-gpu: already initialised");
+    return nullptr;
+  }
+  int ids[64];
+  for (uint32_t i = 0; i < n; i++) {
+    napi_value e;
+    int32_t v = 0;
+    if (napi_get_element(env, argv[0], i, &e) != napi_ok || napi_get_value_int32(env, e, &v) != napi_ok) {
+      napi_throw_type_error(env, nullptr, "noble-gpu: initMulti: device ids must be integers");
+      return nullptr;
+    }
+    ids[i] = v;
+  }
+  if (ncg_multi_init(ids, (int)n, &g_multi) != 0) {
+    napi_throw_error(env, nullptr, ncg_last_error(nullptr));
+    return nullptr;
+  }
+  g_ctx = ncg_multi_ctx(g_multi, 0);
+  napi_value r;
+  napi_create_uint32(env, (uint32_t)ncg_multi_devices(g_multi), &r);
+  return r;
+}
+
 static bool need_ctx(napi_env env) {
   if (g_ctx) return true;
   napi_throw_error(env, nullptr, "noble-gpu: call init() first");
@@ -98,6 +136,13 @@ static napi_value Msm(napi_env env, napi_callback_info info) {
   }
   napi_value res = make_u8(env, pb + 1, &out);
   if (!res) return nullptr;
+  if (g_multi) {  // shard over the device set
+    if (ncg_msm_multi(g_multi, curve, sl / 32, pts, sc, out, out + pb) != 0) {
+      napi_throw_error(env, nullptr, ncg_multi_last_error(g_multi));
+      return nullptr;
+    }
+    return res;
+  }
   if (ncg_msm(g_ctx, curve, sl / 32, pts, sc, out, out + pb) != 0) return throw_native(env);
   return res;
 }
@@ -481,7 +526,7 @@ NAPI_MODULE_INIT() {
   struct {
     const char* name;
     napi_callback fn;
-  } fns[] = {{"init", Init},           {"msm", Msm},
+  } fns[] = {{"init", Init},           {"initMulti", InitMulti}, {"msm", Msm},
              {"mulVarBatch", MulVarBatch}, {"mulBaseBatch", MulBaseBatch},
              {"ed25519VerifyBatch", Ed25519VerifyBatch}, {"pointBytes", PointBytes},
              {"decodePoints", DecodePoints}, {"encodePoints", EncodePoints},

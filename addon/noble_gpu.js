@@ -16,6 +16,9 @@ const CURVE = { SECP256K1: 0, ED25519: 1, BLS12_381_G1: 2, BLS12_381_G2: 3 };
 const registry = new Map();
 let inited = false;
 function init(device) { if (!inited) { native.init(device || 0); inited = true; } }
+// one process, several GPUs: pippenger shards its points over `deviceIds` (ncg_msm_multi: one RCCL all-gather of
+// window sums, combine on the first device); every other call runs on the first device
+function initMulti(deviceIds) { if (!inited) { native.initMulti(deviceIds); inited = true; } return deviceIds.length; }
 function register(c, curveId) { registry.set(c, curveId); }
 
 // BigInt <-> little-endian bytes through hex strings (utils.ts:498 numberToBytesLE / :456
@@ -285,6 +288,6 @@ function hashToCurveBatch(c, msgs, DST) {
   return msgs.map((_, i) => unmarshalPoint(c, id, out, i * pb, out[n * pb + i] === 1));
 }
 
-module.exports = { CURVE, init, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
+module.exports = { CURVE, init, initMulti, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
                    PointSet, uploadPoints, uploadEncoded, pippengerResident, multiplyUnsafeBatchResident, ed25519VerifyBatchDevice,
                    fromBytesBatch, toBytesBatch, aggregateFromBytes, fftFr, hashToCurveBatch, native };

@@ -32,7 +32,8 @@ assert.throws(() => gpu.multiplyUnsafeBatch(Point, [Point.BASE], [N]), /invalid 
 console.log('validation OK, native:', gpu.native.version());
 
 let haveGpu = true;
-try { gpu.init(0); } catch (e) { haveGpu = false; console.log('no GPU here:', e.message); }
+// the device-set context with one device: pippenger goes through ncg_msm_multi, everything else through its first context
+try { gpu.initMulti([0]); } catch (e) { haveGpu = false; console.log('no GPU here:', e.message); }
 if (haveGpu) {
   const rows = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', 'secp256k1_privates2.json')));
   const ks = rows.map((r) => BigInt(r[0]));
