@@ -68,6 +68,21 @@ NCG_DI void words12_neg_mod_p(uint32_t (&w)[12]) {  // w = p - w for w != 0
   for (int i = 0; i < 12; i++) w[i] = __builtin_subc((uint32_t)BlsFpConsts::P32[i], w[i], bw, &bw);
 }
 
+// ---- lane-paired Fp2 helpers (CurveG2P: one Fp2 element per lane pair, fe29.hpp) shared by the G2 decoder's
+// subgroup stage and the hash-to-curve cofactor stage
+NCG_DI Fe29x2P<1> p2_const(const uint32_t (&c0)[14], const uint32_t (&c1)[14]) {
+  return Fe29x2P<1>(fe29_select(pair_odd(), fe29_const(c1), fe29_const(c0)));
+}
+NCG_DI FeBls2P p2_conj(const FeBls2P& a) {  // c0 - c1 u: the odd lane negates its half
+  return FeBls2P(fe29_select(pair_odd(), f_neg(a.h), a.h));
+}
+NCG_DI Jac<FeBls2P> g2p_psi(const Jac<FeBls2P>& P) {
+  if (P.is_inf()) return P;
+  const Fe29x2P<1> psx = p2_const(ParamsBls29::PSI_X_C0, ParamsBls29::PSI_X_C1);
+  const Fe29x2P<1> psy = p2_const(ParamsBls29::PSI_Y_C0, ParamsBls29::PSI_Y_C1);
+  return {p2_conj(P.X) * psx, p2_conj(P.Y) * psy, p2_conj(P.Z)};
+}
+
 // Square root in Fp2 = Fp[u]/(u^2+1), p = 3 mod 4.  The reference's complex method
 // (tower.ts:476-500) spends sqrt(norm) + Legendre(d) + sqrt(d) + one inversion; here the Legendre
 // symbol, the root and the inverse all come out of ONE power t = d^((p-3)/4):

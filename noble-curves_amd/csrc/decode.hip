@@ -12,6 +12,7 @@
 //              [-x]P == psi(P) (src/bls12-381.ts:599-601, psi: src/abstract/tower.ts:240-247)
 //   ed25519    32 bytes: Point.fromBytes(bytes, zip215) (src/abstract/edwards.ts:405-436)
 // out_ok[i] = 0 exactly where the reference throws; the affine output is then (0,0).
+#include <cstdlib>
 #include <vector>
 
 #include "bls_lanes.hpp"
@@ -148,6 +149,8 @@ NCG_DI bool g1_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict_
 
 // ---------------------------------------------------------------------------- bls12-381 G2
 // in: 96 bytes (x.c1 || x.c0, big-endian, flags in byte 0); out: x.c0 x.c1 y.c0 y.c1 wire
+// SUBGROUP = false leaves out the psi test (the split device pipeline runs it lane-paired in a second kernel)
+template <bool SUBGROUP = true>
 NCG_DI bool g2_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint8_t* inf) {
   using F = FeBls2;
   const uint8_t mask = in[0] & 0xE0;
@@ -188,7 +191,7 @@ NCG_DI bool g2_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict_
     auto ny = f_neg(y);
     y = {ny.c0 * Fe29<1>::one(), ny.c1 * Fe29<1>::one()};
   }
-  {  // subgroup: -[|x|]P == psi(P), psi(x, y) = (conj(x) PSI_X, conj(y) PSI_Y)
+  if constexpr (SUBGROUP) {  // subgroup: -[|x|]P == psi(P), psi(x, y) = (conj(x) PSI_X, conj(y) PSI_Y)
     Jac<F> P{x, y, F::one()};
     Jac<F> xP = jac_neg(bls_mul_by_x(P));
     const Fe29x2<1> psx{fe29_const(ParamsBls29::PSI_X_C0), fe29_const(ParamsBls29::PSI_X_C1)};
@@ -259,6 +262,46 @@ __global__ void __launch_bounds__(128, NCG_DEC_G2_MINW) k_decode_g2(const uint8_
   ok[i] = g2_decode_lane(in + (size_t)i * 96, out + (size_t)i * 48, &f) ? 1 : 0;
   inf[i] = f;
 }
+// ---- split G2 decoder (device default): stage A decompresses (range rules, Fp2 square root, sort bit) one
+// point per lane in the unpaired form; stage B runs the subgroup test -[|x|]P == psi(P) (bls12-381.ts:599-601)
+// in the lane-paired form - half the registers per lane instead of 587 spilled ones - and clears rejected rows.
+__global__ void __launch_bounds__(128, NCG_DEC_G2_MINW) k_decode_g2_stage_a(const uint8_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                            uint8_t* __restrict__ ok, uint8_t* __restrict__ inf, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t f = 0;
+  ok[i] = g2_decode_lane<false>(in + (size_t)i * 96, out + (size_t)i * 48, &f) ? 1 : 0;
+  inf[i] = f;
+}
+__global__ void __launch_bounds__(64, 2) k_decode_g2_stage_b(uint32_t* __restrict__ out, uint8_t* __restrict__ ok,
+                                                             const uint8_t* __restrict__ inf, int n) {
+  using F = FeBls2P;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;  // two lanes per point
+  if (i >= n) return;
+  if (!ok[i] || inf[i]) return;                                  // rejected already, or the (valid) infinity encoding
+  uint32_t* row = out + (size_t)i * 48;
+  const F x = FieldWire<F>::load(row), y = FieldWire<F>::load(row + 24);
+  Jac<F> P{x, y, F::one()};
+  Jac<F> xP = jac_neg(bls_mul_by_x(P));
+  const Fe29x2P<1> psx = p2_const(ParamsBls29::PSI_X_C0, ParamsBls29::PSI_X_C1);
+  const Fe29x2P<1> psy = p2_const(ParamsBls29::PSI_Y_C0, ParamsBls29::PSI_Y_C1);
+  auto px = p2_conj(x) * psx;
+  auto py = p2_conj(y) * psy;
+  auto zz = f_sqr(xP.Z);
+  auto dx = xP.X - px * zz;
+  auto dy = xP.Y - py * zz * xP.Z;
+  const bool same = !f_eqz(xP.Z) && f_eqz(dx) && f_eqz(dy);  // pair-uniform
+  if (!same) {
+    const int half = (threadIdx.x & 1) * 12;  // each lane clears its halves of x and y
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      row[half + k] = 0;
+      row[24 + half + k] = 0;
+    }
+    if ((threadIdx.x & 1) == 0) ok[i] = 0;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_decode_ed(const uint8_t* __restrict__ in, int zip215,
                                                    uint32_t* __restrict__ out, uint8_t* __restrict__ ok, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,9 +335,16 @@ hipError_t decode_points_batch(int curve, const uint8_t* in, int flags, uint32_t
     case CURVE_BLS12_381_G1:
       hipLaunchKernelGGL(k_decode_g1, grid, block, 0, st, in, out, ok, inf, n);
       break;
-    case CURVE_BLS12_381_G2:
-      hipLaunchKernelGGL(k_decode_g2, dim3((n + 127) / 128), dim3(128), 0, st, in, out, ok, inf, n);
+    case CURVE_BLS12_381_G2: {
+      static const int fused = [] { const char* e = std::getenv("NCG_DEC_G2_FUSED"); return e ? std::atoi(e) : 0; }();
+      if (fused) {
+        hipLaunchKernelGGL(k_decode_g2, dim3((n + 127) / 128), dim3(128), 0, st, in, out, ok, inf, n);
+      } else {
+        hipLaunchKernelGGL(k_decode_g2_stage_a, dim3((n + 127) / 128), dim3(128), 0, st, in, out, ok, inf, n);
+        hipLaunchKernelGGL(k_decode_g2_stage_b, dim3((unsigned)(((size_t)n * 2 + 63) / 64)), dim3(64), 0, st, out, ok, inf, n);
+      }
       break;
+    }
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

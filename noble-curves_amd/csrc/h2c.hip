@@ -215,18 +215,6 @@ NCG_DI Jac<FeBls2> g2_clear_cofactor(const Jac<FeBls2>& P) {  // bls12-381.ts:60
 // ---- lane-paired G2 tail (CurveG2P: one Fp2 element per lane pair, fe29.hpp): the point addition and the
 // cofactor clearing of the split G2 pipeline below run in this form - half the registers per lane, so
 // the kernel keeps 2 waves/SIMD instead of spilling ~1900 registers at 1 wave.
-NCG_DI Fe29x2P<1> p2_const(const uint32_t (&c0)[14], const uint32_t (&c1)[14]) {
-  return Fe29x2P<1>(fe29_select(pair_odd(), fe29_const(c1), fe29_const(c0)));
-}
-NCG_DI FeBls2P p2_conj(const FeBls2P& a) {  // c0 - c1 u: the odd lane negates its half
-  return FeBls2P(fe29_select(pair_odd(), f_neg(a.h), a.h));
-}
-NCG_DI Jac<FeBls2P> g2p_psi(const Jac<FeBls2P>& P) {
-  if (P.is_inf()) return P;
-  const Fe29x2P<1> psx = p2_const(ParamsBls29::PSI_X_C0, ParamsBls29::PSI_X_C1);
-  const Fe29x2P<1> psy = p2_const(ParamsBls29::PSI_Y_C0, ParamsBls29::PSI_Y_C1);
-  return {p2_conj(P.X) * psx, p2_conj(P.Y) * psy, p2_conj(P.Z)};
-}
 NCG_DI Jac<FeBls2P> g2p_psi2(const Jac<FeBls2P>& P) {
   if (P.is_inf()) return P;
   const Fe29<1> k = fe29_const(BlsH2c::PSI2_X);
