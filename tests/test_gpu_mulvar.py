@@ -469,3 +469,28 @@ def test_pairwise_add_subtract_and_mul_add_gpu(name):
     for r, a, q, b in zip(got, a_s, oqs, b_s):
         e = O.BASE.multiplyUnsafe(a).add(q.multiplyUnsafe(b))
         assert r.toAffine() == e.toAffine() and r.is0() == e.is0()
+
+
+def test_config0_point_multiply_1k_random_scalars():
+    """BASELINE configs[0] (benchmark/point.ts:20-32): `P.multiply(k)` / `P.multiplyUnsafe(k)` on one random
+    secp256k1 point for the benchmark's literal scalar 2^180 - 15820 and 1 000 random scalars, through the
+    shim's batch forms, against the oracle's C restatement (RCB + GLV wNAF-4) and, for a sample, the Python
+    oracle."""
+    from noble_curves_amd import curve as G
+    from oracle import cport
+    n = SECP256K1_N
+    rng = makeRng(0x6E6F626C6501)
+    P = Secp256k1.BASE.multiplyUnsafe(rng.rndBelow(n - 1) + 1)
+    ks = [(1 << 180) - 15820] + [rng.rndBelow(n - 1) + 1 for _ in range(1000)]
+    gp = G.secp256k1_Point.fromAffine(P.toAffine())
+    got_m = G.multiplyBatch(G.secp256k1_Point, [gp] * len(ks), ks)
+    got_u = G.multiplyUnsafeBatch(G.secp256k1_Point, [gp] * len(ks), ks)
+    exp, _ = cport.multiply_unsafe("secp256k1", points_to_wire(SECP256K1, [P] * len(ks)), scalars_to_wire(ks))
+    for i, k in enumerate(ks):
+        e = wire_to_affine(SECP256K1, exp[i])
+        assert got_m[i].toAffine() == e and got_u[i].toAffine() == e, hex(k)
+    for i in (0, 1, 500, 1000):
+        assert got_m[i].toAffine() == P.multiply(ks[i]).toAffine()
+    with pytest.raises(ValueError, match="invalid scalar: out of range"):
+        G.multiplyBatch(G.secp256k1_Point, [gp], [0])            # multiply rejects 0, multiplyUnsafe allows it
+    assert G.multiplyUnsafeBatch(G.secp256k1_Point, [gp], [0])[0].is0()
