@@ -125,6 +125,26 @@ function multiplyUnsafeBatchResident(set, scalars) {
   for (let i = 0; i < n; i++) res[i] = unmarshalPoint(set.c, set.id, out, i * pb, out[n * pb + i] === 1);
   return res;
 }
+// interleavedMSMUnsafe (curve.ts:938-959): MSM over a FIXED point set, returns the closure scalars -> Point.
+// Same argument checks and messages; the closure accepts at most points.length scalars, omitted trailing ones
+// are zero.  windowSize only sizes the reference's wNAF tables and never changes the result: here the set
+// is uploaded once and each call runs the bucket MSM on the resident points.
+function interleavedMSMUnsafe(c, points, windowSize) {
+  const bits = c.Fn.BITS;
+  if (!Number.isSafeInteger(windowSize) || windowSize < 2 || windowSize > bits)
+    throw new Error('invalid window size, expected [2..' + bits + '], got W=' + windowSize);
+  validateMSMPoints(points, c);
+  const n = points.length;
+  const set = n ? uploadPoints(c, points) : null;
+  return (scalars) => {
+    validateMSMScalars(scalars, c.Fn);
+    if (scalars.length > n) throw new Error('array of scalars must not be larger than array of points');
+    if (n === 0) return c.ZERO;
+    const padded = scalars.length === n ? scalars : scalars.concat(new Array(n - scalars.length).fill(0n));
+    const out = native.msmResident(set.handle, padded);
+    return unmarshalPoint(c, set.id, out, 0, out[out.length - 1] === 1);
+  };
+}
 // eddsa.verify for a batch from (sig, msg, publicKey): the SHA-512 challenge is computed on the device
 function ed25519VerifyBatchDevice(items, zip215) {
   const n = items.length;
@@ -289,5 +309,5 @@ function hashToCurveBatch(c, msgs, DST) {
 }
 
 module.exports = { CURVE, init, initMulti, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
-                   PointSet, uploadPoints, uploadEncoded, pippengerResident, multiplyUnsafeBatchResident, ed25519VerifyBatchDevice,
+                   PointSet, uploadPoints, uploadEncoded, interleavedMSMUnsafe, pippengerResident, multiplyUnsafeBatchResident, ed25519VerifyBatchDevice,
                    fromBytesBatch, toBytesBatch, aggregateFromBytes, fftFr, hashToCurveBatch, native };

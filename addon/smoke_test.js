@@ -20,7 +20,7 @@ Point.ZERO = new Point(0n, 0n, true);
 Point.BASE = new Point(0x79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798n,
                        0x483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8n);
 Point.Fp = { ORDER: P, BYTES: 32 };
-Point.Fn = { ORDER: N, BYTES: 32 };
+Point.Fn = { ORDER: N, BYTES: 32, BITS: 256 };
 gpu.register(Point, gpu.CURVE.SECP256K1);
 
 // validation happens before crossing, with the reference's messages
@@ -102,6 +102,25 @@ if (haveGpu) {
   assert.throws(() => gpu.pippengerResident(set, ss.map(() => N)), /invalid scalar at index 0/);
   assert.throws(() => gpu.uploadEncoded(Point, Uint8Array.from(Array.from(enc[0]).concat(Array.from(bad)))), /invalid point encoding at index 1/);
   set.free(); setEnc.free();
+  // interleavedMSMUnsafe (test/point.test.ts:309-317): 3G + 5*2G + 7*4G + 11*8G = 129G for every window size,
+  // window 1 throws, fewer scalars than points = trailing zeros, more = error
+  {
+    const pts2 = gpu.multiplyBaseBatch(Point, [1n, 2n, 4n, 8n]);
+    const want = gpu.multiplyBaseBatch(Point, [129n, 13n]);
+    for (let W = 2; W <= 10; W++) {
+      const mul = gpu.interleavedMSMUnsafe(Point, pts2, W);
+      const r = mul([3n, 5n, 7n, 11n]);
+      assert.strictEqual(r.x, want[0].x); assert.strictEqual(r.y, want[0].y);
+      if (W === 4) {
+        const short = mul([3n, 5n]);
+        assert.strictEqual(short.x, want[1].x); assert.strictEqual(short.y, want[1].y);
+        assert.throws(() => mul([1n, 1n, 1n, 1n, 1n]), /array of scalars must not be larger than array of points/);
+        assert.throws(() => mul([N]), /invalid scalar at index 0/);
+      }
+    }
+    assert.throws(() => gpu.interleavedMSMUnsafe(Point, pts2, 1), /window/);
+    assert.strictEqual(gpu.interleavedMSMUnsafe(Point, [], 4)([]), Point.ZERO);
+  }
   // timing of the resident path at 2^16 (SURVEY 8a gotcha 8: marshalling is the end-to-end cost)
   {
     const n = 1 << 16;

@@ -322,6 +322,31 @@ def uploadEncoded(c, encodings, zip215=False, engine=None):
     return PointSet(c, res)
 
 
+def interleavedMSMUnsafe(c, points, windowSize, engine=None):
+    """curve.ts:938-959: MSM over a FIXED point set; returns the closure `scalars -> Point`.  Same
+    argument checks and messages (window in [2..Fn.BITS], validateMSMPoints); the closure accepts at most
+    len(points) scalars and treats omitted trailing ones as zero.  `windowSize` only sizes the reference's
+    per-point wNAF tables and does not change the result: here the set is uploaded once and every call
+    runs the bucket MSM on the resident points with only the scalars crossing."""
+    bits = c.Fn.BITS
+    if not (isinstance(windowSize, int) and not isinstance(windowSize, bool) and 2 <= windowSize <= bits):
+        raise ValueError("invalid window size, expected [2..%d], got W=%s" % (bits, windowSize))
+    validateMSMPoints(points, c)
+    n = len(points)
+    pset = uploadPoints(c, points, engine) if n else None
+
+    def msm(scalars):
+        validateMSMScalars(scalars, c.Fn)
+        if len(scalars) > n:
+            raise ValueError("array of scalars must not be larger than array of points")
+        if n == 0:
+            return c.ZERO
+        out, inf = pset.resident.msm(_scalars_wire(list(scalars) + [0] * (n - len(scalars))))
+        return c._from_wire(out, inf)
+
+    return msm
+
+
 def multiplyUnsafeBatch(c, points, scalars, engine=None, _err="invalid scalar: out of range"):
     """[p.multiplyUnsafe(k) for p, k in zip(points, scalars)] in one launch
     (weierstrass.ts:915-928: 0 <= k < n else RangeError('invalid scalar: out of range'))."""

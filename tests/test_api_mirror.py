@@ -67,6 +67,54 @@ def test_reference_flow_on_gpu():
     assert [p.toAffine() for p in G.multiplyBaseBatch(K1, ks)] == [Secp256k1.BASE.multiplyUnsafe(k).toAffine() for k in ks]
 
 
+def test_interleaved_msm_validation_messages():
+    """interleavedMSMUnsafe's argument checks happen before anything crosses (curve.ts:943-947,
+    test/point.test.ts:317)."""
+    for bad in (1, 0, 257, 2.5, True, None):
+        with pytest.raises(ValueError, match="invalid window size"):
+            G.interleavedMSMUnsafe(K1, [K1.BASE], bad)
+    with pytest.raises(ValueError, match="invalid point at index 1"):
+        G.interleavedMSMUnsafe(K1, [K1.BASE, 5], 4)
+    with pytest.raises(TypeError, match="array expected"):
+        G.interleavedMSMUnsafe(K1, None, 4)
+    msm = G.interleavedMSMUnsafe(K1, [], 4)           # nothing to upload: no engine needed
+    assert msm([]) is K1.ZERO
+    with pytest.raises(ValueError, match="array of scalars must not be larger than array of points"):
+        msm([1])
+
+
+@pytest.mark.gpu
+def test_interleaved_msm_on_gpu():
+    """test/point.test.ts:309-317 (3G + 5*2G + 7*4G + 11*8G = 129G for window sizes 2..10) on every
+    curve, :854-858 (L = 3, W = 5), the closure's scalar rules (curve.ts:949-952) and a random fixed set
+    against the oracle's pippenger."""
+    import random
+    from oracle.curve import pippenger as o_pippenger
+    from oracle.curves import BlsG2, Ed25519
+    rng = random.Random(77)
+    for Pt, O in ((K1, Secp256k1), (G1, BlsG1), (G2, BlsG2), (G.ed25519_Point, Ed25519)):
+        g = Pt.BASE
+        pts = [g, g.multiplyUnsafe(2), g.multiplyUnsafe(4), g.multiplyUnsafe(8)]
+        want = O.BASE.multiplyUnsafe(129).toAffine()
+        for W in range(2, 11):
+            mul = G.interleavedMSMUnsafe(Pt, pts, W)
+            assert mul([3, 5, 7, 11]).toAffine() == want
+        mul = G.interleavedMSMUnsafe(Pt, pts, 5)
+        assert mul([3, 5]).toAffine() == O.BASE.multiplyUnsafe(13).toAffine()      # trailing scalars = 0
+        assert mul([]).is0() and mul([0, 0, 0, 0]).is0()
+        with pytest.raises(ValueError, match="array of scalars must not be larger than array of points"):
+            mul([1] * 5)
+        with pytest.raises(ValueError, match="invalid scalar at index 1"):
+            mul([1, Pt.Fn.ORDER])
+        n = Pt.Fn.ORDER
+        ks = [rng.randrange(1, n) for _ in range(37)]
+        opts = [O.BASE.multiplyUnsafe(k) for k in ks]
+        fixed = G.interleavedMSMUnsafe(Pt, G.multiplyBaseBatch(Pt, ks), 6)
+        for _ in range(3):                                                         # same set, new scalars
+            ss = [rng.randrange(n) for _ in range(37)]
+            assert fixed(ss).toAffine() == o_pippenger(O, opts, ss).toAffine()
+
+
 def test_h2c_shim_hash_to_field_matches_oracle():
     """The shim's expand_message_xmd / hash_to_field (hash-to-curve.ts:189-228, :312-378) against the oracle's
     restatement (pinned by the reference's signature vectors): short / long messages, empty and oversize
