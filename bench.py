@@ -555,7 +555,9 @@ def main():
         entry = {"metric": "bls12_381_%s_msm_points_per_sec" % cname, "value": world * nn * K / wall, "unit": "points/s",
                  "ms_per_msm": wall / K * 1e3, "points_per_gpu": nn, "total_points": world * nn, "scaling": "weak",
                  "multi_gpu": ("ncg_msm_sharded_dev: RCCL all-gather of grouped window sums + on-device add" if native_multi
-                               else ("gloo dry run: partial points exchanged by torch.distributed" if dist_on else "single GPU")),
+                               else (("%s: partial points exchanged by torch.distributed, pairwise adds on the engine"
+                                      % ("gloo dry run" if args.backend == "gloo" else "fallback (native RCCL communicator unavailable)"))
+                                     if dist_on else "single GPU")),
                  "roofline": {"bound": "hbm", "achieved": alg_b * nn / (wall / K) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": alg_b * nn / (wall / K) / 1e9 / HBM_PEAK_GBS,
                               "traffic": traffic, "traffic_source": tsrc,

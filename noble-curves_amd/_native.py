@@ -348,6 +348,9 @@ class Engine:
     def comm_size(self):
         return self.lib.ncg_comm_size(self.h)
 
+    def comm_destroy(self):
+        self._check(self.lib.ncg_comm_destroy(self.h))
+
     def msm_sharded_dev(self, curve, n_local, d_points, d_scalars, stream=None, n_max=0):
         """Collective MSM over the union of all ranks' device-resident shards (RCCL all-gather of the
         grouped window sums + on-device add); every rank gets (affine wire bytes [PB], is_inf)."""

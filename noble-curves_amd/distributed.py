@@ -29,21 +29,48 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
+_native_comm_failed = False
+
+
 def init_comm(engine, device=None):
     """Collective: give `engine` an RCCL communicator spanning the torch.distributed world (backend nccl).
-    Returns True if the native multi-GPU path is active, False for single-rank / gloo dry runs."""
+    Returns True if the native multi-GPU path is active, False for single-rank / gloo dry runs.  If the
+    communicator cannot be made on ANY rank (RCCL library not loadable, ncclCommInitRank error) every rank
+    learns it through one all-reduce, the reason goes to stderr once, and the callers use the
+    torch.distributed exchange instead - still device buffers over RCCL, only outside the C ABI."""
+    global _native_comm_failed
     import torch
     dist = _dist()
-    if dist is None or dist.get_world_size() == 1 or dist.get_backend() != "nccl":
+    if dist is None or dist.get_world_size() == 1 or dist.get_backend() != "nccl" or _native_comm_failed:
         return False
     if engine.comm_size() == dist.get_world_size():
         return True
     rank, world = dist.get_rank(), dist.get_world_size()
     uid = torch.zeros(128, dtype=torch.uint8, device=device)
+    err = None
     if rank == 0:
-        uid = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).to(device)
-    dist.broadcast(uid, 0)
-    engine.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        try:
+            uid = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).to(device)
+        except Exception as e:  # noqa: BLE001 - reported below, on every rank
+            err = e
+    bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=device)
+    dist.broadcast(bad, 0)
+    if int(bad.item()) == 0:
+        dist.broadcast(uid, 0)
+        try:
+            engine.comm_init(world, rank, bytes(uid.cpu().numpy().tobytes()))
+        except Exception as e:  # noqa: BLE001
+            err = e
+        bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+    if int(bad.item()) != 0:
+        import sys
+        _native_comm_failed = True
+        if engine.comm_size() > 1:
+            engine.comm_destroy()
+        print("[noble-gpu] rank %d: native RCCL communicator unavailable (%s); exchanging through torch.distributed"
+              % (rank, err if err else "another rank failed"), file=sys.stderr, flush=True)
+        return False
     return True
 
 
