@@ -19,30 +19,29 @@ raises NativeError.
 import numpy as np
 
 from . import _native
+from .field import Field
 from ._native import BLS12_381_G1, BLS12_381_G2, ED25519, FIELD_BYTES, POINT_BYTES, SECP256K1, get_engine
 
 _BLS_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
 _BLS_R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 
-class _Field:
-    """The slice of IField the shim needs (src/abstract/modular.ts:429-607)."""
+class _Field(Field):
+    """Fp / Fn of a point class: the full prime-field contract of field.py (IField, src/abstract/modular.ts:429-607);
+    `degree` 2 marks bls12-381's Fp2 base field, whose elements are (c0, c1) pairs and for which only the
+    membership tests the validators need are defined here."""
 
-    def __init__(self, order, degree=1):
-        self.ORDER = order
-        self.BITS = order.bit_length()
-        self.BYTES = (self.BITS + 7) // 8
+    def __init__(self, order, degree=1, isLE=False):
+        super().__init__(order, isLE=isLE)
         self.degree = degree
 
     def isValid(self, n):
         if self.degree == 2:
             return (isinstance(n, tuple) and len(n) == 2 and all(isinstance(c, int) and 0 <= c < self.ORDER for c in n))
-        if not isinstance(n, int) or isinstance(n, bool):
-            raise TypeError("invalid field element: expected bigint, got " + type(n).__name__)
-        return 0 <= n < self.ORDER
+        return super().isValid(n)
 
     def isValidNot0(self, n):
-        return self.isValid(n) and n != 0
+        return self.isValid(n) and not self.is0(n)
 
     def is0(self, n):
         return n == (0, 0) if self.degree == 2 else n == 0
@@ -583,7 +582,7 @@ bls12_381_G2_Point = _make_point_class(
     (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
      0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))  # bls12-381.ts:321-345
 ed25519_Point = _make_edwards_point_class(
-    "ed25519", ED25519, _Field((1 << 255) - 19),
-    _Field(0x1000000000000000000000000000000014DEF9DEA2F79CD65812631A5CF5D3ED),
+    "ed25519", ED25519, _Field((1 << 255) - 19, isLE=True),         # curve.ts:1036: Edwards fields are little-endian
+    _Field(0x1000000000000000000000000000000014DEF9DEA2F79CD65812631A5CF5D3ED, isLE=True),
     0x216936D3CD6E53FEC0A4E231FDD6DC5C692CC7609525A7B2C9562D608F25D51A,
     0x6666666666666666666666666666666666666666666666666666666666666658)                # ed25519.ts:57-65
