@@ -212,6 +212,17 @@ void ncg_points_free(ncg_points* pts);
 size_t ncg_points_count(const ncg_points* pts);
 int ncg_points_curve(const ncg_points* pts);
 const void* ncg_points_dev(const ncg_points* pts); /* device address of the affine wire points */
+/* bls12-381 G1 / G2 sets whose points all lie in the prime-order subgroup get a faster ncg_msm_resident: the
+ * scalars are split along the curve endomorphism (G1: k = k1 + k2 z^2 with phi, the map of the reference's own
+ * subgroup test bls12-381.ts:567-577; G2: k = sum d_e z^e with psi, :599-601), which halves / quarters the
+ * window count for the same group element.  pippenger itself (curve.ts:863-905) takes arbitrary curve points,
+ * so this is never assumed: sets from ncg_points_from_encoded qualify automatically (the decoder runs the
+ * reference's subgroup test on every point); for uploaded affine points ncg_points_verify_subgroup runs the
+ * test once - every point P must satisfy [z^2]P = -phi(P) resp. [z]P = -psi(P) - and enables the path only if
+ * all pass.  A failing set is not an error: *out_bad_index names the first point outside the subgroup and the
+ * set keeps using the generic path.  ncg_points_in_subgroup: 1 if the fast path is active. */
+int ncg_points_verify_subgroup(ncg_ctx* ctx, ncg_points* pts, int64_t* out_bad_index);
+int ncg_points_in_subgroup(const ncg_points* pts);
 /* pippenger(c, <resident points>, scalars) and the batch multiplyUnsafe on them; scalars: host */
 int ncg_msm_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine,
                      uint8_t* out_is_inf);

@@ -117,6 +117,8 @@ _OPTIONAL_PROTOS = {
     "ncg_points_from_encoded": [_vp, _i32, _sz, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int64)],
     "ncg_points_curve": [_vp],
     "ncg_msm_resident": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
+    "ncg_points_verify_subgroup": [_vp, _vp, ctypes.POINTER(ctypes.c_int64)],
+    "ncg_points_in_subgroup": [_vp],
     "ncg_mul_var_batch_resident": [_vp, _vp, _vp, _vp, _vp],
     "ncg_field_check": [_vp, _i32, _i32, _i32, _sz, _vp, _vp, _vp],
     "ncg_comm_unique_id": [_vp],
@@ -483,6 +485,19 @@ class ResidentPoints:
 
     def dev_ptr(self):
         return self.engine.lib.ncg_points_dev(self.h)
+
+    def verify_subgroup(self):
+        """bls12-381 G1 / G2: run the reference's subgroup test on every point once (ncg_points_verify_subgroup);
+        if all pass, MSMs on this set take the endomorphism path.  Returns -1, or the index of the first point
+        outside the prime-order subgroup (the set then keeps the generic path)."""
+        bad = ctypes.c_int64(-1)
+        self.engine._check(self.engine.lib.ncg_points_verify_subgroup(self.engine.h, self.h, ctypes.byref(bad)))
+        return int(bad.value)
+
+    @property
+    def in_subgroup(self):
+        """True once the set is known to lie in the prime-order subgroup (decoded, or verified)."""
+        return bool(self.engine.lib.ncg_points_in_subgroup(self.h)) if self.h else False
 
     def free(self):
         if getattr(self, "h", None):

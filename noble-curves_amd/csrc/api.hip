@@ -75,9 +75,14 @@ static int ensure_scratch(ncg_ctx* ctx, size_t bytes) {
 }
 
 // window plan for an n-point MSM (c_override > 0 fixes the window width) and a workspace big enough for it
+static int msm_ensure_ws(ncg_ctx* ctx, int curve, const ncg::MsmPlan& pl);
 int ncg_msm_plan_ws(ncg_ctx* ctx, int curve, size_t n, int c_override, ncg::MsmPlan* pl) {
   if (ncg::msm_make_plan(curve, (int)n, c_override, pl) != 0)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+  return msm_ensure_ws(ctx, curve, *pl);
+}
+static int msm_ensure_ws(ncg_ctx* ctx, int curve, const ncg::MsmPlan& pl_ref) {
+  const ncg::MsmPlan* pl = &pl_ref;
   size_t need = ncg::msm_workspace_bytes(curve, *pl);
   if (ctx->msm_ws_bytes < need) {
     if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
@@ -399,7 +404,27 @@ struct ncg_points {
   int curve;
   size_t n;
   void* d_pts;
+  void* d_endo = nullptr;  // endomorphism images (msm_endo_expand) once the set is known to lie in the subgroup
 };
+
+// Build the endomorphism images of a set whose points are KNOWN to lie in the prime-order subgroup.
+static int points_build_endo(ncg_ctx* ctx, ncg_points* h) {
+  const int E = ncg::msm_endo_factor(h->curve);
+  if (E == 0 || h->n == 0 || h->d_endo) return NCG_OK;
+  if (h->n * (size_t)E > 0x7fffffffu) return NCG_OK;  // too large for the expanded index space: generic path
+  const size_t bytes = h->n * (size_t)E * ncg::msm_endo_words_per_point(h->curve) * 4;
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, bytes);
+  if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  e = ncg::msm_endo_expand(h->curve, (const uint32_t*)h->d_pts, (int)h->n, (uint32_t*)d, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return set_err(ctx, NCG_ERR_HIP, "noble-gpu: endomorphism images: %s", hipGetErrorString(e));
+  }
+  h->d_endo = d;
+  return NCG_OK;
+}
 
 int ncg_points_upload(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, ncg_points** out) {
   if (!ctx || !out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_upload: NULL argument");
@@ -468,6 +493,9 @@ int ncg_points_from_encoded(ncg_ctx* ctx, int curve, size_t n, const void* encod
           rc = set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_from_encoded: invalid point encoding at index %zu", i);
           break;
         }
+    // the bls12-381 decoders include the subgroup test (bls12-381.ts:567-577, :599-601), so a decoded set
+    // qualifies for the endomorphism MSM; infinity encodings decode to ZERO and stay ZERO in every image
+    if (rc == NCG_OK) rc = points_build_endo(ctx, h);
     if (rc != NCG_OK) {
       (void)hipFree(h->d_pts);
       delete h;
@@ -478,12 +506,70 @@ int ncg_points_from_encoded(ncg_ctx* ctx, int curve, size_t n, const void* encod
   return NCG_OK;
 }
 
+int ncg_points_verify_subgroup(ncg_ctx* ctx, ncg_points* h, int64_t* out_bad_index) {
+  if (out_bad_index) *out_bad_index = -1;
+  if (!ctx || !h || h->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_verify_subgroup: handle does not belong to this context");
+  const int E = ncg::msm_endo_factor(h->curve);
+  if (E == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: points_verify_subgroup: bls12-381 G1 / G2 only");
+  if (h->n == 0 || h->d_endo) return NCG_OK;
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = points_build_endo(ctx, h);
+  if (rc != NCG_OK || !h->d_endo) return rc;
+  // [z^2] P (G1) / [z] P (G2) by the generic (complete) batch multiply, compared with the first image
+  const size_t n = h->n, pb = (size_t)ncg_point_bytes(h->curve);
+  char* tmp = nullptr;
+  const size_t sc_b = (n * 32 + 255) & ~(size_t)255, out_b = (n * pb + 255) & ~(size_t)255, inf_b = (n + 255) & ~(size_t)255;
+  hipError_t e = hipMalloc((void**)&tmp, sc_b + out_b + inf_b + 256);
+  auto drop = [&]() {
+    if (tmp) (void)hipFree(tmp);
+    (void)hipFree(h->d_endo);
+    h->d_endo = nullptr;
+  };
+  if (e != hipSuccess) {
+    tmp = nullptr;
+    drop();
+    return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  uint32_t kz[8];
+  ncg::msm_endo_verify_scalar(h->curve, kz);
+  std::vector<uint32_t> sc(n * 8);
+  for (size_t i = 0; i < n; i++) memcpy(&sc[i * 8], kz, 32);
+  uint32_t bad = 0xFFFFFFFFu;
+  uint32_t* d_bad = (uint32_t*)(tmp + sc_b + out_b + inf_b);
+  e = hipMemcpyAsync(tmp, sc.data(), n * 32, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_bad, &bad, 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `sc` and `bad` are pageable
+  if (e == hipSuccess) {
+    rc = ncg_mul_var_batch_dev(ctx, h->curve, n, h->d_pts, tmp, tmp + sc_b, (uint8_t*)(tmp + sc_b + out_b), ctx->stream);
+    if (rc != NCG_OK) {
+      drop();
+      return rc;
+    }
+    e = ncg::msm_endo_verify(h->curve, (const uint32_t*)(tmp + sc_b), (const uint8_t*)(tmp + sc_b + out_b),
+                             (const uint32_t*)h->d_endo, (int)n, d_bad, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    drop();
+    return set_err(ctx, NCG_ERR_HIP, "noble-gpu: points_verify_subgroup: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(tmp);
+  tmp = nullptr;
+  if (bad != 0xFFFFFFFFu) {  // not an error: the set stays usable through the generic path
+    drop();
+    if (out_bad_index) *out_bad_index = (int64_t)bad;
+  }
+  return NCG_OK;
+}
+
+int ncg_points_in_subgroup(const ncg_points* h) { return h && h->d_endo ? 1 : 0; }
+
 void ncg_points_free(ncg_points* h) {
   if (!h) return;
-  if (h->d_pts) {
-    (void)hipSetDevice(h->ctx->device);
-    (void)hipFree(h->d_pts);
-  }
+  (void)hipSetDevice(h->ctx->device);
+  if (h->d_pts) (void)hipFree(h->d_pts);
+  if (h->d_endo) (void)hipFree(h->d_endo);
   delete h;
 }
 size_t ncg_points_count(const ncg_points* h) { return h ? h->n : 0; }
@@ -508,6 +594,22 @@ int ncg_msm_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, v
   char* d_sc = nullptr;
   int rc = upload_scalars(ctx, pins, pts->n, scalars, &d_sc);
   if (rc) return rc;
+  static const bool no_endo = std::getenv("NCG_NO_ENDO") != nullptr;
+  if (pts->d_endo && !no_endo) {  // verified subgroup set: endomorphism MSM on the expanded images (endo.hpp)
+    ncg::MsmPlan pl;
+    if (ncg::msm_make_plan_endo(pts->curve, (int)pts->n, 0, &pl) != 0)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+    rc = msm_ensure_ws(ctx, pts->curve, pl);
+    if (rc) return rc;
+    uint32_t bad = 0xFFFFFFFFu;
+    uint8_t inf_local = 0;
+    NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, (const uint32_t*)pts->d_endo, (const uint32_t*)d_sc, ctx->msm_ws,
+                              (uint32_t*)out_affine, &inf_local, ctx->stream, &bad));
+    if (bad != 0xFFFFFFFFu)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
+    if (out_is_inf) *out_is_inf = inf_local;
+    return NCG_OK;
+  }
   return ncg_msm_dev(ctx, pts->curve, pts->n, pts->d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
 }
 

@@ -72,6 +72,20 @@ hipError_t msm_sum_partials(int curve, const uint32_t* d_gathered, int nparts, s
 size_t msm_fin_words(int curve, const MsmPlan& pl);
 size_t msm_acc_words(int curve);
 
+// Endomorphism mode for bls12-381 point sets verified to lie in the prime-order subgroup (msm_endo.hip,
+// endo.hpp).  msm_endo_factor: sub-scalars per scalar (2 on G1, 4 on G2, 0 = not offered).  msm_endo_expand
+// writes the factor * n images of n wire points in the accumulate kernel's input format; a plan from
+// msm_make_plan_endo makes msm_device_phase / msm_run take that array as `d_pts`.  msm_endo_verify compares
+// [z^2]P (G1) / [z]P (G2) from the generic batch multiply with image 1: *d_bad = smallest failing index.
+int msm_endo_factor(int curve);
+int msm_make_plan_endo(int curve, int n_src, int c_override, MsmPlan* pl);
+size_t msm_endo_words_per_point(int curve);
+hipError_t msm_endo_expand(int curve, const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st);
+hipError_t msm_endo_digits(const MsmPlan& pl, const uint32_t* d_scalars, int16_t* digits, uint32_t* bad, hipStream_t st);
+hipError_t msm_endo_verify(int curve, const uint32_t* d_mult, const uint8_t* d_mult_inf, const uint32_t* d_images, int n,
+                           uint32_t* d_bad, hipStream_t st);
+void msm_endo_verify_scalar(int curve, uint32_t (&k)[8]);
+
 // ed25519 batch verify (ed25519.hip).  btab: device copy of the table built by ed25519_build_base_table.
 constexpr int ED25519_BTAB_WORDS = 128 * 27;  // [1,3,..,255]B, affine Niels, 3 x 9 stored words each
 void ed25519_build_base_table(uint32_t* out_words);

@@ -479,7 +479,7 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
     off = align256(off + bytes);
     return o;
   };
-  L.pts_mont = take((size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);
+  L.pts_mont = take(pl.endo ? 0 : (size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);  // endo: the caller's expanded set
   L.digits = take((size_t)pl.nwin * pl.n * 2);
   L.counts = take((size_t)pl.nwin * pl.Q * pl.nb * 4);
   L.bucket_start = take((size_t)pl.nwin * (pl.nb + 1) * 4);
@@ -543,12 +543,18 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   const int n = pl.n;
   hipError_t e;
 
-  hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts,
-                     pts_mont, n);
   uint32_t* bad = (uint32_t*)(base + L.bad);
   e = hipMemsetAsync(bad, 0xFF, 4, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl, bad);
+  if (pl.endo) {  // d_pts is the expanded image set, already in storage format (msm_endo_expand)
+    pts_mont = const_cast<uint32_t*>(d_pts);
+    e = msm_endo_digits(pl, d_scalars, digits, bad, st);
+    if (e != hipSuccess) return e;
+  } else {
+    hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts,
+                       pts_mont, n);
+    hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl, bad);
+  }
   size_t lds = (size_t)pl.nb * 4;
   {  // opt in to large dynamic LDS once per process and device (c <= 16: at most 128 KB)
     static bool attr_done[16] = {};

@@ -43,6 +43,11 @@ struct MsmPlan {
   int accum_waves = 2;  // waves/SIMD of the accumulate kernel (sets the resident-lane capacity)
   uint32_t hconst[10];  // H' = sum_w 2^(c-1) * 2^(c w), 10 LE limbs
   uint32_t order[8];    // group order: scalars must be below it (the window plan covers (order-1) + H')
+  // endomorphism mode (endo.hpp; point sets verified to lie in the prime-order subgroup): every scalar is
+  // split into `endo` balanced sub-scalars (2 x 128 bits on G1, 4 x 64 bits on G2) that multiply the point
+  // and its endomorphism images; n = endo * n_src entries, the windows cover the sub-scalar width only
+  int endo = 0;
+  int n_src = 0;
 };
 
 // Group policy of the MSM kernels: how an input point is stored, what the bucket accumulator

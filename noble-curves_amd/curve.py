@@ -290,15 +290,28 @@ class PointSet:
     def __len__(self):
         return len(self.resident)
 
+    @property
+    def inSubgroup(self):
+        """bls12-381: every point is known to be torsion-free (decoded by fromBytes, or verified at upload),
+        so `pippenger` on this set splits the scalars along the curve endomorphism - same result, half (G1) or
+        a quarter (G2) of the windows."""
+        return self.resident.in_subgroup
+
     def free(self):
         self.resident.free()
 
 
-def uploadPoints(c, points, engine=None):
-    """Validate like pippenger (curve.ts:390-395) and keep the points on the device."""
+def uploadPoints(c, points, engine=None, checkSubgroup=False):
+    """Validate like pippenger (curve.ts:390-395) and keep the points on the device.  checkSubgroup (bls12-381
+    G1 / G2): also run p.isTorsionFree() (bls12-381.ts:567-577, :599-601) on every point, once, on the device;
+    if all pass the set takes the faster endomorphism MSM - pippenger accepts points outside the subgroup, so
+    this is never assumed, and a set with such a point simply keeps the generic path."""
     validateMSMPoints(points, c)
     eng = engine or get_engine()
-    return PointSet(c, eng.upload_points(c.CURVE_ID, _points_wire(points, c.POINT_BYTES)))
+    pset = PointSet(c, eng.upload_points(c.CURVE_ID, _points_wire(points, c.POINT_BYTES)))
+    if checkSubgroup and c.CURVE_ID in (BLS12_381_G1, BLS12_381_G2) and len(points):
+        pset.resident.verify_subgroup()
+    return pset
 
 
 def uploadEncoded(c, encodings, zip215=False, engine=None):
