@@ -333,6 +333,35 @@ static napi_value FreePoints(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// (handle) -> -1 if every point lies in the prime-order subgroup (the set then takes the endomorphism MSM),
+// else the index of the first point outside it (the set keeps the generic path); bls12-381 only
+static napi_value VerifySubgroup(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  ncg_points* h = argc >= 1 ? get_set(env, argv[0]) : nullptr;
+  if (!h) return nullptr;
+  int64_t bad = -1;
+  if (ncg_points_verify_subgroup(g_ctx, h, &bad) != NCG_OK) {
+    napi_throw_error(env, nullptr, ncg_last_error(g_ctx));
+    return nullptr;
+  }
+  napi_value r;
+  NAPI_OK(napi_create_int64(env, bad, &r));
+  return r;
+}
+static napi_value InSubgroup(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  ncg_points* h = argc >= 1 ? get_set(env, argv[0]) : nullptr;
+  if (!h) return nullptr;
+  napi_value r;
+  NAPI_OK(napi_get_boolean(env, ncg_points_in_subgroup(h) != 0, &r));
+  return r;
+}
+
 static napi_value MsmResident(napi_env env, napi_callback_info info) {  // (handle, scalars) -> affine || inf
   size_t argc = 2;
   napi_value argv[2];
@@ -532,7 +561,7 @@ NAPI_MODULE_INIT() {
              {"decodePoints", DecodePoints}, {"encodePoints", EncodePoints},
              {"aggregateEncoded", AggregateEncoded},
              {"ntt", Ntt},               {"mapToCurve", MapToCurve},
-             {"uploadPoints", UploadPoints}, {"freePoints", FreePoints},
+             {"uploadPoints", UploadPoints}, {"freePoints", FreePoints}, {"verifySubgroup", VerifySubgroup}, {"inSubgroup", InSubgroup},
              {"msmResident", MsmResident}, {"mulVarResident", MulVarResident},
              {"ed25519VerifyMsgs", Ed25519VerifyMsgs},
              {"version", Version}};

@@ -87,12 +87,19 @@ function pippenger(c, points, scalars) {
 class PointSet {
   constructor(c, id, handle, length) { this.c = c; this.id = id; this.handle = handle; this.length = length; }
   free() { if (this.handle !== null) { native.freePoints(this.handle); this.handle = null; } }
+  // bls12-381: every point is known to be torsion-free (decoded by fromBytes, or verified at upload): pippengerResident
+  // then splits the scalars along the curve endomorphism - same result, half (G1) / a quarter (G2) of the windows
+  get inSubgroup() { return this.handle !== null && native.inSubgroup(this.handle); }
 }
-function uploadPoints(c, points) {
+// opts.checkSubgroup (bls12-381): run p.isTorsionFree() (bls12-381.ts:567-577, :599-601) on every point once, on the
+// device; pippenger accepts points outside the subgroup, so a set holding one simply keeps the generic path
+function uploadPoints(c, points, opts) {
   const id = curveId(c);
   validateMSMPoints(points, c);
   init();
-  return new PointSet(c, id, native.uploadPoints(id, marshalPoints(c, id, points), false, false), points.length);
+  const set = new PointSet(c, id, native.uploadPoints(id, marshalPoints(c, id, points), false, false), points.length);
+  if (opts && opts.checkSubgroup && (id === CURVE.BLS12_381_G1 || id === CURVE.BLS12_381_G2) && points.length) native.verifySubgroup(set.handle);
+  return set;
 }
 function uploadEncoded(c, bytes, zip215) {      // concatenated compressed encodings; decoded + validated on the device
   const id = curveId(c);

@@ -83,6 +83,15 @@ if (haveGpu) {
   const H = gpu.hashToCurveBatch(G2, sig.map((r) => Buffer.from(r.msg, 'hex')));
   const S = gpu.multiplyUnsafeBatch(G2, H, sig.map((r) => BigInt('0x' + r.priv) % BR));
   gpu.toBytesBatch(G2, S).forEach((e, i) => assert.strictEqual(Buffer.from(e).toString('hex'), sig[i].sig));
+  // a G2 set verified to lie in the subgroup takes the endomorphism MSM: same result as the generic path
+  {
+    const scG = sig.map((r, i) => (BigInt('0x' + r.priv) * BigInt(i + 3)) % BR);
+    const plain = gpu.uploadPoints(G2, S), fast = gpu.uploadPoints(G2, S, { checkSubgroup: true });
+    assert.strictEqual(plain.inSubgroup, false); assert.strictEqual(fast.inSubgroup, true);
+    const a = gpu.pippengerResident(plain, scG), b = gpu.pippengerResident(fast, scG), c0 = gpu.pippenger(G2, S, scG);
+    for (const r of [b, c0]) { assert.strictEqual(r.x.c0, a.x.c0); assert.strictEqual(r.x.c1, a.x.c1); assert.strictEqual(r.y.c0, a.y.c0); assert.strictEqual(r.y.c1, a.y.c1); }
+    plain.free(); fast.free();
+  }
   // resident point sets: upload once (points, or their encodings decoded on the device), then MSMs with only
   // the scalars crossing - as BigInt[] (validated) or as packed bytes
   const set = gpu.uploadPoints(Point, viaBase);

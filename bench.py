@@ -564,6 +564,29 @@ def main():
                               "kernel": "k_msm_accum (dominant; achieved is for the whole MSM incl. the host finish, traffic for that kernel)",
                               "valu": valu_block(pmc, key, wall / K, ref_mac_pt * nn,
                                                  (g1_msm_mads_per_point(nwin, nn, 1 << (c - 1)) * (3 if curve == BLS12_381_G2 else 1)) * nn)}}
+        if not dist_on:
+            # the same MSM on a resident set verified to lie in the prime-order subgroup (ncg_points_verify_subgroup,
+            # once per set): the scalars are split along the curve endomorphism (csrc/endo.hpp) - same group
+            # element, half (G1) / a quarter (G2) of the windows.  pippenger itself accepts arbitrary curve
+            # points, so the headline above never assumes this.
+            res = eng.upload_points(curve, pts.cpu().numpy())
+            t0 = time.perf_counter()
+            bad = res.verify_subgroup()
+            verify_ms = (time.perf_counter() - t0) * 1e3
+            assert bad == -1 and res.in_subgroup
+            rh = {}
+
+            def rstep():
+                rh["r"] = res.msm_dev(dev_ptr(sc), stream)
+
+            rwall, _ = time_steps(rstep, K, W, False)
+            assert np.array_equal(rh["r"][0], got), "endomorphism MSM differs from the generic MSM"
+            entry["resident_subgroup_set"] = {
+                "value": nn * K / rwall, "unit": "points/s", "ms_per_msm": rwall / K * 1e3,
+                "verify_once_ms": verify_ms,
+                "note": "ncg_msm_resident_dev on a set that passed the reference's isTorsionFree test on every point "
+                        "(bls12-381.ts:567-577 / :599-601) at upload; result compared bit-exactly with the generic MSM above"}
+            res.free()
         sub = {"pts": pts, "sc": sc, "ks": ks, "pks": pks}
         return entry, sub
 

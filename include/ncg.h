@@ -226,6 +226,8 @@ int ncg_points_in_subgroup(const ncg_points* pts);
 /* pippenger(c, <resident points>, scalars) and the batch multiplyUnsafe on them; scalars: host */
 int ncg_msm_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine,
                      uint8_t* out_is_inf);
+int ncg_msm_resident_dev(ncg_ctx* ctx, const ncg_points* pts, const void* scalars_dev, void* out_affine,
+                         uint8_t* out_is_inf, void* stream); /* scalars: device, 32 B LE each */
 int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars,
                                void* out_affine, uint8_t* out_is_inf);
 

@@ -117,6 +117,7 @@ _OPTIONAL_PROTOS = {
     "ncg_points_from_encoded": [_vp, _i32, _sz, _vp, _i32, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int64)],
     "ncg_points_curve": [_vp],
     "ncg_msm_resident": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
+    "ncg_msm_resident_dev": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_points_verify_subgroup": [_vp, _vp, ctypes.POINTER(ctypes.c_int64)],
     "ncg_points_in_subgroup": [_vp],
     "ncg_mul_var_batch_resident": [_vp, _vp, _vp, _vp, _vp],
@@ -519,6 +520,14 @@ class ResidentPoints:
         inf = ctypes.c_uint8(0)
         self.engine._check(self.engine.lib.ncg_msm_resident(self.engine.h, self.h, scalars.ctypes.data if scalars.size else None,
                                                             out.ctypes.data, ctypes.byref(inf)))
+        return out, bool(inf.value)
+
+    def msm_dev(self, d_scalars, stream=None):
+        """The same with the scalars already on the device (raw pointer, 32 B LE each, len(self) of them)."""
+        out = np.zeros((POINT_BYTES[self.curve],), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self.engine._check(self.engine.lib.ncg_msm_resident_dev(self.engine.h, self.h, d_scalars, out.ctypes.data,
+                                                                ctypes.byref(inf), stream))
         return out, bool(inf.value)
 
     def mul_var_batch(self, scalars):

@@ -585,6 +585,28 @@ static int upload_scalars(ncg_ctx* ctx, PinSet& pins, size_t n, const void* scal
   return NCG_OK;
 }
 
+// MSM on a resident set with the scalars already on the device
+static int msm_resident_core(ncg_ctx* ctx, const ncg_points* pts, const void* d_sc, void* out_affine, uint8_t* out_is_inf,
+                             hipStream_t st) {
+  static const bool no_endo = std::getenv("NCG_NO_ENDO") != nullptr;
+  if (pts->d_endo && !no_endo) {  // verified subgroup set: endomorphism MSM on the expanded images (endo.hpp)
+    ncg::MsmPlan pl;
+    if (ncg::msm_make_plan_endo(pts->curve, (int)pts->n, 0, &pl) != 0)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+    int rc = msm_ensure_ws(ctx, pts->curve, pl);
+    if (rc) return rc;
+    uint32_t bad = 0xFFFFFFFFu;
+    uint8_t inf_local = 0;
+    NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, (const uint32_t*)pts->d_endo, (const uint32_t*)d_sc, ctx->msm_ws,
+                              (uint32_t*)out_affine, &inf_local, st, &bad));
+    if (bad != 0xFFFFFFFFu)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
+    if (out_is_inf) *out_is_inf = inf_local;
+    return NCG_OK;
+  }
+  return ncg_msm_dev(ctx, pts->curve, pts->n, pts->d_pts, d_sc, out_affine, out_is_inf, st);
+}
+
 int ncg_msm_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine, uint8_t* out_is_inf) {
   if (!ctx || !pts || pts->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_resident: handle does not belong to this context");
   if (pts->n == 0) return ncg_msm_dev(ctx, pts->curve, 0, nullptr, nullptr, out_affine, out_is_inf, nullptr);
@@ -594,23 +616,16 @@ int ncg_msm_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, v
   char* d_sc = nullptr;
   int rc = upload_scalars(ctx, pins, pts->n, scalars, &d_sc);
   if (rc) return rc;
-  static const bool no_endo = std::getenv("NCG_NO_ENDO") != nullptr;
-  if (pts->d_endo && !no_endo) {  // verified subgroup set: endomorphism MSM on the expanded images (endo.hpp)
-    ncg::MsmPlan pl;
-    if (ncg::msm_make_plan_endo(pts->curve, (int)pts->n, 0, &pl) != 0)
-      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
-    rc = msm_ensure_ws(ctx, pts->curve, pl);
-    if (rc) return rc;
-    uint32_t bad = 0xFFFFFFFFu;
-    uint8_t inf_local = 0;
-    NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, (const uint32_t*)pts->d_endo, (const uint32_t*)d_sc, ctx->msm_ws,
-                              (uint32_t*)out_affine, &inf_local, ctx->stream, &bad));
-    if (bad != 0xFFFFFFFFu)
-      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
-    if (out_is_inf) *out_is_inf = inf_local;
-    return NCG_OK;
-  }
-  return ncg_msm_dev(ctx, pts->curve, pts->n, pts->d_pts, d_sc, out_affine, out_is_inf, ctx->stream);
+  return msm_resident_core(ctx, pts, d_sc, out_affine, out_is_inf, ctx->stream);
+}
+
+int ncg_msm_resident_dev(ncg_ctx* ctx, const ncg_points* pts, const void* scalars_dev, void* out_affine, uint8_t* out_is_inf,
+                         void* stream) {
+  if (!ctx || !pts || pts->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_resident: handle does not belong to this context");
+  if (pts->n == 0) return ncg_msm_dev(ctx, pts->curve, 0, nullptr, nullptr, out_affine, out_is_inf, nullptr);
+  if (!scalars_dev || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_resident: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  return msm_resident_core(ctx, pts, scalars_dev, out_affine, out_is_inf, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine,
