@@ -9,6 +9,7 @@
 #include "decode.hip"
 #include "ntt.hip"
 #include "h2c.hip"
+#include "endo.hpp"
 
 using namespace ncg;
 
@@ -182,6 +183,28 @@ int ht_ntt_plan(int n, int* out) {
 int ht_ed25519_challenge(const uint8_t* sig, const uint8_t* pk, const uint8_t* msg, uint64_t len, uint32_t* out) {
   ed25519_challenge_host(sig, pk, msg, len, out);
   return 0;
+}
+
+// bls12-381 scalar split of the endomorphism MSM (endo.hpp): E = 2 (G1) or 4 (G2) sub-scalars, 6 words each
+// (192-bit two's complement)
+int ht_bls_endo_split(int E, const uint32_t* k8, uint32_t* out) {
+  uint32_t k[8];
+  for (int i = 0; i < 8; i++) k[i] = k8[i];
+  if (E == 2) {
+    uint32_t o[2][6];
+    bls_endo_split2(o, k);
+    for (int e = 0; e < 2; e++)
+      for (int i = 0; i < 6; i++) out[e * 6 + i] = o[e][i];
+    return 0;
+  }
+  if (E == 4) {
+    uint32_t o[4][6];
+    bls_endo_split4(o, k);
+    for (int e = 0; e < 4; e++)
+      for (int i = 0; i < 6; i++) out[e * 6 + i] = o[e][i];
+    return 0;
+  }
+  return -1;
 }
 
 // ed25519 verify of one item on the CPU through the kernel's lane function

@@ -31,6 +31,7 @@ def lib():
         _lib.ht_ntt_plan.argtypes = [i32, vp]
         _lib.ht_fe9_op.argtypes = [i32, i32, i32, vp, vp, vp]
         _lib.ht_ed25519_challenge.argtypes = [vp, vp, vp, ctypes.c_uint64, vp]
+        _lib.ht_bls_endo_split.argtypes = [i32, vp, vp]
     return _lib
 
 
@@ -153,3 +154,15 @@ def ed25519_challenge(sig, pk, msg):
     out = np.zeros(8, dtype=np.uint32)
     assert lib().ht_ed25519_challenge(S.ctypes.data, P.ctypes.data, M.ctypes.data, len(msg), out.ctypes.data) == 0
     return sum(int(out[i]) << (32 * i) for i in range(8))
+
+
+def bls_endo_split(E, k):
+    """Sub-scalars of the endomorphism MSM (csrc/endo.hpp) as signed Python ints: E = 2 (G1) or 4 (G2)."""
+    a = np.array([(k >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=np.uint32)
+    o = np.zeros(E * 6, dtype=np.uint32)
+    assert lib().ht_bls_endo_split(E, a.ctypes.data, o.ctypes.data) == 0
+    res = []
+    for e in range(E):
+        v = sum(int(o[e * 6 + i]) << (32 * i) for i in range(6))
+        res.append(v - (1 << 192) if v >> 191 else v)
+    return res

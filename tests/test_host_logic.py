@@ -485,3 +485,24 @@ def test_sha512_challenge_matches_hashlib():
         msg = bytes(rng.rnd64() & 0xFF for _ in range(ln))
         exp = int.from_bytes(hashlib.sha512(sig[:32] + pk + msg).digest(), "little") % ED25519_L
         assert hosttest.ed25519_challenge(sig, pk, msg) == exp, ln
+
+
+def test_bls_endomorphism_scalar_split():
+    """csrc/endo.hpp (the digit kernel of the verified-set MSM): k = k1 + k2 z^2 (G1) and k = sum d_e z^e (G2)
+    modulo r = z^4 - z^2 + 1, every sub-scalar balanced so that the signed windows need no sign handling -
+    on edge values around every split boundary and on random scalars."""
+    import random
+    z = 0xD201000000010000
+    X, r = z * z, z ** 4 - z ** 2 + 1
+    assert r == BLS_R
+    rng = random.Random(1)
+    ks = [0, 1, 2, r - 1, r - 2, X, X - 1, X + 1, X // 2, X // 2 + 1, z, z - 1, z + 1, z // 2, z // 2 + 1, z ** 3, z ** 3 - 1, r // 2]
+    ks += [(a * X + b) % r for a in (0, 1, X // 2 - 1, X // 2, X // 2 + 1, X - 2, X - 1) for b in (0, 1, X // 2 - 1, X // 2, X // 2 + 1, X - 2, X - 1)]
+    ks += [(a * z ** 3 + b * z ** 2 + c * z + d) % r for a in (0, z // 2, z // 2 + 1, z - 1) for b in (0, z // 2, z // 2 + 1, z - 1)
+           for c in (0, z // 2 + 1, z - 1) for d in (0, 1, z // 2 + 1, z - 1)]
+    ks += [rng.randrange(r) for _ in range(3000)]
+    for k in ks:
+        k1, k2 = hosttest.bls_endo_split(2, k)
+        assert (k1 + k2 * X - k) % r == 0 and max(abs(k1), abs(k2)) <= X // 2 + 1
+        d = hosttest.bls_endo_split(4, k)
+        assert (sum(d[e] * z ** e for e in range(4)) - k) % r == 0 and max(abs(x) for x in d) <= z // 2 + 2
