@@ -15,6 +15,13 @@
 
 namespace ncg {
 
+// a*b - c*d; a field with a fused multiply-accumulate (fe29.hpp) overloads it with a single reduction
+template <class A, class B, class C, class D>
+NCG_DI auto f_mulsub(const A& a, const B& b, const C& c, const D& d) -> decltype(a * b - c * d) {
+  return a * b - c * d;
+}
+
+
 template <class F>
 struct Affine {  // wire convention: infinity is (0, 0)  (weierstrass.ts:716, :966)
   F x, y;
@@ -227,7 +234,7 @@ NCG_DI Xyzz<F> xyzz_mdbl(const Affine<F>& p) {
   auto xx = f_sqr(p.x);
   auto M = f_dbl(xx) + xx;
   auto X3 = f_sqr(M) - f_dbl(S);
-  auto Y3 = M * (S - X3) - W * p.y;
+  auto Y3 = f_mulsub(M, S - X3, W, p.y);
   return {X3, Y3, V, W};
 }
 
@@ -242,7 +249,7 @@ NCG_DI Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
   auto xx = f_sqr(p.X);
   auto M = f_dbl(xx) + xx;
   auto X3 = f_sqr(M) - f_dbl(S);
-  auto Y3 = M * (S - X3) - W * p.Y;
+  auto Y3 = f_mulsub(M, S - X3, W, p.Y);
   return {X3, Y3, V * p.ZZ, W * p.ZZZ};
 }
 
@@ -265,7 +272,7 @@ NCG_DI Xyzz<F> xyzz_madd(const Xyzz<F>& p, const Affine<F>& q_in, bool neg = fal
   auto PPP = Pq * PP;
   auto Q = p.X * PP;
   auto X3 = f_sqr(R) - PPP - f_dbl(Q);
-  auto Y3 = R * (Q - X3) - p.Y * PPP;
+  auto Y3 = f_mulsub(R, Q - X3, p.Y, PPP);
   return {X3, Y3, p.ZZ * PP, p.ZZZ * PPP};
 }
 
@@ -288,7 +295,7 @@ NCG_DI Xyzz<F> xyzz_add(const Xyzz<F>& p, const Xyzz<F>& q) {
   auto PPP = Pq * PP;
   auto Q = U1 * PP;
   auto X3 = f_sqr(R) - PPP - f_dbl(Q);
-  auto Y3 = R * (Q - X3) - S1 * PPP;
+  auto Y3 = f_mulsub(R, Q - X3, S1, PPP);
   return {X3, Y3, p.ZZ * q.ZZ * PP, p.ZZZ * q.ZZZ * PPP};
 }
 

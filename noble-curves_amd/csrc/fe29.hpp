@@ -157,6 +157,18 @@ NCG_DI Fe29<2 * A> f_dbl(const Fe29<A>& a) {
   return a + a;
 }
 
+// a*b - c*d with one Montgomery reduction (fp29.hpp mont_muladd29 on a, b, -c, d): the pattern
+// Y3 = R (Q - X3) - Y1 PPP of every XYZZ / Jacobian addition.  Saves one reduction (196 of 784 multiply-adds).
+template <int A, int B, int C, int D>
+NCG_DI Fe29<2> f_mulsub(const Fe29<A>& a, const Fe29<B>& b, const Fe29<C>& c, const Fe29<D>& d) {
+  constexpr int KC = 1 << fe29_pow2ceil_log(C);
+  static_assert((long)A * B + (long)KC * D <= (1L << 24), "fused product pair would exceed 2p: reduce an operand");
+  const Fe29<KC> nc = f_neg(c);
+  Fe29<2> r;
+  mont_muladd29<ParamsBls29>(r.v, a.v, b.v, nc.v, d.v);
+  return r;
+}
+
 // canonical residue in [0, p) as 29-bit limbs (still Montgomery form): multiply by the
 // Montgomery one is the identity map and lands below p + 1, then one conditional subtraction.
 template <int A>
