@@ -61,6 +61,14 @@ def main():
                "scaling per line, `extra.msm_g1_strong` / `msm_g2_strong` = one 2²⁰ / 2¹⁸-point MSM split over the N GPUs through "
                "`ncg_msm_sharded_dev` (RCCL all-gather of ~18 KB per rank).\n"
                % (e1["ed25519_verify"]["ms_per_batch"], ko["ms_per_batch"], ko["value"], e["ed25519_verify"]["ms_per_batch"] - ko["ms_per_batch"]))
+    r1, r2 = e["msm_g1"].get("resident_subgroup_set"), e["msm_g2"].get("resident_subgroup_set")
+    if r1 and r2:
+        out.append("MSM on a RESIDENT point set verified once to lie in the prime-order subgroup (`ncg_points_verify_subgroup`, %.0f ms for "
+                   "2²⁰ G1 points / %.0f ms for 2¹⁸ G2 points; sets decoded by `ncg_points_from_encoded` qualify without it) - the scalars "
+                   "are split along the curve endomorphism (DESIGN.md §5), the result is compared bit-exactly with the generic MSM in the "
+                   "same run: G1 2²⁰ **%.2f ms** (%.3g points/s), G2 2¹⁸ **%.2f ms** (%.3g points/s).  The rows above are the generic "
+                   "`pippenger` (arbitrary curve points, like the reference).\n"
+                   % (r1["verify_once_ms"], r2["verify_once_ms"], r1["ms_per_msm"], r1["value"], r2["ms_per_msm"], r2["value"]))
     out.append("Targets: ≥10⁷ secp256k1 scalar-mults/s per MI355X — met (%.1f×); \"≥40 %% HBM roofline\" for the 2²⁰ G1 MSM is not physically "
                "meaningful (§2 caveat): its dominant kernel runs at %.0f %% of the measured multiplier ceiling in EXECUTED multiplies.\n"
                % (b["value"] / 1e7, 100 * e["msm_g1"]["roofline"]["valu"]["mad_frac"]))
