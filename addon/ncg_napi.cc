@@ -249,6 +249,31 @@ static napi_value Ed25519VerifyMsgs(napi_env env, napi_callback_info info) {
   return res;
 }
 
+// ecdsaVerify(sigs [n*64: r || s big-endian], hashes [n*32], keys [n*33 SEC1 compressed], lowS) -> Uint8Array verdicts
+static napi_value EcdsaVerify(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  uint8_t *sig, *hs, *pk, *out;
+  size_t sgl, hl, pkl;
+  bool low_s = true;
+  if (argc < 3 || !get_u8(env, argv[0], &sig, &sgl) || !get_u8(env, argv[1], &hs, &hl) || !get_u8(env, argv[2], &pk, &pkl)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: ecdsaVerify(sigs, hashes, keys, lowS)");
+    return nullptr;
+  }
+  if (argc >= 4) napi_get_value_bool(env, argv[3], &low_s);
+  const size_t n = sgl / 64;
+  if (sgl % 64 || hl != n * 32 || pkl != n * 33) {
+    napi_throw_error(env, nullptr, "arrays of signatures, message hashes and public keys must have matching lengths");
+    return nullptr;
+  }
+  napi_value res = make_u8(env, n, &out);
+  if (!res) return nullptr;
+  if (n && ncg_ecdsa_verify_batch(g_ctx, NCG_SECP256K1, n, sig, hs, pk, low_s ? NCG_ECDSA_LOW_S : 0, out) != 0) return throw_native(env);
+  return res;
+}
+
 static int encoded_bytes(int curve);
 // ---- resident point sets: upload once (affine wire points or compressed encodings), then MSMs / batch
 // multiplies with only the scalars crossing.  Handles are small integers; `scalars` may be a Uint8Array
@@ -563,7 +588,7 @@ NAPI_MODULE_INIT() {
              {"ntt", Ntt},               {"mapToCurve", MapToCurve},
              {"uploadPoints", UploadPoints}, {"freePoints", FreePoints}, {"verifySubgroup", VerifySubgroup}, {"inSubgroup", InSubgroup},
              {"msmResident", MsmResident}, {"mulVarResident", MulVarResident},
-             {"ed25519VerifyMsgs", Ed25519VerifyMsgs},
+             {"ed25519VerifyMsgs", Ed25519VerifyMsgs}, {"ecdsaVerify", EcdsaVerify},
              {"version", Version}};
   for (auto& f : fns) {
     napi_value v;

@@ -173,6 +173,25 @@ function ed25519VerifyBatchDevice(items, zip215) {
   return Array.from(native.ed25519VerifyMsgs(sig, pk, msgs, offs, zip215 !== false)).map((x) => x === 1);
 }
 
+// secp256k1.verify(sig, msgHash, publicKey, { prehash: false, lowS }) for a batch (weierstrass.ts:1571-1620): compact
+// 64-byte signatures, 32-byte message hashes (hash with the reference's own sha256 first for prehash: true), 33-byte
+// compressed keys; key decompression, s^-1 mod n, u1 G + u2 P and the comparison run on the device
+function ecdsaVerifyBatch(items, lowS) {
+  const n = items.length;
+  if (n === 0) return [];
+  const sig = new Uint8Array(64 * n), hs = new Uint8Array(32 * n), pk = new Uint8Array(33 * n);
+  const live = new Array(n).fill(true);
+  items.forEach((it, i) => {
+    if (!(it.sig instanceof Uint8Array) || it.sig.length !== 64) throw new Error('"signature" expected Uint8Array of length 64');
+    if (!(it.msgHash instanceof Uint8Array) || it.msgHash.length !== 32) throw new Error('"msgHash" expected Uint8Array of length 32');
+    if (!(it.publicKey instanceof Uint8Array)) throw new Error('"publicKey" expected Uint8Array');
+    if (it.publicKey.length !== 33) { live[i] = false; pk[33 * i] = 2; return; }   // other encodings: compress them first
+    sig.set(it.sig, 64 * i); hs.set(it.msgHash, 32 * i); pk.set(it.publicKey, 33 * i);
+  });
+  init();
+  return Array.from(native.ecdsaVerify(sig, hs, pk, lowS !== false)).map((x, i) => live[i] && x === 1);
+}
+
 function multiplyUnsafeBatch(c, points, scalars) {
   const id = curveId(c);
   validateMSMPoints(points, c);
@@ -316,5 +335,5 @@ function hashToCurveBatch(c, msgs, DST) {
 }
 
 module.exports = { CURVE, init, initMulti, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
-                   PointSet, uploadPoints, uploadEncoded, interleavedMSMUnsafe, pippengerResident, multiplyUnsafeBatchResident, ed25519VerifyBatchDevice,
+                   PointSet, uploadPoints, uploadEncoded, interleavedMSMUnsafe, pippengerResident, multiplyUnsafeBatchResident, ed25519VerifyBatchDevice, ecdsaVerifyBatch,
                    fromBytesBatch, toBytesBatch, aggregateFromBytes, fftFr, hashToCurveBatch, native };

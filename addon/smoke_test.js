@@ -146,6 +146,17 @@ if (haveGpu) {
     console.log('resident pippenger 2^16 (packed scalars): ' + ms.toFixed(2) + ' ms per call');
     bs.free();
   }
+  // ECDSA verify: the reference's RFC 6979 vectors (test/vectors/secp256k1/ecdsa.json via tests/golden): keys from the GPU,
+  // every signature verifies, a flipped bit does not
+  {
+    const vec = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', 'secp256k1_ecdsa.json'))).valid.slice(0, 24);
+    const keys = gpu.toBytesBatch(Point, gpu.multiplyBaseBatch(Point, vec.map((v) => BigInt('0x' + v.d))));
+    const hex = (h) => Uint8Array.from(Buffer.from(h, 'hex'));
+    const items = vec.map((v, i) => ({ sig: hex(v.signature), msgHash: hex(v.m), publicKey: keys[i] }));
+    assert.deepStrictEqual(gpu.ecdsaVerifyBatch(items), items.map(() => true));
+    items[3].sig[40] ^= 1; items[5].msgHash[0] ^= 1; items[7].publicKey = keys[8];
+    assert.deepStrictEqual(gpu.ecdsaVerifyBatch(items), items.map((_, i) => ![3, 5, 7].includes(i)));
+  }
   // ed25519 from messages (hash on the device): RFC 8032 test 2 and a corrupted copy
   {
     const hex = (h) => Uint8Array.from(Buffer.from(h, 'hex'));

@@ -118,6 +118,8 @@ _OPTIONAL_PROTOS = {
     "ncg_points_curve": [_vp],
     "ncg_msm_resident": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
     "ncg_msm_resident_dev": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
+    "ncg_ecdsa_verify_batch": [_vp, _i32, _sz, _vp, _vp, _vp, _i32, _vp],
+    "ncg_ecdsa_verify_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _i32, _vp, _vp],
     "ncg_points_verify_subgroup": [_vp, _vp, ctypes.POINTER(ctypes.c_int64)],
     "ncg_points_in_subgroup": [_vp],
     "ncg_mul_var_batch_resident": [_vp, _vp, _vp, _vp, _vp],
@@ -416,6 +418,25 @@ class Engine:
     def ed25519_verify_batch_dev(self, n, d_sigs, d_pks, d_ks, zip215, d_ok, stream=None):
         self._check(self.lib.ncg_ed25519_verify_batch_dev(self.h, n, d_sigs, d_pks, d_ks, 1 if zip215 else 0,
                                                           d_ok, stream))
+
+    def ecdsa_verify_batch(self, sigs, hashes, pubs, low_s=True):
+        """secp256k1: sigs uint8 [n,64] (r || s big-endian), hashes [n,32], pubs [n,33] SEC1 compressed -> bool [n]
+        (ecdsa.verify with prehash: false, format 'compact'; weierstrass.ts:1571-1620)."""
+        sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 64)
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint8).reshape(-1, 32)
+        pubs = np.ascontiguousarray(pubs, dtype=np.uint8).reshape(-1, 33)
+        n = sigs.shape[0]
+        if hashes.shape[0] != n or pubs.shape[0] != n:
+            raise ValueError("arrays of signatures, message hashes and public keys must have equal length")
+        ok = np.zeros((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_ecdsa_verify_batch(self.h, SECP256K1, n, sigs.ctypes.data, hashes.ctypes.data,
+                                                        pubs.ctypes.data, 1 if low_s else 0, ok.ctypes.data))
+        return ok.astype(bool)
+
+    def ecdsa_verify_batch_dev(self, n, d_sigs, d_hashes, d_pubs, low_s, d_ok, stream=None):
+        self._check(self.lib.ncg_ecdsa_verify_batch_dev(self.h, SECP256K1, n, d_sigs, d_hashes, d_pubs, 1 if low_s else 0,
+                                                        d_ok, stream))
 
     def map_to_curve_batch(self, curve, u, count):
         """u uint8 [n, count * FIELD_BYTES * (2 for G2)] -> (affine [n, PB], is_inf [n]):

@@ -143,6 +143,7 @@ void ncg_destroy(ncg_ctx* ctx) {
   if (ctx->mul_ws) (void)hipFree(ctx->mul_ws);
   if (ctx->ed_btab) (void)hipFree(ctx->ed_btab);
   if (ctx->ed_ks) (void)hipFree(ctx->ed_ks);
+  if (ctx->ecdsa_ws) (void)hipFree(ctx->ecdsa_ws);
   for (int i = 0; i < 4; i++)
     if (ctx->base_tab[i]) (void)hipFree(ctx->base_tab[i]);
   if (ctx->ub_in) (void)hipFree(ctx->ub_in);
@@ -1096,6 +1097,83 @@ int ncg_ed25519_verify_batch_msgs(ncg_ctx* ctx, size_t n, const void* sig64, con
   if (mbytes) NCG_HIP(ctx, pins.h2d(d_msg, (const char*)msgs + msg_off[0], mbytes));
   rc = ncg_ed25519_verify_batch_msgs_dev(ctx, n, d_sig, d_pk, d_msg, (const uint64_t*)d_off, zip215, (uint8_t*)d_ok,
                                          ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
+// ---- secp256k1 ECDSA batch verify (weierstrass.ts:1571-1620): SEC1 decode of the keys, the scalar side
+// (ecdsa.hip), u1 G by the fixed-base table, u2 P by the variable-base ladder, one pairwise add, compare.
+int ncg_ecdsa_verify_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* sig64_dev, const void* hash32_dev,
+                               const void* pub33_dev, int flags, uint8_t* out_ok_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_SECP256K1) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ecdsa_verify: secp256k1 only");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64_dev || !hash32_dev || !pub33_dev || !out_ok_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ecdsa_verify: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t pt_b = al(n * 64), sc_b = al(n * 32), fl_b = al(n);
+  const size_t need = 4 * pt_b + 2 * sc_b + 6 * fl_b;
+  if (ctx->ecdsa_ws_bytes < need) {
+    NCG_HIP(ctx, hipStreamSynchronize(st));
+    if (ctx->ecdsa_ws) (void)hipFree(ctx->ecdsa_ws);
+    ctx->ecdsa_ws = nullptr;
+    ctx->ecdsa_ws_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->ecdsa_ws, need + (need >> 2));
+    if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    ctx->ecdsa_ws_bytes = need + (need >> 2);
+  }
+  char* p = (char*)ctx->ecdsa_ws;
+  char* d_pub = p;            p += pt_b;
+  char* d_A = p;              p += pt_b;
+  char* d_B = p;              p += pt_b;
+  char* d_R = p;              p += pt_b;
+  char* d_u1 = p;             p += sc_b;
+  char* d_u2 = p;             p += sc_b;
+  uint8_t* d_pub_ok = (uint8_t*)p;   p += fl_b;
+  uint8_t* d_pub_inf = (uint8_t*)p;  p += fl_b;
+  uint8_t* d_sig_ok = (uint8_t*)p;   p += fl_b;
+  uint8_t* d_A_inf = (uint8_t*)p;    p += fl_b;
+  uint8_t* d_B_inf = (uint8_t*)p;    p += fl_b;
+  uint8_t* d_R_inf = (uint8_t*)p;
+  int rc = ncg_decode_points_batch_dev(ctx, curve, n, pub33_dev, 0, d_pub, d_pub_ok, d_pub_inf, st);
+  if (rc) return rc;
+  NCG_HIP(ctx, ncg::ecdsa_prepare((const uint8_t*)sig64_dev, (const uint8_t*)hash32_dev, (int)n, (flags & NCG_ECDSA_LOW_S) != 0,
+                                  (uint32_t*)d_u1, (uint32_t*)d_u2, d_sig_ok, st));
+  rc = ncg_mul_base_batch_dev(ctx, curve, n, d_u1, d_A, d_A_inf, st);
+  if (rc) return rc;
+  rc = ncg_mul_var_batch_dev(ctx, curve, n, d_pub, d_u2, d_B, d_B_inf, st);  // rejected keys decode to (0,0) = O
+  if (rc) return rc;
+  rc = ncg_add_pairs_batch_dev(ctx, curve, n, d_A, d_B, 0, d_R, d_R_inf, st);
+  if (rc) return rc;
+  NCG_HIP(ctx, ncg::ecdsa_finish((const uint8_t*)sig64_dev, (const uint32_t*)d_R, d_R_inf, d_sig_ok, d_pub_ok, d_pub_inf, (int)n,
+                                 out_ok_dev, st));
+  return NCG_OK;
+}
+
+int ncg_ecdsa_verify_batch(ncg_ctx* ctx, int curve, size_t n, const void* sig64, const void* hash32, const void* pub33, int flags,
+                           uint8_t* out_ok) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_SECP256K1) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ecdsa_verify: secp256k1 only");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64 || !hash32 || !pub33 || !out_ok) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ecdsa_verify: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  int rc = ensure_scratch(ctx, al(n * 64) + al(n * 32) + al(n * 33) + al(n) + 1024);
+  if (rc) return rc;
+  char* d_sig = (char*)ctx->scratch;
+  char* d_hash = d_sig + al(n * 64);
+  char* d_pub = d_hash + al(n * 32);
+  char* d_ok = d_pub + al(n * 33);
+  NCG_HIP(ctx, pins.h2d(d_sig, sig64, n * 64));
+  NCG_HIP(ctx, pins.h2d(d_hash, hash32, n * 32));
+  NCG_HIP(ctx, pins.h2d(d_pub, pub33, n * 33));
+  rc = ncg_ecdsa_verify_batch_dev(ctx, curve, n, d_sig, d_hash, d_pub, flags, (uint8_t*)d_ok, ctx->stream);
   if (rc) return rc;
   NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
   NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -21,6 +21,8 @@ struct ncg_ctx {
   uint32_t* ed_btab = nullptr;  // ed25519 base-point table (device)
   void* ed_ks = nullptr;        // ed25519 challenge scalars of the message-taking verify (device)
   size_t ed_ks_bytes = 0;
+  void* ecdsa_ws = nullptr;     // ECDSA batch verify: decoded keys, u1 / u2, partial points (device)
+  size_t ecdsa_ws_bytes = 0;
   uint32_t* base_tab[4] = {nullptr, nullptr, nullptr, nullptr};  // fixed-base tables per curve (device)
   uint32_t* ub_in = nullptr;
   uint32_t* ub_out = nullptr;

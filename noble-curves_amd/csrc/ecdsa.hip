@@ -1,0 +1,181 @@
+// secp256k1 ECDSA verification for a batch (the caller above Point.mulAddUnsafe):
+//   verify(sig, msgHash, publicKey) of src/abstract/weierstrass.ts:1571-1620 with format 'compact' and
+//   prehash: false - r, s in [1, n), optional low-S rule, h = bits2int_modN(msgHash), u1 = h s^-1, u2 = r s^-1
+//   (mod n), R = u1 G + u2 P, accept iff R != O and R.x mod n == r.
+// The group work is the existing batch pipeline (SEC1 decode -> fixed-base multiply -> variable-base multiply
+// -> pairwise add); this file adds the scalar side: Montgomery arithmetic modulo the group order n (fp.hpp's
+// product-scanning multiply with a parameter set for n), the s^-1 of K signatures per lane with one Fermat
+// inversion (Montgomery's trick, the shape of FpInvertBatch, modular.ts:722-747), and the final comparison.
+#include "host_api.hpp"
+#include "scalar.hpp"
+
+namespace ncg {
+
+// Montgomery constants of the group order n (R = 2^256): python -c "n=0xFFFF...4141; R=1<<256; print(-pow(n,-1,2**32) % 2**32, R % n, R*R % n)"
+struct ParamsSecpN {
+  static constexpr int N = 8;
+  static constexpr uint32_t P[8] = {0xd0364141u, 0xbfd25e8cu, 0xaf48a03bu, 0xbaaedce6u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  static constexpr uint32_t INV = 0x5588b13fu;  // -n^-1 mod 2^32
+  static constexpr uint32_t R1[8] = {0x2fc9bebfu, 0x402da173u, 0x50b75fc4u, 0x45512319u, 0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u};
+  static constexpr uint32_t R2[8] = {0x67d7d140u, 0x896cf214u, 0x0e7cf878u, 0x741496c2u, 0x5bcd07c6u, 0xe697f5e4u, 0x81c69bc5u, 0x9d671cd5u};
+  static constexpr bool TOP_SPARE = false;  // n > 2^255: the product keeps its carry word (fp_mul_fips_asm / fp_mul_body)
+  static constexpr bool FOLD = false;
+  static constexpr uint32_t HALF[8] = {0x681b20a0u, 0xdfe92f46u, 0x57a4501du, 0x5d576e73u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x7fffffffu};  // n >> 1
+};
+using Fn = Fp<ParamsSecpN>;
+
+NCG_DI Fn fn_from_words(const uint32_t (&w)[8]) {
+  Fn r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = w[i];
+  return r;
+}
+// a^(n-2), a != 0 (Montgomery form in and out): 4-bit windows over the exponent, 252 squarings + <= 78 products
+NCG_DI Fn fn_inv(const Fn& a) {
+  Fn tab[16];
+  tab[0] = Fn::one();
+  tab[1] = a;
+  for (int j = 2; j < 16; j++) tab[j] = tab[j - 1] * a;
+  uint32_t e[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) e[i] = ParamsSecpN::P[i];
+  e[0] -= 2u;  // n - 2 (no borrow: the low limb is 0xd0364141)
+  Fn acc = tab[e[7] >> 28];
+  for (int w = 62; w >= 0; w--) {
+    for (int s = 0; s < 4; s++) acc = fp_sqr<ParamsSecpN>(acc);
+    const uint32_t dg = (e[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (dg) acc = acc * tab[dg];
+  }
+  return acc;
+}
+
+NCG_DI void be32_to_words(uint32_t (&w)[8], const uint8_t* __restrict__ p) {  // 32 big-endian bytes -> 8 LE limbs
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint8_t* q = p + 4 * (7 - i);
+    w[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+  }
+}
+NCG_DI bool words_lt(const uint32_t (&a)[8], const uint32_t (&b)[8]) {
+  uint32_t d[8];
+  return mp_sub<8>(d, a, b) != 0;
+}
+
+// One lane: K consecutive signatures.  sig: r || s (32 big-endian bytes each, Signature.fromBytes 'compact',
+// weierstrass.ts:1275-1290: both in [1, n)); hash: 32 bytes, h = bits2int_modN (:1333-1347: the integer of the
+// bytes, reduced mod n).  Writes u1, u2 as 32-byte little-endian scalars (the wire format of the batch
+// multiplies) and sig_ok = 0 where the reference returns false before any group operation.
+template <int K>
+NCG_DI void ecdsa_prepare_lane(const uint8_t* __restrict__ sig, const uint8_t* __restrict__ hash, int lo, int hi, bool low_s,
+                               uint32_t* __restrict__ u1, uint32_t* __restrict__ u2, uint8_t* __restrict__ sig_ok) {
+  uint32_t n8[8], half[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    n8[i] = ParamsSecpN::P[i];
+    half[i] = ParamsSecpN::HALF[i];
+  }
+  const Fn r2 = Fn::from_const(ParamsSecpN::R2);
+  Fn sv[K], pre[K];   // s_j and the running products s_0 ... s_{j-1}, Montgomery form
+  bool ok[K];
+  Fn acc = Fn::one();
+  for (int j = 0; j < K; j++) {
+    const int idx = lo + j;
+    ok[j] = false;
+    sv[j] = Fn::one();
+    if (idx < hi) {
+      uint32_t r[8], s[8];
+      be32_to_words(r, sig + (size_t)idx * 64);
+      be32_to_words(s, sig + (size_t)idx * 64 + 32);
+      bool good = !mp_is_zero(r) && !mp_is_zero(s) && words_lt(r, n8) && words_lt(s, n8);
+      if (low_s && good && words_lt(half, s)) good = false;  // hasHighS: s > n >> 1 (weierstrass.ts:1293-1295)
+      ok[j] = good;
+      if (good) sv[j] = fn_from_words(s) * r2;
+    }
+    pre[j] = acc;
+    acc = acc * sv[j];
+  }
+  Fn inv = fn_inv(acc);
+  for (int j = K - 1; j >= 0; j--) {
+    const int idx = lo + j;
+    const Fn is = inv * pre[j];  // s_j^-1 (Montgomery form)
+    inv = inv * sv[j];
+    if (idx >= hi) continue;
+    uint32_t r[8], h[8];
+    be32_to_words(r, sig + (size_t)idx * 64);
+    be32_to_words(h, hash + (size_t)idx * 32);
+    {  // h mod n: h < 2^256 < 2n
+      uint32_t d8[8];
+      const bool ge = mp_sub<8>(d8, h, n8) == 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) h[i] = ge ? d8[i] : h[i];
+    }
+    // plain * Montgomery -> plain: u1 = h s^-1, u2 = r s^-1 (r < n when ok; other rows are rejected anyway)
+    const Fn a = fn_from_words(h) * is;
+    uint32_t rr[8];
+    {
+      uint32_t d8[8];
+      const bool ge = mp_sub<8>(d8, r, n8) == 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) rr[i] = ge ? d8[i] : r[i];
+    }
+    const Fn b = fn_from_words(rr) * is;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      u1[(size_t)idx * 8 + i] = ok[j] ? a.v[i] : 0u;
+      u2[(size_t)idx * 8 + i] = ok[j] ? b.v[i] : 0u;
+    }
+    sig_ok[idx] = ok[j] ? 1 : 0;
+  }
+}
+
+constexpr int ECDSA_K = 4;
+__global__ void __launch_bounds__(64) k_ecdsa_prepare(const uint8_t* __restrict__ sig, const uint8_t* __restrict__ hash, int n,
+                                                      int low_s, uint32_t* __restrict__ u1, uint32_t* __restrict__ u2,
+                                                      uint8_t* __restrict__ sig_ok) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const long lo = (long)t * ECDSA_K;
+  if (lo >= n) return;
+  ecdsa_prepare_lane<ECDSA_K>(sig, hash, (int)lo, n, low_s != 0, u1, u2, sig_ok);
+}
+
+// accept iff the signature and the key were well-formed, R != O and R.x mod n == r  (weierstrass.ts:1607-1612)
+__global__ void __launch_bounds__(256) k_ecdsa_finish(const uint8_t* __restrict__ sig, const uint32_t* __restrict__ R,
+                                                      const uint8_t* __restrict__ R_inf, const uint8_t* __restrict__ sig_ok,
+                                                      const uint8_t* __restrict__ pub_ok, const uint8_t* __restrict__ pub_inf, int n,
+                                                      uint8_t* __restrict__ out_ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool ok = sig_ok[i] != 0 && pub_ok[i] != 0 && pub_inf[i] == 0 && R_inf[i] == 0;
+  uint32_t x[8], n8[8], d8[8], r[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    x[j] = R[(size_t)i * 16 + j];
+    n8[j] = ParamsSecpN::P[j];
+  }
+  const bool ge = mp_sub<8>(d8, x, n8) == 0;  // x < p < 2n
+  be32_to_words(r, sig + (size_t)i * 64);
+  uint32_t diff = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) diff |= (ge ? d8[j] : x[j]) ^ r[j];
+  out_ok[i] = (ok && diff == 0) ? 1 : 0;
+}
+
+hipError_t ecdsa_prepare(const uint8_t* d_sig, const uint8_t* d_hash, int n, bool low_s, uint32_t* d_u1, uint32_t* d_u2,
+                         uint8_t* d_sig_ok, hipStream_t st) {
+  const int lanes = (n + ECDSA_K - 1) / ECDSA_K;
+  hipLaunchKernelGGL(k_ecdsa_prepare, dim3((lanes + 63) / 64), dim3(64), 0, st, d_sig, d_hash, n, low_s ? 1 : 0, d_u1, d_u2, d_sig_ok);
+  return hipGetLastError();
+}
+hipError_t ecdsa_finish(const uint8_t* d_sig, const uint32_t* d_R, const uint8_t* d_R_inf, const uint8_t* d_sig_ok,
+                        const uint8_t* d_pub_ok, const uint8_t* d_pub_inf, int n, uint8_t* d_out_ok, hipStream_t st) {
+  hipLaunchKernelGGL(k_ecdsa_finish, dim3((n + 255) / 256), dim3(256), 0, st, d_sig, d_R, d_R_inf, d_sig_ok, d_pub_ok, d_pub_inf, n,
+                     d_out_ok);
+  return hipGetLastError();
+}
+
+// host entry for the CPU tests (tests/hosttest): one signature through the lane code, K = 1
+void ecdsa_prepare_host(const uint8_t* sig, const uint8_t* hash, bool low_s, uint32_t* u1, uint32_t* u2, uint8_t* ok) {
+  ecdsa_prepare_lane<1>(sig, hash, 0, 1, low_s, u1, u2, ok);
+}
+
+}  // namespace ncg

@@ -72,6 +72,13 @@ hipError_t msm_sum_partials(int curve, const uint32_t* d_gathered, int nparts, s
 size_t msm_fin_words(int curve, const MsmPlan& pl);
 size_t msm_acc_words(int curve);
 
+// secp256k1 ECDSA batch verify, scalar side (ecdsa.hip): sig = r || s (big-endian), hash = 32 bytes.
+hipError_t ecdsa_prepare(const uint8_t* d_sig, const uint8_t* d_hash, int n, bool low_s, uint32_t* d_u1, uint32_t* d_u2,
+                         uint8_t* d_sig_ok, hipStream_t st);
+hipError_t ecdsa_finish(const uint8_t* d_sig, const uint32_t* d_R, const uint8_t* d_R_inf, const uint8_t* d_sig_ok,
+                        const uint8_t* d_pub_ok, const uint8_t* d_pub_inf, int n, uint8_t* d_out_ok, hipStream_t st);
+void ecdsa_prepare_host(const uint8_t* sig, const uint8_t* hash, bool low_s, uint32_t* u1, uint32_t* u2, uint8_t* ok);
+
 // Endomorphism mode for bls12-381 point sets verified to lie in the prime-order subgroup (msm_endo.hip,
 // endo.hpp).  msm_endo_factor: sub-scalars per scalar (2 on G1, 4 on G2, 0 = not offered).  msm_endo_expand
 // writes the factor * n images of n wire points in the accumulate kernel's input format; a plan from

@@ -13,6 +13,9 @@ Sources (data files, not code): /root/reference/test/vectors/...
   ed25519/vectors.txt          cr.yp.to sign.input (test/ed25519.test.ts:50-66)
   ed25519/zip215.json          ZIP-215 verdicts (test/ed25519.test.ts:393-418)
   ed25519/edge-cases.json      (test/ed25519.test.ts:189)
+  secp256k1/ecdsa.json         RFC 6979 sign / verify vectors (test/secp256k1.test.ts:133-146, :263-270)
+  wycheproof/ecdsa_test.json   the secp256k1 / SHA-256 groups, DER signatures (the same cases as the
+                               un-vendored acvp-vectors file of test/secp256k1.test.ts:221-261)
 """
 import json
 import os
@@ -102,6 +105,13 @@ def main():
     wy = json.load(open(f"{REF}/ed25519/ed25519_test_OLD.json"))
     dump("ed25519_wycheproof_old.json", [{"pk": g["key"]["pk"], "msg": t["msg"], "sig": t["sig"], "result": t["result"],
                                           "comment": t["comment"]} for g in wy["testGroups"] for t in g["tests"]])
+    # ECDSA: every invalid.verify case, every 5th valid (d, m, signature) vector (404 of 2019)
+    ec = json.load(open(f"{REF}/secp256k1/ecdsa.json"))
+    wp = json.load(open(f"{REF}/wycheproof/ecdsa_test.json"))
+    groups = [{"pub": g["key"]["uncompressed"],
+               "tests": [{"msg": t["msg"], "sig": t["sig"], "result": t["result"], "comment": t["comment"]} for t in g["tests"]]}
+              for g in wp["testGroups"] if g["key"]["curve"] == "secp256k1" and g["sha"] == "SHA-256"]
+    dump("secp256k1_ecdsa.json", {"valid": ec["valid"][::5], "invalid_verify": ec["invalid"]["verify"], "wycheproof": groups})
 
 
 if __name__ == "__main__":

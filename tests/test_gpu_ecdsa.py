@@ -1,0 +1,153 @@
+"""secp256k1 ECDSA batch verification (include/ncg.h `ncg_ecdsa_verify_batch`, noble-curves_amd/ecdsa.py) against
+the reference's own vectors (tests/golden/secp256k1_ecdsa.json <- test/vectors/secp256k1/ecdsa.json and the
+secp256k1 groups of test/vectors/wycheproof/ecdsa_test.json) and against the oracle's restatement of
+ecdsa.verify (weierstrass.ts:1571-1620) on edge cases and corrupted inputs."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import load_golden
+from noble_curves_amd import curve as G
+from noble_curves_amd import ecdsa as shim
+from oracle import ecdsa as O
+from oracle.curves import SECP256K1_N as N, SECP256K1_P as P, Secp256k1, makeRng
+from oracle.weierstrass import sec1_encode
+
+pytestmark = pytest.mark.gpu
+K1 = G.secp256k1_Point
+
+
+def keys_for(ds):
+    return [bytes(b) for b in G.toBytesBatch(K1, G.multiplyBaseBatch(K1, ds))]
+
+
+def sign_batch(ds, hs, rng):
+    """(r || s) with low S for private keys ds and hashes hs (ints): k G on the GPU, the rest big-int."""
+    ks = [rng.rndBelow(N - 1) + 1 for _ in ds]
+    Rs = G.multiplyBaseBatch(K1, ks)
+    out = []
+    for d, h, k, R in zip(ds, hs, ks, Rs):
+        r = R.toAffine()[0] % N
+        s = pow(k, -1, N) * (h + r * d) % N
+        assert r and s
+        if s > N >> 1:
+            s = N - s
+        out.append(r.to_bytes(32, "big") + s.to_bytes(32, "big"))
+    return out
+
+
+def test_reference_vectors():
+    g = load_golden("secp256k1_ecdsa.json")
+    ds = [int(v["d"], 16) for v in g["valid"]]
+    pubs = keys_for(ds)
+    sigs = [bytes.fromhex(v["signature"]) for v in g["valid"]]
+    msgs = [bytes.fromhex(v["m"]) for v in g["valid"]]
+    assert all(shim.verify_batch(sigs, msgs, pubs, prehash=False))                  # test/secp256k1.test.ts:133-146
+    unc = [sec1_encode(Secp256k1.BASE.multiply(d), False) for d in ds[:40]]        # 65-byte keys
+    assert all(shim.verify_batch(sigs[:40], msgs[:40], unc, prehash=False))
+    inv = g["invalid_verify"]                                                       # :263-270
+    got = shim.verify_batch([bytes.fromhex(v["signature"]) for v in inv], [bytes.fromhex(v["m"]) for v in inv],
+                            [bytes.fromhex(v["Q"]) for v in inv])
+    assert got == [False] * len(inv)
+    n_valid = n_invalid = 0
+    for grp in g["wycheproof"]:                                                     # :221-261, DER signatures
+        pub = bytes.fromhex(grp["pub"])
+        ts = grp["tests"]
+        sg, ms = [bytes.fromhex(t["sig"]) for t in ts], [bytes.fromhex(t["msg"]) for t in ts]
+        got = shim.verify_batch(sg, ms, [pub] * len(ts), format="der")
+        low_any = shim.verify_batch(sg, ms, [pub] * len(ts), format="der", lowS=False)
+        for t, s_, m_, a, b in zip(ts, sg, ms, got, low_any):
+            assert a == O.verify(s_, m_, pub, fmt="der"), t["comment"]
+            assert b == O.verify(s_, m_, pub, fmt="der", lowS=False), t["comment"]
+            if t["result"] == "invalid":
+                assert not a and not b, t["comment"]
+                n_invalid += 1
+            n_valid += a
+    assert n_valid > 50 and n_invalid > 100
+
+
+def test_edge_cases_and_corruptions_match_oracle():
+    rng = makeRng(0xEC5A)
+    n = 96
+    ds = [rng.rndBelow(N - 1) + 1 for _ in range(n)]
+    hs = [rng.rndBelow(1 << 256) for _ in range(n)]
+    hs[0], hs[1], hs[2], hs[3] = 0, N, N - 1, (1 << 256) - 1          # h = 0 (u1 = 0), h >= n
+    pubs = keys_for(ds)
+    sigs = sign_batch(ds, [h % N for h in hs], rng)
+    msgs = [h.to_bytes(32, "big") for h in hs]
+    assert all(shim.verify_batch(sigs, msgs, pubs, prehash=False))
+    cases = []                                                        # (sig, msg, pub)
+    for i in range(n):
+        r, s = sigs[i][:32], sigs[i][32:]
+        si = int.from_bytes(s, "big")
+        kind = i % 12
+        if kind == 0:   c = (r + (N - si).to_bytes(32, "big"), msgs[i], pubs[i])            # high S: lowS decides
+        elif kind == 1: c = (bytes(32) + s, msgs[i], pubs[i])                                # r = 0
+        elif kind == 2: c = (r + bytes(32), msgs[i], pubs[i])                                # s = 0
+        elif kind == 3: c = (N.to_bytes(32, "big") + s, msgs[i], pubs[i])                    # r = n
+        elif kind == 4: c = (r + N.to_bytes(32, "big"), msgs[i], pubs[i])                    # s = n
+        elif kind == 5: c = (sigs[i], msgs[i], bytes([pubs[i][0] ^ 1]) + pubs[i][1:])        # -P
+        elif kind == 6: c = (sigs[i], msgs[i], pubs[i][:1] + P.to_bytes(32, "big"))          # x = p: out of range
+        elif kind == 7: c = (sigs[i], msgs[i], bytes([2]) + (5).to_bytes(32, "big"))         # x = 5: no square root
+        elif kind == 8: c = (sigs[i], msgs[i][:-1] + bytes([msgs[i][-1] ^ 0x80]), pubs[i])   # other message
+        elif kind == 9: c = (sigs[i], msgs[i], pubs[(i + 1) % n])                            # other key
+        elif kind == 10:                                                                     # r + n < p: same x mod n? (r small)
+            c = (((int.from_bytes(r, "big") + 1) % N or 1).to_bytes(32, "big") + s, msgs[i], pubs[i])
+        else:           c = (sigs[i], msgs[i], pubs[i])
+        cases.append(c)
+    # R = O: P = d G with h + r d = 0 (mod n)
+    d0, r0 = ds[5], 0x1234567
+    h0 = (-r0 * d0) % N
+    cases.append((r0.to_bytes(32, "big") + (7).to_bytes(32, "big"), h0.to_bytes(32, "big"), pubs[5]))
+    cases.append((sigs[7], msgs[7], bytes(33)))                       # prefix 0
+    cases.append((sigs[7], msgs[7], pubs[7][:20]))                    # wrong length
+    cases.append((sigs[7], msgs[7], b"\x04" + pubs[7][1:] + (3).to_bytes(32, "big")))       # uncompressed, off the curve
+    for low in (True, False):
+        got = shim.verify_batch([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], lowS=low, prehash=False)
+        exp = [O.verify(c[0], c[1], c[2], lowS=low, prehash=False) for c in cases]
+        assert got == exp, [i for i, (a, b) in enumerate(zip(got, exp)) if a != b]
+        assert any(exp) and not all(exp)
+    # prehash: true hashes with SHA-256 on the host like the reference; any message length
+    long_msgs = [bytes([i]) * (i * 7) for i in range(12)]
+    hh = [int.from_bytes(hashlib.sha256(m).digest(), "big") % N for m in long_msgs]
+    sg = sign_batch(ds[:12], hh, rng)
+    assert all(shim.verify_batch(sg, long_msgs, pubs[:12]))
+    assert shim.verify(sg[3], long_msgs[3], pubs[3]) and not shim.verify(sg[3], long_msgs[4], pubs[3])
+    # prehash: false with a 48-byte "hash": bits2int keeps the leftmost 256 bits
+    m48 = bytes(range(1, 49))
+    s48 = sign_batch([ds[0]], [int.from_bytes(m48[:32], "big") % N], rng)
+    assert shim.verify_batch(s48, [m48], [pubs[0]], prehash=False) == [True] == [O.verify(s48[0], m48, pubs[0], prehash=False)]
+    with pytest.raises(ValueError, match="expected Uint8Array of length 64"):
+        shim.verify_batch([b"\x01" * 63], [b""], [pubs[0]])
+    with pytest.raises(TypeError, match="lowS"):
+        shim.verify_batch(sg[:1], long_msgs[:1], pubs[:1], lowS=1)
+    assert shim.verify_batch([], [], []) == []
+
+
+def test_batch_of_2_16_signatures():
+    """Sizes where every kernel runs full waves and the 16-signature inversion groups straddle rejected rows:
+    every 7th row corrupted, verdicts by construction, a sample against the oracle."""
+    rng = makeRng(0xB16E)
+    n = 1 << 16
+    base = [rng.rndBelow(N - 1) + 1 for _ in range(64)]
+    ds = [base[i % 64] for i in range(n)]
+    pubs64 = keys_for(base)
+    hs = [(rng.rndBelow(1 << 62) * (i + 1) * 0x9E3779B97F4A7C15 + i) % N for i in range(n)]
+    sigs = sign_batch(ds, hs, rng)
+    S = np.frombuffer(b"".join(sigs), np.uint8).reshape(n, 64).copy()
+    H = np.frombuffer(b"".join(h.to_bytes(32, "big") for h in hs), np.uint8).reshape(n, 32).copy()
+    K = np.frombuffer(b"".join(pubs64[i % 64] for i in range(n)), np.uint8).reshape(n, 33).copy()
+    exp = np.ones((n,), bool)
+    bad = np.arange(0, n, 7)
+    S[bad[0::3], 5] ^= 0x10      # r
+    S[bad[1::3], 45] ^= 0x01     # s
+    H[bad[2::3], 31] ^= 0x02     # message
+    exp[bad] = False
+    from noble_curves_amd import get_engine
+    got = get_engine().ecdsa_verify_batch(S, H, K, True)
+    # a corrupted s may still be a low-S value that verifies? no: any change of (r, s, h) breaks the equation,
+    # except with negligible probability; a flipped s can also become high-S - rejected either way
+    assert np.array_equal(got, exp)
+    for i in list(range(0, 40)) + [n - 1, n - 7, n - 8]:
+        assert bool(got[i]) == O.verify(bytes(S[i]), bytes(H[i]), bytes(K[i]), prehash=False)

@@ -365,3 +365,46 @@ def test_hash_to_field_scalar_xmd_vectors_and_sec1_compress():
     for r in rows:
         P = sec1_decode(Secp256k1, bytes.fromhex(r["P"]))
         assert sec1_encode(P, r["compress"]).hex() == r["expected"]
+
+
+def test_ecdsa_verify_reference_vectors():
+    """oracle/ecdsa.py against the reference's own ECDSA vectors: test/secp256k1.test.ts:133-146 (RFC 6979
+    (d, m, signature): the signature verifies under the key of d, prehash: false), :263-270 (invalid.verify ->
+    false) and :221-261 (Wycheproof DER: valid / acceptable verify iff the signature has low S, invalid never)."""
+    from oracle import ecdsa
+    from oracle.weierstrass import sec1_encode
+    g = load("secp256k1_ecdsa.json")
+    assert len(g["valid"]) == 404 and len(g["invalid_verify"]) >= 5 and len(g["wycheproof"]) >= 1
+    for v in g["valid"][:120]:
+        pub = sec1_encode(Secp256k1.BASE.multiply(int(v["d"], 16)))
+        sig, m = bytes.fromhex(v["signature"]), bytes.fromhex(v["m"])
+        assert ecdsa.verify(sig, m, pub, prehash=False)
+        bad = bytearray(sig); bad[40] ^= 1
+        assert not ecdsa.verify(bytes(bad), m, pub, prehash=False)
+        assert not ecdsa.verify(sig, m[:-1] + bytes([m[-1] ^ 1]), pub, prehash=False)
+    for v in g["invalid_verify"]:
+        assert ecdsa.verify(bytes.fromhex(v["signature"]), bytes.fromhex(v["m"]), bytes.fromhex(v["Q"])) is False, v["description"]
+    import hashlib
+    seen = {"valid": 0, "invalid": 0, "highS": 0}
+    for grp in g["wycheproof"]:
+        pub = bytes.fromhex(grp["pub"])
+        for t in grp["tests"]:
+            m = hashlib.sha256(bytes.fromhex(t["msg"])).digest()
+            sig = bytes.fromhex(t["sig"])
+            if t["result"] in ("valid", "acceptable"):
+                try:
+                    r, s = ecdsa.der_to_rs(sig)
+                except ValueError as e:
+                    assert "negative" in str(e), t["comment"]      # the reference skips exactly these
+                    continue
+                if not (1 <= r < SECP256K1_N and 1 <= s < SECP256K1_N):
+                    continue                                        # Signature() throws in the reference's sigFromDER
+                compact = r.to_bytes(32, "big") + s.to_bytes(32, "big")
+                high = s > SECP256K1_N >> 1
+                assert ecdsa.verify(compact, m, pub, prehash=False) == (not high), t["comment"]
+                seen["highS" if high else "valid"] += 1
+            else:
+                assert t["result"] == "invalid"
+                assert not ecdsa.verify(sig, m, pub, prehash=False, fmt="der"), t["comment"]
+                seen["invalid"] += 1
+    assert seen["valid"] > 50 and seen["invalid"] > 100 and seen["highS"] > 0, seen

@@ -83,6 +83,45 @@ def main():
         eng.mul_var_batch_dev(SECP256K1, n, P(kpts), P(sc), P(t2), P(inf), s)
         eng._check(eng.lib.ncg_add_pairs_batch_dev(eng.h, SECP256K1, n, P(t1), P(t2), 0, P(dec), P(inf), s))
     rate("secp256k1 u1*G + u2*P (mulAddUnsafe, ECDSA-verify shape)", n, timeit(ecdsa_shape), "double-mults")
+    # full ECDSA verify (weierstrass.ts:1571-1620) of 2^18 signatures under 64 keys: key decompression, s^-1 mod n,
+    # u1 G + u2 P and the comparison on the device; 1/16 of the rows corrupted, verdicts checked
+    ne = 1 << 18
+    from oracle.curves import SECP256K1_N as NN
+    erng = makeRng(0xEC)
+    dkeys = [erng.rndBelow(NN - 1) + 1 for _ in range(64)]
+    kk = [erng.rndBelow(NN - 1) + 1 for _ in range(ne)]
+    ksc = torch.from_numpy(np.frombuffer(b"".join(k.to_bytes(32, "little") for k in kk), np.uint8).reshape(ne, 32).copy()).to(dev)
+    dsc = torch.from_numpy(np.frombuffer(b"".join(d.to_bytes(32, "little") for d in dkeys), np.uint8).reshape(64, 32).copy()).to(dev)
+    raff = torch.empty((ne, 64), dtype=torch.uint8, device=dev)
+    rinf = torch.empty((ne,), dtype=torch.uint8, device=dev)
+    eng.mul_base_batch_dev(SECP256K1, ne, P(ksc), P(raff), P(rinf), s)
+    kaff = torch.empty((64, 64), dtype=torch.uint8, device=dev)
+    eng.mul_base_batch_dev(SECP256K1, 64, P(dsc), P(kaff), P(rinf), s)
+    torch.cuda.synchronize()
+    kenc, _ = eng.encode_points_batch(SECP256K1, kaff.cpu().numpy())
+    rx = raff.cpu().numpy()[:, :32]
+    sig_rows, hash_rows = [], []
+    for i in range(ne):
+        r = int.from_bytes(bytes(rx[i]), "little") % NN
+        h = (i * 0x9E3779B97F4A7C15 + 12345) % NN
+        sv = pow(kk[i], -1, NN) * (h + r * dkeys[i % 64]) % NN
+        if sv > NN >> 1:
+            sv = NN - sv
+        sig_rows.append(r.to_bytes(32, "big") + sv.to_bytes(32, "big"))
+        hash_rows.append(h.to_bytes(32, "big"))
+    S = np.frombuffer(b"".join(sig_rows), np.uint8).reshape(ne, 64).copy()
+    S[::16, 40] ^= 1
+    # 2^18 distinct signatures tiled to 2^20 rows (the work per row does not depend on its neighbours)
+    Sd = torch.from_numpy(S).to(dev).repeat(4, 1).contiguous()
+    Hd = torch.from_numpy(np.frombuffer(b"".join(hash_rows), np.uint8).reshape(ne, 32).copy()).to(dev).repeat(4, 1).contiguous()
+    Kd = torch.from_numpy(np.ascontiguousarray(kenc[np.arange(ne) % 64])).to(dev).repeat(4, 1).contiguous()
+    okd = torch.empty((4 * ne,), dtype=torch.uint8, device=dev)
+    ev = lambda: eng.ecdsa_verify_batch_dev(4 * ne, P(Sd), P(Hd), P(Kd), True, P(okd), s)  # noqa: E731
+    ms_e = timeit(ev)
+    exp_ok = np.ones((ne,), np.uint8)
+    exp_ok[::16] = 0
+    assert np.array_equal(okd.cpu().numpy(), np.tile(exp_ok, 4)), "ECDSA verdicts"
+    rate("secp256k1 ECDSA verify batch (compressed keys, 64 distinct)", 4 * ne, ms_e, "verifies")
     proj = torch.cat([kpts, torch.zeros((n, 32), dtype=torch.uint8, device=dev)], dim=1)
     proj[:, 64] = 1                                                        # Z = 1
     fn = lambda: eng._check(eng.lib.ncg_normalize_batch_dev(eng.h, SECP256K1, n, P(proj), P(dec), P(inf), s))  # noqa: E731
