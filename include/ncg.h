@@ -316,6 +316,17 @@ int ncg_ecdsa_verify_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* si
                                const void* hash32_dev, const void* pub33_dev, int flags,
                                uint8_t* out_ok_dev, void* stream);
 
+/* ---- secp256k1 BIP-340 Schnorr batch verification ----------------------------------------------
+ * out_ok[i] = schnorr.verify(sig[i], msg[i], publicKey[i]) (src/secp256k1.ts:228-258) given the challenge
+ * e[i] = int(taggedHash('BIP0340/challenge', r || pk || msg)) mod n as 32 big-endian bytes (:176-178; the host
+ * shim hashes, like the reference's host sha256).  sig: r || s big-endian (r in [1, p), s in [1, n), else false);
+ * publicKey: 32-byte x-only, P = lift_x (:158-170: the even root; no root / x >= p gives false).  On the device:
+ * the range checks, lift_x, R = s G + (n - e) P, and R != O, even y(R), x(R) == r. */
+int ncg_schnorr_verify_batch(ncg_ctx* ctx, size_t n, const void* sig64, const void* e32, const void* pkx32,
+                             uint8_t* out_ok);
+int ncg_schnorr_verify_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* e32_dev,
+                                 const void* pkx32_dev, uint8_t* out_ok_dev, void* stream);
+
 /* Runs instruction-rate / field-multiply micro-benchmark `kind` (see csrc/ubench.hip) and
  * returns the kernel time in milliseconds. */
 int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float* out_ms);

@@ -119,6 +119,8 @@ _OPTIONAL_PROTOS = {
     "ncg_msm_resident": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
     "ncg_msm_resident_dev": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_ecdsa_verify_batch": [_vp, _i32, _sz, _vp, _vp, _vp, _i32, _vp],
+    "ncg_schnorr_verify_batch": [_vp, _sz, _vp, _vp, _vp, _vp],
+    "ncg_schnorr_verify_batch_dev": [_vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "ncg_ecdsa_verify_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _i32, _vp, _vp],
     "ncg_points_verify_subgroup": [_vp, _vp, ctypes.POINTER(ctypes.c_int64)],
     "ncg_points_in_subgroup": [_vp],
@@ -433,6 +435,24 @@ class Engine:
             self._check(self.lib.ncg_ecdsa_verify_batch(self.h, SECP256K1, n, sigs.ctypes.data, hashes.ctypes.data,
                                                         pubs.ctypes.data, 1 if low_s else 0, ok.ctypes.data))
         return ok.astype(bool)
+
+    def schnorr_verify_batch(self, sigs, challenges, pubs):
+        """BIP-340: sigs uint8 [n,64], challenges [n,32] (e mod n, big-endian), pubs [n,32] x-only -> bool [n]
+        (src/secp256k1.ts:228-258 after the host-side tagged hash)."""
+        sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 64)
+        es = np.ascontiguousarray(challenges, dtype=np.uint8).reshape(-1, 32)
+        pubs = np.ascontiguousarray(pubs, dtype=np.uint8).reshape(-1, 32)
+        n = sigs.shape[0]
+        if es.shape[0] != n or pubs.shape[0] != n:
+            raise ValueError("arrays of signatures, challenges and public keys must have equal length")
+        ok = np.zeros((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_schnorr_verify_batch(self.h, n, sigs.ctypes.data, es.ctypes.data, pubs.ctypes.data,
+                                                          ok.ctypes.data))
+        return ok.astype(bool)
+
+    def schnorr_verify_batch_dev(self, n, d_sigs, d_es, d_pubs, d_ok, stream=None):
+        self._check(self.lib.ncg_schnorr_verify_batch_dev(self.h, n, d_sigs, d_es, d_pubs, d_ok, stream))
 
     def ecdsa_verify_batch_dev(self, n, d_sigs, d_hashes, d_pubs, low_s, d_ok, stream=None):
         self._check(self.lib.ncg_ecdsa_verify_batch_dev(self.h, SECP256K1, n, d_sigs, d_hashes, d_pubs, 1 if low_s else 0,

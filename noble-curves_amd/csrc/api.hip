@@ -1105,18 +1105,14 @@ int ncg_ed25519_verify_batch_msgs(ncg_ctx* ctx, size_t n, const void* sig64, con
 
 // ---- secp256k1 ECDSA batch verify (weierstrass.ts:1571-1620): SEC1 decode of the keys, the scalar side
 // (ecdsa.hip), u1 G by the fixed-base table, u2 P by the variable-base ladder, one pairwise add, compare.
-int ncg_ecdsa_verify_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* sig64_dev, const void* hash32_dev,
-                               const void* pub33_dev, int flags, uint8_t* out_ok_dev, void* stream) {
-  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
-  if (curve != NCG_SECP256K1) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ecdsa_verify: secp256k1 only");
-  if (n == 0) return NCG_OK;
-  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
-  if (!sig64_dev || !hash32_dev || !pub33_dev || !out_ok_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ecdsa_verify: NULL buffer");
-  NCG_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+struct SigWs {  // device buffers of the signature pipelines (ECDSA, Schnorr)
+  char *pub, *A, *B, *R, *u1, *u2, *pub33;
+  uint8_t *pub_ok, *pub_inf, *pre_ok, *A_inf, *B_inf, *R_inf;
+};
+static int sig_ws(ncg_ctx* ctx, size_t n, hipStream_t st, SigWs* w) {
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t pt_b = al(n * 64), sc_b = al(n * 32), fl_b = al(n);
-  const size_t need = 4 * pt_b + 2 * sc_b + 6 * fl_b;
+  const size_t pt_b = al(n * 64), sc_b = al(n * 32), fl_b = al(n), pk_b = al(n * 33);
+  const size_t need = 4 * pt_b + 2 * sc_b + 6 * fl_b + pk_b;
   if (ctx->ecdsa_ws_bytes < need) {
     NCG_HIP(ctx, hipStreamSynchronize(st));
     if (ctx->ecdsa_ws) (void)hipFree(ctx->ecdsa_ws);
@@ -1127,30 +1123,96 @@ int ncg_ecdsa_verify_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* si
     ctx->ecdsa_ws_bytes = need + (need >> 2);
   }
   char* p = (char*)ctx->ecdsa_ws;
-  char* d_pub = p;            p += pt_b;
-  char* d_A = p;              p += pt_b;
-  char* d_B = p;              p += pt_b;
-  char* d_R = p;              p += pt_b;
-  char* d_u1 = p;             p += sc_b;
-  char* d_u2 = p;             p += sc_b;
-  uint8_t* d_pub_ok = (uint8_t*)p;   p += fl_b;
-  uint8_t* d_pub_inf = (uint8_t*)p;  p += fl_b;
-  uint8_t* d_sig_ok = (uint8_t*)p;   p += fl_b;
-  uint8_t* d_A_inf = (uint8_t*)p;    p += fl_b;
-  uint8_t* d_B_inf = (uint8_t*)p;    p += fl_b;
-  uint8_t* d_R_inf = (uint8_t*)p;
-  int rc = ncg_decode_points_batch_dev(ctx, curve, n, pub33_dev, 0, d_pub, d_pub_ok, d_pub_inf, st);
+  w->pub = p;    p += pt_b;
+  w->A = p;      p += pt_b;
+  w->B = p;      p += pt_b;
+  w->R = p;      p += pt_b;
+  w->u1 = p;     p += sc_b;
+  w->u2 = p;     p += sc_b;
+  w->pub33 = p;  p += pk_b;
+  w->pub_ok = (uint8_t*)p;   p += fl_b;
+  w->pub_inf = (uint8_t*)p;  p += fl_b;
+  w->pre_ok = (uint8_t*)p;   p += fl_b;
+  w->A_inf = (uint8_t*)p;    p += fl_b;
+  w->B_inf = (uint8_t*)p;    p += fl_b;
+  w->R_inf = (uint8_t*)p;
+  return NCG_OK;
+}
+// R = u1 G + u2 P for decoded keys: fixed-base table, variable-base ladder, one pairwise add
+static int sig_mul_add(ncg_ctx* ctx, int curve, size_t n, const SigWs& w, hipStream_t st) {
+  int rc = ncg_mul_base_batch_dev(ctx, curve, n, w.u1, w.A, w.A_inf, st);
+  if (rc) return rc;
+  rc = ncg_mul_var_batch_dev(ctx, curve, n, w.pub, w.u2, w.B, w.B_inf, st);  // rejected keys decode to (0,0) = O
+  if (rc) return rc;
+  return ncg_add_pairs_batch_dev(ctx, curve, n, w.A, w.B, 0, w.R, w.R_inf, st);
+}
+
+int ncg_ecdsa_verify_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* sig64_dev, const void* hash32_dev,
+                               const void* pub33_dev, int flags, uint8_t* out_ok_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_SECP256K1) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ecdsa_verify: secp256k1 only");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64_dev || !hash32_dev || !pub33_dev || !out_ok_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ecdsa_verify: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  SigWs w;
+  int rc = sig_ws(ctx, n, st, &w);
+  if (rc) return rc;
+  rc = ncg_decode_points_batch_dev(ctx, curve, n, pub33_dev, 0, w.pub, w.pub_ok, w.pub_inf, st);
   if (rc) return rc;
   NCG_HIP(ctx, ncg::ecdsa_prepare((const uint8_t*)sig64_dev, (const uint8_t*)hash32_dev, (int)n, (flags & NCG_ECDSA_LOW_S) != 0,
-                                  (uint32_t*)d_u1, (uint32_t*)d_u2, d_sig_ok, st));
-  rc = ncg_mul_base_batch_dev(ctx, curve, n, d_u1, d_A, d_A_inf, st);
+                                  (uint32_t*)w.u1, (uint32_t*)w.u2, w.pre_ok, st));
+  rc = sig_mul_add(ctx, curve, n, w, st);
   if (rc) return rc;
-  rc = ncg_mul_var_batch_dev(ctx, curve, n, d_pub, d_u2, d_B, d_B_inf, st);  // rejected keys decode to (0,0) = O
-  if (rc) return rc;
-  rc = ncg_add_pairs_batch_dev(ctx, curve, n, d_A, d_B, 0, d_R, d_R_inf, st);
-  if (rc) return rc;
-  NCG_HIP(ctx, ncg::ecdsa_finish((const uint8_t*)sig64_dev, (const uint32_t*)d_R, d_R_inf, d_sig_ok, d_pub_ok, d_pub_inf, (int)n,
+  NCG_HIP(ctx, ncg::ecdsa_finish((const uint8_t*)sig64_dev, (const uint32_t*)w.R, w.R_inf, w.pre_ok, w.pub_ok, w.pub_inf, (int)n,
                                  out_ok_dev, st));
+  return NCG_OK;
+}
+
+int ncg_schnorr_verify_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* e32_dev, const void* pkx32_dev,
+                                 uint8_t* out_ok_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64_dev || !e32_dev || !pkx32_dev || !out_ok_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: schnorr_verify: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  SigWs w;
+  int rc = sig_ws(ctx, n, st, &w);
+  if (rc) return rc;
+  NCG_HIP(ctx, ncg::schnorr_prepare((const uint8_t*)sig64_dev, (const uint8_t*)e32_dev, (const uint8_t*)pkx32_dev, (int)n,
+                                    (uint32_t*)w.u1, (uint32_t*)w.u2, (uint8_t*)w.pub33, w.pre_ok, st));
+  rc = ncg_decode_points_batch_dev(ctx, NCG_SECP256K1, n, w.pub33, 0, w.pub, w.pub_ok, w.pub_inf, st);  // lift_x: the even root
+  if (rc) return rc;
+  rc = sig_mul_add(ctx, NCG_SECP256K1, n, w, st);
+  if (rc) return rc;
+  NCG_HIP(ctx, ncg::schnorr_finish((const uint8_t*)sig64_dev, (const uint32_t*)w.R, w.R_inf, w.pre_ok, w.pub_ok, w.pub_inf, (int)n,
+                                   out_ok_dev, st));
+  return NCG_OK;
+}
+
+int ncg_schnorr_verify_batch(ncg_ctx* ctx, size_t n, const void* sig64, const void* e32, const void* pkx32, uint8_t* out_ok) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64 || !e32 || !pkx32 || !out_ok) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: schnorr_verify: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  int rc = ensure_scratch(ctx, al(n * 64) + 2 * al(n * 32) + al(n) + 1024);
+  if (rc) return rc;
+  char* d_sig = (char*)ctx->scratch;
+  char* d_e = d_sig + al(n * 64);
+  char* d_pk = d_e + al(n * 32);
+  char* d_ok = d_pk + al(n * 32);
+  NCG_HIP(ctx, pins.h2d(d_sig, sig64, n * 64));
+  NCG_HIP(ctx, pins.h2d(d_e, e32, n * 32));
+  NCG_HIP(ctx, pins.h2d(d_pk, pkx32, n * 32));
+  rc = ncg_schnorr_verify_batch_dev(ctx, n, d_sig, d_e, d_pk, (uint8_t*)d_ok, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return NCG_OK;
 }
 

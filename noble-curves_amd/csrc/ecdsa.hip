@@ -160,6 +160,64 @@ __global__ void __launch_bounds__(256) k_ecdsa_finish(const uint8_t* __restrict_
   out_ok[i] = (ok && diff == 0) ? 1 : 0;
 }
 
+// ---- BIP-340 Schnorr verification (src/secp256k1.ts:228-258): R = s G + (n - e) P with P = lift_x(pk), accept iff
+// R != O, y(R) even and x(R) == r.  e = challenge mod n arrives from the host shim (tagged SHA-256 of
+// r || pk || m, 32 bytes big-endian); this kernel range-checks r in [1, p) and s in [1, n) and lays out the
+// multiplier inputs: u1 = s, u2 = n - e (0 for e = 0), key = 02 || pk (lift_x picks the even root).
+__global__ void __launch_bounds__(256) k_schnorr_prepare(const uint8_t* __restrict__ sig, const uint8_t* __restrict__ e32,
+                                                         const uint8_t* __restrict__ pkx, int n, uint32_t* __restrict__ u1,
+                                                         uint32_t* __restrict__ u2, uint8_t* __restrict__ pub33,
+                                                         uint8_t* __restrict__ pre_ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t r[8], s[8], e[8], n8[8], p8[8], ne[8];
+  be32_to_words(r, sig + (size_t)i * 64);
+  be32_to_words(s, sig + (size_t)i * 64 + 32);
+  be32_to_words(e, e32 + (size_t)i * 32);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    n8[j] = ParamsSecpN::P[j];
+    p8[j] = ParamsSecpP::P[j];
+  }
+  const bool ok = !mp_is_zero(r) && words_lt(r, p8) && !mp_is_zero(s) && words_lt(s, n8) && words_lt(e, n8);
+  mp_sub<8>(ne, n8, e);
+  const bool ez = mp_is_zero(e);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    u1[(size_t)i * 8 + j] = ok ? s[j] : 0u;
+    u2[(size_t)i * 8 + j] = (ok && !ez) ? ne[j] : 0u;
+  }
+  pub33[(size_t)i * 33] = 2;
+  for (int j = 0; j < 32; j++) pub33[(size_t)i * 33 + 1 + j] = pkx[(size_t)i * 32 + j];
+  pre_ok[i] = ok ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_schnorr_finish(const uint8_t* __restrict__ sig, const uint32_t* __restrict__ R,
+                                                        const uint8_t* __restrict__ R_inf, const uint8_t* __restrict__ pre_ok,
+                                                        const uint8_t* __restrict__ pub_ok, const uint8_t* __restrict__ pub_inf, int n,
+                                                        uint8_t* __restrict__ out_ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool ok = pre_ok[i] != 0 && pub_ok[i] != 0 && pub_inf[i] == 0 && R_inf[i] == 0;
+  uint32_t r[8];
+  be32_to_words(r, sig + (size_t)i * 64);
+  uint32_t diff = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) diff |= R[(size_t)i * 16 + j] ^ r[j];
+  const bool even_y = (R[(size_t)i * 16 + 8] & 1u) == 0;
+  out_ok[i] = (ok && diff == 0 && even_y) ? 1 : 0;
+}
+hipError_t schnorr_prepare(const uint8_t* d_sig, const uint8_t* d_e, const uint8_t* d_pkx, int n, uint32_t* d_u1, uint32_t* d_u2,
+                           uint8_t* d_pub33, uint8_t* d_pre_ok, hipStream_t st) {
+  hipLaunchKernelGGL(k_schnorr_prepare, dim3((n + 255) / 256), dim3(256), 0, st, d_sig, d_e, d_pkx, n, d_u1, d_u2, d_pub33, d_pre_ok);
+  return hipGetLastError();
+}
+hipError_t schnorr_finish(const uint8_t* d_sig, const uint32_t* d_R, const uint8_t* d_R_inf, const uint8_t* d_pre_ok,
+                          const uint8_t* d_pub_ok, const uint8_t* d_pub_inf, int n, uint8_t* d_out_ok, hipStream_t st) {
+  hipLaunchKernelGGL(k_schnorr_finish, dim3((n + 255) / 256), dim3(256), 0, st, d_sig, d_R, d_R_inf, d_pre_ok, d_pub_ok, d_pub_inf, n,
+                     d_out_ok);
+  return hipGetLastError();
+}
+
 hipError_t ecdsa_prepare(const uint8_t* d_sig, const uint8_t* d_hash, int n, bool low_s, uint32_t* d_u1, uint32_t* d_u2,
                          uint8_t* d_sig_ok, hipStream_t st) {
   const int lanes = (n + ECDSA_K - 1) / ECDSA_K;

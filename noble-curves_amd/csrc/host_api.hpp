@@ -77,6 +77,10 @@ hipError_t ecdsa_prepare(const uint8_t* d_sig, const uint8_t* d_hash, int n, boo
                          uint8_t* d_sig_ok, hipStream_t st);
 hipError_t ecdsa_finish(const uint8_t* d_sig, const uint32_t* d_R, const uint8_t* d_R_inf, const uint8_t* d_sig_ok,
                         const uint8_t* d_pub_ok, const uint8_t* d_pub_inf, int n, uint8_t* d_out_ok, hipStream_t st);
+hipError_t schnorr_prepare(const uint8_t* d_sig, const uint8_t* d_e, const uint8_t* d_pkx, int n, uint32_t* d_u1, uint32_t* d_u2,
+                           uint8_t* d_pub33, uint8_t* d_pre_ok, hipStream_t st);
+hipError_t schnorr_finish(const uint8_t* d_sig, const uint32_t* d_R, const uint8_t* d_R_inf, const uint8_t* d_pre_ok,
+                          const uint8_t* d_pub_ok, const uint8_t* d_pub_inf, int n, uint8_t* d_out_ok, hipStream_t st);
 void ecdsa_prepare_host(const uint8_t* sig, const uint8_t* hash, bool low_s, uint32_t* u1, uint32_t* u2, uint8_t* ok);
 
 // Endomorphism mode for bls12-381 point sets verified to lie in the prime-order subgroup (msm_endo.hip,

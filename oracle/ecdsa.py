@@ -97,3 +97,45 @@ def verify(sig, message, public_key, lowS=True, prehash=True, fmt="compact"):
         return R.toAffine()[0] % N == r
     except ValueError:
         return False
+
+
+# ---- BIP-340 Schnorr (src/secp256k1.ts:129-137 taggedHash, :158-170 lift_x, :176-178 challenge, :228-258 verify)
+def tagged_hash(tag, *msgs):
+    t = hashlib.sha256(tag.encode()).digest()
+    return hashlib.sha256(t + t + b"".join(bytes(m) for m in msgs)).digest()
+
+
+def lift_x(x):
+    from .curves import SECP256K1_P as P
+    if not (0 < x < P):
+        raise ValueError("invalid x: Fail if x >= p")
+    c = (x * x * x + 7) % P
+    y = pow(c, (P + 1) // 4, P)
+    if y * y % P != c:
+        raise ValueError("Cannot find square root")
+    if y & 1:
+        y = P - y
+    return Secp256k1.fromAffine((x, y))
+
+
+def schnorr_verify(sig, message, public_key):
+    from .curves import SECP256K1_P as P
+    sig, message, public_key = bytes(sig), bytes(message), bytes(public_key)
+    if len(sig) != 64 or len(public_key) != 32:
+        raise ValueError("expected 64-byte signature and 32-byte public key")
+    try:
+        Pt = lift_x(int.from_bytes(public_key, "big"))
+        r = int.from_bytes(sig[:32], "big")
+        if not (0 < r < P):
+            return False
+        s = int.from_bytes(sig[32:], "big")
+        if not (0 < s < N):
+            return False
+        e = int.from_bytes(tagged_hash("BIP0340/challenge", sig[:32], Pt.toAffine()[0].to_bytes(32, "big"), message), "big") % N
+        R = Secp256k1.BASE.mulAddUnsafe(s, Pt, (N - e) % N)
+        if R.is0():
+            return False
+        x, y = R.toAffine()
+        return (y & 1) == 0 and x == r
+    except ValueError:
+        return False

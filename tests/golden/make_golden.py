@@ -14,6 +14,7 @@ Sources (data files, not code): /root/reference/test/vectors/...
   ed25519/zip215.json          ZIP-215 verdicts (test/ed25519.test.ts:393-418)
   ed25519/edge-cases.json      (test/ed25519.test.ts:189)
   secp256k1/ecdsa.json         RFC 6979 sign / verify vectors (test/secp256k1.test.ts:133-146, :263-270)
+  secp256k1/schnorr.csv        BIP-340 test vectors (test/secp256k1.test.ts:666-684)
   wycheproof/ecdsa_test.json   the secp256k1 / SHA-256 groups, DER signatures (the same cases as the
                                un-vendored acvp-vectors file of test/secp256k1.test.ts:221-261)
 """
@@ -112,6 +113,10 @@ def main():
                "tests": [{"msg": t["msg"], "sig": t["sig"], "result": t["result"], "comment": t["comment"]} for t in g["tests"]]}
               for g in wp["testGroups"] if g["key"]["curve"] == "secp256k1" and g["sha"] == "SHA-256"]
     dump("secp256k1_ecdsa.json", {"valid": ec["valid"][::5], "invalid_verify": ec["invalid"]["verify"], "wycheproof": groups})
+    # BIP-340 Schnorr vectors (test/secp256k1.test.ts:666-684): index, secret key, public key, aux, message, signature, result
+    import csv
+    rows = list(csv.reader(open(f"{REF}/secp256k1/schnorr.csv")))[1:]
+    dump("secp256k1_schnorr.json", [{"pub": r[2], "msg": r[4], "sig": r[5], "result": r[6] == "TRUE", "comment": r[7]} for r in rows if len(r) >= 7])
 
 
 if __name__ == "__main__":

@@ -151,3 +151,51 @@ def test_batch_of_2_16_signatures():
     assert np.array_equal(got, exp)
     for i in list(range(0, 40)) + [n - 1, n - 7, n - 8]:
         assert bool(got[i]) == O.verify(bytes(S[i]), bytes(H[i]), bytes(K[i]), prehash=False)
+
+
+def test_schnorr_bip340_vectors_and_corruptions():
+    """BIP-340 verification (noble-curves_amd/schnorr.py, ncg_schnorr_verify_batch): the vectors the reference
+    tests (test/secp256k1.test.ts:666-684 via tests/golden) and signed batches with corrupted rows against the
+    oracle's restatement of schnorr.verify (src/secp256k1.ts:228-258)."""
+    from noble_curves_amd import schnorr
+    rows = load_golden("secp256k1_schnorr.json")
+    sg, ms, pk = ([bytes.fromhex(r[k]) for r in rows] for k in ("sig", "msg", "pub"))
+    assert schnorr.verify_batch(sg, ms, pk) == [r["result"] for r in rows]
+    rng = makeRng(0x5C4)
+    n = 200
+    ds = [rng.rndBelow(N - 1) + 1 for _ in range(n)]
+    Ps = G.multiplyBaseBatch(K1, ds)
+    ks = [rng.rndBelow(N - 1) + 1 for _ in range(n)]
+    Rs = G.multiplyBaseBatch(K1, ks)
+    sigs, msgs, pks = [], [], []
+    for i in range(n):
+        px, py = Ps[i].toAffine()
+        d = ds[i] if py % 2 == 0 else N - ds[i]
+        rx, ry = Rs[i].toAffine()
+        k = ks[i] if ry % 2 == 0 else N - ks[i]
+        m = bytes([i & 255]) * (i % 70)
+        pkb, rb = px.to_bytes(32, "big"), rx.to_bytes(32, "big")
+        e = schnorr.challenge(rb, pkb, m)
+        sigs.append(rb + ((k + e * d) % N).to_bytes(32, "big"))
+        msgs.append(m); pks.append(pkb)
+    assert all(schnorr.verify_batch(sigs, msgs, pks))
+    cases = []
+    for i in range(n):
+        s_, m_, p_ = bytearray(sigs[i]), msgs[i], pks[i]
+        kind = i % 10
+        if kind == 0:   s_[3] ^= 1                                     # r
+        elif kind == 1: s_[50] ^= 1                                    # s
+        elif kind == 2: m_ = m_ + b"x"
+        elif kind == 3: p_ = pks[(i + 1) % n]
+        elif kind == 4: s_[32:] = bytes(32)                            # s = 0
+        elif kind == 5: s_[32:] = N.to_bytes(32, "big")                # s = n
+        elif kind == 6: s_[:32] = P.to_bytes(32, "big")                # r = p
+        elif kind == 7: p_ = P.to_bytes(32, "big")                     # x = p
+        elif kind == 8: p_ = (5).to_bytes(32, "big")                   # no square root
+        cases.append((bytes(s_), m_, p_))
+    got = schnorr.verify_batch([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+    exp = [O.schnorr_verify(*c) for c in cases]
+    assert got == exp and any(exp) and not all(exp)
+    with pytest.raises(ValueError, match="expected Uint8Array of length 32"):
+        schnorr.verify_batch(sigs[:1], msgs[:1], [pks[0] + b"\x00"])
+    assert schnorr.verify(sigs[1], msgs[1], pks[1]) and schnorr.verify_batch([], [], []) == []

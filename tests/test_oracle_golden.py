@@ -408,3 +408,12 @@ def test_ecdsa_verify_reference_vectors():
                 assert not ecdsa.verify(sig, m, pub, prehash=False, fmt="der"), t["comment"]
                 seen["invalid"] += 1
     assert seen["valid"] > 50 and seen["invalid"] > 100 and seen["highS"] > 0, seen
+
+
+def test_schnorr_bip340_vectors():
+    """oracle schnorr_verify against the BIP-340 vectors the reference tests (test/secp256k1.test.ts:666-684)."""
+    from oracle import ecdsa
+    rows = load("secp256k1_schnorr.json")
+    assert len(rows) >= 15 and any(r["result"] for r in rows) and not all(r["result"] for r in rows)
+    for r in rows:
+        assert ecdsa.schnorr_verify(bytes.fromhex(r["sig"]), bytes.fromhex(r["msg"]), bytes.fromhex(r["pub"])) == r["result"], r["comment"]
