@@ -1,7 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r02h
-(cd /tmp && NCG_TIMING=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02h/st_endo -- python $GRAFT_REPO_ROOT/tools/_scratch/endo_timing.py > $GRAFT_REPO_ROOT/gpurun_out/r02h/st_endo.log 2>&1)
+(cd /tmp && NCG_TIMING=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02h/st_endo -- python $GRAFT_REPO_ROOT/tools/endo_timing.py > $GRAFT_REPO_ROOT/gpurun_out/r02h/st_endo.log 2>&1)
 grep "^curve\|host finish" gpurun_out/r02h/st_endo.log | tail -6
 python - <<'PY'
 import csv,glob
