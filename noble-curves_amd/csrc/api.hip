@@ -496,7 +496,7 @@ int ncg_points_from_encoded(ncg_ctx* ctx, int curve, size_t n, const void* encod
         }
     // the bls12-381 decoders include the subgroup test (bls12-381.ts:567-577, :599-601), so a decoded set
     // qualifies for the endomorphism MSM; infinity encodings decode to ZERO and stay ZERO in every image
-    if (rc == NCG_OK) rc = points_build_endo(ctx, h);
+    if (rc == NCG_OK) (void)points_build_endo(ctx, h);  // best effort: without the images the set uses the generic MSM
     if (rc != NCG_OK) {
       (void)hipFree(h->d_pts);
       delete h;

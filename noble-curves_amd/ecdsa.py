@@ -148,3 +148,39 @@ def verify_batch(signatures, messages, publicKeys, lowS=True, prehash=True, form
 
 def verify(signature, message, publicKey, **opts):
     return verify_batch([signature], [message], [publicKey], **opts)[0]
+
+
+def getSharedSecretBatch(secretKeys, publicKeys, isCompressed=True, engine=None):
+    """[secp256k1.getSharedSecret(sk, pk, isCompressed) for each pair] (weierstrass.ts:1198-1210): the point
+    s * Point.fromBytes(pk) as SEC1 bytes.  Secret keys: 32 big-endian bytes in [1, n) (Fn.fromBytes +
+    isValidNot0, else ValueError like the reference); a public key the reference's decoder rejects raises too."""
+    from . import curve as G
+    K1 = G.secp256k1_Point
+    n = len(secretKeys)
+    if len(publicKeys) != n:
+        raise ValueError("arrays of secret keys and public keys must have equal length")
+    ks = []
+    for sk in secretKeys:
+        sk = _abytes(sk, "secretKey")
+        if len(sk) != 32:
+            raise ValueError('"secretKey" expected Uint8Array of length 32, got length=%d' % len(sk))
+        k = int.from_bytes(sk, "big")
+        if not (1 <= k < N):
+            raise ValueError("invalid private key")
+        ks.append(k)
+    comp = []
+    for i, pk in enumerate(publicKeys):
+        c = _compressed_key(_abytes(pk, "publicKey"))
+        if c is None:
+            raise ValueError("bad point: invalid public key at index %d" % i)
+        comp.append(c)
+    if n == 0:
+        return []
+    pts = G.fromBytesBatch(K1, comp, engine=engine)
+    for i, p in enumerate(pts):
+        if p is None:
+            raise ValueError("bad point: invalid public key at index %d" % i)
+    shared = G.multiplyUnsafeBatch(K1, pts, ks, engine=engine)      # k in [1, n) and P != O: never ZERO
+    if isCompressed:
+        return [bytes(b) for b in G.toBytesBatch(K1, shared, engine=engine)]
+    return [b"\x04" + x.to_bytes(32, "big") + y.to_bytes(32, "big") for x, y in (p.toAffine() for p in shared)]

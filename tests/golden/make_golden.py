@@ -113,6 +113,20 @@ def main():
                "tests": [{"msg": t["msg"], "sig": t["sig"], "result": t["result"], "comment": t["comment"]} for t in g["tests"]]}
               for g in wp["testGroups"] if g["key"]["curve"] == "secp256k1" and g["sha"] == "SHA-256"]
     dump("secp256k1_ecdsa.json", {"valid": ec["valid"][::5], "invalid_verify": ec["invalid"]["verify"], "wycheproof": groups})
+    # Wycheproof ECDH on secp256k1 (test/secp256k1.test.ts:272-292): valid cases whose key is the plain
+    # SubjectPublicKeyInfo of an uncompressed point (the reference's derToPub takes the trailing 65 bytes)
+    eh = json.load(open(f"{REF}/wycheproof/ecdh_test.json"))
+    ecdh_rows = []
+    for g in eh["testGroups"]:
+        if g.get("curve") != "secp256k1":
+            continue
+        for t in g["tests"]:
+            pub, priv = t["public"][-130:], t["private"]
+            if t["result"] == "valid" and pub.startswith("04") and len(t["public"]) == 176:
+                priv = priv[2:] if len(priv) == 66 and priv.startswith("00") else priv
+                if len(priv) <= 64:
+                    ecdh_rows.append({"pub": pub, "priv": priv.rjust(64, "0"), "shared": t["shared"]})
+    dump("secp256k1_ecdh.json", ecdh_rows)
     # BIP-340 Schnorr vectors (test/secp256k1.test.ts:666-684): index, secret key, public key, aux, message, signature, result
     import csv
     rows = list(csv.reader(open(f"{REF}/secp256k1/schnorr.csv")))[1:]

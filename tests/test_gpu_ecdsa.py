@@ -199,3 +199,22 @@ def test_schnorr_bip340_vectors_and_corruptions():
     with pytest.raises(ValueError, match="expected Uint8Array of length 32"):
         schnorr.verify_batch(sigs[:1], msgs[:1], [pks[0] + b"\x00"])
     assert schnorr.verify(sigs[1], msgs[1], pks[1]) and schnorr.verify_batch([], [], []) == []
+
+
+def test_ecdh_shared_secret_batch():
+    """getSharedSecret for a batch (weierstrass.ts:1198-1210) on the Wycheproof ECDH vectors the reference tests
+    (test/secp256k1.test.ts:272-292) and against the oracle, compressed and uncompressed outputs."""
+    rows = load_golden("secp256k1_ecdh.json")
+    assert len(rows) > 100
+    privs = [bytes.fromhex(r["priv"]) for r in rows]
+    pubs = [bytes.fromhex(r["pub"]) for r in rows]
+    got = shim.getSharedSecretBatch(privs, pubs)
+    assert [g[1:].hex() for g in got] == [r["shared"].rjust(64, "0") for r in rows]
+    unc = shim.getSharedSecretBatch(privs[:20], pubs[:20], isCompressed=False)
+    from oracle.weierstrass import sec1_decode
+    for sk, pk, u in zip(privs[:20], pubs[:20], unc):
+        assert u == sec1_encode(sec1_decode(Secp256k1, pk).multiply(int.from_bytes(sk, "big")), False)
+    with pytest.raises(ValueError, match="invalid private key"):
+        shim.getSharedSecretBatch([bytes(32)], pubs[:1])
+    with pytest.raises(ValueError, match="invalid public key at index 1"):
+        shim.getSharedSecretBatch(privs[:2], [pubs[0], b"\x02" + (5).to_bytes(32, "big")])
