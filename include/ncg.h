@@ -220,7 +220,8 @@ const void* ncg_points_dev(const ncg_points* pts); /* device address of the affi
  * reference's subgroup test on every point); for uploaded affine points ncg_points_verify_subgroup runs the
  * test once - every point P must satisfy [z^2]P = -phi(P) resp. [z]P = -psi(P) - and enables the path only if
  * all pass.  A failing set is not an error: *out_bad_index names the first point outside the subgroup and the
- * set keeps using the generic path.  ncg_points_in_subgroup: 1 if the fast path is active. */
+ * set keeps using the generic path.  ncg_points_in_subgroup: 1 if the fast path is active.  On G1 a verified set
+ * also makes ncg_mul_var_batch_resident use the GLV ladder (two 128-bit half-scalars, half the doublings). */
 int ncg_points_verify_subgroup(ncg_ctx* ctx, ncg_points* pts, int64_t* out_bad_index);
 int ncg_points_in_subgroup(const ncg_points* pts);
 /* pippenger(c, <resident points>, scalars) and the batch multiplyUnsafe on them; scalars: host */

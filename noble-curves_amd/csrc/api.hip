@@ -645,8 +645,16 @@ int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* 
   char* d_out = d_sc + sc_b;
   char* d_inf = d_out + out_b;
   NCG_HIP(ctx, pins.h2d(d_sc, scalars, n * 32));
-  rc = ncg_mul_var_batch_dev(ctx, pts->curve, n, pts->d_pts, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
-  if (rc) return rc;
+  static const bool no_endo = std::getenv("NCG_NO_ENDO") != nullptr;
+  if (pts->d_endo && pts->curve == NCG_BLS12_381_G1 && !no_endo) {  // verified subgroup set: GLV ladder (mulvar_endo.hip)
+    rc = ensure_mul_ws(ctx, pts->curve, n, ctx->stream);
+    if (rc) return rc;
+    NCG_HIP(ctx, ncg::mul_var_batch_g1_subgroup((const uint32_t*)pts->d_pts, (const uint32_t*)d_sc, (uint32_t*)d_out, (uint8_t*)d_inf,
+                                                (int)n, (uint32_t*)ctx->mul_ws, ctx->stream));
+  } else {
+    rc = ncg_mul_var_batch_dev(ctx, pts->curve, n, pts->d_pts, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
+    if (rc) return rc;
+  }
   NCG_HIP(ctx, pins.d2h(out_affine, d_out, n * (size_t)pb));
   std::vector<uint8_t> inf_tmp;
   uint8_t* inf_dst = out_is_inf;

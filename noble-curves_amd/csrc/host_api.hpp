@@ -72,6 +72,10 @@ hipError_t msm_sum_partials(int curve, const uint32_t* d_gathered, int nparts, s
 size_t msm_fin_words(int curve, const MsmPlan& pl);
 size_t msm_acc_words(int curve);
 
+// G1 batch multiply on verified subgroup points (mulvar_endo.hip): GLV ladder with the phi endomorphism
+hipError_t mul_var_batch_g1_subgroup(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
+                                     uint32_t* jac_tmp, hipStream_t st);
+
 // secp256k1 ECDSA batch verify, scalar side (ecdsa.hip): sig = r || s (big-endian), hash = 32 bytes.
 hipError_t ecdsa_prepare(const uint8_t* d_sig, const uint8_t* d_hash, int n, bool low_s, uint32_t* d_u1, uint32_t* d_u2,
                          uint8_t* d_sig_ok, hipStream_t st);

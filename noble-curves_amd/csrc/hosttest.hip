@@ -105,6 +105,7 @@ int ht_mul_var(int curve, const uint32_t* pts, const uint32_t* scalars, uint32_t
   switch (curve) {
     case CURVE_SECP256K1: ht_mul_var_t<CurveSecp, 4>(pts, scalars, out, out_inf, n); return 0;
     case CURVE_BLS12_381_G1: ht_mul_var_t<CurveG1, 3>(pts, scalars, out, out_inf, n); return 0;
+    case 12: ht_mul_var_t<CurveG1E, 4>(pts, scalars, out, out_inf, n); return 0;  // subgroup points only (GLV ladder)
     case CURVE_BLS12_381_G2: ht_mul_var_t<CurveG2, 3>(pts, scalars, out, out_inf, n); return 0;
   }
   return -1;

@@ -170,7 +170,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
   SignedOddWindows<NL, W, M> w1, w2;
   bool neg1 = false, neg2 = false;
   if constexpr (C::GLV) {
-    GlvSplit gs = secp_glv_split(k);
+    GlvSplit gs = C::glv_split(k);
     w1.template init<5>(gs.k1);
     w2.template init<5>(gs.k2);
     neg1 = gs.k1neg;

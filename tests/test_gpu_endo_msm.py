@@ -102,3 +102,24 @@ def test_large_verified_set_against_generic_path(c, Pt, log2n):
     assert r_fast.toAffine() == r_plain.toAffine()
     assert r_fast.toAffine() == Pt.BASE.multiplyUnsafe(sum(k * x for k, x in zip(sc, a)) % BLS_R).toAffine()
     fast.free(); plain.free()
+
+
+def test_g1_verified_set_batch_multiply_uses_the_glv_ladder():
+    """multiplyUnsafeBatch on a verified G1 set (ncg_mul_var_batch_resident -> mulvar_endo.hip) against the
+    oracle and against the generic ladder on the same set: edge scalars, ZERO, 3000 rows (full waves)."""
+    c, Pt = G.bls12_381_G1_Point, BlsG1
+    rng = makeRng(0x61F)
+    edges = edge_scalars()
+    n = 3000
+    a = [rng.rndBelow(BLS_R - 1) + 1 for _ in range(n)]
+    pts = G.multiplyBaseBatch(c, a)
+    pts[7] = c.ZERO
+    sc = (edges + [rng.rndBelow(BLS_R) for _ in range(n)])[:n]
+    fast, plain = G.uploadPoints(c, pts, checkSubgroup=True), G.uploadPoints(c, pts)
+    assert fast.inSubgroup and not plain.inSubgroup
+    rf, rp = G.multiplyUnsafeBatch(c, fast, sc), G.multiplyUnsafeBatch(c, plain, sc)
+    assert [p.toAffine() for p in rf] == [p.toAffine() for p in rp]
+    for i in list(range(len(edges))) + [n - 1, n - 2]:
+        exp = Pt.ZERO if i == 7 else Pt.BASE.multiplyUnsafe(a[i] * sc[i] % BLS_R)
+        assert rf[i].toAffine() == exp.toAffine(), i
+    fast.free(); plain.free()

@@ -506,3 +506,23 @@ def test_bls_endomorphism_scalar_split():
         assert (k1 + k2 * X - k) % r == 0 and max(abs(k1), abs(k2)) <= X // 2 + 1
         d = hosttest.bls_endo_split(4, k)
         assert (sum(d[e] * z ** e for e in range(4)) - k) % r == 0 and max(abs(x) for x in d) <= z // 2 + 2
+
+
+def test_lane_ladder_g1_subgroup_glv():
+    from oracle.curves import BlsG1
+    """The GLV ladder for bls12-381 G1 points known to lie in the subgroup (CurveG1E: k = k1 + k2 z^2, second
+    stream on (beta x, y); csrc/curves.hpp, mulvar_endo.hip) through the host twin: edge scalars around the
+    split boundaries, ZERO, and random pairs against the oracle's multiplyUnsafe."""
+    z = 0xD201000000010000
+    X = z * z
+    rng = makeRng(0x61E)
+    ks = [0, 1, 2, 3, BLS_R - 1, BLS_R - 2, X, X - 1, X + 1, X // 2, X // 2 + 1, (X // 2) * X + X // 2 + 1, (X - 1) * X % BLS_R,
+          z, z ** 3, BLS_R // 2, 15, 16, 17]
+    ks += [rng.rndBelow(BLS_R) for _ in range(16)]
+    pts = [BlsG1.BASE.multiplyUnsafe(rng.rndBelow(BLS_R - 1) + 1) for _ in ks]
+    pts[5] = BlsG1.ZERO
+    out, inf = hosttest.mul_var(12, points_to_wire(BLS12_381_G1, pts), scalars_to_wire(ks))
+    for i, (p, k) in enumerate(zip(pts, ks)):
+        exp = p.multiplyUnsafe(k).toAffine()
+        assert wire_to_affine(BLS12_381_G1, out[i]) == exp, (i, hex(k))
+        assert bool(inf[i]) == (exp == BlsG1.ZERO.toAffine())
