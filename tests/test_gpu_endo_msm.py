@@ -123,3 +123,16 @@ def test_g1_verified_set_batch_multiply_uses_the_glv_ladder():
         exp = Pt.ZERO if i == 7 else Pt.BASE.multiplyUnsafe(a[i] * sc[i] % BLS_R)
         assert rf[i].toAffine() == exp.toAffine(), i
     fast.free(); plain.free()
+
+
+@pytest.mark.parametrize("c,Pt", CASES)
+def test_tiny_verified_sets(c, Pt):
+    """Window plans at the small end (c clamps to 3, one sort chunk): 1-, 2-, 5- and 33-point verified sets."""
+    rng = makeRng(0x7171 + c.CURVE_ID)
+    for n in (1, 2, 5, 33):
+        opts = [Pt.BASE.multiplyUnsafe(rng.rndBelow(BLS_R - 1) + 1) for _ in range(n)]
+        s = G.uploadPoints(c, [c.fromAffine(p.toAffine()) for p in opts], checkSubgroup=True)
+        assert s.inSubgroup
+        for sc in ([BLS_R - 1] * n, [rng.rndBelow(BLS_R) for _ in range(n)], [0] * n):
+            assert G.pippenger(c, s, sc).toAffine() == OC.pippenger(Pt, opts, sc).toAffine()
+        s.free()
