@@ -307,10 +307,20 @@ def scalars_to_ints(sc):
     return [int.from_bytes(arr[i].tobytes(), "little") for i in range(arr.shape[0])]
 
 
+PREWARM_S = float(os.environ.get("NCG_BENCH_PREWARM_S", "0.05"))
+
+
 def time_steps(fn, steps, warmup, dist_on):
     """W warm-up steps, then exactly K steps bracketed by barrier + synchronize; returns
     (wall seconds, HIP-event milliseconds on the launch stream)."""
     import torch.distributed as dist
+    # clock pre-warm (untimed, before the W warm-up steps): the boost clock of an idle MI355X needs a few tens of
+    # milliseconds of load to settle - the first workload after host-side setup otherwise reads ~5 % slow
+    t_pre, cnt = time.perf_counter(), 0
+    while time.perf_counter() - t_pre < PREWARM_S and cnt < 64:
+        fn()
+        torch.cuda.synchronize()
+        cnt += 1
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -683,14 +693,8 @@ def main():
         d_ok = torch.empty((nv,), dtype=torch.uint8, device=device)
         d_k2 = torch.empty((nv, 32), dtype=torch.uint8, device=device)
 
-        def step_ed():     # hash on the device + verify: the reference's verify() from (sig, msg, pk)
-            eng.ed25519_verify_batch_msgs_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_blob), dev_ptr(d_off), True, dev_ptr(d_ok), stream)
-
-        wall, ev_ms = time_steps(step_ed, K, W, dist_on)
-        wall = max_over_ranks(wall, dist_on, device)
-        got = d_ok.cpu().numpy().astype(bool)
-        assert np.array_equal(got, expect), "ed25519 verdict mismatch vs construction / zip215.json"
-        # kernel-only rate (pre-hashed challenges, the r01 figure) on the same batch
+        # kernel-only rate first (pre-hashed challenges, the r01 figure): it also brings the clocks to their steady
+        # state before the hash-inclusive measurement that the headline of this workload quotes
         eng.ed25519_challenge_batch_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_blob), dev_ptr(d_off), dev_ptr(d_k2), stream)
 
         def step_ed_k():
@@ -698,7 +702,15 @@ def main():
 
         wall_k, ev_ms_k = time_steps(step_ed_k, K, W, dist_on)
         wall_k = max_over_ranks(wall_k, dist_on, device)
-        assert np.array_equal(d_ok.cpu().numpy().astype(bool), expect)
+        assert np.array_equal(d_ok.cpu().numpy().astype(bool), expect), "ed25519 verdict mismatch (pre-hashed)"
+
+        def step_ed():     # hash on the device + verify: the reference's verify() from (sig, msg, pk)
+            eng.ed25519_verify_batch_msgs_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_blob), dev_ptr(d_off), True, dev_ptr(d_ok), stream)
+
+        wall, ev_ms = time_steps(step_ed, K, W, dist_on)
+        wall = max_over_ranks(wall, dist_on, device)
+        got = d_ok.cpu().numpy().astype(bool)
+        assert np.array_equal(got, expect), "ed25519 verdict mismatch vs construction / zip215.json"
         # strict (RFC 8032) mode once, untimed: construction for the synthetic part, the oracle for the 196 cases
         eng.ed25519_verify_batch_msgs_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_blob), dev_ptr(d_off), False, dev_ptr(d_ok), stream)
         torch.cuda.synchronize()
@@ -817,6 +829,8 @@ def main():
         result["extra"] = extra
     if rank == 0:
         result["host"] = host
+        result["prewarm"] = ("%.0f ms of untimed steps before the W warm-up steps of every timed loop (boost-clock settling; "
+                             "the K timed steps are unchanged)" % (PREWARM_S * 1e3))
         result["pmc"] = "live rocprofv3 passes in this run" if live else "committed profile profiles/r02_pmc.json"
         print(json.dumps(result))
         if args.out:
