@@ -10,6 +10,7 @@
 #include "ntt.hip"
 #include "h2c.hip"
 #include "endo.hpp"
+#include "ecdsa.hip"
 
 using namespace ncg;
 
@@ -206,6 +207,13 @@ int ht_bls_endo_split(int E, const uint32_t* k8, uint32_t* out) {
     return 0;
   }
   return -1;
+}
+
+// ECDSA scalar side of one signature through the lane code (ecdsa.hip): u1 = h / s, u2 = r / s mod n, 8 LE words each
+int ht_ecdsa_prepare(const uint8_t* sig64, const uint8_t* hash32, int low_s, uint32_t* u1, uint32_t* u2) {
+  uint8_t ok = 0;
+  ecdsa_prepare_host(sig64, hash32, low_s != 0, u1, u2, &ok);
+  return ok;
 }
 
 // ed25519 verify of one item on the CPU through the kernel's lane function

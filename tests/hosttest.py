@@ -32,6 +32,7 @@ def lib():
         _lib.ht_fe9_op.argtypes = [i32, i32, i32, vp, vp, vp]
         _lib.ht_ed25519_challenge.argtypes = [vp, vp, vp, ctypes.c_uint64, vp]
         _lib.ht_bls_endo_split.argtypes = [i32, vp, vp]
+        _lib.ht_ecdsa_prepare.argtypes = [vp, vp, i32, vp, vp]
     return _lib
 
 
@@ -166,3 +167,12 @@ def bls_endo_split(E, k):
         v = sum(int(o[e * 6 + i]) << (32 * i) for i in range(6))
         res.append(v - (1 << 192) if v >> 191 else v)
     return res
+
+
+def ecdsa_prepare(sig64, hash32, low_s=True):
+    """(ok, u1, u2): the scalar side of ECDSA verification (csrc/ecdsa.hip) for one signature, on the CPU."""
+    S = np.frombuffer(bytes(sig64), dtype=np.uint8).copy()
+    H = np.frombuffer(bytes(hash32), dtype=np.uint8).copy()
+    u1, u2 = np.zeros(8, dtype=np.uint32), np.zeros(8, dtype=np.uint32)
+    ok = lib().ht_ecdsa_prepare(S.ctypes.data, H.ctypes.data, 1 if low_s else 0, u1.ctypes.data, u2.ctypes.data)
+    return bool(ok), sum(int(u1[i]) << (32 * i) for i in range(8)), sum(int(u2[i]) << (32 * i) for i in range(8))

@@ -526,3 +526,24 @@ def test_lane_ladder_g1_subgroup_glv():
         exp = p.multiplyUnsafe(k).toAffine()
         assert wire_to_affine(BLS12_381_G1, out[i]) == exp, (i, hex(k))
         assert bool(inf[i]) == (exp == BlsG1.ZERO.toAffine())
+
+
+def test_ecdsa_scalar_side_lane_code():
+    """csrc/ecdsa.hip through the host twin: range checks on (r, s), the low-S rule, h = bits2int_modN and
+    u1 = h s^-1, u2 = r s^-1 modulo n (Montgomery arithmetic for a modulus with its top bit set, windowed Fermat
+    inversion) against Python big ints - weierstrass.ts:1596-1606."""
+    n = SECP256K1_N
+    rng = makeRng(0xEC0)
+    cases = [(1, 1, 0), (n - 1, n - 1, (1 << 256) - 1), (n - 1, 1, n), (2, n >> 1, n - 1), (3, (n >> 1) + 1, 5), (1 << 255, 7, 1 << 255)]
+    cases += [(rng.rndBelow(n - 1) + 1, rng.rndBelow(n - 1) + 1, rng.rndBelow(1 << 256)) for _ in range(200)]
+    for r, s, h in cases:
+        sig = r.to_bytes(32, "big") + s.to_bytes(32, "big")
+        for low in (True, False):
+            ok, u1, u2 = hosttest.ecdsa_prepare(sig, h.to_bytes(32, "big"), low)
+            exp_ok = not (low and s > n >> 1)
+            assert ok == exp_ok, (hex(r), hex(s), low)
+            if ok:
+                inv = pow(s, -1, n)
+                assert u1 == (h % n) * inv % n and u2 == r * inv % n
+    for r, s in ((0, 5), (5, 0), (n, 5), (5, n), ((1 << 256) - 1, 5)):
+        assert not hosttest.ecdsa_prepare(r.to_bytes(32, "big") + s.to_bytes(32, "big"), bytes(32), False)[0]
