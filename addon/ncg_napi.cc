@@ -302,6 +302,71 @@ static bool get_scalars(napi_env env, napi_value v, size_t n, std::vector<uint8_
   return true;
 }
 
+// packBigInts(values: BigInt[], byteLen) -> Uint8Array(values.length * byteLen), little-endian: the marshalling of
+// coordinates / scalars without hex strings (napi_get_value_bigint_words); negative or too wide values throw
+static napi_value PackBigInts(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  bool is_arr = false;
+  uint32_t m = 0, blen = 0;
+  if (argc < 2 || napi_is_array(env, argv[0], &is_arr) != napi_ok || !is_arr || napi_get_array_length(env, argv[0], &m) != napi_ok ||
+      napi_get_value_uint32(env, argv[1], &blen) != napi_ok || blen == 0 || blen > 64 || blen % 8) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: packBigInts(BigInt[], byteLen multiple of 8, <= 64)");
+    return nullptr;
+  }
+  uint8_t* out;
+  napi_value res = make_u8(env, (size_t)m * blen, &out);
+  if (!res) return nullptr;
+  const size_t maxw = blen / 8;
+  for (uint32_t i = 0; i < m; i++) {
+    napi_value e;
+    int sign = 0;
+    size_t words = 8;
+    uint64_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (napi_get_element(env, argv[0], i, &e) != napi_ok || napi_get_value_bigint_words(env, e, &sign, &words, w) != napi_ok) {
+      napi_throw_type_error(env, nullptr, "noble-gpu: packBigInts: expected bigint");
+      return nullptr;
+    }
+    if (sign != 0 || words > maxw) {
+      bool zero = true;
+      for (size_t k = 0; k < words && k < 8; k++) zero = zero && w[k] == 0;
+      if (!zero) {
+        napi_throw_range_error(env, nullptr, "noble-gpu: packBigInts: value out of range");
+        return nullptr;
+      }
+    }
+    memcpy(out + (size_t)i * blen, w, blen);  // little-endian host
+  }
+  return res;
+}
+
+// unpackBigInts(bytes: Uint8Array, byteLen) -> BigInt[]: little-endian fields of byteLen bytes each
+static napi_value UnpackBigInts(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  uint8_t* buf;
+  size_t len;
+  uint32_t blen = 0;
+  if (argc < 2 || !get_u8(env, argv[0], &buf, &len) || napi_get_value_uint32(env, argv[1], &blen) != napi_ok || blen == 0 || blen > 64 ||
+      blen % 8 || len % blen) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: unpackBigInts(Uint8Array, byteLen multiple of 8, <= 64)");
+    return nullptr;
+  }
+  const size_t m = len / blen;
+  napi_value arr;
+  NAPI_OK(napi_create_array_with_length(env, m, &arr));
+  for (size_t i = 0; i < m; i++) {
+    uint64_t w[8];
+    memcpy(w, buf + i * blen, blen);
+    napi_value v;
+    NAPI_OK(napi_create_bigint_words(env, 0, blen / 8, w, &v));
+    NAPI_OK(napi_set_element(env, arr, (uint32_t)i, v));
+  }
+  return arr;
+}
+
 static napi_value UploadPoints(napi_env env, napi_callback_info info) {  // (curveId, Uint8Array affine | encoded, encoded?, zip215?)
   size_t argc = 4;
   napi_value argv[4];
@@ -586,7 +651,7 @@ NAPI_MODULE_INIT() {
              {"decodePoints", DecodePoints}, {"encodePoints", EncodePoints},
              {"aggregateEncoded", AggregateEncoded},
              {"ntt", Ntt},               {"mapToCurve", MapToCurve},
-             {"uploadPoints", UploadPoints}, {"freePoints", FreePoints}, {"verifySubgroup", VerifySubgroup}, {"inSubgroup", InSubgroup},
+             {"packBigInts", PackBigInts}, {"unpackBigInts", UnpackBigInts}, {"uploadPoints", UploadPoints}, {"freePoints", FreePoints}, {"verifySubgroup", VerifySubgroup}, {"inSubgroup", InSubgroup},
              {"msmResident", MsmResident}, {"mulVarResident", MulVarResident},
              {"ed25519VerifyMsgs", Ed25519VerifyMsgs}, {"ecdsaVerify", EcdsaVerify},
              {"version", Version}};

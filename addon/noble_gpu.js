@@ -45,25 +45,40 @@ function validateMSMScalars(scalars, field) {   // curve.ts:398-404
     if (typeof s !== 'bigint' || s < 0n || s >= field.ORDER) throw new Error('invalid scalar at index ' + i);
   });
 }
+// coordinates / scalars cross as packed little-endian bytes; the BigInt -> bytes step runs natively
+// (napi_get_value_bigint_words), ~5x faster than the hex-string route it replaces
 function marshalPoints(c, id, points) {
   const pb = native.pointBytes(id), isFp2 = id === CURVE.BLS12_381_G2, fb = pb / (isFp2 ? 4 : 2);
-  const buf = new Uint8Array(points.length * pb);
-  points.forEach((p, i) => {
-    coordsOf(p.toAffine(), isFp2).forEach((v, j) => leBytes(id === CURVE.ED25519 ? v % c.Fp.ORDER : v, fb, buf, i * pb + j * fb));
-  });
-  return buf;
+  const flat = new Array(points.length * (isFp2 ? 4 : 2));
+  let k = 0;
+  for (const p of points) {
+    const a = p.toAffine();
+    if (isFp2) { flat[k++] = a.x.c0; flat[k++] = a.x.c1; flat[k++] = a.y.c0; flat[k++] = a.y.c1; }
+    else if (id === CURVE.ED25519) { flat[k++] = a.x % c.Fp.ORDER; flat[k++] = a.y % c.Fp.ORDER; }
+    else { flat[k++] = a.x; flat[k++] = a.y; }
+  }
+  return native.packBigInts(flat, fb);
 }
-function marshalScalars(scalars) {
-  const buf = new Uint8Array(scalars.length * 32);
-  scalars.forEach((s, i) => leBytes(s, 32, buf, 32 * i));
-  return buf;
-}
+function marshalScalars(scalars) { return native.packBigInts(scalars, 32); }
 function unmarshalPoint(c, id, buf, off, inf) {
   if (inf) return c.ZERO;
   const pb = native.pointBytes(id), isFp2 = id === CURVE.BLS12_381_G2, fb = pb / (isFp2 ? 4 : 2);
   const v = [];
   for (let j = 0; j < pb / fb; j++) v.push(leNumber(buf, off + j * fb, fb));
   return isFp2 ? c.fromAffine({ x: { c0: v[0], c1: v[1] }, y: { c0: v[2], c1: v[3] } }) : c.fromAffine({ x: v[0], y: v[1] });
+}
+// n points at the start of `out` (pb bytes each), their infinity flags at out[infOff + i]; `keep(i)` (optional) filters
+function unmarshalPoints(c, id, out, n, infOff, keep) {
+  const pb = native.pointBytes(id), isFp2 = id === CURVE.BLS12_381_G2, per = isFp2 ? 4 : 2, fb = pb / per;
+  const v = native.unpackBigInts(out.subarray(0, n * pb), fb);     // all coordinates in one native call
+  const res = new Array(n);
+  for (let i = 0; i < n; i++) {
+    if (keep && !keep(i)) { res[i] = null; continue; }
+    if (out[infOff + i] === 1) { res[i] = c.ZERO; continue; }
+    const o = i * per;
+    res[i] = isFp2 ? c.fromAffine({ x: { c0: v[o], c1: v[o + 1] }, y: { c0: v[o + 2], c1: v[o + 3] } }) : c.fromAffine({ x: v[o], y: v[o + 1] });
+  }
+  return res;
 }
 function curveId(c) {
   const id = registry.get(c);
@@ -128,9 +143,7 @@ function multiplyUnsafeBatchResident(set, scalars) {
   if (set.length === 0) return [];
   const n = set.length, pb = native.pointBytes(set.id);
   const out = native.mulVarResident(set.handle, sc);
-  const res = new Array(n);
-  for (let i = 0; i < n; i++) res[i] = unmarshalPoint(set.c, set.id, out, i * pb, out[n * pb + i] === 1);
-  return res;
+  return unmarshalPoints(set.c, set.id, out, n, n * pb);
 }
 // interleavedMSMUnsafe (curve.ts:938-959): MSM over a FIXED point set, returns the closure scalars -> Point.
 // Same argument checks and messages; the closure accepts at most points.length scalars, omitted trailing ones
@@ -203,7 +216,7 @@ function multiplyUnsafeBatch(c, points, scalars) {
   init();
   const n = points.length, pb = native.pointBytes(id);
   const out = native.mulVarBatch(id, marshalPoints(c, id, points), marshalScalars(scalars));
-  return points.map((_, i) => unmarshalPoint(c, id, out, i * pb, out[n * pb + i] === 1));
+  return unmarshalPoints(c, id, out, n, n * pb);
 }
 function multiplyBaseBatch(c, scalars) {
   const id = curveId(c);
@@ -215,7 +228,7 @@ function multiplyBaseBatch(c, scalars) {
   init();
   const n = scalars.length, pb = native.pointBytes(id);
   const out = native.mulBaseBatch(id, marshalScalars(scalars));
-  return scalars.map((_, i) => unmarshalPoint(c, id, out, i * pb, out[n * pb + i] === 1));
+  return unmarshalPoints(c, id, out, n, n * pb);
 }
 const ED_L = 0x1000000000000000000000000000000014def9dea2f79cd65812631a5cf5d3edn;
 function ed25519VerifyBatch(items, zip215) {   // items: [{sig, msg, publicKey}] of Uint8Array
@@ -249,9 +262,7 @@ function fromBytesBatch(c, encodings, zip215) {
   if (n === 0) return [];
   init();
   const out = native.decodePoints(id, buf, !!zip215);
-  const res = [];
-  for (let i = 0; i < n; i++) res.push(out[n * pb + i] ? unmarshalPoint(c, id, out, i * pb, out[n * pb + n + i] === 1) : null);
-  return res;
+  return unmarshalPoints(c, id, out, n, n * pb + n, (i) => out[n * pb + i] === 1);
 }
 function toBytesBatch(c, points) {
   const id = curveId(c), eb = ENC[id];
@@ -331,7 +342,7 @@ function hashToCurveBatch(c, msgs, DST) {
   init();
   const pb = native.pointBytes(id), n = msgs.length;
   const out = native.mapToCurve(id, count, u);
-  return msgs.map((_, i) => unmarshalPoint(c, id, out, i * pb, out[n * pb + i] === 1));
+  return unmarshalPoints(c, id, out, n, n * pb);
 }
 
 module.exports = { CURVE, init, initMulti, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
