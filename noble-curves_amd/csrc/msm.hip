@@ -61,12 +61,29 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
   }
 }
 
+// Block -> (chunk q, window w) of the two sort kernels.  With pl.xcd_map the grid is 1-D and the window index is
+// the fastest-varying one modulo 8, so every block of a window lands on the same XCD (consecutive workgroup ids
+// go round-robin over the 8 XCDs): the window's sorted list (4 MB at 2^20 points) is then written through ONE L2.
+__device__ __forceinline__ bool msm_sort_block(const MsmPlan& pl, int& q, int& w) {
+  if (pl.xcd_map) {
+    const int nw8 = (pl.nwin + 7) & ~7;
+    const int id = blockIdx.x;
+    w = id % nw8;
+    q = id / nw8;
+    return w < pl.nwin;
+  }
+  q = blockIdx.x;
+  w = blockIdx.y;
+  return true;
+}
+
 // ------------------------------------------------------------------ 3. counting sort
 // counts[(w*Q + q)*nb + b]: number of entries of chunk q in bucket b (bucket value b+1)
 __global__ void __launch_bounds__(1024) k_msm_hist(const int16_t* __restrict__ digits, uint32_t* __restrict__ counts,
                                                    MsmPlan pl) {
   extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
-  const int q = blockIdx.x, w = blockIdx.y;
+  int q, w;
+  if (!msm_sort_block(pl, q, w)) return;
   for (int b = threadIdx.x; b < pl.nb; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
@@ -128,7 +145,8 @@ __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict_
                                                       const uint32_t* __restrict__ bucket_start,
                                                       uint32_t* __restrict__ sorted, MsmPlan pl) {
   extern __shared__ __attribute__((aligned(16))) uint32_t offs[];
-  const int q = blockIdx.x, w = blockIdx.y;
+  int q, w;
+  if (!msm_sort_block(pl, q, w)) return;
   const uint32_t* src = counts + ((size_t)w * pl.Q + q) * pl.nb;
   const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
   for (int b = threadIdx.x; b < pl.nb; b += blockDim.x) offs[b] = src[b] + bs[b];
@@ -432,6 +450,8 @@ int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) {
   Q = std::min(Q, std::max(1, n / 4096));
   pl->Q = Q;
   pl->chunk = (n + Q - 1) / Q;
+  static const int xcd = [] { const char* e = std::getenv("NCG_MSM_XCD"); return e ? std::atoi(e) : 0; }();
+  pl->xcd_map = xcd;
   return 0;
 }
 
@@ -569,10 +589,11 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       if (dev >= 0 && dev < 16) attr_done[dev] = true;
     }
   }
-  hipLaunchKernelGGL(k_msm_hist, dim3(pl.Q, pl.nwin), dim3(1024), lds, st, digits, counts, pl);
+  const dim3 sort_grid = pl.xcd_map ? dim3((unsigned)(pl.Q * ((pl.nwin + 7) & ~7))) : dim3(pl.Q, pl.nwin);
+  hipLaunchKernelGGL(k_msm_hist, sort_grid, dim3(1024), lds, st, digits, counts, pl);
   hipLaunchKernelGGL(k_msm_bucket_totals, dim3((pl.nb + 255) / 256, pl.nwin), dim3(256), 0, st, counts, bstart, pl);
   hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), 0, st, bstart, pl);
-  hipLaunchKernelGGL(k_msm_scatter, dim3(pl.Q, pl.nwin), dim3(1024), lds, st, digits, counts, bstart, sorted, pl);
+  hipLaunchKernelGGL(k_msm_scatter, sort_grid, dim3(1024), lds, st, digits, counts, bstart, sorted, pl);
   {
     MsmSeg sg = msm_seg(pl);
     uint32_t* part_pts = (uint32_t*)(base + L.part_pts);

@@ -48,6 +48,7 @@ struct MsmPlan {
   // and its endomorphism images; n = endo * n_src entries, the windows cover the sub-scalar width only
   int endo = 0;
   int n_src = 0;
+  int xcd_map = 0;  // sort kernels: window-major block ids so that a window's blocks share an XCD (one L2)
 };
 
 // Group policy of the MSM kernels: how an input point is stored, what the bucket accumulator
