@@ -575,7 +575,7 @@ def main():
                               "traffic": traffic, "traffic_source": tsrc,
                               "kernel": "k_msm_accum (dominant; achieved is for the whole MSM incl. the host finish, traffic for that kernel)",
                               "valu": valu_block(pmc, key, wall / K, ref_mac_pt * nn,
-                                                 (g1_msm_mads_per_point(nwin, nn, 1 << (c - 1), curve == BLS12_381_G1) * (3 if curve == BLS12_381_G2 else 1)) * nn)}}
+                                                 (g1_msm_mads_per_point(nwin, nn, 1 << (c - 1), True) * (3 if curve == BLS12_381_G2 else 1)) * nn)}}
         if not dist_on:
             # the same MSM on a resident set verified to lie in the prime-order subgroup (ncg_points_verify_subgroup,
             # once per set): the scalars are split along the curve endomorphism (csrc/endo.hpp) - same group

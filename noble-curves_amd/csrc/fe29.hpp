@@ -500,6 +500,102 @@ NCG_DI Fe29x2P<2> operator*(const Fe29x2P<A>& a, const Fe29x2P<B>& b) {
   for (int i = 0; i < 14; i++) o.v[i] = r.v[i];
   return Fe29x2P<2>(o);
 }
+// a*b - c*d in Fp2 with ONE reduction per lane (the XYZZ pattern Y3 = R (Q - X3) - Y1 PPP): four products share
+// the column registers.  56 product terms + 14 reduction terms per column stay below 2^64 only because limb 13 of
+// any value below 2^12 p is at most 53256: the exact worst case over all columns is 0.922 * 2^64 (limbs 0..12 at
+// 2^29 - 1, limb 13 at its maximum, q at 2^29 - 1).
+//   even lane: a0 b0 + (-a1) b1 + (-c0) d0 + c1 d1        odd lane: a0 b1 + a1 b0 + (-c0) d1 + (-c1) d0
+template <int A, int B, int C, int D>
+NCG_DI Fe29x2P<2> f_mulsub(const Fe29x2P<A>& a, const Fe29x2P<B>& b, const Fe29x2P<C>& c, const Fe29x2P<D>& d) {
+  constexpr int KA = fe29_pow2ceil_log(A), KC = fe29_pow2ceil_log(C);
+  static_assert(4L * (1 << KA) * B + 4L * (1 << KC) * D <= (1L << 25), "fused paired products would exceed 2p: reduce an operand");
+  static_assert((1 << KA) <= 4096 && (1 << KC) <= 4096 && B <= 4096 && D <= 4096, "operand bound above 2^12 p: column bound unproven");
+  Fe29<2> o;
+#ifdef __HIP_DEVICE_COMPILE__
+  constexpr int N = 14;
+  constexpr uint32_t MASK = (1u << 29) - 1u;
+  const bool odd = pair_odd();
+  uint64_t t[2 * N];
+#pragma unroll
+  for (int k = 0; k < 2 * N; k++) t[k] = 0;
+  const Fe29<(1 << KA)> na = f_neg(a.h);  // 2^KA p - own a
+  const Fe29<(1 << KC)> nc = f_neg(c.h);  // 2^KC p - own c
+  {  // (odd ? a_partner : a_own) * b_own
+    uint32_t x[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const uint32_t pa = pair_swap(a.h.v[i]);
+      x[i] = odd ? pa : a.h.v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+      for (int j = 0; j < N; j++) t[i + j] += (uint64_t)x[i] * b.h.v[j];
+    }
+  }
+  {  // (odd ? a_own : -a_partner) * b_partner
+    uint32_t z[N], w[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const uint32_t pna = pair_swap(na.v[i]);
+      z[i] = odd ? a.h.v[i] : pna;
+      w[i] = pair_swap(b.h.v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+      for (int j = 0; j < N; j++) t[i + j] += (uint64_t)z[i] * w[j];
+    }
+  }
+  {  // (odd ? -c_partner : -c_own) * d_own
+    uint32_t x[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const uint32_t pnc = pair_swap(nc.v[i]);
+      x[i] = odd ? pnc : nc.v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+      for (int j = 0; j < N; j++) t[i + j] += (uint64_t)x[i] * d.h.v[j];
+    }
+  }
+  {  // (odd ? -c_own : c_partner) * d_partner
+    uint32_t z[N], w[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const uint32_t pc = pair_swap(c.h.v[i]);
+      z[i] = odd ? nc.v[i] : pc;
+      w[i] = pair_swap(d.h.v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+      for (int j = 0; j < N; j++) t[i + j] += (uint64_t)z[i] * w[j];
+    }
+  }
+  uint64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    uint64_t T = t[k] + carry;
+    uint32_t q = ((uint32_t)T * ParamsBls29::INV) & MASK;
+    T += (uint64_t)q * (uint32_t)ParamsBls29::P[0];
+    carry = T >> 29;
+#pragma unroll
+    for (int j = 1; j < N; j++) t[k + j] += (uint64_t)q * (uint32_t)ParamsBls29::P[j];
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N; k++) {
+    uint64_t T = t[k] + carry;
+    o.v[k - N] = (uint32_t)T & MASK;
+    carry = T >> 29;
+  }
+#else
+  for (int i = 0; i < 14; i++) o.v[i] = 0;
+#endif
+  return Fe29x2P<2>(o);
+}
+
 // even lane (a0 + a1)(a0 - a1), odd lane (a0 + a0) a1  (tower.ts:432-438 value)
 template <int A>
 NCG_DI Fe29x2P<2> f_sqr(const Fe29x2P<A>& a) {
