@@ -306,11 +306,13 @@ int ncg_ed25519_challenge_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_de
  * out_ok[i] = ecdsa.verify(sig[i], msgHash[i], publicKey[i], { prehash: false, format: 'compact', lowS })
  * (src/abstract/weierstrass.ts:1571-1620; the caller above Point.mulAddUnsafe, :1609).  sig: r || s, 32
  * big-endian bytes each (Signature.fromBytes 'compact': both in [1, n), else false); msgHash: 32 bytes, taken as
- * h = bits2int_modN; publicKey: 33-byte SEC1 compressed (Point.fromBytes; a key the reference rejects or the
- * identity gives false).  flags: NCG_ECDSA_LOW_S = the reference's default lowS rule (s <= n/2).  Everything -
+ * h = bits2int_modN; publicKey: 33-byte SEC1 compressed, or 65-byte uncompressed rows with NCG_ECDSA_PUB_UNCOMPRESSED
+ * (Point.fromBytes; a key the reference rejects or the identity gives false).  flags: NCG_ECDSA_LOW_S = the reference's default lowS rule (s <= n/2).  Everything -
  * key decompression, s^-1 mod n (one inversion per 16 signatures), u1 G + u2 P, R.x mod n == r - runs on the
  * device.  NCG_SECP256K1 only. */
 #define NCG_ECDSA_LOW_S 1
+#define NCG_ECDSA_PUB_UNCOMPRESSED 2 /* public keys are 65-byte uncompressed SEC1 rows (04 || x || y): prefix, range and
+                                        curve-equation checks on the device (weierstrass.ts:589-597), no square root */
 int ncg_ecdsa_verify_batch(ncg_ctx* ctx, int curve, size_t n, const void* sig64, const void* hash32,
                            const void* pub33, int flags, uint8_t* out_ok);
 int ncg_ecdsa_verify_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* sig64_dev,

@@ -422,18 +422,21 @@ class Engine:
                                                           d_ok, stream))
 
     def ecdsa_verify_batch(self, sigs, hashes, pubs, low_s=True):
-        """secp256k1: sigs uint8 [n,64] (r || s big-endian), hashes [n,32], pubs [n,33] SEC1 compressed -> bool [n]
-        (ecdsa.verify with prehash: false, format 'compact'; weierstrass.ts:1571-1620)."""
+        """secp256k1: sigs uint8 [n,64] (r || s big-endian), hashes [n,32], pubs [n,33] SEC1 compressed or [n,65]
+        uncompressed -> bool [n] (ecdsa.verify with prehash: false, format 'compact'; weierstrass.ts:1571-1620)."""
         sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 64)
         hashes = np.ascontiguousarray(hashes, dtype=np.uint8).reshape(-1, 32)
-        pubs = np.ascontiguousarray(pubs, dtype=np.uint8).reshape(-1, 33)
+        pubs = np.ascontiguousarray(pubs, dtype=np.uint8)
         n = sigs.shape[0]
+        kb = 65 if (pubs.ndim == 2 and pubs.shape[1] == 65) else 33
+        pubs = pubs.reshape(-1, kb)
         if hashes.shape[0] != n or pubs.shape[0] != n:
             raise ValueError("arrays of signatures, message hashes and public keys must have equal length")
         ok = np.zeros((n,), dtype=np.uint8)
         if n:
+            flags = (1 if low_s else 0) | (2 if kb == 65 else 0)
             self._check(self.lib.ncg_ecdsa_verify_batch(self.h, SECP256K1, n, sigs.ctypes.data, hashes.ctypes.data,
-                                                        pubs.ctypes.data, 1 if low_s else 0, ok.ctypes.data))
+                                                        pubs.ctypes.data, flags, ok.ctypes.data))
         return ok.astype(bool)
 
     def schnorr_verify_batch(self, sigs, challenges, pubs):
@@ -454,9 +457,9 @@ class Engine:
     def schnorr_verify_batch_dev(self, n, d_sigs, d_es, d_pubs, d_ok, stream=None):
         self._check(self.lib.ncg_schnorr_verify_batch_dev(self.h, n, d_sigs, d_es, d_pubs, d_ok, stream))
 
-    def ecdsa_verify_batch_dev(self, n, d_sigs, d_hashes, d_pubs, low_s, d_ok, stream=None):
-        self._check(self.lib.ncg_ecdsa_verify_batch_dev(self.h, SECP256K1, n, d_sigs, d_hashes, d_pubs, 1 if low_s else 0,
-                                                        d_ok, stream))
+    def ecdsa_verify_batch_dev(self, n, d_sigs, d_hashes, d_pubs, low_s, d_ok, stream=None, uncompressed=False):
+        self._check(self.lib.ncg_ecdsa_verify_batch_dev(self.h, SECP256K1, n, d_sigs, d_hashes, d_pubs,
+                                                        (1 if low_s else 0) | (2 if uncompressed else 0), d_ok, stream))
 
     def map_to_curve_batch(self, curve, u, count):
         """u uint8 [n, count * FIELD_BYTES * (2 for G2)] -> (affine [n, PB], is_inf [n]):

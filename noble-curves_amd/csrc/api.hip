@@ -1167,8 +1167,12 @@ int ncg_ecdsa_verify_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* si
   SigWs w;
   int rc = sig_ws(ctx, n, st, &w);
   if (rc) return rc;
-  rc = ncg_decode_points_batch_dev(ctx, curve, n, pub33_dev, 0, w.pub, w.pub_ok, w.pub_inf, st);
-  if (rc) return rc;
+  if (flags & NCG_ECDSA_PUB_UNCOMPRESSED) {  // 65-byte keys: range + curve-equation check, no square root
+    NCG_HIP(ctx, ncg::secp_load_uncompressed((const uint8_t*)pub33_dev, (uint32_t*)w.pub, w.pub_ok, w.pub_inf, (int)n, st));
+  } else {
+    rc = ncg_decode_points_batch_dev(ctx, curve, n, pub33_dev, 0, w.pub, w.pub_ok, w.pub_inf, st);
+    if (rc) return rc;
+  }
   NCG_HIP(ctx, ncg::ecdsa_prepare((const uint8_t*)sig64_dev, (const uint8_t*)hash32_dev, (int)n, (flags & NCG_ECDSA_LOW_S) != 0,
                                   (uint32_t*)w.u1, (uint32_t*)w.u2, w.pre_ok, st));
   rc = sig_mul_add(ctx, curve, n, w, st);
@@ -1234,15 +1238,16 @@ int ncg_ecdsa_verify_batch(ncg_ctx* ctx, int curve, size_t n, const void* sig64,
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   PinSet pins(ctx);
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  int rc = ensure_scratch(ctx, al(n * 64) + al(n * 32) + al(n * 33) + al(n) + 1024);
+  const size_t kb = (flags & NCG_ECDSA_PUB_UNCOMPRESSED) ? 65 : 33;  // bytes per key row
+  int rc = ensure_scratch(ctx, al(n * 64) + al(n * 32) + al(n * kb) + al(n) + 1024);
   if (rc) return rc;
   char* d_sig = (char*)ctx->scratch;
   char* d_hash = d_sig + al(n * 64);
   char* d_pub = d_hash + al(n * 32);
-  char* d_ok = d_pub + al(n * 33);
+  char* d_ok = d_pub + al(n * kb);
   NCG_HIP(ctx, pins.h2d(d_sig, sig64, n * 64));
   NCG_HIP(ctx, pins.h2d(d_hash, hash32, n * 32));
-  NCG_HIP(ctx, pins.h2d(d_pub, pub33, n * 33));
+  NCG_HIP(ctx, pins.h2d(d_pub, pub33, n * kb));
   rc = ncg_ecdsa_verify_batch_dev(ctx, curve, n, d_sig, d_hash, d_pub, flags, (uint8_t*)d_ok, ctx->stream);
   if (rc) return rc;
   NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));

@@ -218,6 +218,41 @@ hipError_t schnorr_finish(const uint8_t* d_sig, const uint32_t* d_R, const uint8
   return hipGetLastError();
 }
 
+// Uncompressed SEC1 keys (04 || x || y, 65 bytes): Point.fromBytes checks the prefix, 0 <= x, y < p and the curve
+// equation (weierstrass.ts:589-597, isValidXY) - no square root.  out: affine wire (x, y), ok, inf = 0.
+__global__ void __launch_bounds__(256) k_secp_load_uncompressed(const uint8_t* __restrict__ pub65, uint32_t* __restrict__ out,
+                                                                uint8_t* __restrict__ ok_out, uint8_t* __restrict__ inf_out, int n) {
+  using PR = ParamsSecpP;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* in = pub65 + (size_t)i * 65;
+  uint32_t xw[8], yw[8], p8[8];
+  be32_to_words(xw, in + 1);
+  be32_to_words(yw, in + 33);
+#pragma unroll
+  for (int j = 0; j < 8; j++) p8[j] = PR::P[j];
+  bool ok = in[0] == 4 && words_lt(xw, p8) && words_lt(yw, p8);
+  FpSecp x, y, seven = FpSecp::zero();
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    x.v[j] = ok ? xw[j] : 0u;
+    y.v[j] = ok ? yw[j] : 0u;
+  }
+  seven.v[0] = 7;
+  ok = ok && (fp_sqr<PR>(y) == fp_sqr<PR>(x) * x + seven);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    out[(size_t)i * 16 + j] = ok ? xw[j] : 0u;
+    out[(size_t)i * 16 + 8 + j] = ok ? yw[j] : 0u;
+  }
+  ok_out[i] = ok ? 1 : 0;
+  inf_out[i] = 0;
+}
+hipError_t secp_load_uncompressed(const uint8_t* d_pub65, uint32_t* d_out, uint8_t* d_ok, uint8_t* d_inf, int n, hipStream_t st) {
+  hipLaunchKernelGGL(k_secp_load_uncompressed, dim3((n + 255) / 256), dim3(256), 0, st, d_pub65, d_out, d_ok, d_inf, n);
+  return hipGetLastError();
+}
+
 hipError_t ecdsa_prepare(const uint8_t* d_sig, const uint8_t* d_hash, int n, bool low_s, uint32_t* d_u1, uint32_t* d_u2,
                          uint8_t* d_sig_ok, hipStream_t st) {
   const int lanes = (n + ECDSA_K - 1) / ECDSA_K;

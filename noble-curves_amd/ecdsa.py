@@ -109,7 +109,10 @@ def verify_batch(signatures, messages, publicKeys, lowS=True, prehash=True, form
         raise ValueError('Signature format must be "compact" or "der"')   # 'recovered' is not offered in batch
     S = np.zeros((n, 64), np.uint8)
     H = np.zeros((n, 32), np.uint8)
-    K = np.zeros((n, 33), np.uint8)
+    # all keys uncompressed (65 bytes, e.g. Ethereum-style callers): the rows go up as they are and the prefix /
+    # range / curve-equation checks run on the device; otherwise every key is brought to the 33-byte form here
+    all_unc = n > 0 and all(isinstance(k, (bytes, bytearray, memoryview, np.ndarray)) and len(k) == 65 for k in publicKeys)
+    K = np.zeros((n, 65 if all_unc else 33), np.uint8)
     live = np.zeros((n,), bool)
     for i in range(n):
         pk = _abytes(publicKeys[i], "publicKey")
@@ -128,7 +131,7 @@ def verify_batch(signatures, messages, publicKeys, lowS=True, prehash=True, form
                 if not (1 <= r < N and 1 <= s < N):
                     continue
                 sig = r.to_bytes(32, "big") + s.to_bytes(32, "big")
-            key = _compressed_key(pk)
+            key = pk if all_unc else _compressed_key(pk)
             if key is None:
                 continue
             h = bits2int(msg)
@@ -140,7 +143,8 @@ def verify_batch(signatures, messages, publicKeys, lowS=True, prehash=True, form
         live[i] = True
     if n == 0:
         return []
-    K[~live, 0] = 2                                                        # well-formed filler rows; verdict forced below
+    if not all_unc:
+        K[~live, 0] = 2                                                    # well-formed filler rows; verdict forced below
     eng = engine or get_engine()
     ok = eng.ecdsa_verify_batch(S, H, K, lowS)
     return [bool(a and b) for a, b in zip(ok, live)]

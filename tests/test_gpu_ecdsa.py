@@ -44,8 +44,18 @@ def test_reference_vectors():
     sigs = [bytes.fromhex(v["signature"]) for v in g["valid"]]
     msgs = [bytes.fromhex(v["m"]) for v in g["valid"]]
     assert all(shim.verify_batch(sigs, msgs, pubs, prehash=False))                  # test/secp256k1.test.ts:133-146
-    unc = [sec1_encode(Secp256k1.BASE.multiply(d), False) for d in ds[:40]]        # 65-byte keys
+    unc = [sec1_encode(Secp256k1.BASE.multiply(d), False) for d in ds[:40]]        # 65-byte keys: checked on the device
     assert all(shim.verify_batch(sigs[:40], msgs[:40], unc, prehash=False))
+    mixed = unc[:20] + pubs[20:40]                                                  # mixed lengths: host brings them to 33 bytes
+    assert all(shim.verify_batch(sigs[:40], msgs[:40], mixed, prehash=False))
+    bad = list(unc)
+    bad[1] = bad[1][:64] + bytes([bad[1][64] ^ 1])                                  # off the curve
+    bad[2] = b"\x05" + bad[2][1:]                                                   # wrong prefix
+    bad[3] = b"\x04" + P.to_bytes(32, "big") + bad[3][33:]                          # x = p
+    bad[4] = unc[5]                                                                 # another (valid) key
+    exp = [i not in (1, 2, 3, 4) for i in range(40)]
+    assert shim.verify_batch(sigs[:40], msgs[:40], bad, prehash=False) == exp
+    assert exp == [O.verify(s_, m_, k_, prehash=False) for s_, m_, k_ in zip(sigs[:40], msgs[:40], bad)]
     inv = g["invalid_verify"]                                                       # :263-270
     got = shim.verify_batch([bytes.fromhex(v["signature"]) for v in inv], [bytes.fromhex(v["m"]) for v in inv],
                             [bytes.fromhex(v["Q"]) for v in inv])
