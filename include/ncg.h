@@ -319,6 +319,15 @@ int ncg_ecdsa_verify_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* si
                                const void* hash32_dev, const void* pub33_dev, int flags,
                                uint8_t* out_ok_dev, void* stream);
 
+/* Public-key recovery for a batch: out[i] = Signature.fromBytes(sig65[i], 'recovered').recoverPublicKey(msgHash[i])
+ * (src/abstract/weierstrass.ts:1391-1407) as an affine wire point.  sig65: recovery id (0..3) || r || s, 32 big-endian
+ * bytes each; out_ok[i] = 0 where the reference throws (recid > 3, r or s outside [1, n), r + n >= p for recid 2 / 3,
+ * no point with that x, Q = O) and the point is then zeroed.  NCG_SECP256K1 only. */
+int ncg_ecdsa_recover_batch(ncg_ctx* ctx, int curve, size_t n, const void* sig65, const void* hash32,
+                            void* out_affine, uint8_t* out_ok);
+int ncg_ecdsa_recover_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* sig65_dev,
+                                const void* hash32_dev, void* out_affine_dev, uint8_t* out_ok_dev, void* stream);
+
 /* ---- secp256k1 BIP-340 Schnorr batch verification ----------------------------------------------
  * out_ok[i] = schnorr.verify(sig[i], msg[i], publicKey[i]) (src/secp256k1.ts:228-258) given the challenge
  * e[i] = int(taggedHash('BIP0340/challenge', r || pk || msg)) mod n as 32 big-endian bytes (:176-178; the host

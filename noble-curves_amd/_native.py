@@ -119,6 +119,8 @@ _OPTIONAL_PROTOS = {
     "ncg_msm_resident": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
     "ncg_msm_resident_dev": [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_ecdsa_verify_batch": [_vp, _i32, _sz, _vp, _vp, _vp, _i32, _vp],
+    "ncg_ecdsa_recover_batch": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
+    "ncg_ecdsa_recover_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp, _vp],
     "ncg_schnorr_verify_batch": [_vp, _sz, _vp, _vp, _vp, _vp],
     "ncg_schnorr_verify_batch_dev": [_vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "ncg_ecdsa_verify_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _i32, _vp, _vp],
@@ -438,6 +440,21 @@ class Engine:
             self._check(self.lib.ncg_ecdsa_verify_batch(self.h, SECP256K1, n, sigs.ctypes.data, hashes.ctypes.data,
                                                         pubs.ctypes.data, flags, ok.ctypes.data))
         return ok.astype(bool)
+
+    def ecdsa_recover_batch(self, sigs65, hashes):
+        """secp256k1: sigs65 uint8 [n,65] (recid || r || s), hashes [n,32] -> (affine points [n,64], ok [n] bool):
+        Signature.recoverPublicKey (weierstrass.ts:1391-1407)."""
+        sigs = np.ascontiguousarray(sigs65, dtype=np.uint8).reshape(-1, 65)
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint8).reshape(-1, 32)
+        n = sigs.shape[0]
+        if hashes.shape[0] != n:
+            raise ValueError("arrays of signatures and message hashes must have equal length")
+        out = np.zeros((n, 64), dtype=np.uint8)
+        ok = np.zeros((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_ecdsa_recover_batch(self.h, SECP256K1, n, sigs.ctypes.data, hashes.ctypes.data,
+                                                         out.ctypes.data, ok.ctypes.data))
+        return out, ok.astype(bool)
 
     def schnorr_verify_batch(self, sigs, challenges, pubs):
         """BIP-340: sigs uint8 [n,64], challenges [n,32] (e mod n, big-endian), pubs [n,32] x-only -> bool [n]

@@ -1182,6 +1182,59 @@ int ncg_ecdsa_verify_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* si
   return NCG_OK;
 }
 
+// Q[i] = recoverPublicKey(sig65[i], hash[i]) as an affine wire point, out_ok[i] = 0 where the reference throws
+int ncg_ecdsa_recover_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* sig65_dev, const void* hash32_dev,
+                                void* out_affine_dev, uint8_t* out_ok_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_SECP256K1) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ecdsa_recover: secp256k1 only");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig65_dev || !hash32_dev || !out_affine_dev || !out_ok_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ecdsa_recover: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  SigWs w;
+  int rc = sig_ws(ctx, n, st, &w);
+  if (rc) return rc;
+  NCG_HIP(ctx, ncg::ecdsa_recover_prepare((const uint8_t*)sig65_dev, (const uint8_t*)hash32_dev, (int)n, (uint32_t*)w.u1, (uint32_t*)w.u2,
+                                          (uint8_t*)w.pub33, w.pre_ok, st));
+  rc = ncg_decode_points_batch_dev(ctx, curve, n, w.pub33, 0, w.pub, w.pub_ok, w.pub_inf, st);  // R from (x, parity)
+  if (rc) return rc;
+  rc = ncg_mul_base_batch_dev(ctx, curve, n, w.u1, w.A, w.A_inf, st);
+  if (rc) return rc;
+  rc = ncg_mul_var_batch_dev(ctx, curve, n, w.pub, w.u2, w.B, w.B_inf, st);
+  if (rc) return rc;
+  rc = ncg_add_pairs_batch_dev(ctx, curve, n, w.A, w.B, 0, out_affine_dev, w.R_inf, st);
+  if (rc) return rc;
+  NCG_HIP(ctx, ncg::ecdsa_recover_finish((uint32_t*)out_affine_dev, w.R_inf, w.pre_ok, w.pub_ok, (int)n, out_ok_dev, st));
+  return NCG_OK;
+}
+
+int ncg_ecdsa_recover_batch(ncg_ctx* ctx, int curve, size_t n, const void* sig65, const void* hash32, void* out_affine,
+                            uint8_t* out_ok) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_SECP256K1) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ecdsa_recover: secp256k1 only");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig65 || !hash32 || !out_affine || !out_ok) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ecdsa_recover: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  int rc = ensure_scratch(ctx, al(n * 65) + al(n * 32) + al(n * 64) + al(n) + 1024);
+  if (rc) return rc;
+  char* d_sig = (char*)ctx->scratch;
+  char* d_hash = d_sig + al(n * 65);
+  char* d_out = d_hash + al(n * 32);
+  char* d_ok = d_out + al(n * 64);
+  NCG_HIP(ctx, pins.h2d(d_sig, sig65, n * 65));
+  NCG_HIP(ctx, pins.h2d(d_hash, hash32, n * 32));
+  rc = ncg_ecdsa_recover_batch_dev(ctx, curve, n, d_sig, d_hash, d_out, (uint8_t*)d_ok, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, pins.d2h(out_affine, d_out, n * 64));
+  NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NCG_OK;
+}
+
 int ncg_schnorr_verify_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* e32_dev, const void* pkx32_dev,
                                  uint8_t* out_ok_dev, void* stream) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");

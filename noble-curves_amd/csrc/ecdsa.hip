@@ -218,6 +218,122 @@ hipError_t schnorr_finish(const uint8_t* d_sig, const uint32_t* d_R, const uint8
   return hipGetLastError();
 }
 
+// ---- public-key recovery (Signature.recoverPublicKey, weierstrass.ts:1391-1407): sig65 = recid || r || s.
+// R = the point with x = r (+ n for recid 2, 3; must stay below p) and the parity of recid bit 0; u1 = -h r^-1,
+// u2 = s r^-1 (mod n); Q = u1 G + u2 R, rejected if O.  One lane handles K signatures with one inversion of the
+// product of their r values.  Writes the 33-byte encoding of R, u1, u2 and pre_ok.
+template <int K>
+NCG_DI void ecdsa_recover_lane(const uint8_t* __restrict__ sig65, const uint8_t* __restrict__ hash, int lo, int hi,
+                               uint32_t* __restrict__ u1, uint32_t* __restrict__ u2, uint8_t* __restrict__ pub33,
+                               uint8_t* __restrict__ pre_ok) {
+  uint32_t n8[8], p8[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    n8[i] = ParamsSecpN::P[i];
+    p8[i] = ParamsSecpP::P[i];
+  }
+  const Fn r2 = Fn::from_const(ParamsSecpN::R2);
+  Fn rv[K], pre[K];
+  bool ok[K];
+  Fn acc = Fn::one();
+  for (int j = 0; j < K; j++) {
+    const int idx = lo + j;
+    ok[j] = false;
+    rv[j] = Fn::one();
+    if (idx < hi) {
+      const uint8_t* sg = sig65 + (size_t)idx * 65;
+      const uint32_t recid = sg[0];
+      uint32_t r[8], s[8], radj[8];
+      be32_to_words(r, sg + 1);
+      be32_to_words(s, sg + 33);
+      bool good = recid < 4 && !mp_is_zero(r) && !mp_is_zero(s) && words_lt(r, n8) && words_lt(s, n8);
+      const uint32_t cy = mp_add<8>(radj, r, n8);
+      if (recid >= 2) good = good && cy == 0 && words_lt(radj, p8);  // Fp.isValid(r + n)
+      ok[j] = good;
+      if (good) rv[j] = fn_from_words(r) * r2;
+      // R's encoding: prefix 02 for an even y (recid bit 0 clear), x = radj big-endian
+      uint8_t* pk = pub33 + (size_t)idx * 33;
+      pk[0] = (recid & 1u) ? 3 : 2;
+#pragma unroll
+      for (int w = 0; w < 8; w++) {
+        const uint32_t v = recid >= 2 ? radj[7 - w] : r[7 - w];
+        pk[1 + 4 * w] = (uint8_t)(v >> 24);
+        pk[2 + 4 * w] = (uint8_t)(v >> 16);
+        pk[3 + 4 * w] = (uint8_t)(v >> 8);
+        pk[4 + 4 * w] = (uint8_t)v;
+      }
+    }
+    pre[j] = acc;
+    acc = acc * rv[j];
+  }
+  Fn inv = fn_inv(acc);
+  for (int j = K - 1; j >= 0; j--) {
+    const int idx = lo + j;
+    const Fn ir = inv * pre[j];  // r_j^-1 (Montgomery form)
+    inv = inv * rv[j];
+    if (idx >= hi) continue;
+    uint32_t s[8], h[8];
+    be32_to_words(s, sig65 + (size_t)idx * 65 + 33);
+    be32_to_words(h, hash + (size_t)idx * 32);
+    {
+      uint32_t d8[8];
+      const bool ge = mp_sub<8>(d8, h, n8) == 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) h[i] = ge ? d8[i] : h[i];
+    }
+    uint32_t ss[8];
+    {
+      uint32_t d8[8];
+      const bool ge = mp_sub<8>(d8, s, n8) == 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) ss[i] = ge ? d8[i] : s[i];
+    }
+    const Fn a = fn_from_words(h) * ir;   // h r^-1
+    const Fn b = fn_from_words(ss) * ir;  // s r^-1
+    uint32_t na[8];
+    mp_sub<8>(na, n8, a.v);               // -(h r^-1): n - a, or 0 when a == 0
+    const bool az = a.is_zero();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      u1[(size_t)idx * 8 + i] = (ok[j] && !az) ? na[i] : 0u;
+      u2[(size_t)idx * 8 + i] = ok[j] ? b.v[i] : 0u;
+    }
+    pre_ok[idx] = ok[j] ? 1 : 0;
+  }
+}
+__global__ void __launch_bounds__(64) k_ecdsa_recover_prepare(const uint8_t* __restrict__ sig65, const uint8_t* __restrict__ hash, int n,
+                                                              uint32_t* __restrict__ u1, uint32_t* __restrict__ u2,
+                                                              uint8_t* __restrict__ pub33, uint8_t* __restrict__ pre_ok) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const long lo = (long)t * 4;
+  if (lo >= n) return;
+  ecdsa_recover_lane<4>(sig65, hash, (int)lo, n, u1, u2, pub33, pre_ok);
+}
+// ok = the signature was well-formed, R decoded and Q != O; rejected rows get a zeroed point
+__global__ void __launch_bounds__(256) k_ecdsa_recover_finish(uint32_t* __restrict__ Q, const uint8_t* __restrict__ Q_inf,
+                                                              const uint8_t* __restrict__ pre_ok, const uint8_t* __restrict__ pub_ok,
+                                                              int n, uint8_t* __restrict__ out_ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool ok = pre_ok[i] != 0 && pub_ok[i] != 0 && Q_inf[i] == 0;
+  if (!ok) {
+#pragma unroll
+    for (int j = 0; j < 16; j++) Q[(size_t)i * 16 + j] = 0;
+  }
+  out_ok[i] = ok ? 1 : 0;
+}
+hipError_t ecdsa_recover_prepare(const uint8_t* d_sig65, const uint8_t* d_hash, int n, uint32_t* d_u1, uint32_t* d_u2,
+                                 uint8_t* d_pub33, uint8_t* d_pre_ok, hipStream_t st) {
+  const int lanes = (n + 3) / 4;
+  hipLaunchKernelGGL(k_ecdsa_recover_prepare, dim3((lanes + 63) / 64), dim3(64), 0, st, d_sig65, d_hash, n, d_u1, d_u2, d_pub33, d_pre_ok);
+  return hipGetLastError();
+}
+hipError_t ecdsa_recover_finish(uint32_t* d_Q, const uint8_t* d_Q_inf, const uint8_t* d_pre_ok, const uint8_t* d_pub_ok, int n,
+                                uint8_t* d_out_ok, hipStream_t st) {
+  hipLaunchKernelGGL(k_ecdsa_recover_finish, dim3((n + 255) / 256), dim3(256), 0, st, d_Q, d_Q_inf, d_pre_ok, d_pub_ok, n, d_out_ok);
+  return hipGetLastError();
+}
+
 // Uncompressed SEC1 keys (04 || x || y, 65 bytes): Point.fromBytes checks the prefix, 0 <= x, y < p and the curve
 // equation (weierstrass.ts:589-597, isValidXY) - no square root.  out: affine wire (x, y), ok, inf = 0.
 __global__ void __launch_bounds__(256) k_secp_load_uncompressed(const uint8_t* __restrict__ pub65, uint32_t* __restrict__ out,

@@ -154,6 +154,42 @@ def verify(signature, message, publicKey, **opts):
     return verify_batch([signature], [message], [publicKey], **opts)[0]
 
 
+def recoverPublicKeyBatch(signatures, messages, prehash=True, isCompressed=True, engine=None):
+    """[secp256k1.recoverPublicKey(sig, msg, {prehash}) for each pair] (weierstrass.ts:1621-1630): signatures in the
+    'recovered' format (65 bytes: recovery id || r || s), result = the key's SEC1 bytes.  Entries for which the
+    reference throws (bad recovery id, r / s out of range, no such R, Q = O) come back as None."""
+    n = len(signatures)
+    if len(messages) != n:
+        raise ValueError("arrays of signatures and messages must have equal length")
+    if not isinstance(prehash, bool):
+        raise TypeError('"prehash" expected boolean')
+    if n == 0:
+        return []
+    S = np.zeros((n, 65), np.uint8)
+    H = np.zeros((n, 32), np.uint8)
+    for i in range(n):
+        sig = _abytes(signatures[i], "signature")
+        if len(sig) != 65:
+            raise ValueError('"signature" expected Uint8Array of length 65, got length=%d' % len(sig))
+        msg = _abytes(messages[i], "message")
+        if prehash:
+            msg = hashlib.sha256(msg).digest()
+        S[i] = np.frombuffer(sig, np.uint8)
+        H[i] = np.frombuffer(bits2int(msg).to_bytes(32, "big"), np.uint8)
+    eng = engine or get_engine()
+    pts, ok = eng.ecdsa_recover_batch(S, H)
+    enc, enc_ok = eng.encode_points_batch(0, pts)                          # SEC1 compressed (curve id 0 = secp256k1)
+    out = []
+    for i in range(n):
+        if not (ok[i] and enc_ok[i]):
+            out.append(None)
+        elif isCompressed:
+            out.append(bytes(enc[i]))
+        else:
+            out.append(b"\x04" + bytes(pts[i][31::-1]) + bytes(pts[i][:31:-1]))
+    return out
+
+
 def getSharedSecretBatch(secretKeys, publicKeys, isCompressed=True, engine=None):
     """[secp256k1.getSharedSecret(sk, pk, isCompressed) for each pair] (weierstrass.ts:1198-1210): the point
     s * Point.fromBytes(pk) as SEC1 bytes.  Secret keys: 32 big-endian bytes in [1, n) (Fn.fromBytes +

@@ -139,3 +139,29 @@ def schnorr_verify(sig, message, public_key):
         return (y & 1) == 0 and x == r
     except ValueError:
         return False
+
+
+def recover_public_key(sig65, message, prehash=True):
+    """Signature.fromBytes(sig, 'recovered').recoverPublicKey (weierstrass.ts:1352-1366, :1391-1407, :1621-1630):
+    sig65 = recid || r || s; returns the point Q or raises ValueError where the reference throws."""
+    from .curves import SECP256K1_P as P
+    sig65 = bytes(sig65)
+    if len(sig65) != 65:
+        raise ValueError("bad recovered signature length")
+    msg = hashlib.sha256(bytes(message)).digest() if prehash else bytes(message)
+    rec = sig65[0]
+    r, s = int.from_bytes(sig65[1:33], "big"), int.from_bytes(sig65[33:], "big")
+    if not (1 <= r < N and 1 <= s < N):
+        raise ValueError("invalid signature: out of range")
+    if rec not in (0, 1, 2, 3):
+        raise ValueError("invalid recovery id")
+    radj = r + N if rec in (2, 3) else r
+    if not radj < P:
+        raise ValueError("invalid recovery id: sig.r+curve.n != R.x")
+    R = sec1_decode(Secp256k1, bytes([2 if rec & 1 == 0 else 3]) + radj.to_bytes(32, "big"))
+    ir = pow(radj, -1, N)
+    h = bits2int(msg) % N
+    Q = Secp256k1.BASE.mulAddUnsafe(-h * ir % N, R, s * ir % N)
+    if Q.is0():
+        raise ValueError("invalid recovery: point at infinify")
+    return Q

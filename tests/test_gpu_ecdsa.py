@@ -228,3 +228,40 @@ def test_ecdh_shared_secret_batch():
         shim.getSharedSecretBatch([bytes(32)], pubs[:1])
     with pytest.raises(ValueError, match="invalid public key at index 1"):
         shim.getSharedSecretBatch(privs[:2], [pubs[0], b"\x02" + (5).to_bytes(32, "big")])
+
+
+def test_recover_public_key_batch():
+    """recoverPublicKey (weierstrass.ts:1391-1407, :1621-1630; test/secp256k1.test.ts:299-306): for the reference's
+    RFC 6979 vectors exactly one recovery id gives back the signer's key; every id, valid or not, matches the oracle."""
+    g = load_golden("secp256k1_ecdsa.json")["valid"][:60]
+    ds = [int(v["d"], 16) for v in g]
+    pubs = keys_for(ds)
+    sigs, msgs, owner = [], [], []
+    for i, v in enumerate(g):
+        for rec in range(4):
+            sigs.append(bytes([rec]) + bytes.fromhex(v["signature"]))
+            msgs.append(bytes.fromhex(v["m"]))
+            owner.append(i)
+    sigs.append(bytes([4]) + sigs[0][1:]); msgs.append(msgs[0]); owner.append(0)             # bad recovery id
+    sigs.append(bytes([0]) + bytes(32) + sigs[0][33:]); msgs.append(msgs[0]); owner.append(0)  # r = 0
+    sigs.append(bytes([1]) + sigs[0][1:33] + N.to_bytes(32, "big")); msgs.append(msgs[0]); owner.append(0)  # s = n
+    got = shim.recoverPublicKeyBatch(sigs, msgs, prehash=False)
+    hits = [0] * len(g)
+    for sg, m, o, q in zip(sigs, msgs, owner, got):
+        try:
+            exp = sec1_encode(O.recover_public_key(sg, m, prehash=False))
+        except ValueError:
+            exp = None
+        assert q == exp, (o, sg[0])
+        if q == pubs[o]:
+            hits[o] += 1
+    assert hits == [1] * len(g)
+    unc = shim.recoverPublicKeyBatch(sigs[:8], msgs[:8], prehash=False, isCompressed=False)
+    for sg, m, q in zip(sigs[:8], msgs[:8], unc):
+        try:
+            exp = sec1_encode(O.recover_public_key(sg, m, prehash=False), False)
+        except ValueError:
+            exp = None
+        assert q == exp
+    with pytest.raises(ValueError, match="length 65"):
+        shim.recoverPublicKeyBatch([sigs[0][:64]], [msgs[0]])

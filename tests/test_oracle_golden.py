@@ -417,3 +417,22 @@ def test_schnorr_bip340_vectors():
     assert len(rows) >= 15 and any(r["result"] for r in rows) and not all(r["result"] for r in rows)
     for r in rows:
         assert ecdsa.schnorr_verify(bytes.fromhex(r["sig"]), bytes.fromhex(r["msg"]), bytes.fromhex(r["pub"])) == r["result"], r["comment"]
+
+
+def test_ecdsa_recover_reference_vectors():
+    """oracle recover_public_key on the reference's RFC 6979 vectors (test/secp256k1.test.ts:299-306: the key recovered
+    from a 'recovered'-format signature equals getPublicKey(d)): exactly one recovery id returns the signer's key."""
+    from oracle import ecdsa
+    for v in load("secp256k1_ecdsa.json")["valid"][:25]:
+        pub = Secp256k1.BASE.multiply(int(v["d"], 16)).toAffine()
+        hits = 0
+        for rec in range(4):
+            try:
+                q = ecdsa.recover_public_key(bytes([rec]) + bytes.fromhex(v["signature"]), bytes.fromhex(v["m"]), prehash=False)
+            except ValueError:
+                continue
+            hits += q.toAffine() == pub
+            # whatever comes back verifies the signature (the defining property of recovery)
+            from oracle.weierstrass import sec1_encode
+            assert ecdsa.verify(bytes.fromhex(v["signature"]), bytes.fromhex(v["m"]), sec1_encode(q), prehash=False, lowS=False)
+        assert hits == 1
