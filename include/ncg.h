@@ -339,6 +339,22 @@ int ncg_schnorr_verify_batch(ncg_ctx* ctx, size_t n, const void* sig64, const vo
 int ncg_schnorr_verify_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* e32_dev,
                                  const void* pkx32_dev, uint8_t* out_ok_dev, void* stream);
 
+/* ---- the two verifications from MESSAGES (hash on the device, csrc/sha256.hpp) -------------------------------
+ * ncg_ecdsa_verify_batch_msgs: ecdsa.verify(sig, msg, publicKey, { prehash: true, ... }) - SHA-256(msg) is the message
+ * representative (weierstrass.ts:1465-1470); ncg_schnorr_verify_batch_msgs: schnorr.verify(sig, msg, pk) with the tagged
+ * challenge hash (src/secp256k1.ts:129-137, :176-178).  msgs = all messages back to back, msg_off = n + 1 byte
+ * offsets (message i = msgs[msg_off[i] .. msg_off[i+1])); everything else as in the entry points above. */
+int ncg_ecdsa_verify_batch_msgs(ncg_ctx* ctx, int curve, size_t n, const void* sig64, const void* msgs,
+                                const uint64_t* msg_off, const void* pub, int flags, uint8_t* out_ok);
+int ncg_ecdsa_verify_batch_msgs_dev(ncg_ctx* ctx, int curve, size_t n, const void* sig64_dev, const void* msgs_dev,
+                                    const uint64_t* msg_off_dev, const void* pub_dev, int flags,
+                                    uint8_t* out_ok_dev, void* stream);
+int ncg_schnorr_verify_batch_msgs(ncg_ctx* ctx, size_t n, const void* sig64, const void* msgs,
+                                  const uint64_t* msg_off, const void* pkx32, uint8_t* out_ok);
+int ncg_schnorr_verify_batch_msgs_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* msgs_dev,
+                                      const uint64_t* msg_off_dev, const void* pkx32_dev, uint8_t* out_ok_dev,
+                                      void* stream);
+
 /* Runs instruction-rate / field-multiply micro-benchmark `kind` (see csrc/ubench.hip) and
  * returns the kernel time in milliseconds. */
 int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float* out_ms);

@@ -122,6 +122,10 @@ _OPTIONAL_PROTOS = {
     "ncg_ecdsa_recover_batch": [_vp, _i32, _sz, _vp, _vp, _vp, _vp],
     "ncg_ecdsa_recover_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp, _vp],
     "ncg_schnorr_verify_batch": [_vp, _sz, _vp, _vp, _vp, _vp],
+    "ncg_ecdsa_verify_batch_msgs": [_vp, _i32, _sz, _vp, _vp, _vp, _vp, _i32, _vp],
+    "ncg_ecdsa_verify_batch_msgs_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
+    "ncg_schnorr_verify_batch_msgs": [_vp, _sz, _vp, _vp, _vp, _vp, _vp],
+    "ncg_schnorr_verify_batch_msgs_dev": [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp],
     "ncg_schnorr_verify_batch_dev": [_vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "ncg_ecdsa_verify_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _i32, _vp, _vp],
     "ncg_points_verify_subgroup": [_vp, _vp, ctypes.POINTER(ctypes.c_int64)],
@@ -455,6 +459,45 @@ class Engine:
             self._check(self.lib.ncg_ecdsa_recover_batch(self.h, SECP256K1, n, sigs.ctypes.data, hashes.ctypes.data,
                                                          out.ctypes.data, ok.ctypes.data))
         return out, ok.astype(bool)
+
+    @staticmethod
+    def _msg_blob(msgs):
+        off = np.zeros((len(msgs) + 1,), np.uint64)
+        if len(msgs):
+            off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+        blob = np.frombuffer(b"".join(bytes(m) for m in msgs), np.uint8) if len(msgs) and off[-1] else np.zeros((0,), np.uint8)
+        return blob, off
+
+    def ecdsa_verify_batch_msgs(self, sigs, msgs, pubs, low_s=True):
+        """The same as ecdsa_verify_batch from the messages themselves: SHA-256 (the reference's prehash) on the device."""
+        sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 64)
+        pubs = np.ascontiguousarray(pubs, dtype=np.uint8)
+        n = sigs.shape[0]
+        kb = 65 if (pubs.ndim == 2 and pubs.shape[1] == 65) else 33
+        pubs = pubs.reshape(-1, kb)
+        if len(msgs) != n or pubs.shape[0] != n:
+            raise ValueError("arrays of signatures, messages and public keys must have equal length")
+        blob, off = self._msg_blob(msgs)
+        ok = np.zeros((n,), dtype=np.uint8)
+        if n:
+            flags = (1 if low_s else 0) | (2 if kb == 65 else 0)
+            self._check(self.lib.ncg_ecdsa_verify_batch_msgs(self.h, SECP256K1, n, sigs.ctypes.data, blob.ctypes.data if blob.size else None,
+                                                             off.ctypes.data, pubs.ctypes.data, flags, ok.ctypes.data))
+        return ok.astype(bool)
+
+    def schnorr_verify_batch_msgs(self, sigs, msgs, pubs):
+        """BIP-340 verification from the messages: the tagged challenge hash runs on the device too."""
+        sigs = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 64)
+        pubs = np.ascontiguousarray(pubs, dtype=np.uint8).reshape(-1, 32)
+        n = sigs.shape[0]
+        if len(msgs) != n or pubs.shape[0] != n:
+            raise ValueError("arrays of signatures, messages and public keys must have equal length")
+        blob, off = self._msg_blob(msgs)
+        ok = np.zeros((n,), dtype=np.uint8)
+        if n:
+            self._check(self.lib.ncg_schnorr_verify_batch_msgs(self.h, n, sigs.ctypes.data, blob.ctypes.data if blob.size else None,
+                                                               off.ctypes.data, pubs.ctypes.data, ok.ctypes.data))
+        return ok.astype(bool)
 
     def schnorr_verify_batch(self, sigs, challenges, pubs):
         """BIP-340: sigs uint8 [n,64], challenges [n,32] (e mod n, big-endian), pubs [n,32] x-only -> bool [n]

@@ -1114,13 +1114,13 @@ int ncg_ed25519_verify_batch_msgs(ncg_ctx* ctx, size_t n, const void* sig64, con
 // ---- secp256k1 ECDSA batch verify (weierstrass.ts:1571-1620): SEC1 decode of the keys, the scalar side
 // (ecdsa.hip), u1 G by the fixed-base table, u2 P by the variable-base ladder, one pairwise add, compare.
 struct SigWs {  // device buffers of the signature pipelines (ECDSA, Schnorr)
-  char *pub, *A, *B, *R, *u1, *u2, *pub33;
+  char *pub, *A, *B, *R, *u1, *u2, *pub33, *hash;
   uint8_t *pub_ok, *pub_inf, *pre_ok, *A_inf, *B_inf, *R_inf;
 };
 static int sig_ws(ncg_ctx* ctx, size_t n, hipStream_t st, SigWs* w) {
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t pt_b = al(n * 64), sc_b = al(n * 32), fl_b = al(n), pk_b = al(n * 33);
-  const size_t need = 4 * pt_b + 2 * sc_b + 6 * fl_b + pk_b;
+  const size_t need = 4 * pt_b + 3 * sc_b + 6 * fl_b + pk_b;
   if (ctx->ecdsa_ws_bytes < need) {
     NCG_HIP(ctx, hipStreamSynchronize(st));
     if (ctx->ecdsa_ws) (void)hipFree(ctx->ecdsa_ws);
@@ -1138,6 +1138,7 @@ static int sig_ws(ncg_ctx* ctx, size_t n, hipStream_t st, SigWs* w) {
   w->u1 = p;     p += sc_b;
   w->u2 = p;     p += sc_b;
   w->pub33 = p;  p += pk_b;
+  w->hash = p;   p += sc_b;
   w->pub_ok = (uint8_t*)p;   p += fl_b;
   w->pub_inf = (uint8_t*)p;  p += fl_b;
   w->pre_ok = (uint8_t*)p;   p += fl_b;
@@ -1255,6 +1256,87 @@ int ncg_schnorr_verify_batch_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, 
   NCG_HIP(ctx, ncg::schnorr_finish((const uint8_t*)sig64_dev, (const uint32_t*)w.R, w.R_inf, w.pre_ok, w.pub_ok, w.pub_inf, (int)n,
                                    out_ok_dev, st));
   return NCG_OK;
+}
+
+// ---- the same from messages: SHA-256 on the device (csrc/sha256.hpp) - the prehash of ecdsa.verify and the BIP-340
+// tagged challenge - then the entry points above
+int ncg_ecdsa_verify_batch_msgs_dev(ncg_ctx* ctx, int curve, size_t n, const void* sig64_dev, const void* msgs_dev,
+                                    const uint64_t* msg_off_dev, const void* pub_dev, int flags, uint8_t* out_ok_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (curve != NCG_SECP256K1) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ecdsa_verify: secp256k1 only");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64_dev || !msg_off_dev || !pub_dev || !out_ok_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ecdsa_verify_msgs: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  SigWs w;
+  int rc = sig_ws(ctx, n, st, &w);
+  if (rc) return rc;
+  NCG_HIP(ctx, ncg::sha256_msgs((const uint8_t*)msgs_dev, msg_off_dev, nullptr, nullptr, 0, (int)n, (uint8_t*)w.hash, st));
+  return ncg_ecdsa_verify_batch_dev(ctx, curve, n, sig64_dev, w.hash, pub_dev, flags, out_ok_dev, st);
+}
+
+int ncg_schnorr_verify_batch_msgs_dev(ncg_ctx* ctx, size_t n, const void* sig64_dev, const void* msgs_dev,
+                                      const uint64_t* msg_off_dev, const void* pkx32_dev, uint8_t* out_ok_dev, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64_dev || !msg_off_dev || !pkx32_dev || !out_ok_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: schnorr_verify_msgs: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  SigWs w;
+  int rc = sig_ws(ctx, n, st, &w);
+  if (rc) return rc;
+  NCG_HIP(ctx, ncg::sha256_msgs((const uint8_t*)msgs_dev, msg_off_dev, (const uint8_t*)sig64_dev, (const uint8_t*)pkx32_dev, 1, (int)n,
+                                (uint8_t*)w.hash, st));
+  return ncg_schnorr_verify_batch_dev(ctx, n, sig64_dev, w.hash, pkx32_dev, out_ok_dev, st);
+}
+
+// host-pointer variants: mode 0 = ECDSA (keys: kb bytes per row), mode 1 = Schnorr (32-byte x-only keys)
+static int sig_verify_msgs_host(ncg_ctx* ctx, int mode, size_t n, const void* sig64, const void* msgs, const uint64_t* msg_off,
+                                const void* keys, size_t kb, int flags, uint8_t* out_ok) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (n == 0) return NCG_OK;
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: batch too large");
+  if (!sig64 || !msg_off || !keys || !out_ok) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: verify_msgs: NULL buffer");
+  for (size_t i = 0; i < n; i++)
+    if (msg_off[i + 1] < msg_off[i]) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: verify_msgs: offsets must not decrease (index %zu)", i);
+  const size_t mbytes = (size_t)(msg_off[n] - msg_off[0]);
+  if (mbytes && !msgs) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: verify_msgs: NULL message buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  PinSet pins(ctx);
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t off_b = (n + 1) * 8;
+  int rc = ensure_scratch(ctx, al(n * 64) + al(n * kb) + al(off_b) + al(mbytes + 8) + al(n) + 1024);
+  if (rc) return rc;
+  char* d_sig = (char*)ctx->scratch;
+  char* d_key = d_sig + al(n * 64);
+  char* d_off = d_key + al(n * kb);
+  char* d_msg = d_off + al(off_b);
+  char* d_ok = d_msg + al(mbytes + 8);
+  NCG_HIP(ctx, pins.h2d(d_sig, sig64, n * 64));
+  NCG_HIP(ctx, pins.h2d(d_key, keys, n * kb));
+  std::vector<uint64_t> rel(n + 1);
+  for (size_t i = 0; i <= n; i++) rel[i] = msg_off[i] - msg_off[0];
+  NCG_HIP(ctx, hipMemcpyAsync(d_off, rel.data(), off_b, hipMemcpyHostToDevice, ctx->stream));
+  if (mbytes) NCG_HIP(ctx, pins.h2d(d_msg, (const char*)msgs + msg_off[0], mbytes));
+  if (mode == 0)
+    rc = ncg_ecdsa_verify_batch_msgs_dev(ctx, NCG_SECP256K1, n, d_sig, d_msg, (const uint64_t*)d_off, d_key, flags, (uint8_t*)d_ok, ctx->stream);
+  else
+    rc = ncg_schnorr_verify_batch_msgs_dev(ctx, n, d_sig, d_msg, (const uint64_t*)d_off, d_key, (uint8_t*)d_ok, ctx->stream);
+  if (rc) return rc;
+  NCG_HIP(ctx, pins.d2h(out_ok, d_ok, n));
+  NCG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `rel` alive until its copy is done
+  return NCG_OK;
+}
+int ncg_ecdsa_verify_batch_msgs(ncg_ctx* ctx, int curve, size_t n, const void* sig64, const void* msgs, const uint64_t* msg_off,
+                                const void* pub, int flags, uint8_t* out_ok) {
+  if (ctx && curve != NCG_SECP256K1) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: ecdsa_verify: secp256k1 only");
+  return sig_verify_msgs_host(ctx, 0, n, sig64, msgs, msg_off, pub, (flags & NCG_ECDSA_PUB_UNCOMPRESSED) ? 65 : 33, flags, out_ok);
+}
+int ncg_schnorr_verify_batch_msgs(ncg_ctx* ctx, size_t n, const void* sig64, const void* msgs, const uint64_t* msg_off,
+                                  const void* pkx32, uint8_t* out_ok) {
+  return sig_verify_msgs_host(ctx, 1, n, sig64, msgs, msg_off, pkx32, 32, 0, out_ok);
 }
 
 int ncg_schnorr_verify_batch(ncg_ctx* ctx, size_t n, const void* sig64, const void* e32, const void* pkx32, uint8_t* out_ok) {

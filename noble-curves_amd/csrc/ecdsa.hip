@@ -8,6 +8,7 @@
 // inversion (Montgomery's trick, the shape of FpInvertBatch, modular.ts:722-747), and the final comparison.
 #include "host_api.hpp"
 #include "scalar.hpp"
+#include "sha256.hpp"
 
 namespace ncg {
 
@@ -366,6 +367,56 @@ __global__ void __launch_bounds__(256) k_secp_load_uncompressed(const uint8_t* _
 }
 hipError_t secp_load_uncompressed(const uint8_t* d_pub65, uint32_t* d_out, uint8_t* d_ok, uint8_t* d_inf, int n, hipStream_t st) {
   hipLaunchKernelGGL(k_secp_load_uncompressed, dim3((n + 255) / 256), dim3(256), 0, st, d_pub65, d_out, d_ok, d_inf, n);
+  return hipGetLastError();
+}
+
+// ---- message hashing on the device (sha256.hpp): one lane per item; msgs = all messages back to back,
+// msg_off = n + 1 byte offsets.  mode 0: out[i] = SHA-256(msg_i) (the prehash of ecdsa.verify); mode 1: the BIP-340
+// challenge e_i = int(SHA-256(tag || tag || r_i || pk_i || msg_i)) mod n as 32 big-endian bytes.
+struct Bip340Tag {  // SHA-256("BIP0340/challenge")
+  static constexpr uint8_t H[32] = {0x7b, 0xb5, 0x2d, 0x7a, 0x9f, 0xef, 0x58, 0x32, 0x3e, 0xb1, 0xbf, 0x7a, 0x40, 0x7d, 0xb3, 0x82,
+                                    0xd2, 0xf3, 0xf2, 0xd8, 0x1b, 0xb1, 0x22, 0x4f, 0x49, 0xfe, 0x51, 0x8f, 0x6d, 0x48, 0xd3, 0x7c};
+};
+__global__ void __launch_bounds__(256) k_sha256_msgs(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ msg_off,
+                                                     const uint8_t* __restrict__ sig64, const uint8_t* __restrict__ pkx, int mode, int n,
+                                                     uint8_t* __restrict__ out32) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t lo = msg_off[i], hi = msg_off[i + 1];
+  uint32_t h[8];
+  if (mode == 0) {
+    sha256_3(h, nullptr, 0, nullptr, 0, msgs + lo, hi - lo);
+  } else {
+    uint8_t pre[128];
+    for (int j = 0; j < 32; j++) {
+      pre[j] = Bip340Tag::H[j];
+      pre[32 + j] = Bip340Tag::H[j];
+      pre[64 + j] = sig64[(size_t)i * 64 + j];
+      pre[96 + j] = pkx[(size_t)i * 32 + j];
+    }
+    sha256_3(h, pre, 128, nullptr, 0, msgs + lo, hi - lo);
+    // e = digest mod n: the digest is below 2^256 < 2n
+    uint32_t v[8], n8[8], d8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      v[j] = h[7 - j];
+      n8[j] = ParamsSecpN::P[j];
+    }
+    const bool ge = mp_sub<8>(d8, v, n8) == 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) h[7 - j] = ge ? d8[j] : v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    out32[(size_t)i * 32 + 4 * j] = (uint8_t)(h[j] >> 24);
+    out32[(size_t)i * 32 + 4 * j + 1] = (uint8_t)(h[j] >> 16);
+    out32[(size_t)i * 32 + 4 * j + 2] = (uint8_t)(h[j] >> 8);
+    out32[(size_t)i * 32 + 4 * j + 3] = (uint8_t)h[j];
+  }
+}
+hipError_t sha256_msgs(const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sig64, const uint8_t* d_pkx, int mode, int n,
+                       uint8_t* d_out32, hipStream_t st) {
+  hipLaunchKernelGGL(k_sha256_msgs, dim3((n + 255) / 256), dim3(256), 0, st, d_msgs, d_off, d_sig64, d_pkx, mode, n, d_out32);
   return hipGetLastError();
 }
 

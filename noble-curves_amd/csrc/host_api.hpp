@@ -81,6 +81,8 @@ hipError_t ecdsa_prepare(const uint8_t* d_sig, const uint8_t* d_hash, int n, boo
                          uint8_t* d_sig_ok, hipStream_t st);
 hipError_t ecdsa_finish(const uint8_t* d_sig, const uint32_t* d_R, const uint8_t* d_R_inf, const uint8_t* d_sig_ok,
                         const uint8_t* d_pub_ok, const uint8_t* d_pub_inf, int n, uint8_t* d_out_ok, hipStream_t st);
+hipError_t sha256_msgs(const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sig64, const uint8_t* d_pkx, int mode, int n,
+                       uint8_t* d_out32, hipStream_t st);
 hipError_t ecdsa_recover_prepare(const uint8_t* d_sig65, const uint8_t* d_hash, int n, uint32_t* d_u1, uint32_t* d_u2,
                                  uint8_t* d_pub33, uint8_t* d_pre_ok, hipStream_t st);
 hipError_t ecdsa_recover_finish(uint32_t* d_Q, const uint8_t* d_Q_inf, const uint8_t* d_pre_ok, const uint8_t* d_pub_ok, int n,

@@ -97,8 +97,10 @@ def _compressed_key(pk):
     return None
 
 
-def verify_batch(signatures, messages, publicKeys, lowS=True, prehash=True, format="compact", engine=None):
-    """[secp256k1.verify(sig, msg, key, {lowS, prehash, format}) for each triple] in one launch."""
+def verify_batch(signatures, messages, publicKeys, lowS=True, prehash=True, format="compact", engine=None, hash_on_device=True):
+    """[secp256k1.verify(sig, msg, key, {lowS, prehash, format}) for each triple] in one launch.  With prehash (the
+    reference's default) and hash_on_device the SHA-256 of every message runs in a HIP kernel too
+    (ncg_ecdsa_verify_batch_msgs); hash_on_device=False hashes here with hashlib."""
     n = len(signatures)
     if len(messages) != n or len(publicKeys) != n:
         raise ValueError("arrays of signatures, messages and public keys must have equal length")
@@ -114,6 +116,7 @@ def verify_batch(signatures, messages, publicKeys, lowS=True, prehash=True, form
     all_unc = n > 0 and all(isinstance(k, (bytes, bytearray, memoryview, np.ndarray)) and len(k) == 65 for k in publicKeys)
     K = np.zeros((n, 65 if all_unc else 33), np.uint8)
     live = np.zeros((n,), bool)
+    raw_msgs = []
     for i in range(n):
         pk = _abytes(publicKeys[i], "publicKey")
         msg = _abytes(messages[i], "message")
@@ -123,30 +126,35 @@ def verify_batch(signatures, messages, publicKeys, lowS=True, prehash=True, form
         sig = bytes(sig)
         if format == "compact" and len(sig) != 64:                         # validateSigLength: loud, like the reference
             raise ValueError('"signature" expected Uint8Array of length 64, got length=%d' % len(sig))
-        if prehash:
+        dev_hash = prehash and hash_on_device
+        if prehash and not dev_hash:
             msg = hashlib.sha256(msg).digest()
         try:
             if format == "der":
                 r, s = der_to_rs(sig)
                 if not (1 <= r < N and 1 <= s < N):
+                    raw_msgs.append(b"")
                     continue
                 sig = r.to_bytes(32, "big") + s.to_bytes(32, "big")
             key = pk if all_unc else _compressed_key(pk)
             if key is None:
+                raw_msgs.append(b"")
                 continue
-            h = bits2int(msg)
+            h = 0 if dev_hash else bits2int(msg)
         except ValueError:
+            raw_msgs.append(b"")
             continue                                                       # the reference's catch: false
         S[i] = np.frombuffer(sig, np.uint8)
         H[i] = np.frombuffer(h.to_bytes(32, "big"), np.uint8)
         K[i] = np.frombuffer(key, np.uint8)
+        raw_msgs.append(msg)
         live[i] = True
     if n == 0:
         return []
     if not all_unc:
         K[~live, 0] = 2                                                    # well-formed filler rows; verdict forced below
     eng = engine or get_engine()
-    ok = eng.ecdsa_verify_batch(S, H, K, lowS)
+    ok = eng.ecdsa_verify_batch_msgs(S, raw_msgs, K, lowS) if (prehash and hash_on_device) else eng.ecdsa_verify_batch(S, H, K, lowS)
     return [bool(a and b) for a, b in zip(ok, live)]
 
 

@@ -27,8 +27,9 @@ def challenge(r_bytes, pk_bytes, msg):
     return int.from_bytes(hashlib.sha256(_TAG + r_bytes + pk_bytes + msg).digest(), "big") % N
 
 
-def verify_batch(signatures, messages, publicKeys, engine=None):
-    """[schnorr.verify(sig, msg, pk) for each triple] in one launch."""
+def verify_batch(signatures, messages, publicKeys, engine=None, hash_on_device=True):
+    """[schnorr.verify(sig, msg, pk) for each triple] in one launch.  hash_on_device: the tagged challenge hash runs in
+    a HIP kernel as well (ncg_schnorr_verify_batch_msgs); False computes it here with hashlib."""
     n = len(signatures)
     if len(messages) != n or len(publicKeys) != n:
         raise ValueError("arrays of signatures, messages and public keys must have equal length")
@@ -37,6 +38,7 @@ def verify_batch(signatures, messages, publicKeys, engine=None):
     S = np.zeros((n, 64), np.uint8)
     E = np.zeros((n, 32), np.uint8)
     K = np.zeros((n, 32), np.uint8)
+    ms = []
     for i in range(n):
         sig = _abytes(signatures[i], 64, "signature")
         msg = _abytes(messages[i], None, "message")
@@ -44,10 +46,15 @@ def verify_batch(signatures, messages, publicKeys, engine=None):
         S[i] = np.frombuffer(sig, np.uint8)
         K[i] = np.frombuffer(pk, np.uint8)
         # pointToBytes(lift_x(pk)) is pk itself whenever lift_x succeeds; where it fails the verdict is false anyway
-        E[i] = np.frombuffer(challenge(sig[:32], pk, msg).to_bytes(32, "big"), np.uint8)
+        if hash_on_device:
+            ms.append(msg)
+        else:
+            E[i] = np.frombuffer(challenge(sig[:32], pk, msg).to_bytes(32, "big"), np.uint8)
     eng = engine or get_engine()
+    if hash_on_device:
+        return [bool(x) for x in eng.schnorr_verify_batch_msgs(S, ms, K)]
     return [bool(x) for x in eng.schnorr_verify_batch(S, E, K)]
 
 
-def verify(signature, message, publicKey, engine=None):
-    return verify_batch([signature], [message], [publicKey], engine)[0]
+def verify(signature, message, publicKey, engine=None, hash_on_device=True):
+    return verify_batch([signature], [message], [publicKey], engine, hash_on_device)[0]

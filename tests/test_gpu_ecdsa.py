@@ -265,3 +265,44 @@ def test_recover_public_key_batch():
         assert q == exp
     with pytest.raises(ValueError, match="length 65"):
         shim.recoverPublicKeyBatch([sigs[0][:64]], [msgs[0]])
+
+
+def test_device_hashing_matches_host_hashing():
+    """prehash: true / the BIP-340 challenge with SHA-256 on the device (csrc/sha256.hpp) against hashlib on the host:
+    message lengths around every padding boundary (0, 55, 56, 63, 64, 119, 120, ... bytes), long messages, and the
+    verdicts of both routes on signed and corrupted rows."""
+    from noble_curves_amd import schnorr
+    rng = makeRng(0x5A256)
+    lens = [0, 1, 31, 32, 54, 55, 56, 57, 63, 64, 65, 118, 119, 120, 127, 128, 129, 200, 1000, 4097]
+    n = len(lens)
+    msgs = [bytes((7 * i + j) & 255 for j in range(L)) for i, L in enumerate(lens)]
+    ds = [rng.rndBelow(N - 1) + 1 for _ in range(n)]
+    pubs = keys_for(ds)
+    hs = [int.from_bytes(hashlib.sha256(m).digest(), "big") % N for m in msgs]
+    sigs = sign_batch(ds, hs, rng)
+    sigs[3] = sigs[3][:40] + bytes([sigs[3][40] ^ 1]) + sigs[3][41:]
+    on_dev = shim.verify_batch(sigs, msgs, pubs)
+    on_host = shim.verify_batch(sigs, msgs, pubs, hash_on_device=False)
+    assert on_dev == on_host == [i != 3 for i in range(n)]
+    assert on_dev == [O.verify(s_, m_, p_) for s_, m_, p_ in zip(sigs, msgs, pubs)]
+    # BIP-340
+    Ps = G.multiplyBaseBatch(K1, ds)
+    ks = [rng.rndBelow(N - 1) + 1 for _ in range(n)]
+    Rs = G.multiplyBaseBatch(K1, ks)
+    ssig, pks = [], []
+    for i in range(n):
+        px, py = Ps[i].toAffine()
+        d = ds[i] if py % 2 == 0 else N - ds[i]
+        rx, ry = Rs[i].toAffine()
+        k = ks[i] if ry % 2 == 0 else N - ks[i]
+        pkb, rb = px.to_bytes(32, "big"), rx.to_bytes(32, "big")
+        ssig.append(rb + ((k + schnorr.challenge(rb, pkb, msgs[i]) * d) % N).to_bytes(32, "big"))
+        pks.append(pkb)
+    msgs2 = list(msgs)
+    msgs2[5] = msgs2[5] + b"!"
+    dev = schnorr.verify_batch(ssig, msgs2, pks)
+    host = schnorr.verify_batch(ssig, msgs2, pks, hash_on_device=False)
+    assert dev == host == [i != 5 for i in range(n)]
+    rows = load_golden("secp256k1_schnorr.json")                       # the BIP-340 vectors through both routes
+    sg, ms, pk = ([bytes.fromhex(r[k]) for r in rows] for k in ("sig", "msg", "pub"))
+    assert schnorr.verify_batch(sg, ms, pk) == schnorr.verify_batch(sg, ms, pk, hash_on_device=False) == [r["result"] for r in rows]
