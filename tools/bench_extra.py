@@ -100,28 +100,61 @@ def main():
     torch.cuda.synchronize()
     kenc, _ = eng.encode_points_batch(SECP256K1, kaff.cpu().numpy())
     rx = raff.cpu().numpy()[:, :32]
-    sig_rows, hash_rows = [], []
+    import hashlib
+    from noble_curves_amd.schnorr import challenge as bip340_challenge
+    ry = raff.cpu().numpy()[:, 32:]
+    kx = kaff.cpu().numpy()
+    sig_rows, hash_rows, msg_rows, ssig_rows, spk_rows = [], [], [], [], []
     for i in range(ne):
-        r = int.from_bytes(bytes(rx[i]), "little") % NN
-        h = (i * 0x9E3779B97F4A7C15 + 12345) % NN
-        sv = pow(kk[i], -1, NN) * (h + r * dkeys[i % 64]) % NN
+        rx_i = int.from_bytes(bytes(rx[i]), "little")
+        r = rx_i % NN
+        msg = (i * 0x9E3779B97F4A7C15 + 12345).to_bytes(32, "big")
+        hb = hashlib.sha256(msg).digest()
+        h = int.from_bytes(hb, "big") % NN
+        d = dkeys[i % 64]
+        sv = pow(kk[i], -1, NN) * (h + r * d) % NN
         if sv > NN >> 1:
             sv = NN - sv
         sig_rows.append(r.to_bytes(32, "big") + sv.to_bytes(32, "big"))
-        hash_rows.append(h.to_bytes(32, "big"))
+        hash_rows.append(hb)
+        msg_rows.append(msg)
+        # BIP-340 with the same nonce point and key (negated where y is odd)
+        py_odd = kx[i % 64][32] & 1
+        ry_odd = ry[i][0] & 1
+        dd = NN - d if py_odd else d
+        k2 = NN - kk[i] if ry_odd else kk[i]
+        pkb = bytes(kx[i % 64][31::-1])
+        rb = rx_i.to_bytes(32, "big")
+        ssig_rows.append(rb + ((k2 + bip340_challenge(rb, pkb, msg) * dd) % NN).to_bytes(32, "big"))
+        spk_rows.append(pkb)
     S = np.frombuffer(b"".join(sig_rows), np.uint8).reshape(ne, 64).copy()
     S[::16, 40] ^= 1
     # 2^18 distinct signatures tiled to 2^20 rows (the work per row does not depend on its neighbours)
-    Sd = torch.from_numpy(S).to(dev).repeat(4, 1).contiguous()
-    Hd = torch.from_numpy(np.frombuffer(b"".join(hash_rows), np.uint8).reshape(ne, 32).copy()).to(dev).repeat(4, 1).contiguous()
-    Kd = torch.from_numpy(np.ascontiguousarray(kenc[np.arange(ne) % 64])).to(dev).repeat(4, 1).contiguous()
-    okd = torch.empty((4 * ne,), dtype=torch.uint8, device=dev)
-    ev = lambda: eng.ecdsa_verify_batch_dev(4 * ne, P(Sd), P(Hd), P(Kd), True, P(okd), s)  # noqa: E731
-    ms_e = timeit(ev)
+    T = 4
+    Sd = torch.from_numpy(S).to(dev).repeat(T, 1).contiguous()
+    Hd = torch.from_numpy(np.frombuffer(b"".join(hash_rows), np.uint8).reshape(ne, 32).copy()).to(dev).repeat(T, 1).contiguous()
+    Md = torch.from_numpy(np.frombuffer(b"".join(msg_rows), np.uint8).reshape(ne, 32).copy()).to(dev).repeat(T, 1).contiguous()
+    Od = (torch.arange(T * ne + 1, dtype=torch.int64, device=dev) * 32).contiguous()
+    Kd = torch.from_numpy(np.ascontiguousarray(kenc[np.arange(ne) % 64])).to(dev).repeat(T, 1).contiguous()
+    okd = torch.empty((T * ne,), dtype=torch.uint8, device=dev)
     exp_ok = np.ones((ne,), np.uint8)
     exp_ok[::16] = 0
-    assert np.array_equal(okd.cpu().numpy(), np.tile(exp_ok, 4)), "ECDSA verdicts"
-    rate("secp256k1 ECDSA verify batch (compressed keys, 64 distinct)", 4 * ne, ms_e, "verifies")
+    ev = lambda: eng.ecdsa_verify_batch_dev(T * ne, P(Sd), P(Hd), P(Kd), True, P(okd), s)  # noqa: E731
+    ms_e = timeit(ev)
+    assert np.array_equal(okd.cpu().numpy(), np.tile(exp_ok, T)), "ECDSA verdicts"
+    rate("secp256k1 ECDSA verify batch (compressed keys, 64 distinct)", T * ne, ms_e, "verifies")
+    evm = lambda: eng._check(eng.lib.ncg_ecdsa_verify_batch_msgs_dev(eng.h, SECP256K1, T * ne, P(Sd), P(Md), P(Od), P(Kd), 1, P(okd), s))  # noqa: E731
+    ms_m = timeit(evm)
+    assert np.array_equal(okd.cpu().numpy(), np.tile(exp_ok, T)), "ECDSA verdicts (device hash)"
+    rate("secp256k1 ECDSA verify from 32-byte messages (SHA-256 on the device)", T * ne, ms_m, "verifies")
+    SS = np.frombuffer(b"".join(ssig_rows), np.uint8).reshape(ne, 64).copy()
+    SS[::16, 40] ^= 1
+    SSd = torch.from_numpy(SS).to(dev).repeat(T, 1).contiguous()
+    PKd = torch.from_numpy(np.frombuffer(b"".join(spk_rows), np.uint8).reshape(ne, 32).copy()).to(dev).repeat(T, 1).contiguous()
+    evs = lambda: eng._check(eng.lib.ncg_schnorr_verify_batch_msgs_dev(eng.h, T * ne, P(SSd), P(Md), P(Od), P(PKd), P(okd), s))  # noqa: E731
+    ms_s = timeit(evs)
+    assert np.array_equal(okd.cpu().numpy(), np.tile(exp_ok, T)), "Schnorr verdicts"
+    rate("secp256k1 BIP-340 Schnorr verify from 32-byte messages (tagged hash on the device)", T * ne, ms_s, "verifies")
     proj = torch.cat([kpts, torch.zeros((n, 32), dtype=torch.uint8, device=dev)], dim=1)
     proj[:, 64] = 1                                                        # Z = 1
     fn = lambda: eng._check(eng.lib.ncg_normalize_batch_dev(eng.h, SECP256K1, n, P(proj), P(dec), P(inf), s))  # noqa: E731
