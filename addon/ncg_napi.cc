@@ -274,6 +274,75 @@ static napi_value EcdsaVerify(napi_env env, napi_callback_info info) {
   return res;
 }
 
+// secpVerifyMsgs(kind, sigs [n*64], keys [n*33 | n*65 | n*32], msgs, offsets [(n+1)*8 LE], lowS) -> Uint8Array verdicts
+// kind 0: ECDSA with prehash (SHA-256 on the device), keys compressed (33 B) or uncompressed (65 B) rows;
+// kind 1: BIP-340 Schnorr, x-only keys (32 B), tagged challenge hash on the device
+static napi_value SecpVerifyMsgs(napi_env env, napi_callback_info info) {
+  size_t argc = 6;
+  napi_value argv[6];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  int32_t kind = 0;
+  uint8_t *sig, *pk, *msgs, *offs, *out;
+  size_t sgl, pkl, ml, ol;
+  bool low_s = true;
+  if (argc < 5 || napi_get_value_int32(env, argv[0], &kind) != napi_ok || !get_u8(env, argv[1], &sig, &sgl) || !get_u8(env, argv[2], &pk, &pkl) ||
+      !get_u8(env, argv[3], &msgs, &ml) || !get_u8(env, argv[4], &offs, &ol)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: secpVerifyMsgs(kind, sigs, keys, msgs, offsets, lowS)");
+    return nullptr;
+  }
+  if (argc >= 6) napi_get_value_bool(env, argv[5], &low_s);
+  const size_t n = sgl / 64;
+  const size_t kb = n ? pkl / n : 0;
+  if (sgl % 64 || ol != (n + 1) * 8 || (n && (pkl % n || (kind == 1 ? kb != 32 : (kb != 33 && kb != 65))))) {
+    napi_throw_error(env, nullptr, "arrays of signatures, public keys and message offsets must have matching lengths");
+    return nullptr;
+  }
+  std::vector<uint64_t> off(n + 1);
+  memcpy(off.data(), offs, ol);
+  if (off[n] > ml) {
+    napi_throw_error(env, nullptr, "noble-gpu: message offsets run past the message buffer");
+    return nullptr;
+  }
+  napi_value res = make_u8(env, n, &out);
+  if (!res) return nullptr;
+  int rc = 0;
+  if (n && kind == 0)
+    rc = ncg_ecdsa_verify_batch_msgs(g_ctx, NCG_SECP256K1, n, sig, msgs, off.data(), pk,
+                                     (low_s ? NCG_ECDSA_LOW_S : 0) | (kb == 65 ? NCG_ECDSA_PUB_UNCOMPRESSED : 0), out);
+  else if (n)
+    rc = ncg_schnorr_verify_batch_msgs(g_ctx, n, sig, msgs, off.data(), pk, out);
+  if (rc != 0) return throw_native(env);
+  return res;
+}
+// ecdsaRecover(sigs65 [n*65: recid || r || s], hashes [n*32]) -> Uint8Array(n*33 compressed keys || n ok flags)
+static napi_value EcdsaRecover(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  uint8_t *sig, *hs, *out;
+  size_t sgl, hl;
+  if (argc < 2 || !get_u8(env, argv[0], &sig, &sgl) || !get_u8(env, argv[1], &hs, &hl)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: ecdsaRecover(sigs65, hashes)");
+    return nullptr;
+  }
+  const size_t n = sgl / 65;
+  if (sgl % 65 || hl != n * 32) {
+    napi_throw_error(env, nullptr, "arrays of signatures and message hashes must have matching lengths");
+    return nullptr;
+  }
+  napi_value res = make_u8(env, n * 34, &out);
+  if (!res) return nullptr;
+  if (n) {
+    std::vector<uint8_t> aff(n * 64), ok(n), eok(n);
+    if (ncg_ecdsa_recover_batch(g_ctx, NCG_SECP256K1, n, sig, hs, aff.data(), ok.data()) != 0) return throw_native(env);
+    if (ncg_encode_points_batch(g_ctx, NCG_SECP256K1, n, aff.data(), out, eok.data()) != 0) return throw_native(env);
+    for (size_t i = 0; i < n; i++) out[n * 33 + i] = (ok[i] && eok[i]) ? 1 : 0;
+  }
+  return res;
+}
+
 static int encoded_bytes(int curve);
 // ---- resident point sets: upload once (affine wire points or compressed encodings), then MSMs / batch
 // multiplies with only the scalars crossing.  Handles are small integers; `scalars` may be a Uint8Array
@@ -653,7 +722,7 @@ NAPI_MODULE_INIT() {
              {"ntt", Ntt},               {"mapToCurve", MapToCurve},
              {"packBigInts", PackBigInts}, {"unpackBigInts", UnpackBigInts}, {"uploadPoints", UploadPoints}, {"freePoints", FreePoints}, {"verifySubgroup", VerifySubgroup}, {"inSubgroup", InSubgroup},
              {"msmResident", MsmResident}, {"mulVarResident", MulVarResident},
-             {"ed25519VerifyMsgs", Ed25519VerifyMsgs}, {"ecdsaVerify", EcdsaVerify},
+             {"ed25519VerifyMsgs", Ed25519VerifyMsgs}, {"ecdsaVerify", EcdsaVerify}, {"secpVerifyMsgs", SecpVerifyMsgs}, {"ecdsaRecover", EcdsaRecover},
              {"version", Version}};
   for (auto& f : fns) {
     napi_value v;

@@ -205,6 +205,68 @@ function ecdsaVerifyBatch(items, lowS) {
   return Array.from(native.ecdsaVerify(sig, hs, pk, lowS !== false)).map((x, i) => live[i] && x === 1);
 }
 
+function packMsgs(items, n) {
+  let total = 0;
+  items.forEach((it) => { total += it.msg.length; });
+  const msgs = new Uint8Array(total), offs = new Uint8Array(8 * (n + 1));
+  const dv = new DataView(offs.buffer);
+  let pos = 0;
+  items.forEach((it, i) => {
+    if (!(it.msg instanceof Uint8Array)) throw new Error('"message" expected Uint8Array');
+    msgs.set(it.msg, pos);
+    dv.setUint32(8 * i, pos % 4294967296, true); dv.setUint32(8 * i + 4, Math.floor(pos / 4294967296), true);
+    pos += it.msg.length;
+  });
+  dv.setUint32(8 * n, pos % 4294967296, true); dv.setUint32(8 * n + 4, Math.floor(pos / 4294967296), true);
+  return [msgs, offs];
+}
+// secp256k1.verify(sig, msg, publicKey, { lowS }) with the default prehash for a batch: SHA-256 of every message, key
+// handling (all keys 33-byte compressed or all 65-byte uncompressed) and the verification run on the device
+function ecdsaVerifyBatchMsgs(items, lowS) {
+  const n = items.length;
+  if (n === 0) return [];
+  const kb = items[0].publicKey.length;
+  if (kb !== 33 && kb !== 65) throw new Error('noble-gpu: ecdsaVerifyBatchMsgs: 33- or 65-byte public keys');
+  const sig = new Uint8Array(64 * n), pk = new Uint8Array(kb * n);
+  items.forEach((it, i) => {
+    if (!(it.sig instanceof Uint8Array) || it.sig.length !== 64) throw new Error('"signature" expected Uint8Array of length 64');
+    if (!(it.publicKey instanceof Uint8Array) || it.publicKey.length !== kb) throw new Error('noble-gpu: ecdsaVerifyBatchMsgs: mixed public-key lengths');
+    sig.set(it.sig, 64 * i); pk.set(it.publicKey, kb * i);
+  });
+  const [msgs, offs] = packMsgs(items, n);
+  init();
+  return Array.from(native.secpVerifyMsgs(0, sig, pk, msgs, offs, lowS !== false)).map((x) => x === 1);
+}
+// schnorr.verify(sig, msg, publicKey) (src/secp256k1.ts:228-258) for a batch, tagged challenge hash on the device
+function schnorrVerifyBatch(items) {
+  const n = items.length;
+  if (n === 0) return [];
+  const sig = new Uint8Array(64 * n), pk = new Uint8Array(32 * n);
+  items.forEach((it, i) => {
+    if (!(it.sig instanceof Uint8Array) || it.sig.length !== 64) throw new Error('"signature" expected Uint8Array of length 64');
+    if (!(it.publicKey instanceof Uint8Array) || it.publicKey.length !== 32) throw new Error('"publicKey" expected Uint8Array of length 32');
+    sig.set(it.sig, 64 * i); pk.set(it.publicKey, 32 * i);
+  });
+  const [msgs, offs] = packMsgs(items, n);
+  init();
+  return Array.from(native.secpVerifyMsgs(1, sig, pk, msgs, offs, true)).map((x) => x === 1);
+}
+// recoverPublicKey for a batch of { sig (65 bytes: recovery id || r || s), msgHash (32 bytes) }: compressed keys, null
+// where the reference throws
+function ecdsaRecoverBatch(items) {
+  const n = items.length;
+  if (n === 0) return [];
+  const sig = new Uint8Array(65 * n), hs = new Uint8Array(32 * n);
+  items.forEach((it, i) => {
+    if (!(it.sig instanceof Uint8Array) || it.sig.length !== 65) throw new Error('"signature" expected Uint8Array of length 65');
+    if (!(it.msgHash instanceof Uint8Array) || it.msgHash.length !== 32) throw new Error('"msgHash" expected Uint8Array of length 32');
+    sig.set(it.sig, 65 * i); hs.set(it.msgHash, 32 * i);
+  });
+  init();
+  const out = native.ecdsaRecover(sig, hs);
+  return items.map((_, i) => (out[33 * n + i] === 1 ? out.slice(33 * i, 33 * i + 33) : null));
+}
+
 function multiplyUnsafeBatch(c, points, scalars) {
   const id = curveId(c);
   validateMSMPoints(points, c);
@@ -346,5 +408,5 @@ function hashToCurveBatch(c, msgs, DST) {
 }
 
 module.exports = { CURVE, init, initMulti, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
-                   PointSet, uploadPoints, uploadEncoded, interleavedMSMUnsafe, pippengerResident, multiplyUnsafeBatchResident, ed25519VerifyBatchDevice, ecdsaVerifyBatch,
+                   PointSet, uploadPoints, uploadEncoded, interleavedMSMUnsafe, pippengerResident, multiplyUnsafeBatchResident, ed25519VerifyBatchDevice, ecdsaVerifyBatch, ecdsaVerifyBatchMsgs, schnorrVerifyBatch, ecdsaRecoverBatch,
                    fromBytesBatch, toBytesBatch, aggregateFromBytes, fftFr, hashToCurveBatch, native };

@@ -156,6 +156,17 @@ if (haveGpu) {
     assert.deepStrictEqual(gpu.ecdsaVerifyBatch(items), items.map(() => true));
     items[3].sig[40] ^= 1; items[5].msgHash[0] ^= 1; items[7].publicKey = keys[8];
     assert.deepStrictEqual(gpu.ecdsaVerifyBatch(items), items.map((_, i) => ![3, 5, 7].includes(i)));
+    // recovery: exactly one recovery id gives the signer's key back
+    const rec = [];
+    vec.slice(0, 6).forEach((v) => { for (let r = 0; r < 4; r++) rec.push({ sig: Uint8Array.from([r, ...hex(v.signature)]), msgHash: hex(v.m) }); });
+    const keysBack = gpu.ecdsaRecoverBatch(rec);
+    for (let i = 0; i < 6; i++) {
+      const hits = keysBack.slice(4 * i, 4 * i + 4).filter((k) => k !== null && Buffer.from(k).equals(Buffer.from(keys[i]))).length;
+      assert.strictEqual(hits, 1);
+    }
+    // BIP-340 vectors (test/vectors/secp256k1/schnorr.csv via tests/golden): hash and verification on the device
+    const sv = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', 'secp256k1_schnorr.json')));
+    assert.deepStrictEqual(gpu.schnorrVerifyBatch(sv.map((r) => ({ sig: hex(r.sig), msg: hex(r.msg), publicKey: hex(r.pub) }))), sv.map((r) => r.result));
   }
   // ed25519 from messages (hash on the device): RFC 8032 test 2 and a corrupted copy
   {
