@@ -99,7 +99,8 @@ int msm_make_plan_endo(int curve, int n_src, int c_override, MsmPlan* pl) {
   }
   static const uint32_t BLS_R[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
   for (int i = 0; i < 8; i++) pl->order[i] = BLS_R[i];
-  int Q = std::max(1, 1024 / pl->nwin);
+  static const int q_blocks = [] { const char* e = std::getenv("NCG_MSM_QBLOCKS"); return e ? std::max(64, std::atoi(e)) : 512; }();
+  int Q = std::max(1, q_blocks / pl->nwin);
   Q = std::min(Q, std::max(1, n / 4096));
   pl->Q = Q;
   pl->chunk = (n + Q - 1) / Q;
