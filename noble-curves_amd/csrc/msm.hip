@@ -113,15 +113,20 @@ __global__ void __launch_bounds__(256) k_msm_bucket_totals(uint32_t* __restrict_
   bucket_start[(size_t)w * (pl.nb + 1) + b] = tot;  // size for now; k_msm_scan turns it into a start
 }
 
-// One block per window: exclusive scan of the bucket sizes -> bucket_start[w][0..nb].
+// One block per window: exclusive scan of the bucket sizes -> bucket_start[w][0..nb].  The sizes are staged in
+// LDS with coalesced loads (row stride padded by one word per 32 so that the per-thread runs do not share a bank),
+// every thread scans its run of nb / 1024 values there, a Hillis-Steele scan joins the per-thread totals.
 __global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ bucket_start, MsmPlan pl) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t sizes[];   // nb + nb / 32 words
   __shared__ uint32_t part[1024];
   const int w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  for (int b = t; b < pl.nb; b += T) sizes[b + (b >> 5)] = bs[b];
+  __syncthreads();
   const int per = (pl.nb + T - 1) / T;
   const int b0 = min(pl.nb, t * per), b1 = min(pl.nb, b0 + per);
-  uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
   uint32_t mine = 0;
-  for (int b = b0; b < b1; b++) mine += bs[b];
+  for (int b = b0; b < b1; b++) mine += sizes[b + (b >> 5)];
   part[t] = mine;
   __syncthreads();
   for (int off = 1; off < T; off <<= 1) {  // inclusive Hillis-Steele scan of per-thread totals
@@ -132,10 +137,12 @@ __global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ bucket
   }
   uint32_t run = part[t] - mine;
   for (int b = b0; b < b1; b++) {
-    uint32_t size = bs[b];
-    bs[b] = run;
+    const uint32_t size = sizes[b + (b >> 5)];
+    sizes[b + (b >> 5)] = run;
     run += size;
   }
+  __syncthreads();
+  for (int b = t; b < pl.nb; b += T) bs[b] = sizes[b + (b >> 5)];
   if (t == T - 1) bs[pl.nb] = part[T - 1];
 }
 
@@ -588,13 +595,15 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       if (e != hipSuccess) return e;
       e = hipFuncSetAttribute((const void*)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
       if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute((const void*)k_msm_scan, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds + max_lds / 32 + 64);
+      if (e != hipSuccess) return e;
       if (dev >= 0 && dev < 16) attr_done[dev] = true;
     }
   }
   const dim3 sort_grid = pl.xcd_map ? dim3((unsigned)(pl.Q * ((pl.nwin + 7) & ~7))) : dim3(pl.Q, pl.nwin);
   hipLaunchKernelGGL(k_msm_hist, sort_grid, dim3(1024), lds, st, digits, counts, pl);
   hipLaunchKernelGGL(k_msm_bucket_totals, dim3((pl.nb + 255) / 256, pl.nwin), dim3(256), 0, st, counts, bstart, pl);
-  hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), 0, st, bstart, pl);
+  hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), (size_t)(pl.nb + pl.nb / 32 + 1) * 4, st, bstart, pl);
   hipLaunchKernelGGL(k_msm_scatter, sort_grid, dim3(1024), lds, st, digits, counts, bstart, sorted, pl);
   {
     MsmSeg sg = msm_seg(pl);
