@@ -310,9 +310,31 @@ def scalars_to_ints(sc):
 PREWARM_S = float(os.environ.get("NCG_BENCH_PREWARM_S", "0.05"))
 
 
+class StepTimes(tuple):
+    """(wall seconds, HIP-event milliseconds) of the K timed steps, plus the per-step distributions:
+    `ev` = HIP-event time between consecutive steps on the launch stream, `wl` = host wall clock per step
+    (for calls that synchronise inside - the MSM - this is the step's latency; for asynchronous launches it
+    is the enqueue time and the event figure is the one that counts)."""
+
+    def __new__(cls, wall, ev_ms, ev_steps, wl_steps):
+        o = super().__new__(cls, (wall, ev_ms))
+        o.ev_steps, o.wl_steps = ev_steps, wl_steps
+        return o
+
+    @staticmethod
+    def _dist(v):
+        s = sorted(v)
+        return {"min": s[0], "median": s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2]),
+                "max": s[-1], "list": [round(x, 4) for x in v]}
+
+    def dist(self):
+        return {"event_ms": self._dist(self.ev_steps), "wall_ms": self._dist(self.wl_steps)}
+
+
 def time_steps(fn, steps, warmup, dist_on):
-    """W warm-up steps, then exactly K steps bracketed by barrier + synchronize; returns
-    (wall seconds, HIP-event milliseconds on the launch stream)."""
+    """W warm-up steps, then exactly K steps bracketed by barrier + synchronize; returns a StepTimes:
+    (wall seconds, HIP-event milliseconds on the launch stream) + per-step event / wall lists (an event is
+    recorded between steps - no synchronisation is added inside the timed region)."""
     import torch.distributed as dist
     # clock pre-warm (untimed, before the W warm-up steps): the boost clock of an idle MI355X needs a few tens of
     # milliseconds of load to settle - the first workload after host-side setup otherwise reads ~5 % slow
@@ -327,18 +349,23 @@ def time_steps(fn, steps, warmup, dist_on):
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ts = [0.0] * (steps + 1)
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
+    ts[0] = t0
+    evs[0].record()
+    for i in range(steps):
         fn()
-    e1.record()
+        evs[i + 1].record()
+        ts[i + 1] = time.perf_counter()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    return wall, e0.elapsed_time(e1)
+    return StepTimes(wall, evs[0].elapsed_time(evs[steps]),
+                     [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)],
+                     [(ts[i + 1] - ts[i]) * 1e3 for i in range(steps)])
 
 
 def max_over_ranks(x, dist_on, device):
@@ -419,6 +446,21 @@ def cpu_baseline_rates(work, total_items, chunk, seconds, check=None):
     return r1, d1, dall / dt, dall, threads
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU) under
+    torch.distributed.run on this node; the torchrun form the driver uses keeps working (WORLD_SIZE is then set)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -434,11 +476,17 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_on = world > 1
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    if dist_on and args.backend == "nccl" and torch.cuda.device_count() < world:
+        # fewer GPUs than ranks (a 1-GPU box): RCCL refuses two ranks on one device, so the ranks share GPUs and
+        # exchange through gloo - the native per-shard phase and the native combine still run (host-staged slots)
+        args.backend = "gloo"
     dev_index = local_rank % torch.cuda.device_count()   # (dry runs may put several ranks on one GPU)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -495,7 +543,8 @@ def main():
         def step():
             eng.mul_var_batch_dev(SECP256K1, n, dev_ptr(pts), dev_ptr(sc), dev_ptr(out), dev_ptr(inf), stream)
 
-        wall, ev_ms = time_steps(step, K, W, dist_on)
+        st_secp = time_steps(step, K, W, dist_on)
+        wall, ev_ms = st_secp
         wall = max_over_ranks(wall, dist_on, device)
         ev_ms = max_over_ranks(ev_ms, dist_on, device)
         # ---- verification (outside the timed region)
@@ -521,6 +570,7 @@ def main():
             "data": "synthetic: P_i=(a+i*b)G, k_i uniform in [0,2^255) with k=0,1,n-1 planted; seed xorshift64",
             "config": {"workload": "secp256k1 batch variable-base multiplyUnsafe (GLV), 2^%d pairs per GPU"
                        % args.log2n, "items_per_gpu": n, "parallelism": "shard-by-index x%d" % world},
+            "step_times": st_secp.dist(),
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": tsrc,
@@ -556,7 +606,8 @@ def main():
         def step():
             holder["r"] = msm_sharded(eng, curve, nn, dev_ptr(pts), dev_ptr(sc), stream, device)
 
-        wall, ev_ms = time_steps(step, K, W, dist_on)
+        st_msm = time_steps(step, K, W, dist_on)
+        wall, ev_ms = st_msm
         wall = max_over_ranks(wall, dist_on, device)
         expect = sum_over_ranks_bigint(local_expect, BLS_R, dist_on, device)
         got, got_inf = holder["r"]
@@ -565,7 +616,8 @@ def main():
         nwin = -(-(255 + 1) // c)
         traffic, tsrc = pmc.traffic(key) if (curve == BLS12_381_G1 and args.log2n == 20) or (curve == BLS12_381_G2 and args.log2n == 20) else (None, None)
         entry = {"metric": "bls12_381_%s_msm_points_per_sec" % cname, "value": world * nn * K / wall, "unit": "points/s",
-                 "ms_per_msm": wall / K * 1e3, "points_per_gpu": nn, "total_points": world * nn, "scaling": "weak",
+                 "ms_per_msm": wall / K * 1e3, "step_times": st_msm.dist(),
+                 "points_per_gpu": nn, "total_points": world * nn, "scaling": "weak",
                  "multi_gpu": ("ncg_msm_sharded_dev: RCCL all-gather of grouped window sums + on-device add" if native_multi
                                else (("%s: partial points exchanged by torch.distributed, pairwise adds on the engine"
                                       % ("gloo dry run" if args.backend == "gloo" else "fallback (native RCCL communicator unavailable)"))
@@ -591,10 +643,11 @@ def main():
             def rstep():
                 rh["r"] = res.msm_dev(dev_ptr(sc), stream)
 
-            rwall, _ = time_steps(rstep, K, W, False)
+            st_res = time_steps(rstep, K, W, False)
+            rwall, _ = st_res
             assert np.array_equal(rh["r"][0], got), "endomorphism MSM differs from the generic MSM"
             entry["resident_subgroup_set"] = {
-                "value": nn * K / rwall, "unit": "points/s", "ms_per_msm": rwall / K * 1e3,
+                "value": nn * K / rwall, "unit": "points/s", "ms_per_msm": rwall / K * 1e3, "step_times": st_res.dist(),
                 "verify_once_ms": verify_ms,
                 "note": "ncg_msm_resident_dev on a set that passed the reference's isTorsionFree test on every point "
                         "(bls12-381.ts:567-577 / :599-601) at upload; result compared bit-exactly with the generic MSM above"}
@@ -636,14 +689,15 @@ def main():
             def step_strong():
                 hs["r"] = msm_sharded(eng, BLS12_381_G1, ns, dev_ptr(sub["pts"]), dev_ptr(sub["sc"]), stream, device)
 
-            wall_s, _ = time_steps(step_strong, K, W, dist_on)
+            st_s = time_steps(step_strong, K, W, dist_on)
+            wall_s, _ = st_s
             wall_s = max_over_ranks(wall_s, dist_on, device)
             tot = sum_over_ranks_bigint(sub_expect, BLS_R, dist_on, device)
             got_s, _ = hs["r"]
             assert wire_to_affine(BLS12_381_G1, got_s) == BlsG1.BASE.multiplyUnsafe(tot).toAffine(), "strong MSM mismatch"
             extra["msm_g1_strong"] = {"metric": "bls12_381_g1_msm_points_per_sec", "value": ns * world * K / wall_s,
                                       "unit": "points/s", "ms_per_msm": wall_s / K * 1e3, "total_points": ns * world,
-                                      "points_per_gpu": ns, "scaling": "strong"}
+                                      "points_per_gpu": ns, "scaling": "strong", "step_times": st_s.dist()}
         if not result:
             result = dict(msm)
             result.update({"n_gpus": world, "steps": K, "warmup": W, "ms_per_step": msm["ms_per_msm"],
@@ -664,14 +718,15 @@ def main():
             def step_strong2():
                 hs2["r"] = msm_sharded(eng, BLS12_381_G2, ns, dev_ptr(sub2["pts"]), dev_ptr(sub2["sc"]), stream, device)
 
-            wall_s, _ = time_steps(step_strong2, K, W, dist_on)
+            st_s2 = time_steps(step_strong2, K, W, dist_on)
+            wall_s, _ = st_s2
             wall_s = max_over_ranks(wall_s, dist_on, device)
             tot = sum_over_ranks_bigint(sub_expect, BLS_R, dist_on, device)
             got_s, _ = hs2["r"]
             assert wire_to_affine(BLS12_381_G2, got_s) == BlsG2.BASE.multiplyUnsafe(tot).toAffine(), "strong G2 MSM mismatch"
             extra["msm_g2_strong"] = {"metric": "bls12_381_g2_msm_points_per_sec", "value": ns * world * K / wall_s,
                                       "unit": "points/s", "ms_per_msm": wall_s / K * 1e3, "total_points": ns * world,
-                                      "points_per_gpu": ns, "scaling": "strong"}
+                                      "points_per_gpu": ns, "scaling": "strong", "step_times": st_s2.dist()}
         if not result:
             result = dict(msm2)
             result.update({"n_gpus": world, "steps": K, "warmup": W, "ms_per_step": msm2["ms_per_msm"],
@@ -700,14 +755,16 @@ def main():
         def step_ed_k():
             eng.ed25519_verify_batch_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_k2), True, dev_ptr(d_ok), stream)
 
-        wall_k, ev_ms_k = time_steps(step_ed_k, K, W, dist_on)
+        st_edk = time_steps(step_ed_k, K, W, dist_on)
+        wall_k, ev_ms_k = st_edk
         wall_k = max_over_ranks(wall_k, dist_on, device)
         assert np.array_equal(d_ok.cpu().numpy().astype(bool), expect), "ed25519 verdict mismatch (pre-hashed)"
 
         def step_ed():     # hash on the device + verify: the reference's verify() from (sig, msg, pk)
             eng.ed25519_verify_batch_msgs_dev(nv, dev_ptr(d_sig), dev_ptr(d_pk), dev_ptr(d_blob), dev_ptr(d_off), True, dev_ptr(d_ok), stream)
 
-        wall, ev_ms = time_steps(step_ed, K, W, dist_on)
+        st_ed = time_steps(step_ed, K, W, dist_on)
+        wall, ev_ms = st_ed
         wall = max_over_ranks(wall, dist_on, device)
         got = d_ok.cpu().numpy().astype(bool)
         assert np.array_equal(got, expect), "ed25519 verdict mismatch vs construction / zip215.json"
@@ -741,7 +798,9 @@ def main():
         traffic, tsrc = pmc.traffic("ed25519") if nv == 1 << 18 else (None, None)
         extra["ed25519_verify"] = {"metric": "ed25519_verifies_per_sec", "value": world * nv * K / wall,
                                    "unit": "verifies/s", "ms_per_batch": wall / K * 1e3, "sigs_per_gpu": nv,
+                                   "step_times": st_ed.dist(),
                                    "kernel_only": {"value": world * nv * K / wall_k, "ms_per_batch": wall_k / K * 1e3,
+                                                   "step_times": st_edk.dist(),
                                                    "note": "pre-hashed challenges (ncg_ed25519_verify_batch_dev)"},
                                    "note": "verify from (sig, msg, pk): SHA-512(R||A||M) mod L and the curve arithmetic both on the device "
                                            "(ncg_ed25519_verify_batch_msgs_dev); %d distinct key pairs, 32-byte messages, 1/64 corrupted "
@@ -776,7 +835,8 @@ def main():
         def step_ntt():
             eng.ntt_dev(bits, 1, om, dev_ptr(x), dev_ptr(y), stream)
 
-        wall, ev_ms = time_steps(step_ntt, K, W, dist_on)
+        st_ntt = time_steps(step_ntt, K, W, dist_on)
+        wall, ev_ms = st_ntt
         wall = max_over_ranks(wall, dist_on, device)
         eng.ntt_dev(bits, 1, om, dev_ptr(y), dev_ptr(z), stream, inverse=True)
         torch.cuda.synchronize()
@@ -805,6 +865,7 @@ def main():
         traffic, tsrc = pmc.traffic("ntt", npass) if npass else (None, None)
         extra["ntt_fr"] = {"metric": "bls12_381_fr_ntt_elements_per_sec", "value": world * nn * K / wall,
                            "unit": "elements/s", "ms_per_transform": wall / K * 1e3, "log2n": bits,
+                           "step_times": st_ntt.dist(),
                            "note": "FFT(roots, Fr).direct, natural in / natural out, one 2^%d transform per GPU" % bits,
                            "roofline": {"bound": "hbm", "achieved": 64.0 * nn / (ev_ms / K * 1e-3) / 1e9,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
