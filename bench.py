@@ -604,7 +604,7 @@ def main():
         holder = {}
 
         def step():
-            holder["r"] = msm_sharded(eng, curve, nn, dev_ptr(pts), dev_ptr(sc), stream, device)
+            holder["r"] = msm_sharded(eng, curve, nn, dev_ptr(pts), dev_ptr(sc), stream, device, n_max=nn)
 
         st_msm = time_steps(step, K, W, dist_on)
         wall, ev_ms = st_msm
@@ -619,8 +619,9 @@ def main():
                  "ms_per_msm": wall / K * 1e3, "step_times": st_msm.dist(),
                  "points_per_gpu": nn, "total_points": world * nn, "scaling": "weak",
                  "multi_gpu": ("ncg_msm_sharded_dev: RCCL all-gather of grouped window sums + on-device add" if native_multi
-                               else (("%s: partial points exchanged by torch.distributed, pairwise adds on the engine"
-                                      % ("gloo dry run" if args.backend == "gloo" else "fallback (native RCCL communicator unavailable)"))
+                               else (("%s: ncg_msm_shard_local_dev -> torch.distributed all-gather of the slots (window-plan header + "
+                                      "grouped window sums) -> ncg_msm_shard_combine (native header check, adding kernel, finish)"
+                                      % ("host-staged exchange over gloo (ranks share GPUs)" if args.backend == "gloo" else "host-staged exchange (native RCCL communicator unavailable)"))
                                      if dist_on else "single GPU")),
                  "roofline": {"bound": "hbm", "achieved": alg_b * nn / (wall / K) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": alg_b * nn / (wall / K) / 1e9 / HBM_PEAK_GBS,
@@ -687,7 +688,7 @@ def main():
             hs = {}
 
             def step_strong():
-                hs["r"] = msm_sharded(eng, BLS12_381_G1, ns, dev_ptr(sub["pts"]), dev_ptr(sub["sc"]), stream, device)
+                hs["r"] = msm_sharded(eng, BLS12_381_G1, ns, dev_ptr(sub["pts"]), dev_ptr(sub["sc"]), stream, device, n_max=ns)
 
             st_s = time_steps(step_strong, K, W, dist_on)
             wall_s, _ = st_s
@@ -716,7 +717,7 @@ def main():
             hs2 = {}
 
             def step_strong2():
-                hs2["r"] = msm_sharded(eng, BLS12_381_G2, ns, dev_ptr(sub2["pts"]), dev_ptr(sub2["sc"]), stream, device)
+                hs2["r"] = msm_sharded(eng, BLS12_381_G2, ns, dev_ptr(sub2["pts"]), dev_ptr(sub2["sc"]), stream, device, n_max=ns)
 
             st_s2 = time_steps(step_strong2, K, W, dist_on)
             wall_s, _ = st_s2

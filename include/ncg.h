@@ -236,7 +236,7 @@ int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* 
  * pippenger is a sum over points (src/abstract/curve.ts:863-905; its last step is the chain
  * `sum = sum.add(resI)` :895-902), so the points are sharded: each GPU runs the single-GPU pipeline on
  * its slice up to the grouped window sums (~18 KB for G1), ONE ncclAllGather over xGMI exchanges those,
- * a one-wave kernel adds the G arrays (G - 1 additions per lane) and the usual finish follows.  No
+ * a small kernel adds the G arrays (pairwise tree, log2 G additions deep) and the usual finish follows.  No
  * bucket-sized data moves and nothing but the final point reaches the host.  All four curves
  * (BASELINE configs[3] G1 and configs[4] G2).  SURVEY 8(b): "one RCCL communicator for the device
  * set, all hidden behind the call"; RCCL (librccl.so) is loaded on first use.
@@ -245,8 +245,10 @@ int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* 
  *     ships the 128 bytes to the other ranks by any means; every rank calls ncg_comm_init on its own
  *     context (collective).  ncg_msm_sharded_dev is then a collective: every rank passes ITS points
  *     (n_local of them, device memory) and n_max = the largest n_local of any rank (it fixes the
- *     window plan, which must agree on all ranks; pass 0 if all ranks hold n_local points); every
- *     rank receives the same sum in host memory.  Without a communicator it is ncg_msm_dev. */
+ *     window plan, which must agree on all ranks; pass 0 only if all ranks hold n_local points); every
+ *     rank receives the same sum in host memory.  Without a communicator it is ncg_msm_dev.
+ *     Every rank posts a slot of the same fixed size (ncg_msm_shard_slot_bytes) whatever plan it derived;
+ *     ranks whose plans disagree get NCG_ERR_INVALID_ARG after the gather, never a mismatched collective. */
 #define NCG_COMM_ID_BYTES 128
 int ncg_comm_unique_id(uint8_t* out_id128);
 int ncg_comm_init(ncg_ctx* ctx, int nranks, int rank, const uint8_t* id128);
@@ -256,6 +258,17 @@ int ncg_comm_rank(ncg_ctx* ctx);
 int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max,
                         const void* points_affine_dev, const void* scalars_dev, void* out_affine,
                         uint8_t* out_is_inf, void* stream);
+/* The same sharded MSM with a HOST-STAGED exchange, for transports other than RCCL (gloo, MPI, sockets; also how
+ * two ranks sharing one GPU are tested): ncg_msm_shard_local_dev runs this rank's per-shard phase and writes its
+ * slot - a 16-byte header (window plan) + the grouped window sums, ncg_msm_shard_slot_bytes(curve) bytes, zero
+ * padded - to host memory; the caller gathers the slots of all ranks (rank order) and any rank calls
+ * ncg_msm_shard_combine on the concatenation: upload, header check, adding kernel, finish - the code
+ * ncg_msm_sharded_dev runs after its all-gather.  n_max as above (the same value on every rank and in combine). */
+size_t ncg_msm_shard_slot_bytes(int curve);
+int ncg_msm_shard_local_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max, const void* points_affine_dev,
+                            const void* scalars_dev, void* slot_out, void* stream);
+int ncg_msm_shard_combine(ncg_ctx* ctx, int curve, size_t n_max, int nparts, const void* slots, void* out_affine,
+                          uint8_t* out_is_inf, void* stream);
 /* The sharded pipeline on ONE GPU (self-check, shard-plan A/B): the points are cut into `parts` slices,
  * each runs the per-shard phase in turn, the slices' window sums go through the multi-GPU combine kernel
  * and finish - everything of ncg_msm_sharded_dev except the all-gather. */
@@ -362,7 +375,12 @@ int ncg_ubench(ncg_ctx* ctx, int kind, int blocks, int threads, int iters, float
  * (host buffers).  field 0 / 1 = secp256k1 / ed25519 base field in the radix-2^29 lazy form (fe9.hpp): a, b
  * are 9 RAW 32-bit limbs per element, `variant` = 10 A + B names the operand bound types; out = 8 canonical
  * LE words.  field 2 = bls12-381 Fp: 12-word canonical operands and results.  op: 0 mul, 1 sqr, 2 add, 3 sub,
- * 4 neg, 5 inv, 6 normalise, 7 is-zero-mod-p, 9 largest output limb of the product. */
+ * 4 neg, 5 inv, 6 normalise, 7 is-zero-mod-p, 9 largest output limb of the product.
+ * field 3 = bls12-381 Fp on RAW radix-2^29 limbs (fe29.hpp, Montgomery R = 2^406): a = [a, c], b = [b, d], 14 limbs
+ * each, values up to the top of the lazy bounds (a, c < 4096 p; b, d < 4096 p for op 0, 2048 p for op 6);
+ * field 4 = the lane-paired Fp2 form: every element c0 then c1 (28 limbs), a, c < 4096 p (2048 p for op 1), b, d <
+ * 2048 p (op 0) / 1024 p (op 6).  ops 0 a*b, 1 a^2, 6 a*b - c*d (the fused reduction); out = canonical wire words
+ * of the result taken out of Montgomery form (12, or 12 + 12 for Fp2). */
 int ncg_field_check(ncg_ctx* ctx, int field, int op, int variant, size_t n, const void* a, const void* b, void* out);
 
 #ifdef __cplusplus

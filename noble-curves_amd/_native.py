@@ -139,6 +139,8 @@ _OPTIONAL_PROTOS = {
     "ncg_comm_rank": [_vp],
     "ncg_msm_sharded_dev": [_vp, _i32, _sz, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_msm_split_dev": [_vp, _i32, _sz, _i32, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
+    "ncg_msm_shard_local_dev": [_vp, _i32, _sz, _sz, _vp, _vp, _vp, _vp],
+    "ncg_msm_shard_combine": [_vp, _i32, _sz, _i32, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_multi_init": [ctypes.POINTER(_i32), _i32, ctypes.POINTER(_vp)],
     "ncg_multi_devices": [_vp],
     "ncg_msm_multi": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
@@ -374,6 +376,29 @@ class Engine:
                                                  ctypes.byref(inf), stream))
         return out, bool(inf.value)
 
+    def msm_shard_slot_bytes(self, curve):
+        fn = self.lib.ncg_msm_shard_slot_bytes
+        fn.argtypes, fn.restype = [ctypes.c_int], ctypes.c_size_t
+        return int(fn(curve))
+
+    def msm_shard_local_dev(self, curve, n_local, d_points, d_scalars, stream=None, n_max=0):
+        """This rank's part of a sharded MSM with a host-staged exchange: per-shard phase on the device, the slot
+        (window-plan header + grouped window sums, fixed size per curve) comes back as a uint8 array."""
+        slot = np.zeros((self.msm_shard_slot_bytes(curve),), dtype=np.uint8)
+        self._check(self.lib.ncg_msm_shard_local_dev(self.h, curve, n_local, n_max, d_points, d_scalars, slot.ctypes.data, stream))
+        return slot
+
+    def msm_shard_combine(self, curve, n_max, slots, stream=None):
+        """slots: uint8 [nparts, slot_bytes] in rank order -> (affine wire bytes [PB], is_inf): upload, header check,
+        adding kernel, finish - what ncg_msm_sharded_dev runs after its all-gather."""
+        slots = np.ascontiguousarray(slots, dtype=np.uint8)
+        pb = POINT_BYTES[curve]
+        out = np.zeros((pb,), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self._check(self.lib.ncg_msm_shard_combine(self.h, curve, n_max, int(slots.shape[0]), slots.ctypes.data, out.ctypes.data,
+                                                   ctypes.byref(inf), stream))
+        return out, bool(inf.value)
+
     def msm_split_dev(self, curve, n, parts, d_points, d_scalars, stream=None):
         """The sharded pipeline on this one GPU: `parts` slices, per-shard phase each, multi-GPU combine
         kernel, finish (ncg_msm_split_dev)."""
@@ -562,12 +587,13 @@ class Engine:
                                          self._ntt_flags(inverse, brp_input, brp_output), stream))
 
     def field_check(self, field, op, variant, a_words, b_words):
-        """Device field code on raw operands (ncg_field_check): a_words, b_words uint32 [n, 9] (fields 0/1) or
-        [n, 12] (field 2) -> uint32 [n, 8 | 12]."""
+        """Device field code on raw operands (ncg_field_check): a_words, b_words uint32 [n, 9] (fields 0/1),
+        [n, 12] (field 2), [n, 28] (field 3: raw Fe29 limbs [a, c]) or [n, 56] (field 4: lane-paired Fp2 raw limbs)
+        -> uint32 [n, 8 | 12 | 24]."""
         a = np.ascontiguousarray(a_words, dtype=np.uint32)
         b = np.ascontiguousarray(b_words, dtype=np.uint32)
         n = a.shape[0]
-        out = np.zeros((n, 12 if field == 2 else 8), dtype=np.uint32)
+        out = np.zeros((n, 24 if field == 4 else 12 if field >= 2 else 8), dtype=np.uint32)
         if n:
             self._check(self.lib.ncg_field_check(self.h, field, op, variant, n, a.ctypes.data, b.ctypes.data, out.ctypes.data))
         return out

@@ -126,6 +126,9 @@ int ncg_init(int device_id, ncg_ctx** out_ctx) {
   ctx->device = device_id;
   e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->msm_side.stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->msm_side.fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->msm_side.join, hipEventDisableTiming);
   if (e != hipSuccess) {
     int rc = set_err(nullptr, NCG_ERR_HIP, "noble-gpu: cannot create stream on device %d: %s", device_id, hipGetErrorString(e));
     delete ctx;
@@ -153,6 +156,9 @@ void ncg_destroy(ncg_ctx* ctx) {
   if (ctx->ntt_ws) (void)hipFree(ctx->ntt_ws);
   (void)ncg_comm_destroy(ctx);
   if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
+  if (ctx->msm_side.fork) (void)hipEventDestroy(ctx->msm_side.fork);
+  if (ctx->msm_side.join) (void)hipEventDestroy(ctx->msm_side.join);
+  if (ctx->msm_side.stream) (void)hipStreamDestroy(ctx->msm_side.stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -372,7 +378,7 @@ int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   uint32_t bad = 0xFFFFFFFFu;
   NCG_HIP(ctx, ncg::msm_run(curve, pl, (const uint32_t*)points_affine_dev, (const uint32_t*)scalars_dev, ctx->msm_ws,
-                            (uint32_t*)out_affine, &inf_local, st, &bad));
+                            (uint32_t*)out_affine, &inf_local, st, &bad, &ctx->msm_side));
   if (bad != 0xFFFFFFFFu)  // validateMSMScalars (curve.ts:398-404): scalars must be below the group order
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
   if (out_is_inf) *out_is_inf = inf_local;
@@ -406,7 +412,27 @@ struct ncg_points {
   size_t n;
   void* d_pts;
   void* d_endo = nullptr;  // endomorphism images (msm_endo_expand) once the set is known to lie in the subgroup
+  void* d_stored = nullptr;  // the points in the accumulate kernel's storage format (built at the first generic MSM)
 };
+
+// The point of a resident set (curve.ts:907-918: precompute once, call with scalars): the wire -> storage
+// conversion of the points is paid at the first MSM, every later call starts at the digits.
+static int points_build_stored(ncg_ctx* ctx, ncg_points* h, hipStream_t st) {
+  if (h->d_stored || h->n == 0) return NCG_OK;
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, h->n * ncg::msm_stored_words_per_point(h->curve) * 4);
+  if (e != hipSuccess) {  // not fatal: the generic path converts per call
+    (void)hipGetLastError();
+    return NCG_OK;
+  }
+  e = ncg::msm_points_to_stored(h->curve, (const uint32_t*)h->d_pts, (int)h->n, (uint32_t*)d, st);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return set_err(ctx, NCG_ERR_HIP, "noble-gpu: points_to_stored: %s", hipGetErrorString(e));
+  }
+  h->d_stored = d;
+  return NCG_OK;
+}
 
 // Build the endomorphism images of a set whose points are KNOWN to lie in the prime-order subgroup.
 static int points_build_endo(ncg_ctx* ctx, ncg_points* h) {
@@ -571,6 +597,7 @@ void ncg_points_free(ncg_points* h) {
   (void)hipSetDevice(h->ctx->device);
   if (h->d_pts) (void)hipFree(h->d_pts);
   if (h->d_endo) (void)hipFree(h->d_endo);
+  if (h->d_stored) (void)hipFree(h->d_stored);
   delete h;
 }
 size_t ncg_points_count(const ncg_points* h) { return h ? h->n : 0; }
@@ -599,6 +626,26 @@ static int msm_resident_core(ncg_ctx* ctx, const ncg_points* pts, const void* d_
     uint32_t bad = 0xFFFFFFFFu;
     uint8_t inf_local = 0;
     NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, (const uint32_t*)pts->d_endo, (const uint32_t*)d_sc, ctx->msm_ws,
+                              (uint32_t*)out_affine, &inf_local, st, &bad));
+    if (bad != 0xFFFFFFFFu)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
+    if (out_is_inf) *out_is_inf = inf_local;
+    return NCG_OK;
+  }
+  if (pts->n <= 0x7fffffffu) {
+    int rc = points_build_stored(ctx, const_cast<ncg_points*>(pts), st);  // a cache inside the handle
+    if (rc) return rc;
+  }
+  if (pts->d_stored) {
+    ncg::MsmPlan pl;
+    if (ncg::msm_make_plan(pts->curve, (int)pts->n, 0, &pl) != 0)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+    pl.pts_stored = 1;
+    int rc = msm_ensure_ws(ctx, pts->curve, pl);
+    if (rc) return rc;
+    uint32_t bad = 0xFFFFFFFFu;
+    uint8_t inf_local = 0;
+    NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, (const uint32_t*)pts->d_stored, (const uint32_t*)d_sc, ctx->msm_ws,
                               (uint32_t*)out_affine, &inf_local, st, &bad));
     if (bad != 0xFFFFFFFFu)
       return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
@@ -1392,10 +1439,11 @@ int ncg_ecdsa_verify_batch(ncg_ctx* ctx, int curve, size_t n, const void* sig64,
 
 int ncg_field_check(ncg_ctx* ctx, int field, int op, int variant, size_t n, const void* a, const void* b, void* out) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
-  if (field < 0 || field > 2) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: field_check: unknown field %d", field);
+  if (field < 0 || field > 4) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: field_check: unknown field %d", field);
   if (n == 0) return NCG_OK;
   if (n > (1u << 24) || !a || !b || !out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: field_check: bad arguments");
-  const size_t in_w = field == 2 ? 12 : 9, out_w = field == 2 ? 12 : 8;
+  // words per item: fe9 9 in / 8 out; Fe29 from wire 12 / 12; Fe29 raw limbs [a, c] 28 / 12; lane-paired Fp2 raw [a, c] 56 / 24
+  const size_t in_w = field == 4 ? 56 : field == 3 ? 28 : field == 2 ? 12 : 9, out_w = field == 4 ? 24 : field >= 2 ? 12 : 8;
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   const size_t in_b = (n * in_w * 4 + 255) & ~(size_t)255, out_b = n * out_w * 4;
   int rc = ensure_scratch(ctx, 2 * in_b + out_b + 1024);

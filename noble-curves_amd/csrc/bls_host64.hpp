@@ -1,0 +1,298 @@
+// HOST side of the bls12-381 MSM: the serial Horner combine of the window sums (src/abstract/curve.ts:901-902:
+// `sum = sum.add(resI); sum = sum.double() x c`) and the final toAffine (weierstrass.ts:951-969).
+//
+// 255 dependent doublings are a latency chain: one GPU lane needs ~10 us per doubling, a CPU core well under
+// 0.2 us, so this stays on the host - and is written for the host: 6 x 64-bit limbs,
+// Montgomery R = 2^384 (CIOS with 128-bit products), Jacobian coordinates (dbl-2009-l 2M + 5S, add-2007-bl
+// 11M + 5S), values canonical in [0, p) so the exceptional cases of the group law are exact comparisons.
+// The device hands over XYZZ accumulators in its own storage format (radix 2^29, R = 2^406, lazily reduced);
+// `from_fe29` canonicalises and changes the Montgomery radix with one multiplication by 2^362.
+// Round 2 ran this step through the device templates compiled for the host (radix 2^58 twin of the 29-bit
+// form, XYZZ): 0.19 ms (G1) / 0.72 ms (G2) per MSM; this form: see DESIGN.md section 5.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "fe29.hpp"
+
+namespace ncg {
+namespace h64 {
+
+typedef unsigned __int128 u128;
+
+struct Fp {
+  uint64_t v[6];
+};
+
+struct Consts {
+  uint64_t p[6];
+  uint64_t inv;   // -p^-1 mod 2^64
+  Fp one;         // 2^384 mod p
+  Fp c362;        // the integer 2^362 mod p (NOT in Montgomery form)
+  Fp raw_one;     // the integer 1
+};
+
+inline bool geq(const uint64_t* a, const uint64_t* b) {
+  for (int i = 5; i >= 0; i--) {
+    if (a[i] != b[i]) return a[i] > b[i];
+  }
+  return true;
+}
+inline void sub_in_place(uint64_t* a, const uint64_t* b) {
+  u128 br = 0;
+  for (int i = 0; i < 6; i++) {
+    u128 d = (u128)a[i] - b[i] - (uint64_t)br;
+    a[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+}
+inline void dbl_mod(uint64_t* a, const uint64_t* p) {  // a = 2a mod p for a < p < 2^383
+  uint64_t c = 0;
+  for (int i = 0; i < 6; i++) {
+    uint64_t n = (a[i] << 1) | c;
+    c = a[i] >> 63;
+    a[i] = n;
+  }
+  if (geq(a, p)) sub_in_place(a, p);
+}
+
+inline const Consts& K() {
+  static const Consts k = [] {
+    Consts c;
+    for (int i = 0; i < 6; i++) c.p[i] = (uint64_t)ParamsBlsP::P[2 * i] | ((uint64_t)ParamsBlsP::P[2 * i + 1] << 32);
+    uint64_t x = 1;  // Newton: x = p^-1 mod 2^64
+    for (int i = 0; i < 6; i++) x *= 2 - c.p[0] * x;
+    c.inv = 0 - x;
+    uint64_t t[6] = {1, 0, 0, 0, 0, 0};
+    memset(&c.raw_one, 0, sizeof c.raw_one);
+    c.raw_one.v[0] = 1;
+    for (int i = 0; i < 384; i++) {
+      if (i == 362) memcpy(c.c362.v, t, sizeof t);
+      dbl_mod(t, c.p);
+    }
+    memcpy(c.one.v, t, sizeof t);
+    return c;
+  }();
+  return k;
+}
+
+inline bool is_zero(const Fp& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3] | a.v[4] | a.v[5]) == 0; }
+inline bool eq(const Fp& a, const Fp& b) {
+  uint64_t d = 0;
+  for (int i = 0; i < 6; i++) d |= a.v[i] ^ b.v[i];
+  return d == 0;
+}
+inline Fp zero() {
+  Fp r;
+  memset(&r, 0, sizeof r);
+  return r;
+}
+
+// Montgomery product a b 2^-384 mod p, result in [0, p).  CIOS; p < 2^382 leaves the top word room for the carries.
+inline Fp mul(const Fp& a, const Fp& b) {
+  const Consts& k = K();
+  uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 6; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 6; j++) {
+      c += (u128)a.v[j] * b.v[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[6];
+    t[6] = (uint64_t)c;
+    t[7] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * k.inv;
+    c = (u128)m * k.p[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 6; j++) {
+      c += (u128)m * k.p[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[6];
+    t[5] = (uint64_t)c;
+    t[6] = t[7] + (uint64_t)(c >> 64);
+  }
+  Fp r;
+  memcpy(r.v, t, sizeof r.v);
+  if (t[6] || geq(r.v, k.p)) sub_in_place(r.v, k.p);
+  return r;
+}
+inline Fp sqr(const Fp& a) { return mul(a, a); }
+inline Fp add(const Fp& a, const Fp& b) {
+  const Consts& k = K();
+  Fp r;
+  u128 c = 0;
+  for (int i = 0; i < 6; i++) {
+    c += (u128)a.v[i] + b.v[i];
+    r.v[i] = (uint64_t)c;
+    c >>= 64;
+  }
+  if (geq(r.v, k.p)) sub_in_place(r.v, k.p);  // a + b < 2p < 2^383: no carry out
+  return r;
+}
+inline Fp sub(const Fp& a, const Fp& b) {
+  const Consts& k = K();
+  Fp r = a;
+  if (!geq(a.v, b.v)) {  // a + p - b
+    u128 c = 0;
+    for (int i = 0; i < 6; i++) {
+      c += (u128)r.v[i] + k.p[i];
+      r.v[i] = (uint64_t)c;
+      c >>= 64;
+    }
+  }
+  sub_in_place(r.v, b.v);
+  return r;
+}
+inline Fp dbl(const Fp& a) { return add(a, a); }
+inline Fp neg(const Fp& a) { return is_zero(a) ? a : sub(zero(), a); }
+inline Fp one(const Fp*) { return K().one; }
+inline Fp inv(const Fp& a) {  // a^(p-2): value of modular.ts:159-182 invert for a != 0
+  const Consts& k = K();
+  uint64_t e[6];
+  memcpy(e, k.p, sizeof e);
+  e[0] -= 2;
+  Fp r = k.one;
+  for (int w = 5; w >= 0; w--)
+    for (int bit = 63; bit >= 0; bit--) {
+      r = sqr(r);
+      if ((e[w] >> bit) & 1) r = mul(r, a);
+    }
+  return r;
+}
+
+// stored device element (14 x 29-bit limbs, R = 2^406, value below 64 p) -> canonical Montgomery form here
+inline Fp from_fe29(const uint32_t* limbs) {
+  Fe29<64> x;
+  for (int i = 0; i < 14; i++) x.v[i] = limbs[i];
+  const Fe29<1> c = fe29_canon(x);
+  Fp t = zero();
+  for (int i = 0; i < 14; i++) {
+    const int bit = 29 * i, w = bit >> 6, sh = bit & 63;
+    t.v[w] |= (uint64_t)c.v[i] << sh;
+    if (sh > 35 && w + 1 < 6) t.v[w + 1] |= (uint64_t)c.v[i] >> (64 - sh);
+  }
+  return mul(t, K().c362);  // x 2^406 * 2^362 * 2^-384 = x 2^384
+}
+// -> canonical residue as 12 x 32-bit LE words (the wire format of include/ncg.h)
+inline void to_wire(uint32_t* out, const Fp& a) {
+  const Fp r = mul(a, K().raw_one);
+  for (int i = 0; i < 6; i++) {
+    out[2 * i] = (uint32_t)r.v[i];
+    out[2 * i + 1] = (uint32_t)(r.v[i] >> 32);
+  }
+}
+
+// ---- Fp2 = Fp[u] / (u^2 + 1): values of `_Field2` ops, src/abstract/tower.ts:393-475
+struct Fp2 {
+  Fp c0, c1;
+};
+inline bool is_zero(const Fp2& a) { return is_zero(a.c0) && is_zero(a.c1); }
+inline bool eq(const Fp2& a, const Fp2& b) { return eq(a.c0, b.c0) && eq(a.c1, b.c1); }
+inline Fp2 add(const Fp2& a, const Fp2& b) { return {add(a.c0, b.c0), add(a.c1, b.c1)}; }
+inline Fp2 sub(const Fp2& a, const Fp2& b) { return {sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+inline Fp2 dbl(const Fp2& a) { return {dbl(a.c0), dbl(a.c1)}; }
+inline Fp2 mul(const Fp2& a, const Fp2& b) {  // Karatsuba, tower.ts:420-431
+  const Fp t1 = mul(a.c0, b.c0), t2 = mul(a.c1, b.c1);
+  const Fp m = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+  return {sub(t1, t2), sub(m, add(t1, t2))};
+}
+inline Fp2 sqr(const Fp2& a) {  // tower.ts:432-438
+  return {mul(add(a.c0, a.c1), sub(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
+}
+inline Fp2 one(const Fp2*) { return {K().one, zero()}; }
+inline Fp2 inv(const Fp2& a) {  // tower.ts:458-475
+  const Fp f = inv(add(sqr(a.c0), sqr(a.c1)));
+  return {mul(f, a.c0), mul(f, neg(a.c1))};
+}
+inline Fp2 from_fe29x2(const uint32_t* limbs) { return {from_fe29(limbs), from_fe29(limbs + 14)}; }
+inline void to_wire(uint32_t* out, const Fp2& a) {
+  to_wire(out, a.c0);
+  to_wire(out + 12, a.c1);
+}
+inline Fp from_stored(const uint32_t* p, const Fp*) { return from_fe29(p); }
+inline Fp2 from_stored(const uint32_t* p, const Fp2*) { return from_fe29x2(p); }
+
+// ---- Jacobian (X, Y, Z), x = X / Z^2, y = Y / Z^3, infinity Z = 0; a = 0
+template <class F>
+struct JacH {
+  F X, Y, Z;
+  bool inf;
+};
+template <class F>
+inline JacH<F> jac_inf() {
+  JacH<F> r;
+  memset(&r, 0, sizeof r);
+  r.inf = true;
+  return r;
+}
+template <class F>
+inline JacH<F> jac_dbl(const JacH<F>& p) {  // dbl-2009-l
+  if (p.inf) return p;
+  const F A = sqr(p.X), B = sqr(p.Y), C = sqr(B);
+  const F D = dbl(sub(sub(sqr(add(p.X, B)), A), C));
+  const F E = add(dbl(A), A), Fq = sqr(E);
+  JacH<F> r;
+  r.X = sub(Fq, dbl(D));
+  r.Y = sub(mul(E, sub(D, r.X)), dbl(dbl(dbl(C))));
+  r.Z = dbl(mul(p.Y, p.Z));
+  r.inf = false;  // no point of order 2 on these curves
+  return r;
+}
+template <class F>
+inline JacH<F> jac_add(const JacH<F>& p, const JacH<F>& q) {  // add-2007-bl, exceptional cases explicit
+  if (q.inf) return p;
+  if (p.inf) return q;
+  const F Z1Z1 = sqr(p.Z), Z2Z2 = sqr(q.Z);
+  const F U1 = mul(p.X, Z2Z2), U2 = mul(q.X, Z1Z1);
+  const F S1 = mul(mul(p.Y, q.Z), Z2Z2), S2 = mul(mul(q.Y, p.Z), Z1Z1);
+  const F H = sub(U2, U1), rr = dbl(sub(S2, S1));
+  if (is_zero(H)) {
+    if (is_zero(rr)) return jac_dbl(p);  // P == Q
+    return jac_inf<F>();                  // P == -Q
+  }
+  const F I = sqr(dbl(H)), J = mul(H, I), V = mul(U1, I);
+  JacH<F> r;
+  r.X = sub(sub(sqr(rr), J), dbl(V));
+  r.Y = sub(mul(rr, sub(V, r.X)), dbl(mul(S1, J)));
+  r.Z = mul(sub(sub(sqr(add(p.Z, q.Z)), Z1Z1), Z2Z2), H);
+  r.inf = false;
+  return r;
+}
+// XYZZ accumulator in device storage (X, Y, ZZ, ZZZ; FW words per coordinate) -> Jacobian (X ZZ, Y ZZZ, ZZ)
+template <class F>
+inline JacH<F> jac_from_xyzz(const uint32_t* p, int FW) {
+  const F ZZ = from_stored(p + 2 * FW, (const F*)nullptr);
+  if (is_zero(ZZ)) return jac_inf<F>();
+  JacH<F> r;
+  r.X = mul(from_stored(p, (const F*)nullptr), ZZ);
+  r.Y = mul(from_stored(p + FW, (const F*)nullptr), from_stored(p + 3 * FW, (const F*)nullptr));
+  r.Z = ZZ;
+  r.inf = false;
+  return r;
+}
+
+// fin: [ngroups][nwin] grouped sums V_j (msm.hip k_msm_tail): W_w = sum_j 2^(g j) V_j, result = sum_w 2^(c w) W_w.
+// out: affine wire (x, y), infinity = (0, 0) + flag.  WW = wire words per coordinate (12 / 24).
+template <class F>
+inline void msm_finish(const uint32_t* fin, int c, int nwin, int g, int ngroups, int FW, int WW, uint32_t* out, uint8_t* out_inf) {
+  const int XW = 4 * FW;
+  JacH<F> acc = jac_inf<F>();
+  for (int w = nwin - 1; w >= 0; w--)
+    for (int j = ngroups - 1; j >= 0; j--) {
+      const int shift = j == ngroups - 1 ? c - g * j : g;
+      for (int d = 0; d < shift; d++) acc = jac_dbl(acc);
+      acc = jac_add(acc, jac_from_xyzz<F>(fin + ((size_t)j * nwin + w) * XW, FW));
+    }
+  memset(out, 0, (size_t)2 * WW * 4);
+  *out_inf = acc.inf ? 1 : 0;
+  if (acc.inf) return;
+  const F zi = inv(acc.Z), zi2 = sqr(zi);
+  to_wire(out, mul(acc.X, zi2));
+  to_wire(out + WW, mul(mul(acc.Y, zi2), zi));
+}
+
+}  // namespace h64
+}  // namespace ncg

@@ -26,6 +26,9 @@
 #include "ctx.hpp"
 #include "host_api.hpp"
 #include "msm.hpp"
+#include "msm_shard.hpp"
+
+using ncg::FinHeader;
 
 namespace {
 
@@ -76,6 +79,18 @@ const Rccl* rccl() {
                      __FILE__, __LINE__);                                                                     \
   } while (0)
 
+// like NCG_HIP, for code that has asynchronous copies into host objects in flight on `st`: drain the stream
+// before the early return destroys them
+#define NCG_HIP_DRAIN(ctx, st, expr)                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      (void)hipStreamSynchronize(st);                                                         \
+      return set_err(ctx, NCG_ERR_HIP, "noble-gpu: HIP error %d (%s) at %s:%d", (int)_e,     \
+                     hipGetErrorString(_e), __FILE__, __LINE__);                              \
+    }                                                                                         \
+  } while (0)
+
 int ensure_comm_buf(ncg_ctx* ctx, size_t bytes) {
   if (ctx->comm_buf_bytes >= bytes) return NCG_OK;
   if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
@@ -89,10 +104,8 @@ int ensure_comm_buf(ncg_ctx* ctx, size_t bytes) {
 
 // Window plan shared by all shards of one MSM: every rank must cut the same windows, so the width is
 // chosen for the LARGEST shard (the caller passes it) - which also re-tunes c for the shard size:
-// the bucket fold costs ~2^c per window whatever the shard holds.
-struct FinHeader {  // first 16 bytes of every rank's contribution: the plans must agree
-  uint32_t c, nwin, words, curve;
-};
+// the bucket fold costs ~2^c per window whatever the shard holds.  Slot format: msm_shard.hpp.
+size_t comm_buf_need(size_t stride, size_t fin_words, int nparts);
 
 // this rank's contribution = header + grouped window sums, written at comm_buf + rank * stride
 int local_phase(ncg_ctx* ctx, int curve, size_t n_local, size_t n_plan, const void* d_pts, const void* d_sc, int slot,
@@ -107,8 +120,8 @@ int local_phase(ncg_ctx* ctx, int curve, size_t n_local, size_t n_plan, const vo
     if (rc) return rc;
   }
   const size_t fin_bytes = ncg::msm_fin_words(curve, pl) * 4;
-  const size_t stride = (sizeof(FinHeader) + fin_bytes + 255) & ~(size_t)255;
-  rc = ensure_comm_buf(ctx, stride * (size_t)(nslots + 1));
+  const size_t stride = ncg::msm_shard_slot_bytes(curve);  // the same on every rank, whatever its plan
+  rc = ensure_comm_buf(ctx, comm_buf_need(stride, ncg::msm_shard_max_fin_words(curve), nslots));
   if (rc) return rc;
   char* mine = (char*)ctx->comm_buf + stride * (size_t)slot;
   FinHeader h{(uint32_t)pl.c, (uint32_t)pl.nwin, (uint32_t)(fin_bytes / 4), (uint32_t)curve};
@@ -117,7 +130,7 @@ int local_phase(ncg_ctx* ctx, int curve, size_t n_local, size_t n_plan, const vo
     NCG_HIP(ctx, hipMemsetAsync(mine + sizeof h, 0, fin_bytes, st));
   } else {
     const uint32_t *d_fin = nullptr, *d_bad = nullptr;
-    NCG_HIP(ctx, ncg::msm_device_phase(curve, pl, (const uint32_t*)d_pts, (const uint32_t*)d_sc, ctx->msm_ws, &d_fin, st, &d_bad));
+    NCG_HIP(ctx, ncg::msm_device_phase(curve, pl, (const uint32_t*)d_pts, (const uint32_t*)d_sc, ctx->msm_ws, &d_fin, st, &d_bad, &ctx->msm_side));
     if (d_bad_out) *d_bad_out = d_bad;
     NCG_HIP(ctx, hipMemcpyAsync(mine + sizeof h, d_fin, fin_bytes, hipMemcpyDeviceToDevice, st));
   }
@@ -132,31 +145,23 @@ int combine_and_finish(ncg_ctx* ctx, int curve, const ncg::MsmPlan& pl, size_t s
                        uint8_t* out_is_inf, hipStream_t st) {
   const size_t fin_words = ncg::msm_fin_words(curve, pl);
   char* base = (char*)ctx->comm_buf;
-  // contiguous [nparts][fin_words] view for the adding kernel: compact the payloads behind the headers
-  // (slots are 256-byte aligned, payloads start 16 bytes in): the kernel takes a stride-free layout, so
-  // gather into a packed area first.  The packed area reuses the front of slot `nparts`.. no: keep it
-  // simple - headers travel to the host, payloads are added in place with the slot stride expressed in
-  // words (stride is a multiple of 4).
+  // the headers travel to the host (checked after the stream is drained); the payloads are compacted into a
+  // contiguous [nparts][fin_words] scratch behind the slots, which the adding kernel reduces in place
   std::vector<FinHeader> hs(nparts);
   for (int r = 0; r < nparts; r++)
-    NCG_HIP(ctx, hipMemcpyAsync(&hs[r], base + stride * (size_t)r, sizeof(FinHeader), hipMemcpyDeviceToHost, st));
-  // pack payloads: [nparts][fin_words] at slot nparts (sized by ensure_comm_buf callers via pack_bytes)
+    NCG_HIP_DRAIN(ctx, st, hipMemcpyAsync(&hs[r], base + stride * (size_t)r, sizeof(FinHeader), hipMemcpyDeviceToHost, st));
+  // pack payloads: [nparts][fin_words] behind the slots (sized by comm_buf_need)
   uint32_t* packed = (uint32_t*)(base + stride * (size_t)nparts);
   for (int r = 0; r < nparts; r++)
-    NCG_HIP(ctx, hipMemcpyAsync(packed + (size_t)r * fin_words, base + stride * (size_t)r + sizeof(FinHeader), fin_words * 4,
-                                hipMemcpyDeviceToDevice, st));
+    NCG_HIP_DRAIN(ctx, st, hipMemcpyAsync(packed + (size_t)r * fin_words, base + stride * (size_t)r + sizeof(FinHeader), fin_words * 4,
+                                          hipMemcpyDeviceToDevice, st));
   uint32_t* sum = packed + (size_t)nparts * fin_words;
   const size_t npoints = fin_words / ncg::msm_acc_words(curve);
-  NCG_HIP(ctx, ncg::msm_sum_partials(curve, packed, nparts, npoints, sum, st));
+  NCG_HIP_DRAIN(ctx, st, ncg::msm_sum_partials(curve, packed, nparts, npoints, sum, st));
   uint8_t inf_local = 0;
-  NCG_HIP(ctx, ncg::msm_finish(curve, pl, sum, (uint32_t*)out_affine, &inf_local, st));  // synchronises st
-  for (int r = 0; r < nparts; r++)
-    if (hs[r].c != (uint32_t)pl.c || hs[r].nwin != (uint32_t)pl.nwin || hs[r].words != (uint32_t)fin_words ||
-        hs[r].curve != (uint32_t)curve)
-      return set_err(ctx, NCG_ERR_INVALID_ARG,
-                     "noble-gpu: msm_sharded: rank %d planned c=%u nwin=%u (curve %u), this rank c=%d nwin=%d - all ranks "
-                     "must pass the same curve and n_max",
-                     r, hs[r].c, hs[r].nwin, hs[r].curve, pl.c, pl.nwin);
+  NCG_HIP_DRAIN(ctx, st, ncg::msm_finish(curve, pl, sum, (uint32_t*)out_affine, &inf_local, st));  // synchronises st
+  char msg[320];
+  if (ncg::msm_shard_check(hs.data(), nparts, curve, pl, fin_words, msg, sizeof msg) >= 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "%s", msg);
   if (out_is_inf) *out_is_inf = inf_local;
   return NCG_OK;
 }
@@ -241,11 +246,7 @@ int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max, c
   ncg::MsmPlan pl;
   size_t stride = 0;
   {  // size the gather buffer before anything is enqueued
-    ncg::MsmPlan probe;
-    if (ncg::msm_make_plan(curve, (int)n_max, 0, &probe) != 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
-    const size_t fw = ncg::msm_fin_words(curve, probe);
-    const size_t sd = (sizeof(FinHeader) + fw * 4 + 255) & ~(size_t)255;
-    int rc = ensure_comm_buf(ctx, comm_buf_need(sd, fw, G));
+    int rc = ensure_comm_buf(ctx, comm_buf_need(ncg::msm_shard_slot_bytes(curve), ncg::msm_shard_max_fin_words(curve), G));
     if (rc) return rc;
   }
   const uint32_t* d_bad = nullptr;
@@ -261,11 +262,63 @@ int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max, c
   }
   uint32_t bad = 0xFFFFFFFFu;  // this rank's scalar-range verdict (validateMSMScalars, curve.ts:398-404); read in stream order
   if (d_bad) NCG_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
-  rc = combine_and_finish(ctx, curve, pl, stride, G, out_affine, out_is_inf, st);
+  rc = combine_and_finish(ctx, curve, pl, stride, G, out_affine, out_is_inf, st);  // drains st on every path
   if (rc) return rc;
   if (bad != 0xFFFFFFFFu)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: invalid scalar at index %u of this rank's shard (not below the group order)", bad);
   return NCG_OK;
+}
+
+// ---- host-staged exchange: the same sharded MSM for transports other than RCCL (gloo, MPI, sockets) --------
+// ncg_msm_shard_local_dev runs this rank's phase and returns its slot (header + grouped window sums,
+// ncg_msm_shard_slot_bytes(curve) bytes) in host memory; the caller moves the slots of all ranks by whatever
+// means it has and hands them to ncg_msm_shard_combine on any rank, which uploads them and runs the same
+// header check, adding kernel and finish that ncg_msm_sharded_dev runs after its all-gather.
+size_t ncg_msm_shard_slot_bytes(int curve) { return ncg_point_bytes(curve) ? ncg::msm_shard_slot_bytes(curve) : 0; }
+
+int ncg_msm_shard_local_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max, const void* points_affine_dev,
+                            const void* scalars_dev, void* slot_out, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (ncg_point_bytes(curve) == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm_shard_local: unsupported curve %d", curve);
+  if (!slot_out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_local: NULL output");
+  if (n_max == 0) n_max = n_local;
+  if (n_local > n_max || n_max > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_local: n_local > n_max");
+  if (n_local && (!points_affine_dev || !scalars_dev)) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_local: NULL buffer");
+  const size_t slot_bytes = ncg::msm_shard_slot_bytes(curve);
+  memset(slot_out, 0, slot_bytes);
+  if (n_max == 0) return NCG_OK;  // every shard empty: an all-zero slot (combine returns the identity for n_max = 0)
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  ncg::MsmPlan pl;
+  size_t stride = 0;
+  const uint32_t* d_bad = nullptr;
+  int rc = local_phase(ctx, curve, n_local, n_max, points_affine_dev, scalars_dev, 0, 1, &pl, &stride, st, &d_bad);
+  if (rc) return rc;
+  uint32_t bad = 0xFFFFFFFFu;
+  if (d_bad) NCG_HIP_DRAIN(ctx, st, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+  NCG_HIP_DRAIN(ctx, st, hipMemcpyAsync(slot_out, ctx->comm_buf, sizeof(FinHeader) + ncg::msm_fin_words(curve, pl) * 4, hipMemcpyDeviceToHost, st));
+  NCG_HIP(ctx, hipStreamSynchronize(st));
+  if (bad != 0xFFFFFFFFu)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: invalid scalar at index %u of this rank's shard (not below the group order)", bad);
+  return NCG_OK;
+}
+
+int ncg_msm_shard_combine(ncg_ctx* ctx, int curve, size_t n_max, int nparts, const void* slots, void* out_affine, uint8_t* out_is_inf,
+                          void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (ncg_point_bytes(curve) == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm_shard_combine: unsupported curve %d", curve);
+  if (!out_affine || !slots || nparts < 1 || nparts > 4096) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_combine: bad arguments");
+  if (n_max > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_combine: too many points");
+  if (n_max == 0) return identity_out(curve, out_affine, out_is_inf);  // every shard empty (curve.ts:878)
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  ncg::MsmPlan pl;
+  if (ncg::msm_make_plan(curve, (int)n_max, 0, &pl) != 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+  const size_t stride = ncg::msm_shard_slot_bytes(curve);
+  int rc = ensure_comm_buf(ctx, comm_buf_need(stride, ncg::msm_shard_max_fin_words(curve), nparts));
+  if (rc) return rc;
+  NCG_HIP(ctx, hipMemcpyAsync(ctx->comm_buf, slots, stride * (size_t)nparts, hipMemcpyHostToDevice, st));
+  return combine_and_finish(ctx, curve, pl, stride, nparts, out_affine, out_is_inf, st);
 }
 
 // The sharded pipeline on ONE GPU (self-check and A/B of the shard-size plan): the point set is cut into
@@ -283,11 +336,8 @@ int ncg_msm_split_dev(ncg_ctx* ctx, int curve, size_t n, int parts, const void* 
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   const size_t per = (n + parts - 1) / parts;
   if (per > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: too many points");
-  ncg::MsmPlan probe, pl;
-  if (ncg::msm_make_plan(curve, (int)per, 0, &probe) != 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
-  const size_t fw = ncg::msm_fin_words(curve, probe);
-  const size_t sd = (sizeof(FinHeader) + fw * 4 + 255) & ~(size_t)255;
-  int rc = ensure_comm_buf(ctx, comm_buf_need(sd, fw, parts));
+  ncg::MsmPlan pl;
+  int rc = ensure_comm_buf(ctx, comm_buf_need(ncg::msm_shard_slot_bytes(curve), ncg::msm_shard_max_fin_words(curve), parts));
   if (rc) return rc;
   size_t stride = 0;
   for (int g = 0; g < parts; g++) {
@@ -381,11 +431,7 @@ int ncg_msm_multi(ncg_multi* m, int curve, size_t n, const void* points_affine, 
     ncg_ctx* ctx = m->ctx[g];
     const size_t lo = std::min(n, per * (size_t)g), cnt = std::min(n, lo + per) - lo;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(set_err(ctx, NCG_ERR_HIP, "noble-gpu: hipSetDevice failed"));
-    ncg::MsmPlan probe;
-    if (ncg::msm_make_plan(curve, (int)per, 0, &probe) != 0) return fail(set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows"));
-    const size_t fw = ncg::msm_fin_words(curve, probe);
-    const size_t sd = (sizeof(FinHeader) + fw * 4 + 255) & ~(size_t)255;
-    int rc = ensure_comm_buf(ctx, comm_buf_need(sd, fw, G));
+    int rc = ensure_comm_buf(ctx, comm_buf_need(ncg::msm_shard_slot_bytes(curve), ncg::msm_shard_max_fin_words(curve), G));
     if (rc) return fail(rc);
     const size_t pts_b = cnt * (size_t)pb, sc_b = cnt * 32;
     const size_t pts_al = (pts_b + 255) & ~(size_t)255;

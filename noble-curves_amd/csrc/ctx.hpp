@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/ncg.h"
+#include "host_api.hpp"
 
 struct ncg_ctx {
   int device = 0;
@@ -18,6 +19,7 @@ struct ncg_ctx {
   size_t mul_ws_bytes = 0;
   void* msm_ws = nullptr;  // MSM workspace (device)
   size_t msm_ws_bytes = 0;
+  ncg::MsmSide msm_side;   // second stream + fork / join events of the MSM (msm.hip)
   uint32_t* ed_btab = nullptr;  // ed25519 base-point table (device)
   void* ed_ks = nullptr;        // ed25519 challenge scalars of the message-taking verify (device)
   size_t ed_ks_bytes = 0;

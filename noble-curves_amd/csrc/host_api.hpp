@@ -51,24 +51,37 @@ hipError_t ntt_run(int n, size_t batch, const uint32_t* src, uint32_t* dst, uint
 void ntt_host(int n, const uint32_t* omega_wire, const uint32_t* src, uint32_t* dst, int flags);
 
 struct MsmPlan;
+// Optional second stream of a context: the wire -> storage conversion of the points has no consumer before
+// the accumulate kernel, so it runs beside the digit / sort kernels (LDS- and memory-bound) instead of in
+// front of them.  fork / join are timing-disabled events.
+struct MsmSide {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
 int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl);
 size_t msm_workspace_bytes(int curve, const MsmPlan& pl);
 // d_pts / d_scalars: device; out_*: host.  Synchronises `st` (host-side Horner finish).
 // *bad_index (optional): smallest index of a scalar >= the group order, 0xFFFFFFFF if none (the result is
 // then meaningless: the caller fails the call like the reference's validateMSMScalars, curve.ts:398-404)
 hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index = nullptr);
+                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index = nullptr,
+                   const MsmSide* side = nullptr);
+// wire points -> the accumulate kernel's storage format (what a plan with pts_stored = 1 takes as d_pts)
+size_t msm_stored_words_per_point(int curve);
+hipError_t msm_points_to_stored(int curve, const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st);
 
 // The same in two phases, for the multi-GPU path: msm_device_phase leaves the grouped window sums
 // (msm_fin_words(curve, pl) words = npoints accumulators of msm_acc_words(curve) words) in the workspace
 // and returns their device address; msm_sum_partials adds nparts such arrays element by element;
 // msm_finish brings one array to the host and finishes (synchronises `st`).
 hipError_t msm_device_phase(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                            const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad = nullptr);
+                            const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad = nullptr,
+                            const MsmSide* side = nullptr);
 hipError_t msm_finish(int curve, const MsmPlan& pl, const uint32_t* d_fin, uint32_t* out_affine_host,
                       uint8_t* out_inf_host, hipStream_t st);
-hipError_t msm_sum_partials(int curve, const uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
-                            hipStream_t st);
+hipError_t msm_sum_partials(int curve, uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
+                            hipStream_t st);  // d_gathered is scratch: reduced in place
 size_t msm_fin_words(int curve, const MsmPlan& pl);
 size_t msm_acc_words(int curve);
 

@@ -11,6 +11,7 @@
 #include "h2c.hip"
 #include "endo.hpp"
 #include "ecdsa.hip"
+#include "msm_shard.hpp"
 
 using namespace ncg;
 
@@ -92,6 +93,85 @@ static int ht_fe9_t(int op, int variant, const uint32_t* a, const uint32_t* b, u
   }
   return -1;
 }
+
+
+// ---- sharded MSM twin (tests/test_distributed_cpu.py): the per-shard grouped window sums computed naively with the
+// group-law templates, then the REAL slot format, header check, partial-sum order and finish of comm.hip / msm_finish.hpp
+template <class C>
+static int ht_shard_local_t(int curve, int n_local, int n_max, const uint32_t* pts_wire, const uint32_t* scalars, uint8_t* slot) {
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
+  MsmPlan pl;
+  if (msm_make_plan_impl(curve, n_max, 0, &pl) != 0) return -1;
+  const int ng = msm_ngroups(pl.c);
+  const size_t fin_words = (size_t)ng * pl.nwin * XW;
+  memset(slot, 0, msm_shard_slot_bytes(curve));
+  FinHeader h{(uint32_t)pl.c, (uint32_t)pl.nwin, (uint32_t)fin_words, (uint32_t)curve};
+  memcpy(slot, &h, sizeof h);
+  uint32_t* fin = (uint32_t*)(slot + sizeof h);
+  std::vector<typename G::Acc> win(pl.nwin, G::identity());
+  std::vector<uint32_t> st(G::AFF_WORDS);
+  const uint32_t mask = (1u << pl.c) - 1u;
+  const int half = 1 << (pl.c - 1);
+  for (int i = 0; i < n_local; i++) {
+    G::wire_to_storage(pts_wire + (size_t)i * G::WIRE_AFF, st.data());
+    const typename G::Aff P = G::aff_load(st.data());
+    uint32_t my[11];
+    uint32_t cy = 0;
+    for (int j = 0; j < 8; j++) my[j] = __builtin_addc(scalars[(size_t)i * 8 + j], pl.hconst[j], cy, &cy);
+    my[8] = __builtin_addc(0u, pl.hconst[8], cy, &cy);
+    my[9] = pl.hconst[9] + cy;
+    my[10] = 0;
+    for (int w = 0; w < pl.nwin; w++) {
+      const int bp = w * pl.c, limb = bp >> 5, sft = bp & 31;
+      const uint64_t two = ((uint64_t)my[limb + 1] << 32) | my[limb];
+      const int d = (int)((uint32_t)(two >> sft) & mask) - half;
+      if (d == 0) continue;
+      const unsigned a = (unsigned)(d < 0 ? -d : d);
+      typename G::Acc t = G::identity();
+      for (int bit = 15; bit >= 0; bit--) {
+        t = G::dbl(t);
+        if ((a >> bit) & 1u) t = G::madd(t, P, d < 0);
+      }
+      win[w] = G::add(win[w], t);
+    }
+  }
+  for (int w = 0; w < pl.nwin; w++) G::acc_store(fin + (size_t)w * XW, win[w]);  // V_0 = W_w; V_j = identity for j >= 1
+  return 0;
+}
+template <class C>
+static int ht_shard_combine_t(int curve, int n_max, int nparts, const uint8_t* slots, uint32_t* out, uint8_t* out_inf, char* err, int errlen) {
+  using G = MsmGroup<C>;
+  constexpr int XW = G::ACC_WORDS;
+  MsmPlan pl;
+  if (msm_make_plan_impl(curve, n_max, 0, &pl) != 0) return -1;
+  const size_t stride = msm_shard_slot_bytes(curve);
+  const size_t fin_words = (size_t)msm_ngroups(pl.c) * pl.nwin * XW;
+  std::vector<FinHeader> hs(nparts);
+  for (int r = 0; r < nparts; r++) memcpy(&hs[r], slots + stride * r, sizeof(FinHeader));
+  char msg[320];
+  if (msm_shard_check(hs.data(), nparts, curve, pl, fin_words, msg, sizeof msg) >= 0) {
+    if (err && errlen > 0) snprintf(err, errlen, "%s", msg);
+    return 1;
+  }
+  const size_t npoints = fin_words / XW;
+  std::vector<uint32_t> sum(fin_words);
+  for (size_t t = 0; t < npoints; t++) {
+    typename G::Acc acc = G::acc_load((const uint32_t*)(slots + sizeof(FinHeader)) + t * XW);
+    for (int r = 1; r < nparts; r++) acc = G::add(acc, G::acc_load((const uint32_t*)(slots + stride * r + sizeof(FinHeader)) + t * XW));
+    G::acc_store(sum.data() + t * XW, acc);
+  }
+  msm_host_finish_any<C>(sum.data(), pl.c, pl.nwin, out, out_inf);
+  return 0;
+}
+#define HT_CURVE_DISPATCH(curve, CALL)                \
+  switch (curve) {                                    \
+    case CURVE_SECP256K1: return CALL(CurveSecp);     \
+    case CURVE_ED25519: return CALL(CurveEd);         \
+    case CURVE_BLS12_381_G1: return CALL(CurveG1);    \
+    case CURVE_BLS12_381_G2: return CALL(CurveG2);    \
+    default: return -1;                               \
+  }
 
 extern "C" {
 
@@ -225,6 +305,39 @@ int ht_ed25519_verify(const uint32_t* sig, const uint32_t* pk, const uint32_t* k
     built = true;
   }
   return ed25519_verify_host(sig, pk, k, btab, zip215 != 0) ? 1 : 0;
+}
+
+size_t ht_msm_shard_slot_bytes(int curve) { return msm_shard_slot_bytes(curve); }
+int ht_msm_shard_local(int curve, int n_local, int n_max, const uint32_t* pts_wire, const uint32_t* scalars, uint8_t* slot) {
+#define CALL(C) ht_shard_local_t<C>(curve, n_local, n_max, pts_wire, scalars, slot)
+  HT_CURVE_DISPATCH(curve, CALL)
+#undef CALL
+}
+int ht_msm_shard_combine(int curve, int n_max, int nparts, const uint8_t* slots, uint32_t* out, uint8_t* out_inf, char* err, int errlen) {
+#define CALL(C) ht_shard_combine_t<C>(curve, n_max, nparts, slots, out, out_inf, err, errlen)
+  HT_CURVE_DISPATCH(curve, CALL)
+#undef CALL
+}
+// host finish of the MSM alone: variant 0 = the device templates compiled for the host, 1 = the default
+// (bls12-381: 64-bit-limb Jacobian form of bls_host64.hpp)
+int ht_msm_finish(int curve, int c, int nwin, const uint32_t* fin, uint32_t* out, uint8_t* out_inf, int variant) {
+  if (variant == 0) {
+#define CALL(C) (msm_host_finish<C>(fin, c, nwin, out, out_inf), 0)
+    HT_CURVE_DISPATCH(curve, CALL)
+#undef CALL
+  }
+#define CALL(C) (msm_host_finish_any<C>(fin, c, nwin, out, out_inf), 0)
+  HT_CURVE_DISPATCH(curve, CALL)
+#undef CALL
+}
+int ht_msm_plan(int curve, int n, int* out) {  // c, nwin, ngroups, acc words
+  MsmPlan pl;
+  if (msm_make_plan_impl(curve, n, 0, &pl) != 0) return -1;
+  out[0] = pl.c;
+  out[1] = pl.nwin;
+  out[2] = msm_ngroups(pl.c);
+  out[3] = (int)msm_acc_words_inl(curve);
+  return 0;
 }
 
 }  // extern "C"

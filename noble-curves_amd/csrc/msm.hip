@@ -8,6 +8,9 @@
 #include <vector>
 
 #include "host_api.hpp"
+#include "msm_coop.hpp"
+#include "msm_finish.hpp"
+#include "msm_plan.hpp"
 
 namespace ncg {
 
@@ -261,57 +264,48 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
 }
 
 // Adds up the pieces of every bucket that was cut by lane boundaries.  The pieces of one bucket
-// are the "tail" of the lane where it starts (run index 0) followed by the "head" of every later
+// are the "tail" of the lane where it starts (piece 0) followed by the "head" of every later
 // lane it covers; lane s0 = bucket_start / seg and s1 = (bucket_end - 1) / seg delimit the run,
-// so every piece knows its run index without a scan.  Pass `d` (d = 1, 2, 4, ...) adds piece
-// idx + d into piece idx for idx % 2d == 0: log2(longest run) passes, each fully parallel - a
-// bucket holding every entry of a window (identical scalars; the short top window) costs
-// ~log2(n/seg) additions of latency instead of n/seg.
+// so every piece knows its place without a scan.  With `seg` entries per lane a bucket of m
+// entries is cut into at most m / seg + 2 pieces: for scalars that look random the runs are 2
+// (rarely 3) pieces long, so the owner of piece 0 adds the few heads itself and writes the bucket -
+// ONE launch (round 2 ran 13-14 log-step passes that all but the first found nothing to do).
+// A run longer than MSM_RUN_SERIAL heads (identical scalars: benchmark/bls12-381.ts:64-79 feeds
+// them; the short top window of most plans) goes to a work list instead, and k_msm_fixup_long (below, after the
+// cooperative operations it uses) gives each such run a whole workgroup: strided partial sums, then an LDS tree -
+// log depth in the run length.
+constexpr int MSM_RUN_SERIAL = 2;
+constexpr int MSM_LONG_BLOCKS = 512;
 template <class C>
-__global__ void __launch_bounds__(256, TailMinWaves<C>::value) k_msm_fixup_pass(uint32_t* __restrict__ part_pts,
+__global__ void __launch_bounds__(256, TailMinWaves<C>::value) k_msm_fixup_merge(const uint32_t* __restrict__ part_pts,
                                                         const int* __restrict__ part_meta,
-                                                        const uint32_t* __restrict__ bucket_start, MsmPlan pl,
-                                                        MsmSeg sg, int d, uint32_t* __restrict__ pass_flags,
-                                                        int pass) {
+                                                        const uint32_t* __restrict__ bucket_start,
+                                                        uint32_t* __restrict__ buckets, MsmPlan pl, MsmSeg sg,
+                                                        uint32_t* __restrict__ long_runs, int run_serial) {
   using G = MsmGroup<C>;
-  constexpr int XW = G::ACC_WORDS;
-  // a run longer than 2d pieces is also longer than d: if the previous pass found nothing to
-  // add, neither will this one (wave-uniform early exit; flags are zeroed before the passes)
-  if (pass > 0 && pass_flags[pass - 1] == 0) return;
-  const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value, w = blockIdx.y;
-  if (s >= sg.nseg) return;
-  const int* meta = part_meta + ((size_t)w * sg.nseg + s) * 4;
-  const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
-  uint32_t* pp = part_pts + (size_t)w * sg.nseg * 2 * XW;
-  // role 0: my head piece (member idx >= 1 of its bucket's run); role 1: my tail piece (idx 0)
-#pragma unroll
-  for (int role = 0; role < 2; role++) {
-    const int b = meta[role == 0 ? 0 : 2];
-    if (b < 0) continue;
-    const int s0 = role == 0 ? (int)(bs[b] / (uint32_t)sg.seg) : s;
-    const int s1 = (int)((bs[b + 1] - 1) / (uint32_t)sg.seg);
-    const int idx = s - s0;
-    if ((idx & (2 * d - 1)) != 0 || s + d > s1) continue;
-    pass_flags[pass] = 1;
-    uint32_t* mine = pp + ((size_t)s * 2 + role) * XW;
-    const uint32_t* other = pp + ((size_t)(s + d) * 2) * XW;  // always a head piece
-    G::acc_store(mine, G::add(G::acc_load(mine), G::acc_load(other)));
-  }
-}
-
-// After the passes, the run totals sit in the tail slots: write them to their buckets.
-template <class C>
-__global__ void __launch_bounds__(256) k_msm_fixup_write(const uint32_t* __restrict__ part_pts,
-                                                         const int* __restrict__ part_meta,
-                                                         uint32_t* __restrict__ buckets, MsmPlan pl, MsmSeg sg) {
-  using G = MsmGroup<C>;
-  constexpr int XW = G::ACC_WORDS;
-  const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value, w = blockIdx.y;
+  constexpr int XW = G::ACC_WORDS, LS = LaneShift<C>::value;
+  const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> LS, w = blockIdx.y;
   if (s >= sg.nseg) return;
   const int tb = part_meta[((size_t)w * sg.nseg + s) * 4 + 2];
   if (tb < 0) return;
-  const uint32_t* src = part_pts + (((size_t)w * sg.nseg + s) * 2 + 1) * XW;
-  G::acc_store(buckets + ((size_t)w * pl.nb + tb) * XW, G::acc_load(src));
+  const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  const int s1 = (int)((bs[tb + 1] - 1) / (uint32_t)sg.seg);
+  const int heads = s1 - s;
+  if (heads > run_serial) {
+    if ((threadIdx.x & ((1 << LS) - 1)) == 0) {
+      const uint32_t k = atomicAdd(long_runs, 1u);
+      uint32_t* e = long_runs + 4 + (size_t)k * 4;
+      e[0] = (uint32_t)w;
+      e[1] = (uint32_t)tb;
+      e[2] = (uint32_t)s;
+      e[3] = (uint32_t)s1;
+    }
+    return;
+  }
+  const uint32_t* pp = part_pts + (size_t)w * sg.nseg * 2 * XW;
+  typename G::Acc acc = G::acc_load(pp + ((size_t)s * 2 + 1) * XW);
+  for (int k = 1; k <= heads; k++) acc = G::add(acc, G::acc_load(pp + ((size_t)(s + k) * 2) * XW));
+  G::acc_store(buckets + ((size_t)w * pl.nb + tb) * XW, acc);
 }
 
 // ------------------------------------------------------------------ 5. bucket fold, one level
@@ -339,135 +333,241 @@ __global__ void __launch_bounds__(256, TailMinWaves<C>::value) k_msm_reduce_leve
   G::acc_store(out + (((size_t)a * nwin + w) * n_out + q) * XW, r);
 }
 
-// ------------------------------------------------------------------ 5b. group the pending sums
+// ------------------------------------------------------------------ 5a. the same level, four items per addition
+// For the levels that no longer fill the chip (msm_coop.hpp): same indexing, one task per GROUP of four items.
+template <class C>
+__global__ void __launch_bounds__(256) k_msm_reduce_level_coop(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                               int narr, int nwin, int n_in) {
+#ifdef __HIP_DEVICE_COMPILE__
+  using K = CoopXyzz<C>;
+  constexpr int XW = MsmGroup<C>::ACC_WORDS;
+  extern __shared__ __attribute__((aligned(16))) uint32_t coop_lds[];
+  uint32_t* lds = coop_lds + (size_t)K::group_in_block() * K::GROUP_WORDS;
+  const int n_out = n_in >> 1;
+  const long total = (long)(narr + 1) * nwin * n_out;
+  const long t = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> (K::LS + 2);
+  if (t >= total) return;
+  const int q = (int)(t % n_out);
+  const int w = (int)((t / n_out) % nwin);
+  const int a = (int)(t / ((long)n_out * nwin));
+  uint32_t* dst = out + (((size_t)a * nwin + w) * n_out + q) * XW;
+  if (a < narr) {
+    const uint32_t* base = in + (((size_t)a * nwin + w) * n_in + 2 * (size_t)q) * XW;
+    K::add(lds, base, base + XW, dst);
+  } else {
+    K::copy(in + (((size_t)w) * n_in + 2 * (size_t)q + 1) * XW, dst);
+  }
+#endif
+}
+
+// ------------------------------------------------------------------ 5b. the narrow end in ONE launch
+// One workgroup per window runs the last fold levels (from the point where a level's additions fit the
+// workgroup once or twice) and then groups the pending sums, with workgroup barriers instead of launches:
 // After the fold every window holds narr = c points: array 0 = S (weight 1) and array a >= 1 =
 // the level-a pending sum (weight 2^(a-1)), i.e. terms u_e = at(e+1) (+ at(0) for e = 0) with
 // weight 2^e, e < c-1.  The host Horner would spend one addition per term; here g consecutive
-// terms are pre-combined, V_j = sum_{i<g} 2^i u_{jg+i} (g-1 doublings + additions per lane, all
+// terms are pre-combined, V_j = sum_{i<g} 2^i u_{jg+i} (g-1 doublings + additions per unit, all
 // groups in parallel), so the host does one addition per GROUP - its doublings (one per scalar
 // bit) are the part only a latency-optimised core can do quickly.
+// TailOps<C, COOP>: a "unit" is one item (lane / lane pair) running the complete single-lane routines, or a
+// group of four items sharing each operation (msm_coop.hpp).  Operands and results live in memory; `lds` is the
+// unit's scratch: the exchange slots of the cooperative form, then one accumulator for the grouping chain.
+constexpr int MSM_TAIL_THREADS = 512;
+template <class C, bool COOP> struct TailOps;
 template <class C>
-__global__ void __launch_bounds__(256, TailMinWaves<C>::value) k_msm_group_pending(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                           int narr, int nwin, int g, int ngroups) {
+struct TailOps<C, false> {
   using G = MsmGroup<C>;
-  constexpr int XW = G::ACC_WORDS;
-  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
-  if (t >= ngroups * nwin) return;
-  const int j = t / nwin, w = t % nwin;
-  auto at = [&](int a) { return G::acc_load(in + ((size_t)a * nwin + w) * XW); };
-  const int e_lo = j * g;
-  const int e_hi = min((j + 1) * g, narr - 1) - 1;
-  typename G::Acc acc = at(e_hi + 1);
-  if (e_hi == 0) acc = G::add(acc, at(0));
-  for (int e = e_hi - 1; e >= e_lo; e--) {
-    acc = G::dbl(acc);
-    acc = G::add(acc, at(e + 1));
-    if (e == 0) acc = G::add(acc, at(0));
+  static constexpr int UNIT_SHIFT = LaneShift<C>::value;
+  static constexpr int SCRATCH_WORDS = 0;
+  static constexpr int LDS_WORDS = G::ACC_WORDS;  // the chain accumulator
+  static __device__ __noinline__ void add(uint32_t* lds, const uint32_t* p, const uint32_t* q, uint32_t* out) {
+    G::acc_store(out, G::add(G::acc_load(p), G::acc_load(q)));
   }
-  G::acc_store(out + ((size_t)j * nwin + w) * XW, acc);
+  static __device__ __noinline__ void dbl(uint32_t* lds, const uint32_t* p, uint32_t* out) { G::acc_store(out, G::dbl(G::acc_load(p))); }
+  static __device__ __forceinline__ void copy(const uint32_t* p, uint32_t* out) { G::acc_store(out, G::acc_load(p)); }
+  static __device__ __forceinline__ void sync() {}
+};
+#ifdef __HIP_DEVICE_COMPILE__
+template <class C>
+struct TailOps<C, true> {
+  using K = CoopXyzz<C>;
+  static constexpr int UNIT_SHIFT = LaneShift<C>::value + 2;
+  static constexpr int SCRATCH_WORDS = K::GROUP_WORDS;
+  static constexpr int LDS_WORDS = K::GROUP_WORDS + MsmGroup<C>::ACC_WORDS;
+  static __device__ __noinline__ void add(uint32_t* lds, const uint32_t* p, const uint32_t* q, uint32_t* out) { K::add(lds, p, q, out); }
+  static __device__ __noinline__ void dbl(uint32_t* lds, const uint32_t* p, uint32_t* out) { K::dbl(lds, p, out); }
+  static __device__ __forceinline__ void copy(const uint32_t* p, uint32_t* out) { K::copy(p, out); }
+  static __device__ __forceinline__ void sync() { coop_sync(); }
+};
+#else
+template <class C>
+struct TailOps<C, true> : TailOps<C, false> {
+  static constexpr int UNIT_SHIFT = LaneShift<C>::value + 2;
+  static constexpr int SCRATCH_WORDS = COOP_SLOTS * MsmGroup<C>::FW;
+  static constexpr int LDS_WORDS = COOP_SLOTS * MsmGroup<C>::FW + MsmGroup<C>::ACC_WORDS;
+};
+#endif
+
+// Long runs of the fix-up (see k_msm_fixup_merge): one workgroup per run of the work list.  Unit t sums the pieces
+// t, t + act, ... (act = the power of two >= the run length, at most the workgroup's units), then a tree over the
+// units' accumulators in LDS.  Units are cooperative groups where the curve offers them: a run of 50 pieces (the
+// short top window of a 2^17-point shard) costs 1 + 6 cooperative additions.
+template <class C, bool COOP>
+__global__ void __launch_bounds__(MSM_TAIL_THREADS) k_msm_fixup_long(const uint32_t* __restrict__ part_pts,
+                                                                     uint32_t* __restrict__ buckets, MsmPlan pl, MsmSeg sg,
+                                                                     const uint32_t* __restrict__ long_runs) {
+#ifdef __HIP_DEVICE_COMPILE__
+  using T = TailOps<C, COOP>;
+  constexpr int XW = MsmGroup<C>::ACC_WORDS;
+  extern __shared__ __attribute__((aligned(16))) uint32_t long_lds[];
+  const uint32_t count = long_runs[0];
+  if (count == 0) return;  // the usual case for full top windows: one wave-uniform load and out
+  const int unit = (int)(threadIdx.x >> T::UNIT_SHIFT), units = (int)(blockDim.x >> T::UNIT_SHIFT);
+  const int lane_in_unit = (int)(threadIdx.x & ((1u << T::UNIT_SHIFT) - 1u));
+  uint32_t* lds = long_lds + (size_t)unit * T::LDS_WORDS;
+  uint32_t* acc = lds + T::SCRATCH_WORDS;
+  for (uint32_t r = blockIdx.x; r < count; r += gridDim.x) {
+    const uint32_t* e = long_runs + 4 + (size_t)r * 4;
+    const int w = (int)e[0], tb = (int)e[1], s0 = (int)e[2], s1 = (int)e[3];
+    const uint32_t* pp = part_pts + (size_t)w * sg.nseg * 2 * XW;
+    const int np = s1 - s0 + 1;  // piece 0 = the tail slot of lane s0, piece k >= 1 = the head slot of lane s0 + k
+    auto piece = [&](int k) { return pp + ((size_t)(s0 + k) * 2 + (k == 0 ? 1 : 0)) * XW; };
+    int act = units;
+    while ((act >> 1) >= np) act >>= 1;
+    if (unit < act) {
+      if (unit < np) {
+        T::copy(piece(unit), acc);
+      } else {
+        for (int i = lane_in_unit; i < XW; i += (1 << T::UNIT_SHIFT)) acc[i] = 0;  // identity
+      }
+      T::sync();
+      for (int k = unit + act; k < np; k += act) {
+        T::add(lds, acc, piece(k), acc);
+        T::sync();
+      }
+    }
+    for (int off = act >> 1; off >= 1; off >>= 1) {
+      __syncthreads();
+      if (unit < off) T::add(lds, acc, long_lds + (size_t)(unit + off) * T::LDS_WORDS + T::SCRATCH_WORDS, acc);
+    }
+    __syncthreads();
+    if (unit == 0) T::copy(acc, buckets + ((size_t)w * pl.nb + tb) * XW);
+    __syncthreads();
+  }
+#endif
+}
+
+// in: [narr][nwin][n_in] accumulators (read-only here: other workgroups read their windows from it);
+// s0 / s1: scratch, MSM_TAIL_REGION accumulators PER WINDOW each - a window's levels ping-pong inside its own
+// regions, laid out [array][n] (workgroups run at different levels, so they must not share a layout);
+// fin: [ngroups][nwin] grouped sums.
+constexpr int MSM_TAIL_REGION = 2 * MSM_TAIL_THREADS + 64;
+template <class C, bool COOP>
+__global__ void __launch_bounds__(MSM_TAIL_THREADS) k_msm_tail(const uint32_t* __restrict__ in, uint32_t* __restrict__ s0,
+                                                               uint32_t* __restrict__ s1, uint32_t* __restrict__ fin,
+                                                               int narr, int nwin, int n_in, int g, int ngroups) {
+#ifdef __HIP_DEVICE_COMPILE__
+  using T = TailOps<C, COOP>;
+  constexpr int XW = MsmGroup<C>::ACC_WORDS;
+  extern __shared__ __attribute__((aligned(16))) uint32_t tail_lds[];
+  const int unit = (int)(threadIdx.x >> T::UNIT_SHIFT), units = (int)(blockDim.x >> T::UNIT_SHIFT);
+  uint32_t* lds = tail_lds + (size_t)unit * T::LDS_WORDS;
+  const int w = blockIdx.x;
+  // element (array a, index i) of the current level: the input array is [a][w][i], the private regions [a][i]
+  const uint32_t* cur = in;
+  size_t cur_a = (size_t)nwin * n_in, cur_w = (size_t)w * n_in;  // strides / offset in accumulators
+  uint32_t* nxt = s0 + (size_t)w * MSM_TAIL_REGION * XW;
+  uint32_t* spare = s1 + (size_t)w * MSM_TAIL_REGION * XW;
+  while (n_in > 1) {
+    const int n_out = n_in >> 1;
+    const int tasks = (narr + 1) * n_out;
+    for (int t = unit; t < tasks; t += units) {
+      const int a = t / n_out, q = t - a * n_out;
+      uint32_t* dst = nxt + ((size_t)a * n_out + q) * XW;
+      if (a < narr) {
+        const uint32_t* base = cur + ((size_t)a * cur_a + cur_w + 2 * (size_t)q) * XW;
+        T::add(lds, base, base + XW, dst);
+      } else {
+        T::copy(cur + (cur_w + 2 * (size_t)q + 1) * XW, dst);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t* done = nxt;
+    nxt = spare;
+    spare = done;
+    cur = done;
+    cur_a = (size_t)n_out;
+    cur_w = 0;
+    narr++;
+    n_in = n_out;
+  }
+  if (cur == in) {  // no level ran here (a one-bucket window): array a of this window sits at [a][w]
+    cur_a = (size_t)nwin;
+    cur_w = (size_t)w;
+  }
+  // grouping: unit j combines the terms e_lo .. e_hi of this window into fin[j][w]; the chain runs in the unit's LDS accumulator
+  uint32_t* acc = lds + T::SCRATCH_WORDS;
+  for (int j = unit; j < ngroups; j += units) {
+    const int e_lo = j * g;
+    const int e_hi = min((j + 1) * g, narr - 1) - 1;
+    auto at = [&](int a) { return cur + ((size_t)a * cur_a + cur_w) * XW; };
+    T::copy(at(e_hi + 1), acc);
+    T::sync();
+    if (e_hi == 0) T::add(lds, acc, at(0), acc);
+    for (int e = e_hi - 1; e >= e_lo; e--) {
+      T::sync();
+      T::dbl(lds, acc, acc);
+      T::sync();
+      T::add(lds, acc, at(e + 1), acc);
+      if (e == 0) {
+        T::sync();
+        T::add(lds, acc, at(0), acc);
+      }
+    }
+    T::sync();
+    T::copy(acc, fin + ((size_t)j * nwin + w) * XW);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ 5c. multi-GPU combine
-// in: [nparts][npoints] accumulators (the grouped window sums of nparts GPUs, all-gathered);
-// out[t] = sum_r in[r][t] - the reference's final `sum.add(resI)` chain over disjoint point ranges
+// in: [nparts][npoints] accumulators (the grouped window sums of nparts shards, all-gathered; scratch - reduced in
+// place); out[t] = sum_r in[r][t] - the reference's final `sum.add(resI)` chain over disjoint point ranges
 // (src/abstract/curve.ts:895-902 is linear in the points, so partial MSMs add up term by term).
-template <class C>
-__global__ void __launch_bounds__(64, TailMinWaves<C>::value) k_msm_sum_partials(const uint32_t* __restrict__ in,
-                                                                                 uint32_t* __restrict__ out, int nparts,
-                                                                                 int npoints) {
-  using G = MsmGroup<C>;
-  constexpr int XW = G::ACC_WORDS;
-  const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
-  if (t >= npoints) return;
-  typename G::Acc acc = G::acc_load(in + (size_t)t * XW);
-  for (int r = 1; r < nparts; r++) acc = G::add(acc, G::acc_load(in + ((size_t)r * npoints + t) * XW));
-  G::acc_store(out + (size_t)t * XW, acc);
-}
-
-// ------------------------------------------------------------------ planning
-static void mp_set_bit(uint32_t* a, int bit) { a[bit >> 5] |= 1u << (bit & 31); }
-
-// Largest scalar is order-1; choose the fewest windows with (order-1) + H' < 2^(c*nwin).
-static int plan_windows(int c, const uint32_t* order8, uint32_t* hconst10) {
-  for (int nwin = (252 / c); nwin <= 300 / c + 2; nwin++) {
-    if (nwin < 1 || c * nwin > 10 * 32 - 2) continue;
-    uint32_t h[10] = {0};
-    for (int w = 0; w < nwin; w++) mp_set_bit(h, c * w + c - 1);
-    // s = (order - 1) + h
-    uint32_t s[10];
-    uint64_t cy = 0;
-    for (int i = 0; i < 10; i++) {
-      uint64_t o = i < 8 ? order8[i] : 0;
-      uint64_t t = o + h[i] + cy;
-      s[i] = (uint32_t)t;
-      cy = t >> 32;
+// One workgroup per point, a pairwise tree over the shards (log2(nparts) dependent additions instead of
+// nparts - 1; cooperative additions where the group offers them): 8 shards = 3 x ~8 us instead of 7 x ~16 us.
+template <class C, bool COOP>
+__global__ void __launch_bounds__(256) k_msm_sum_partials(uint32_t* __restrict__ in, uint32_t* __restrict__ out, int nparts,
+                                                          int npoints) {
+#ifdef __HIP_DEVICE_COMPILE__
+  using T = TailOps<C, COOP>;
+  constexpr int XW = MsmGroup<C>::ACC_WORDS;
+  extern __shared__ __attribute__((aligned(16))) uint32_t sum_lds[];
+  const int unit = (int)(threadIdx.x >> T::UNIT_SHIFT), units = (int)(blockDim.x >> T::UNIT_SHIFT);
+  uint32_t* lds = sum_lds + (size_t)unit * T::SCRATCH_WORDS;
+  const int t = blockIdx.x;
+  auto at = [&](int r) { return in + ((size_t)r * npoints + t) * XW; };
+  for (int s = 1; s < nparts; s <<= 1) {
+    const int pairs = (nparts + 2 * s - 1) / (2 * s);
+    for (int k = unit; k < pairs; k += units) {
+      const int i = k * 2 * s;
+      if (i + s < nparts) T::add(lds, at(i), at(i + s), at(i));
     }
-    // subtract 1 (order >= 1): fine to skip - being conservative by one is harmless
-    // check s < 2^(c*nwin)
-    bool ok = (cy == 0);
-    int top = c * nwin;
-    for (int bit = top; ok && bit < 320; bit++)
-      if (s[bit >> 5] & (1u << (bit & 31))) ok = false;
-    if (ok) {
-      for (int i = 0; i < 10; i++) hconst10[i] = h[i];
-      return nwin;
-    }
+    __threadfence_block();
+    __syncthreads();
   }
-  return -1;
+  if (unit == 0) T::copy(at(0), out + (size_t)t * XW);
+#endif
 }
 
-static const uint32_t* curve_order(int curve) {
-  switch (curve) {
-    case CURVE_SECP256K1: return Orders::SECP_N;
-    case CURVE_ED25519: return Orders::ED_L;
-    default: return Orders::BLS_R;
-  }
-}
-
-static int ilog2(unsigned x) {
-  int r = 0;
-  while (x >>= 1) r++;
-  return r;
-}
-
-int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) {
-  int c = c_override;
-  if (c <= 0) {
-    const char* env = std::getenv("NCG_MSM_C");
-    if (env) c = std::atoi(env);
-  }
-  if (c <= 0) {
-    // accumulate cost nwin*n mixed adds vs fold cost ~2*nwin*2^(c-1) full adds: c ~ log2(n) - 4.
-    // G2 (measured at 2^18, profiles/): one bit more - its per-window fix-up / fold latency is
-    // 3x G1's, and c = 15 also fills the top window of a 255-bit scalar (c = 14 leaves 3 bits)
-    c = ilog2((unsigned)std::max(n, 1)) - (curve == CURVE_BLS12_381_G2 ? 3 : 4);
-  }
-  c = std::max(2, std::min(16, c));
-  pl->n = n;
-  pl->ls = curve == CURVE_BLS12_381_G2 ? 1 : 0;  // lane-paired kernels: 2 lanes per item
-  // waves/SIMD the accumulate kernel runs at (registers): 4 for the 256-bit fields, 2 for bls12-381
-  pl->accum_waves = (curve == CURVE_SECP256K1 || curve == CURVE_ED25519) ? 4 : 2;
-  pl->c = c;
-  pl->nb = 1 << (c - 1);
-  pl->nwin = plan_windows(c, curve_order(curve), pl->hconst);
-  if (pl->nwin < 0) return -1;
-  for (int i = 0; i < 8; i++) pl->order[i] = curve_order(curve)[i];
-  // sort chunks: ~512 blocks per sort kernel (two per CU; measured 2 % faster than 1024 on the 2^20 G1 MSM,
-  // tools/ab_q.sh: half the per-chunk count arrays to write, prefix and read), at least 4096 points per chunk
-  static const int q_blocks = [] { const char* e = std::getenv("NCG_MSM_QBLOCKS"); return e ? std::max(64, std::atoi(e)) : 512; }();
-  int Q = std::max(1, q_blocks / pl->nwin);
-  Q = std::min(Q, std::max(1, n / 4096));
-  pl->Q = Q;
-  pl->chunk = (n + Q - 1) / Q;
-  static const int xcd = [] { const char* e = std::getenv("NCG_MSM_XCD"); return e ? std::atoi(e) : 0; }();
-  pl->xcd_map = xcd;
-  return 0;
-}
+// ------------------------------------------------------------------ planning (msm_plan.hpp)
+int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) { return msm_make_plan_impl(curve, n, c_override, pl); }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct MsmLayout {
-  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, part_pts, part_meta, pass_flags, bad, red0, red1, total;
+  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, part_pts, part_meta, long_runs, bad, red0, red1, tail0, tail1, fin, total;
 };
 
 static MsmSeg msm_seg(const MsmPlan& pl) {
@@ -508,7 +608,7 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
     off = align256(off + bytes);
     return o;
   };
-  L.pts_mont = take(pl.endo ? 0 : (size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);  // endo: the caller's expanded set
+  L.pts_mont = take((pl.endo || pl.pts_stored) ? 0 : (size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);  // else: the caller's array
   L.digits = take((size_t)pl.nwin * pl.n * 2);
   L.counts = take((size_t)pl.nwin * pl.Q * pl.nb * 4);
   L.bucket_start = take((size_t)pl.nwin * (pl.nb + 1) * 4);
@@ -517,45 +617,30 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
   MsmSeg sg = msm_seg(pl);
   L.part_pts = take((size_t)pl.nwin * sg.nseg * 2 * MsmGroup<C>::ACC_WORDS * 4);
   L.part_meta = take((size_t)pl.nwin * sg.nseg * 4 * 4);
-  L.pass_flags = take(64 * 4);
+  // work list of the long runs: a counter + (window, bucket, first lane, last lane) per run of more than
+  // MSM_RUN_SERIAL heads - such runs cover disjoint lane ranges, so there are at most nwin * nseg / MSM_RUN_SERIAL
+  L.long_runs = take(16 + ((size_t)pl.nwin * (sg.nseg / MSM_RUN_SERIAL + 1)) * 16);
   L.bad = take(64);
   // fold ping-pong: level l output holds (l+1) * nwin * nb/2^l points <= nwin*nb (l = 1, 2)
   size_t red = (size_t)pl.nwin * std::max(pl.nb, pl.c) * MsmGroup<C>::ACC_WORDS * 4;
   L.red0 = take(red);
   L.red1 = take(red);
+  // the tail workgroups' private ping-pong (levels that fit one workgroup per window: at most 2 * 512 additions
+  // per window and level) and the grouped window sums
+  const size_t tail = (size_t)pl.nwin * MSM_TAIL_REGION * MsmGroup<C>::ACC_WORDS * 4;
+  L.tail0 = take(tail);
+  L.tail1 = take(tail);
+  L.fin = take((size_t)msm_ngroups(pl.c) * pl.nwin * MsmGroup<C>::ACC_WORDS * 4);
   L.total = off;
   return L;
-}
-
-// ------------------------------------------------------------------ host finish
-// Horner over all surviving points (see msm.hpp step 6), then affine canonical output.
-// fin: [ngroups][nwin] grouped sums V_j (k_msm_group_pending): window sum W_w = sum_j 2^(g j) V_j,
-// result = sum_w 2^(c w) W_w - c doublings per window in total, one addition per group.
-constexpr int MSM_GROUP = 3;
-static int msm_ngroups(int c) { return c >= 2 ? (c - 1 + MSM_GROUP - 1) / MSM_GROUP : 1; }
-template <class C>
-static void msm_host_finish(const std::vector<uint32_t>& fin, const MsmPlan& pl, uint32_t* out_affine,
-                            uint8_t* out_inf) {
-  using G = MsmGroup<C>;
-  constexpr int XW = G::ACC_WORDS;
-  const int ng = msm_ngroups(pl.c);
-  auto at = [&](int j, int w) { return G::acc_load(fin.data() + ((size_t)j * pl.nwin + w) * XW); };
-  typename G::Acc acc = G::identity();
-  for (int w = pl.nwin - 1; w >= 0; w--) {
-    for (int j = ng - 1; j >= 0; j--) {
-      const int shift = j == ng - 1 ? pl.c - MSM_GROUP * j : MSM_GROUP;
-      for (int d = 0; d < shift; d++) acc = G::dbl(acc);
-      acc = G::add(acc, at(j, w));
-    }
-  }
-  G::to_affine_wire(acc, out_affine, out_inf);
 }
 
 // Device phase: everything up to the grouped window sums (ng x nwin accumulators, device memory,
 // inside the workspace).  Asynchronous on `st`.
 template <class C>
 static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                               const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad = nullptr) {
+                               const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad = nullptr,
+                               const MsmSide* side = nullptr) {
   using G = MsmGroup<C>;
   using D = typename DeviceCurve<C>::type;  // kernels: lane-paired form for G2
   constexpr int LS = LaneShift<D>::value;
@@ -572,6 +657,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   const int n = pl.n;
   hipError_t e;
 
+  bool forked = false;
   uint32_t* bad = (uint32_t*)(base + L.bad);
   e = hipMemsetAsync(bad, 0xFF, 4, st);
   if (e != hipSuccess) return e;
@@ -580,8 +666,21 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     e = msm_endo_digits(pl, d_scalars, digits, bad, st);
     if (e != hipSuccess) return e;
   } else {
-    hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts,
-                       pts_mont, n);
+    if (pl.pts_stored) {
+      pts_mont = const_cast<uint32_t*>(d_pts);
+    } else if (side && side->stream) {  // beside the digits / sort kernels; joined in front of the accumulate kernel
+      e = hipEventRecord(side->fork, st);
+      if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, side->stream,
+                         d_pts, pts_mont, n);
+      e = hipEventRecord(side->join, side->stream);
+      if (e != hipSuccess) return e;
+      forked = true;
+    } else {
+      hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts,
+                         pts_mont, n);
+    }
     hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl, bad);
   }
   size_t lds = (size_t)pl.nb * 4;
@@ -612,24 +711,72 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     e = hipMemsetAsync(buckets, 0, (size_t)pl.nwin * pl.nb * XW * 4, st);  // empty buckets = infinity
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)((((size_t)sg.nseg << LS) + 255) / 256), pl.nwin);
+    if (forked) {
+      e = hipStreamWaitEvent(st, side->join, 0);
+      if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_msm_accum<D>, grid, dim3(256), 0, st, pts_mont, sorted, bstart, buckets, part_pts, part_meta,
                        pl, sg);
-    uint32_t* pass_flags = (uint32_t*)(base + L.pass_flags);
-    e = hipMemsetAsync(pass_flags, 0, 64 * 4, st);
+    uint32_t* long_runs = (uint32_t*)(base + L.long_runs);
+    e = hipMemsetAsync(long_runs, 0, 16, st);
     if (e != hipSuccess) return e;
-    int pass = 0;
-    for (int d = 1; d < sg.nseg; d <<= 1, pass++)
-      hipLaunchKernelGGL(k_msm_fixup_pass<D>, grid, dim3(256), 0, st, part_pts, part_meta, bstart, pl, sg, d,
-                         pass_flags, pass);
-    hipLaunchKernelGGL(k_msm_fixup_write<D>, grid, dim3(256), 0, st, part_pts, part_meta, buckets, pl, sg);
+    const int run_serial = [] { const char* e = std::getenv("NCG_MSM_RUN_SERIAL"); return e ? std::atoi(e) : MSM_RUN_SERIAL; }();
+    hipLaunchKernelGGL(k_msm_fixup_merge<D>, grid, dim3(256), 0, st, part_pts, part_meta, bstart, buckets, pl, sg, long_runs,
+                       std::max(run_serial, MSM_RUN_SERIAL));
+    {
+      constexpr bool LCOOP = CoopOK<D>::value;
+      using K = TailOps<D, LCOOP>;
+      const size_t lds_b = (size_t)(MSM_TAIL_THREADS >> K::UNIT_SHIFT) * K::LDS_WORDS * 4;
+      static bool attr_done[16] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+        e = hipFuncSetAttribute((const void*)k_msm_fixup_long<D, LCOOP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 16) attr_done[dev] = true;
+      }
+      hipLaunchKernelGGL((k_msm_fixup_long<D, LCOOP>), dim3(MSM_LONG_BLOCKS), dim3(MSM_TAIL_THREADS), lds_b, st, part_pts, buckets, pl, sg,
+                         long_runs);
+    }
   }
-  // fold: nb -> 1 per window in c-1 levels
+  // fold: nb -> 1 per window in c-1 levels.  Wide levels: one item per addition (throughput); levels that no longer
+  // fill the chip: four items per addition (latency, msm_coop.hpp); the last levels + the grouping: k_msm_tail.
+  // cooperative form wherever the group offers it (compile-time); NCG_MSM_COOP_LEVEL=0 keeps the separate level
+  // launches on the one-item-per-addition kernel (A/B of the level kernel only)
+  constexpr bool CAN_COOP = CoopOK<D>::value;
+  constexpr bool coop = CAN_COOP;
+  const int tail_units = MSM_TAIL_THREADS >> (LS + (coop ? 2 : 0));
+  // lanes the chip keeps resident for these kernels (2 waves/SIMD): beyond that the cooperative form costs throughput
+  const long coop_max_tasks = (65536L * 2) >> (LS + 2);
   const uint32_t* cur = buckets;
   int narr = 1, n_in = pl.nb, flip = 0;
-  while (n_in > 1) {
-    long total = (long)(narr + 1) * pl.nwin * (n_in >> 1);
-    hipLaunchKernelGGL(k_msm_reduce_level<D>, dim3((unsigned)(((total << LS) + 255) / 256)), dim3(256), 0, st, cur, red[flip],
-                       narr, pl.nwin, n_in);
+  {
+    static bool attr_done[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+      const int max_lds = 128 * 1024;
+      e = hipFuncSetAttribute((const void*)k_msm_tail<D, CAN_COOP>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 16) attr_done[dev] = true;
+    }
+  }
+  while (n_in > 1 && (long)(narr + 1) * (n_in >> 1) > 2L * tail_units) {
+    const long total = (long)(narr + 1) * pl.nwin * (n_in >> 1);
+    bool done = false;
+    if constexpr (CAN_COOP) {
+      const bool coop_level = [] { const char* e = std::getenv("NCG_MSM_COOP_LEVEL"); return e ? std::atoi(e) != 0 : true; }();
+      if (coop && coop_level && total <= coop_max_tasks) {
+        using K = TailOps<D, true>;
+        const size_t lds_b = (size_t)(256 >> K::UNIT_SHIFT) * COOP_SLOTS * G::FW * 4;
+        hipLaunchKernelGGL(k_msm_reduce_level_coop<D>, dim3((unsigned)(((total << K::UNIT_SHIFT) + 255) / 256)), dim3(256), lds_b, st,
+                           cur, red[flip], narr, pl.nwin, n_in);
+        done = true;
+      }
+    }
+    if (!done)
+      hipLaunchKernelGGL(k_msm_reduce_level<D>, dim3((unsigned)(((total << LS) + 255) / 256)), dim3(256), 0, st, cur, red[flip],
+                         narr, pl.nwin, n_in);
     cur = red[flip];
     flip ^= 1;
     narr++;
@@ -637,10 +784,13 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   }
   const int ng = msm_ngroups(pl.c);
   {
-    const size_t lanes = ((size_t)ng * pl.nwin) << LS;
-    hipLaunchKernelGGL(k_msm_group_pending<D>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, cur, red[flip],
-                       narr, pl.nwin, MSM_GROUP, ng);
-    cur = red[flip];
+    uint32_t* t0 = (uint32_t*)(base + L.tail0);
+    uint32_t* t1 = (uint32_t*)(base + L.tail1);
+    uint32_t* fin = (uint32_t*)(base + L.fin);
+    using K = TailOps<D, CAN_COOP>;
+    hipLaunchKernelGGL((k_msm_tail<D, CAN_COOP>), dim3(pl.nwin), dim3(MSM_TAIL_THREADS), (size_t)tail_units * K::LDS_WORDS * 4, st, cur,
+                       t0, t1, fin, narr, pl.nwin, n_in, MSM_GROUP, ng);
+    cur = fin;
   }
   *d_fin = cur;
   if (d_bad) *d_bad = bad;
@@ -686,7 +836,7 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
   if (land != fin.data()) std::copy(land, land + fin_words, fin.begin());
   static const bool timing = std::getenv("NCG_TIMING") != nullptr;
   auto t0 = std::chrono::steady_clock::now();
-  msm_host_finish<C>(fin, pl, out_affine_host, out_inf_host);
+  msm_host_finish_any<C>(fin.data(), pl.c, pl.nwin, out_affine_host, out_inf_host);
   if (timing) {
     auto t1 = std::chrono::steady_clock::now();
     fprintf(stderr, "[ncg] msm host finish: %.1f us (c=%d nwin=%d)\n",
@@ -697,20 +847,21 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
 
 template <class C>
 static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                            uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index) {
+                            uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index,
+                            const MsmSide* side) {
   const uint32_t *d_fin = nullptr, *d_bad = nullptr;
-  hipError_t e = msm_device_t<C>(pl, d_pts, d_scalars, ws, &d_fin, st, &d_bad);
+  hipError_t e = msm_device_t<C>(pl, d_pts, d_scalars, ws, &d_fin, st, &d_bad, side);
   if (e != hipSuccess) return e;
   return msm_finish_t<C>(pl, d_fin, out_affine_host, out_inf_host, st, d_bad, bad_index);
 }
 
 template <class C>
-static hipError_t msm_sum_partials_t(const uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
-                                     hipStream_t st) {
+static hipError_t msm_sum_partials_t(uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out, hipStream_t st) {
   using D = typename DeviceCurve<C>::type;
-  constexpr int LS = LaneShift<D>::value;
-  hipLaunchKernelGGL(k_msm_sum_partials<D>, dim3((unsigned)(((npoints << LS) + 63) / 64)), dim3(64), 0, st, d_gathered,
-                     d_out, nparts, (int)npoints);
+  constexpr bool COOP = CoopOK<D>::value;
+  using T = TailOps<D, COOP>;
+  hipLaunchKernelGGL((k_msm_sum_partials<D, COOP>), dim3((unsigned)npoints), dim3(256), (size_t)(256 >> T::UNIT_SHIFT) * T::SCRATCH_WORDS * 4,
+                     st, d_gathered, d_out, nparts, (int)npoints);
   return hipGetLastError();
 }
 
@@ -724,8 +875,8 @@ static hipError_t msm_sum_partials_t(const uint32_t* d_gathered, int nparts, siz
   }
 
 hipError_t msm_device_phase(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                            const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad) {
-#define CALL(C) msm_device_t<C>(pl, d_pts, d_scalars, ws, d_fin, st, d_bad)
+                            const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad, const MsmSide* side) {
+#define CALL(C) msm_device_t<C>(pl, d_pts, d_scalars, ws, d_fin, st, d_bad, side)
   NCG_MSM_DISPATCH(curve, CALL)
 #undef CALL
 }
@@ -735,7 +886,7 @@ hipError_t msm_finish(int curve, const MsmPlan& pl, const uint32_t* d_fin, uint3
   NCG_MSM_DISPATCH(curve, CALL)
 #undef CALL
 }
-hipError_t msm_sum_partials(int curve, const uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
+hipError_t msm_sum_partials(int curve, uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
                             hipStream_t st) {
 #define CALL(C) msm_sum_partials_t<C>(d_gathered, nparts, npoints, d_out, st)
   NCG_MSM_DISPATCH(curve, CALL)
@@ -770,16 +921,39 @@ size_t msm_workspace_bytes(int curve, const MsmPlan& pl) {
   }
 }
 
+size_t msm_stored_words_per_point(int curve) {
+  switch (curve) {
+    case CURVE_SECP256K1: return MsmGroup<CurveSecp>::AFF_WORDS;
+    case CURVE_BLS12_381_G1: return MsmGroup<CurveG1>::AFF_WORDS;
+    case CURVE_BLS12_381_G2: return MsmGroup<CurveG2>::AFF_WORDS;
+    case CURVE_ED25519: return MsmGroup<CurveEd>::AFF_WORDS;
+    default: return 0;
+  }
+}
+template <class C>
+static hipError_t msm_points_to_stored_t(const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st) {
+  using D = typename DeviceCurve<C>::type;
+  constexpr int LS = LaneShift<D>::value;
+  hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts_wire, d_out, n);
+  return hipGetLastError();
+}
+hipError_t msm_points_to_stored(int curve, const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st) {
+#define CALL(C) msm_points_to_stored_t<C>(d_pts_wire, n, d_out, st)
+  NCG_MSM_DISPATCH(curve, CALL)
+#undef CALL
+}
+
 hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
-                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index) {
+                   uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index,
+                   const MsmSide* side) {
   uint32_t dummy = 0xFFFFFFFFu;
   if (!bad_index) bad_index = &dummy;
   *bad_index = 0xFFFFFFFFu;
   switch (curve) {
-    case CURVE_SECP256K1: return msm_run_t<CurveSecp>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index);
-    case CURVE_BLS12_381_G1: return msm_run_t<CurveG1>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index);
-    case CURVE_BLS12_381_G2: return msm_run_t<CurveG2>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index);
-    case CURVE_ED25519: return msm_run_t<CurveEd>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index);
+    case CURVE_SECP256K1: return msm_run_t<CurveSecp>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index, side);
+    case CURVE_BLS12_381_G1: return msm_run_t<CurveG1>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index, side);
+    case CURVE_BLS12_381_G2: return msm_run_t<CurveG2>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index, side);
+    case CURVE_ED25519: return msm_run_t<CurveEd>(pl, d_pts, d_scalars, ws, out_affine_host, out_inf_host, st, bad_index, side);
     default: return hipErrorInvalidValue;
   }
 }

@@ -29,6 +29,7 @@
 // bucket are handled by the group-law routines (ec_sw.hpp).
 #pragma once
 #include "curves.hpp"
+#include "host_api.hpp"
 
 namespace ncg {
 
@@ -49,6 +50,7 @@ struct MsmPlan {
   int endo = 0;
   int n_src = 0;
   int xcd_map = 0;  // sort kernels: window-major block ids so that a window's blocks share an XCD (one L2)
+  int pts_stored = 0;  // the caller's points are already in the accumulate kernel's storage format (resident sets)
 };
 
 // Group policy of the MSM kernels: how an input point is stored, what the bucket accumulator

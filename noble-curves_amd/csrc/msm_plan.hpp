@@ -1,0 +1,112 @@
+// Window plan of the MSM (host side; shared by msm.hip, comm.hip and the CPU test twin).
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+
+#include "msm.hpp"
+
+namespace ncg {
+
+inline void mp_set_bit(uint32_t* a, int bit) { a[bit >> 5] |= 1u << (bit & 31); }
+
+// Largest scalar is order-1; choose the fewest windows with (order-1) + H' < 2^(c*nwin).
+inline int plan_windows(int c, const uint32_t* order8, uint32_t* hconst10) {
+  for (int nwin = (252 / c); nwin <= 300 / c + 2; nwin++) {
+    if (nwin < 1 || c * nwin > 10 * 32 - 2) continue;
+    uint32_t h[10] = {0};
+    for (int w = 0; w < nwin; w++) mp_set_bit(h, c * w + c - 1);
+    // s = (order - 1) + h
+    uint32_t s[10];
+    uint64_t cy = 0;
+    for (int i = 0; i < 10; i++) {
+      uint64_t o = i < 8 ? order8[i] : 0;
+      uint64_t t = o + h[i] + cy;
+      s[i] = (uint32_t)t;
+      cy = t >> 32;
+    }
+    // subtract 1 (order >= 1): fine to skip - being conservative by one is harmless
+    // check s < 2^(c*nwin)
+    bool ok = (cy == 0);
+    int top = c * nwin;
+    for (int bit = top; ok && bit < 320; bit++)
+      if (s[bit >> 5] & (1u << (bit & 31))) ok = false;
+    if (ok) {
+      for (int i = 0; i < 10; i++) hconst10[i] = h[i];
+      return nwin;
+    }
+  }
+  return -1;
+}
+
+inline const uint32_t* curve_order(int curve) {
+  switch (curve) {
+    case CURVE_SECP256K1: return Orders::SECP_N;
+    case CURVE_ED25519: return Orders::ED_L;
+    default: return Orders::BLS_R;
+  }
+}
+
+inline int ilog2(unsigned x) {
+  int r = 0;
+  while (x >>= 1) r++;
+  return r;
+}
+
+inline int msm_make_plan_impl(int curve, int n, int c_override, MsmPlan* pl) {
+  int c = c_override;
+  if (c <= 0) {
+    const char* env = std::getenv("NCG_MSM_C");
+    if (env) c = std::atoi(env);
+  }
+  if (c <= 0) {
+    // accumulate cost nwin*n mixed adds vs fold cost ~2*nwin*2^(c-1) full adds: c ~ log2(n) - 4 - but the width also
+    // decides how many bits the TOP window holds: 255-bit scalars in windows of 12 or 14 bits leave it 3 bits, i.e. a
+    // handful of buckets holding every point of the window, which the fix-up then has to merge as very long runs
+    // (measured: G1 2^17 c = 12 2.7 ms, c = 13 1.06 ms).  For bls12-381 the widths below are the measured best per
+    // size on MI355X (tools/msm_csweep.py, profiles/r03_msm_csweep.json): 8, 9, 10 (top window 1-5 bits short), 13, 15, 16.
+    const int lg = ilog2((unsigned)std::max(n, 1));
+    if (curve == CURVE_BLS12_381_G1) {
+      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 13, 13, 15, 15, 16};
+      c = tab[std::min(lg, 20)];
+    } else if (curve == CURVE_BLS12_381_G2) {
+      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 13, 13, 13, 13, 15, 16};
+      c = tab[std::min(lg, 20)];
+    } else {
+      c = lg - 4;
+    }
+  }
+  c = std::max(2, std::min(16, c));
+  pl->n = n;
+  pl->ls = curve == CURVE_BLS12_381_G2 ? 1 : 0;  // lane-paired kernels: 2 lanes per item
+  // waves/SIMD the accumulate kernel runs at (registers): 4 for the 256-bit fields, 2 for bls12-381
+  pl->accum_waves = (curve == CURVE_SECP256K1 || curve == CURVE_ED25519) ? 4 : 2;
+  pl->c = c;
+  pl->nb = 1 << (c - 1);
+  pl->nwin = plan_windows(c, curve_order(curve), pl->hconst);
+  if (pl->nwin < 0) return -1;
+  for (int i = 0; i < 8; i++) pl->order[i] = curve_order(curve)[i];
+  // sort chunks: ~512 blocks per sort kernel (two per CU; measured 2 % faster than 1024 on the 2^20 G1 MSM,
+  // tools/ab_q.sh: half the per-chunk count arrays to write, prefix and read), at least 4096 points per chunk
+  static const int q_blocks = [] { const char* e = std::getenv("NCG_MSM_QBLOCKS"); return e ? std::max(64, std::atoi(e)) : 512; }();
+  int Q = std::max(1, q_blocks / pl->nwin);
+  Q = std::min(Q, std::max(1, n / 4096));
+  pl->Q = Q;
+  pl->chunk = (n + Q - 1) / Q;
+  static const int xcd = [] { const char* e = std::getenv("NCG_MSM_XCD"); return e ? std::atoi(e) : 0; }();
+  pl->xcd_map = xcd;
+  return 0;
+}
+
+
+
+inline size_t msm_acc_words_inl(int curve) {
+  switch (curve) {
+    case CURVE_SECP256K1: return MsmGroup<CurveSecp>::ACC_WORDS;
+    case CURVE_BLS12_381_G1: return MsmGroup<CurveG1>::ACC_WORDS;
+    case CURVE_BLS12_381_G2: return MsmGroup<CurveG2>::ACC_WORDS;
+    case CURVE_ED25519: return MsmGroup<CurveEd>::ACC_WORDS;
+    default: return 0;
+  }
+}
+
+}  // namespace ncg

@@ -224,6 +224,49 @@ __global__ void __launch_bounds__(64) k_field_check_fe29(int op, const uint32_t*
     default: break;
   }
 }
+// Fe29 / lane-paired Fp2 on RAW limb arrays at the TOP of their value bounds (the column bounds of the fused products -
+// "56 product + 14 reduction terms below 2^64 only because limb 13 of a value below 2^12 p is at most 53256", fe29.hpp -
+// are only exercised by operands that generic values never reach).  Inputs per item: a = [a, c], b = [b, d] (each
+// element 14 words unpaired / 28 words paired: c0 then c1); ops: 0 a*b, 1 a^2, 6 a*b - c*d; output: canonical wire.
+//   unpaired (field 3): a, c < 4096 p;  b, d < 4096 p (mul) / 2048 p (mulsub)
+//   paired   (field 4): a, c < 4096 p;  b, d < 2048 p (mul) / 1024 p (mulsub);  a < 2048 p for the square
+template <int B>
+__device__ __forceinline__ Fe29<B> fe29_raw(const uint32_t* p) {
+  Fe29<B> r;
+#pragma unroll
+  for (int i = 0; i < 14; i++) r.v[i] = p[i];
+  return r;
+}
+__global__ void __launch_bounds__(64) k_field_check_fe29raw(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                            uint32_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t *pa = a + (size_t)i * 28, *pb = b + (size_t)i * 28;
+  uint32_t* r = out + (size_t)i * 12;
+  switch (op) {
+    case 0: fe29_to_wire(r, fe29_raw<4096>(pa) * fe29_raw<4096>(pb)); break;
+    case 1: fe29_to_wire(r, f_sqr(fe29_raw<4096>(pa))); break;
+    case 6: fe29_to_wire(r, f_mulsub(fe29_raw<4096>(pa), fe29_raw<2048>(pb), fe29_raw<4096>(pa + 14), fe29_raw<2048>(pb + 14))); break;
+    default: break;
+  }
+}
+__global__ void __launch_bounds__(64) k_field_check_fe29x2p(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                            uint32_t* __restrict__ out, int n) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;  // one Fp2 element per lane pair
+  if (i >= n) return;
+  const int h = pair_odd() ? 14 : 0;
+  const uint32_t *pa = a + (size_t)i * 56 + h, *pb = b + (size_t)i * 56 + h;
+  uint32_t* r = out + (size_t)i * 24 + (pair_odd() ? 12 : 0);
+  switch (op) {
+    case 0: fe29_to_wire(r, (Fe29x2P<4096>(fe29_raw<4096>(pa)) * Fe29x2P<2048>(fe29_raw<2048>(pb))).h); break;
+    case 1: fe29_to_wire(r, f_sqr(Fe29x2P<2048>(fe29_raw<2048>(pa))).h); break;
+    case 6:
+      fe29_to_wire(r, f_mulsub(Fe29x2P<4096>(fe29_raw<4096>(pa)), Fe29x2P<1024>(fe29_raw<1024>(pb)),
+                               Fe29x2P<4096>(fe29_raw<4096>(pa + 28)), Fe29x2P<1024>(fe29_raw<1024>(pb + 28))).h);
+      break;
+    default: break;
+  }
+}
 hipError_t field_check_run(int field, int op, int variant, const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, int n,
                            hipStream_t st) {
   if (n <= 0) return hipSuccess;
@@ -231,6 +274,8 @@ hipError_t field_check_run(int field, int op, int variant, const uint32_t* d_a, 
   if (field == 0) hipLaunchKernelGGL(k_field_check_fe9<Fe9SecpPR>, grid, block, 0, st, op, variant, d_a, d_b, d_out, n);
   else if (field == 1) hipLaunchKernelGGL(k_field_check_fe9<Fe9EdPR>, grid, block, 0, st, op, variant, d_a, d_b, d_out, n);
   else if (field == 2) hipLaunchKernelGGL(k_field_check_fe29, grid, block, 0, st, op, d_a, d_b, d_out, n);
+  else if (field == 3) hipLaunchKernelGGL(k_field_check_fe29raw, grid, block, 0, st, op, d_a, d_b, d_out, n);
+  else if (field == 4) hipLaunchKernelGGL(k_field_check_fe29x2p, dim3((2 * n + 63) / 64), block, 0, st, op, d_a, d_b, d_out, n);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -8,9 +8,13 @@
   over xGMI, a one-wave kernel adding the per-rank arrays, one finish.  RCCL cannot reduce with a group
   law, hence all-gather + local add.  This module only boot-straps the communicator: rank 0 makes the
   RCCL unique id and torch.distributed broadcasts its 128 bytes.
-* Dry runs without RCCL (backend "gloo": CPU unit tests, or several ranks sharing one GPU): the same
-  per-rank pipeline, then torch.distributed all-gathers the per-rank partial POINTS and the engine adds
-  them pairwise (`add_pairs_batch`).
+* Without RCCL (backend "gloo": several ranks sharing one GPU, hosts without xGMI): the SAME native pipeline
+  with a host-staged exchange - `ncg_msm_shard_local_dev` returns this rank's slot (window-plan header +
+  grouped window sums, a fixed size per curve), torch.distributed all-gathers the slots, and
+  `ncg_msm_shard_combine` runs the header check, the adding kernel and the finish that the RCCL path runs
+  after its own all-gather.
+* `n_max` (the largest shard, which fixes the window plan on every rank) is found with one MAX all-reduce
+  when the caller does not pass it, so ragged shards always agree on the plan.
 """
 import numpy as np
 
@@ -107,16 +111,40 @@ def combine_partials(engine, curve, gathered):
     return out, bool((out == ident).all())
 
 
+def _agree_n_max(n_local, device=None):
+    """largest shard over all ranks (one small all-reduce)."""
+    import torch
+    dist = _dist()
+    t = torch.tensor([int(n_local)], dtype=torch.int64, device=device if (device is not None and dist.get_backend() == "nccl") else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def all_gather_slots(slot, device=None):
+    """all-gather one fixed-size slot (uint8 array) per rank -> uint8 [world, slot_bytes] in rank order."""
+    import torch
+    dist = _dist()
+    t = torch.from_numpy(slot)
+    if device is not None and dist.get_backend() == "nccl":
+        t = t.to(device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return torch.stack(parts).cpu().numpy()
+
+
 def msm_sharded(engine, curve, n_local, d_points, d_scalars, stream=None, device=None, n_max=0):
     """MSM over the union of all ranks' shards.  `d_points` / `d_scalars` are this rank's device-resident
-    shard (raw pointers).  Every rank returns the same (affine bytes, is_inf)."""
+    shard (raw pointers).  Every rank returns the same (affine bytes, is_inf).  n_max = 0: the largest
+    shard is agreed with one all-reduce (ranks may hold different counts)."""
     dist = _dist()
     if dist is None or dist.get_world_size() == 1:
         return engine.msm_dev(curve, n_local, d_points, d_scalars, stream)
+    if n_max == 0:
+        n_max = _agree_n_max(n_local, device)
     if init_comm(engine, device):
         return engine.msm_sharded_dev(curve, n_local, d_points, d_scalars, stream, n_max)
-    part, part_inf = engine.msm_dev(curve, n_local, d_points, d_scalars, stream)
-    return combine_partials(engine, curve, all_gather_partials(part, part_inf, device))
+    slot = engine.msm_shard_local_dev(curve, n_local, d_points, d_scalars, stream, n_max)
+    return engine.msm_shard_combine(curve, n_max, all_gather_slots(slot, device), stream)
 
 
 def msm_sharded_host(engine, curve, points_wire, scalars_wire, device=None):

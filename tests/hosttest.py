@@ -33,6 +33,12 @@ def lib():
         _lib.ht_ed25519_challenge.argtypes = [vp, vp, vp, ctypes.c_uint64, vp]
         _lib.ht_bls_endo_split.argtypes = [i32, vp, vp]
         _lib.ht_ecdsa_prepare.argtypes = [vp, vp, i32, vp, vp]
+        _lib.ht_msm_shard_slot_bytes.argtypes = [i32]
+        _lib.ht_msm_shard_slot_bytes.restype = ctypes.c_size_t
+        _lib.ht_msm_shard_local.argtypes = [i32, i32, i32, vp, vp, vp]
+        _lib.ht_msm_shard_combine.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32]
+        _lib.ht_msm_finish.argtypes = [i32, i32, i32, vp, vp, vp, i32]
+        _lib.ht_msm_plan.argtypes = [i32, i32, vp]
     return _lib
 
 
@@ -176,3 +182,41 @@ def ecdsa_prepare(sig64, hash32, low_s=True):
     u1, u2 = np.zeros(8, dtype=np.uint32), np.zeros(8, dtype=np.uint32)
     ok = lib().ht_ecdsa_prepare(S.ctypes.data, H.ctypes.data, 1 if low_s else 0, u1.ctypes.data, u2.ctypes.data)
     return bool(ok), sum(int(u1[i]) << (32 * i) for i in range(8)), sum(int(u2[i]) << (32 * i) for i in range(8))
+
+
+# ---- sharded MSM twin: the slot format, header check, partial-sum order and host finish of the native multi-GPU
+# path (csrc/msm_shard.hpp, msm_finish.hpp, msm_plan.hpp) around a naive per-shard window-sum computation
+def msm_plan(curve, n):
+    out = np.zeros(4, dtype=np.int32)
+    assert lib().ht_msm_plan(curve, n, out.ctypes.data) == 0
+    return {"c": int(out[0]), "nwin": int(out[1]), "ngroups": int(out[2]), "acc_words": int(out[3])}
+
+
+def msm_shard_slot_bytes(curve):
+    return int(lib().ht_msm_shard_slot_bytes(curve))
+
+
+def msm_shard_local(curve, n_local, n_max, pts_ptr, scalars_ptr):
+    """pts_ptr / scalars_ptr: HOST addresses of this shard's wire arrays (the twin of the device pointers)."""
+    slot = np.zeros((msm_shard_slot_bytes(curve),), dtype=np.uint8)
+    assert lib().ht_msm_shard_local(curve, n_local, n_max, pts_ptr, scalars_ptr, slot.ctypes.data) == 0
+    return slot
+
+
+def msm_shard_combine(curve, n_max, slots, point_bytes):
+    slots = np.ascontiguousarray(slots, dtype=np.uint8)
+    out = np.zeros((point_bytes,), dtype=np.uint8)
+    inf = np.zeros((1,), dtype=np.uint8)
+    err = ctypes.create_string_buffer(400)
+    rc = lib().ht_msm_shard_combine(curve, n_max, int(slots.shape[0]), slots.ctypes.data, out.ctypes.data, inf.ctypes.data, err, 400)
+    if rc != 0:
+        raise ValueError(err.value.decode() or "msm_shard_combine failed")
+    return out, bool(inf[0])
+
+
+def msm_finish(curve, c, nwin, fin_words, point_bytes, variant):
+    fin = np.ascontiguousarray(fin_words, dtype=np.uint32)
+    out = np.zeros((point_bytes,), dtype=np.uint8)
+    inf = np.zeros((1,), dtype=np.uint8)
+    assert lib().ht_msm_finish(curve, c, nwin, fin.ctypes.data, out.ctypes.data, inf.ctypes.data, variant) == 0
+    return out, bool(inf[0])

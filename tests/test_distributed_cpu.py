@@ -1,9 +1,13 @@
-"""world_size-2 gloo test of the multi-rank MSM glue (shard -> local MSM -> exchange -> combine) that runs
-without a GPU.  The native engine needs a GPU, so here the per-rank engine is an oracle-backed stand-in
-with the same `msm` / `add_pairs_batch` signatures: this checks shard_range, the collective and the
-combine order.  The NATIVE multi-rank paths are covered on the GPU box by tests/test_gpu_multi.py
-(2 ranks sharing the GPU over gloo with the real engine; the RCCL communicator path with one rank; the
-per-shard phase + combine kernel with 2-8 shards on one GPU)."""
+"""world_size-2 gloo tests of the multi-rank MSM that run without a GPU.
+
+The per-rank engine is the HOST TWIN of the native one (tests/hosttest.py -> csrc/hosttest.hip): the per-shard
+window sums are computed naively with the kernels' group-law templates on the CPU, everything around them is the
+code the GPU path runs - the window plan from n_max (csrc/msm_plan.hpp), the fixed-size slot with its plan header
+(csrc/msm_shard.hpp), the header check, the order in which the shards' sums are added and the host finish
+(csrc/msm_finish.hpp, bls_host64.hpp).  `noble_curves_amd.distributed.msm_sharded` drives it exactly as it drives
+the native engine on a gloo backend: agree n_max, local phase, all-gather of the slots, combine on every rank.
+Ragged shards (sizes straddling a power of two - the case ADVICE r02 flagged), an empty shard and a rank that
+passes a wrong n_max are covered.  The NATIVE engine runs the same flow on the GPU box (tests/test_gpu_multi.py)."""
 import os
 import socket
 import sys
@@ -15,53 +19,80 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class OracleEngine:
-    """Stand-in engine: MSM through the CPU oracle (test infrastructure only)."""
+class HostTwinEngine:
+    """Same method names / argument meaning as NativeEngine's sharded-MSM entry points; `d_points` / `d_scalars`
+    are host addresses here (test infrastructure only)."""
 
-    def msm(self, curve, points, scalars):
-        from helpers import ORACLE_CURVE, affine_to_wire, wire_to_affine
-        from oracle import curve as C
-        Pt = ORACLE_CURVE[curve]
-        pts = [Pt.fromAffine(wire_to_affine(curve, row)) for row in points]
-        sc = [int.from_bytes(bytes(row), "little") for row in scalars]
-        r = C.pippenger(Pt, pts, sc)
-        aff = r.toAffine()
-        return np.frombuffer(affine_to_wire(curve, aff), dtype=np.uint8).copy(), r.is0()
+    def __init__(self):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hosttest
+        self.ht = hosttest
 
-    def add_pairs_batch(self, curve, a, b, subtract=False):
-        from helpers import ORACLE_CURVE, affine_to_wire, wire_to_affine
-        Pt = ORACLE_CURVE[curve]
-        out = np.zeros_like(a)
-        inf = np.zeros((a.shape[0],), np.uint8)
-        for i in range(a.shape[0]):
-            p, q = Pt.fromAffine(wire_to_affine(curve, a[i])), Pt.fromAffine(wire_to_affine(curve, b[i]))
-            r = p.subtract(q) if subtract else p.add(q)
-            out[i] = np.frombuffer(affine_to_wire(curve, r.toAffine()), dtype=np.uint8)
-            inf[i] = r.is0()
-        return out, inf
+    def comm_size(self):
+        return 1
+
+    def msm_shard_local_dev(self, curve, n_local, d_points, d_scalars, stream=None, n_max=0):
+        return self.ht.msm_shard_local(curve, n_local, n_max or n_local, d_points, d_scalars)
+
+    def msm_shard_combine(self, curve, n_max, slots, stream=None):
+        from noble_curves_amd._native import POINT_BYTES
+        return self.ht.msm_shard_combine(curve, n_max, slots, POINT_BYTES[curve])
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, curve_name, sizes, q, wrong_n_max):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from helpers import points_to_wire, scalars_to_wire, wire_to_affine
-    from noble_curves_amd._native import BLS12_381_G1
-    from noble_curves_amd.distributed import msm_sharded_host, shard_range
-    from oracle.curves import BLS_R, BlsG1, makeRng
+    from helpers import ORACLE_CURVE, points_to_wire, scalars_to_wire, wire_to_affine
+    from noble_curves_amd import _native
+    from noble_curves_amd.distributed import msm_sharded
+    curve = getattr(_native, curve_name)
+    Pt = ORACLE_CURVE[curve]
+    order = Pt.Fn.ORDER
+    from oracle.curves import makeRng
     rng = makeRng(0xD157)
-    ks = [rng.rndBelow(BLS_R - 1) + 1 for _ in range(n)]
-    pts = [BlsG1.BASE.multiplyUnsafe(k) for k in ks]
-    sc = [0 if i % 5 == 0 else rng.rndBelow(BLS_R) for i in range(n)]
-    out, inf = msm_sharded_host(OracleEngine(), BLS12_381_G1, points_to_wire(BLS12_381_G1, pts), scalars_to_wire(sc))
-    exp = BlsG1.BASE.multiplyUnsafe(sum(k * s for k, s in zip(ks, sc)) % BLS_R).toAffine()
-    lo, hi = shard_range(n, rank, world)
-    q.put((rank, wire_to_affine(BLS12_381_G1, out) == exp, inf, (lo, hi)))
+    n = sum(sizes)
+    ks = [rng.rndBelow(order - 1) + 1 for _ in range(n)]
+    sc = [0 if i % 5 == 0 else (order - 1 if i % 7 == 0 else rng.rndBelow(order)) for i in range(n)]
+    lo = sum(sizes[:rank])
+    hi = lo + sizes[rank]
+    pts_w = points_to_wire(curve, [Pt.BASE.multiplyUnsafe(k) for k in ks[lo:hi]]) if hi > lo else np.zeros((0, 1), np.uint8)
+    sc_w = scalars_to_wire(sc[lo:hi]) if hi > lo else np.zeros((0, 32), np.uint8)
+    eng = HostTwinEngine()
+    exp = Pt.BASE.multiplyUnsafe(sum(k * s for k, s in zip(ks, sc)) % order).toAffine()
+    try:
+        n_max = 0
+        if wrong_n_max and rank == 1:
+            n_max = 1 << 12           # this rank plans other windows than rank 0
+        elif wrong_n_max:
+            n_max = max(sizes)
+        out, inf = msm_sharded(eng, curve, hi - lo, pts_w.ctypes.data, sc_w.ctypes.data, n_max=n_max)
+        q.put((rank, wire_to_affine(curve, out) == exp, inf, None))
+    except ValueError as e:
+        q.put((rank, False, False, str(e)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _run(curve_name, sizes, wrong_n_max=False):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = len(sizes)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, curve_name, sizes, q, wrong_n_max)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    return res
 
 
 def test_shard_range_covers_everything():
@@ -74,20 +105,22 @@ def test_shard_range_covers_everything():
                 assert a1 == b0 and a1 - a0 - (b1 - b0) in (0, 1)
 
 
-@pytest.mark.timeout(180)
-def test_msm_sharded_two_ranks_gloo():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 13, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=150) for _ in range(2)]
-    for p in procs:
-        p.join(30)
-        assert p.exitcode == 0
-    assert sorted(r[0] for r in res) == [0, 1]
-    assert all(r[1] for r in res) and not any(r[2] for r in res)
-    assert {r[3] for r in res} == {(0, 7), (7, 13)}
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("curve_name,sizes", [
+    ("BLS12_381_G1", (33, 31)),       # ragged, straddling 2^5: the plans would differ without the agreed n_max
+    ("BLS12_381_G2", (9, 4)),
+    ("SECP256K1", (16, 0)),           # an empty shard contributes identities
+    ("ED25519", (5, 12)),
+])
+def test_msm_sharded_two_ranks_gloo_native_combine_twin(curve_name, sizes):
+    res = _run(curve_name, sizes)
+    assert all(r[1] for r in res), res
+    assert not any(r[2] for r in res)
+
+
+@pytest.mark.timeout(300)
+def test_msm_sharded_rejects_disagreeing_plans():
+    """rank 1 passes another n_max: every rank must get the header-check error, not a wrong sum (and, on the RCCL
+    path, not a collective with mismatched counts: the slot size does not depend on the plan)."""
+    res = _run("BLS12_381_G1", (20, 20), wrong_n_max=True)
+    assert all((not r[1]) and r[3] and "all ranks must pass the same curve and n_max" in r[3] for r in res), res

@@ -83,3 +83,88 @@ def test_fe29_ops_on_device():
                   (3, lambda x, y: (x - y) % p), (4, lambda x, y: (-x) % p), (5, lambda x, y: pow(x, -1, p) if x else 0)):
         got = eng.field_check(2, op, 0, a, b)
         assert [_words(r) for r in got] == [f(x, y) for x, y in zip(xs, ys)], op
+
+
+# ---- bls12-381: RAW radix-2^29 limbs at the top of the lazy value bounds:
+# the fused products keep up to 56 product + 14 reduction terms per 64-bit column, which only fits because limb 13
+# of a value below 2^12 p is at most 53256 (fe29.hpp) - generic values never come near that bound.
+R406 = 1 << 406
+
+
+def _max_limbs(bound):
+    """largest value below bound * p whose 13 low limbs are all 2^29 - 1"""
+    top = (bound * BLS_P - 1) >> 377
+    v = (top << 377) | ((1 << 377) - 1)
+    if v >= bound * BLS_P:
+        v -= 1 << 377
+    assert v < bound * BLS_P
+    return v
+
+
+def _limbs14(v):
+    assert v < (1 << 406)
+    return [(v >> (29 * i)) & M29 for i in range(13)] + [v >> 377]
+
+
+def _operand29(bound, kind, rng):
+    if kind == 0:
+        return _max_limbs(bound)
+    if kind == 1:
+        return bound * BLS_P - 1                     # the largest value of the bound type
+    if kind == 2:
+        return [0, 1, BLS_P, BLS_P - 1, (bound - 1) * BLS_P + 1][rng.rnd64() % 5]
+    return rng.rndBelow(bound * BLS_P)
+
+
+def _unmont(v):
+    return v * pow(R406, -2, BLS_P) % BLS_P          # product of two Montgomery-form operands, taken out of the form
+
+
+@pytest.mark.parametrize("op", [0, 1, 6])
+def test_fe29_raw_limbs_at_the_bounds(op):
+    eng = get_engine()
+    rng = makeRng(0x29F + op)
+    ba, bb = 4096, (4096 if op == 0 else 2048)
+    A, B, exp = [], [], []
+    for it in range(96):
+        ka, kb = (it % 4, (it // 4) % 4) if it < 16 else (3, 3)
+        a, c = _operand29(ba, ka, rng), _operand29(ba, ka if it < 16 else 3, rng)
+        b, d = _operand29(bb, kb, rng), _operand29(bb, kb if it < 16 else 3, rng)
+        A.append(_limbs14(a) + _limbs14(c))
+        B.append(_limbs14(b) + _limbs14(d))
+        exp.append(_unmont(a * b if op == 0 else a * a if op == 1 else a * b - c * d))
+    out = eng.field_check(3, op, 0, np.array(A, dtype=np.uint32), np.array(B, dtype=np.uint32))
+    for i in range(len(exp)):
+        assert _words(out[i]) == exp[i], (op, i)
+
+
+@pytest.mark.parametrize("op", [0, 1, 6])
+def test_lane_paired_fp2_raw_limbs_at_the_bounds(op):
+    """Fe29x2P multiply / square / fused a*b - c*d (tower.ts:420-438 values) with every limb of every half at its maximum."""
+    eng = get_engine()
+    rng = makeRng(0x2F2 + op)
+    ba = 2048 if op == 1 else 4096
+    bb = 2048 if op == 0 else 1024
+    A, B, exp = [], [], []
+
+    def fp2mul(x, y):
+        return (x[0] * y[0] - x[1] * y[1], x[0] * y[1] + x[1] * y[0])
+    for it in range(96):
+        ka, kb = (it % 4, (it // 4) % 4) if it < 16 else (3, 3)
+        a = (_operand29(ba, ka, rng), _operand29(ba, ka, rng))
+        c = (_operand29(ba, ka, rng), _operand29(ba, ka, rng))
+        b = (_operand29(bb, kb, rng), _operand29(bb, kb, rng))
+        d = (_operand29(bb, kb, rng), _operand29(bb, kb, rng))
+        A.append(_limbs14(a[0]) + _limbs14(a[1]) + _limbs14(c[0]) + _limbs14(c[1]))
+        B.append(_limbs14(b[0]) + _limbs14(b[1]) + _limbs14(d[0]) + _limbs14(d[1]))
+        if op == 0:
+            r = fp2mul(a, b)
+        elif op == 1:
+            r = fp2mul(a, a)
+        else:
+            ab, cd = fp2mul(a, b), fp2mul(c, d)
+            r = (ab[0] - cd[0], ab[1] - cd[1])
+        exp.append((_unmont(r[0]), _unmont(r[1])))
+    out = eng.field_check(4, op, 0, np.array(A, dtype=np.uint32), np.array(B, dtype=np.uint32))
+    for i in range(len(exp)):
+        assert (_words(out[i][:12]), _words(out[i][12:])) == exp[i], (op, i)

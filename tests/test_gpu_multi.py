@@ -4,7 +4,10 @@
   everything of ncg_msm_sharded_dev except the all-gather), all four curves, ragged and empty shards;
 * the RCCL communicator path with one rank (ncg_comm_unique_id / ncg_comm_init / ncg_msm_sharded_dev);
 * the single-process device-set context with one device (ncg_multi_init / ncg_msm_multi);
-* two ranks sharing the GPU over gloo with the REAL engine (the dry-run exchange of distributed.py).
+* the host-staged exchange (ncg_msm_shard_local_dev / ncg_msm_shard_combine) in one process: G = 2, 3, 8 slots of
+  ragged and empty shards through the NATIVE header check, adding kernel and finish; disagreeing plans rejected;
+* two ranks sharing the GPU over gloo with the REAL engine driving that same exchange (distributed.msm_sharded),
+  ragged shards straddling a power of two, n_max agreed by all-reduce.
 Results are compared with the oracle (pippenger, src/abstract/curve.ts:863-905) and the single-GPU MSM."""
 import os
 import socket
@@ -105,6 +108,36 @@ def test_rccl_communicator_single_rank():
         eng.close()
 
 
+@pytest.mark.parametrize("curve", [SECP256K1, ED25519, BLS12_381_G1, BLS12_381_G2])
+def test_host_staged_exchange_native_combine(curve):
+    """ncg_msm_shard_local_dev per shard -> slots concatenated on the host -> ncg_msm_shard_combine: the code path of G
+    ranks with a non-RCCL transport, here with the shards of one process."""
+    eng = get_engine()
+    n = 130 if curve != BLS12_381_G2 else 66
+    pw, sw, exp = _case(curve, n, 0x51075 + curve)
+    dp, ds = _dev(pw), _dev(sw)
+    pb = POINT_BYTES[curve]
+    assert eng.msm_shard_slot_bytes(curve) % 256 == 0
+    for cuts in ((65, n), (64, n), (33, 64, n), (n, n), tuple(range(17, n, 17)) + (n,)):   # ragged, straddling 2^6, an empty shard
+        sizes = [b - a for a, b in zip((0,) + cuts[:-1], cuts)]
+        n_max = max(sizes)
+        slots, lo = [], 0
+        for m in sizes:
+            slots.append(eng.msm_shard_local_dev(curve, m, dp.data_ptr() + lo * pb, ds.data_ptr() + lo * 32, None, n_max))
+            lo += m
+        got, inf = eng.msm_shard_combine(curve, n_max, np.stack(slots))
+        assert wire_to_affine(curve, got) == exp.toAffine(), sizes
+        assert inf == exp.is0()
+    # a shard planned with another n_max is refused by the header check
+    a = eng.msm_shard_local_dev(curve, 40, dp.data_ptr(), ds.data_ptr(), None, 40)
+    b = eng.msm_shard_local_dev(curve, 40, dp.data_ptr() + 40 * pb, ds.data_ptr() + 40 * 32, None, 1 << 14)
+    with pytest.raises(Exception, match="all ranks must pass the same curve and n_max"):
+        eng.msm_shard_combine(curve, 40, np.stack([a, b]))
+    # every shard empty: the identity
+    got, inf = eng.msm_shard_combine(curve, 0, np.stack([eng.msm_shard_local_dev(curve, 0, 0, 0)] * 2))
+    assert inf
+
+
 def test_multi_engine_one_device():
     m = MultiEngine([0])
     try:
@@ -131,7 +164,7 @@ def _worker(rank, world, port, n, q):
     from noble_curves_amd.distributed import msm_sharded, shard_range
     eng = ge(0)                                   # both ranks on the one GPU of the box
     pw, sw, exp = _case(BLS12_381_G1, n, 0xD157)
-    lo, hi = shard_range(n, rank, world)
+    lo, hi = (0, 129) if rank == 0 else (129, n)    # ragged: 129 and 71 points plan different windows on their own
     dp, ds = torch.from_numpy(pw[lo:hi].copy()).cuda(), torch.from_numpy(sw[lo:hi].copy()).cuda()
     out, inf = msm_sharded(eng, BLS12_381_G1, hi - lo, dp.data_ptr(), ds.data_ptr(), None, torch.device("cuda", 0))
     q.put((rank, wire_to_affine(BLS12_381_G1, out) == exp.toAffine(), bool(inf)))
