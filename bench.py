@@ -147,6 +147,11 @@ class Pmc:
         return v["SQ_INSTS_VALU"], src
 
 
+BOUND_NOTE = ("bound by VALU issue (integer multiply-add chains), not by HBM or MFMA - SURVEY 8d; `achieved` / `peak` / `frac` "
+              "are the contract's HBM figures (algorithmic bytes / kernel time vs 8 TB/s), the fractions that describe the "
+              "kernel are roofline.valu.mad_frac and valu_issue_frac")
+
+
 def valu_block(pmc, workload, kern_s, ref_mac, exec_mads, launches=1):
     """roofline.valu: reference-equivalent work, executed multiplier work and executed VALU instructions."""
     blk = {"ref_equiv_mac_per_s": ref_mac / kern_s, "ref_equiv_note": "limb-MACs of the reference's op sequence (SURVEY 8d), "
@@ -308,6 +313,7 @@ def scalars_to_ints(sc):
 
 
 PREWARM_S = float(os.environ.get("NCG_BENCH_PREWARM_S", "0.05"))
+PREWARM_DIST_STEPS = 6
 
 
 class StepTimes(tuple):
@@ -338,8 +344,9 @@ def time_steps(fn, steps, warmup, dist_on):
     import torch.distributed as dist
     # clock pre-warm (untimed, before the W warm-up steps): the boost clock of an idle MI355X needs a few tens of
     # milliseconds of load to settle - the first workload after host-side setup otherwise reads ~5 % slow
+    # (with several ranks the steps may be collectives, so the count must be the same on every rank: a fixed number)
     t_pre, cnt = time.perf_counter(), 0
-    while time.perf_counter() - t_pre < PREWARM_S and cnt < 64:
+    while (cnt < PREWARM_DIST_STEPS) if dist_on else (time.perf_counter() - t_pre < PREWARM_S and cnt < 64):
         fn()
         torch.cuda.synchronize()
         cnt += 1
@@ -571,7 +578,7 @@ def main():
             "config": {"workload": "secp256k1 batch variable-base multiplyUnsafe (GLV), 2^%d pairs per GPU"
                        % args.log2n, "items_per_gpu": n, "parallelism": "shard-by-index x%d" % world},
             "step_times": st_secp.dist(),
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "valu", "bound_note": BOUND_NOTE, "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": tsrc,
                          "kernel": "k_mul_var_gtab<CurveSecpI,4,3> (+ k_jac_batch_affine<16>, included in kernel_ms); "
@@ -587,6 +594,38 @@ def main():
 
             def check(lo, hi, r):
                 assert np.array_equal(r, out_h[lo:hi]), "CPU baseline output differs from the GPU's"
+            # BASELINE configs[0] (benchmark/point.ts:20-32, the reference's own CPU case): ONE point, Point.multiply and
+            # Point.multiplyUnsafe on 1 000 random scalars and on the benchmark's literal 2^180 - 15820, through the port
+            # (Point.multiply = the blinded constant-time fixed-window path an un-precomputed point takes, curve.ts:663-729)
+            rng0 = makeRng(0x6E6F626C6501)
+            k0 = [rng0.rndBelow(SECP256K1_N - 1) + 1 for _ in range(1000)] + [(1 << 180) - 15820]
+            p0 = np.tile(pts_h[7], (len(k0), 1))
+            k0w = ints_to_le_bytes(k0)
+            bl0 = np.frombuffer(bytes((rng0.rnd64() >> 11) & 0xFF for _ in range(16 * len(k0))), np.uint8).reshape(-1, 16)
+            t0 = time.perf_counter()
+            o_ct, _ = cport.multiply(p0, k0w, bl0)
+            t_ct = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            o_un, _ = cport.multiply_unsafe("secp256k1", p0, k0w)
+            t_un = time.perf_counter() - t0
+            g0 = torch.empty((len(k0), 64), dtype=torch.uint8, device=device)
+            i0 = torch.empty((len(k0),), dtype=torch.uint8, device=device)
+            d_p0, d_k0 = torch.from_numpy(p0.copy()).to(device), torch.from_numpy(k0w.copy()).to(device)
+            torch.cuda.synchronize()
+            eng.mul_var_batch_dev(SECP256K1, len(k0), dev_ptr(d_p0), dev_ptr(d_k0), dev_ptr(g0), dev_ptr(i0), stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(o_ct, o_un), "configs[0]: Point.multiply and Point.multiplyUnsafe ports disagree"
+            assert np.array_equal(o_un, g0.cpu().numpy()), "configs[0]: the GPU batch multiply differs from the CPU port"
+            extra["configs0_point_multiply"] = {
+                "metric": "secp256k1_point_multiply_ops_per_sec", "unit": "ops/s", "kind": "port", "cores": 1,
+                "Point_multiply": {"value": len(k0) / t_ct, "us_per_op": t_ct / len(k0) * 1e6,
+                                   "shape": "fixedWindowCT W=5, 128-bit blind: 77 windows x (5 dbl + 1 add) + 31-add table"},
+                "Point_multiplyUnsafe": {"value": len(k0) / t_un, "us_per_op": t_un / len(k0) * 1e6,
+                                         "shape": "GLV split + joint wNAF-4 (curve.ts:820-836)"},
+                "sample": "1 point, 1000 random scalars (xorshift64 seed 0x6e6f626c6501) + the literal 2^180-15820 of benchmark/point.ts:20; "
+                          "oracle/c restatement (RCB formulas, 64-bit Montgomery limbs), results equal and equal to the GPU batch multiply",
+                "cpu_model": host.get("cpu_model"),
+                "note": "BASELINE configs[0] is the reference's CPU plumbing case; the TypeScript itself cannot run here (host.reference_note)"}
             r1, d1, rall, dall, thr = cpu_baseline_rates(work, n, 500, args.cpu_seconds, check)
             result["cpu_baseline"] = baseline_entry(r1, d1, rall, dall, thr, "scalar-mults/s",
                                                     "first %d pairs of the same batch through oracle/c (RCB + GLV wNAF-4), outputs "
@@ -612,18 +651,18 @@ def main():
         expect = sum_over_ranks_bigint(local_expect, BLS_R, dist_on, device)
         got, got_inf = holder["r"]
         assert wire_to_affine(curve, got) == Pt.BASE.multiplyUnsafe(expect).toAffine(), "MSM mismatch"
-        c = max(2, min(16, (nn.bit_length() - 1) - (3 if curve == BLS12_381_G2 else 4)))
-        nwin = -(-(255 + 1) // c)
+        plan = eng.msm_plan_info(curve, nn)
+        c, nwin = plan["c"], plan["nwin"]
         traffic, tsrc = pmc.traffic(key) if (curve == BLS12_381_G1 and args.log2n == 20) or (curve == BLS12_381_G2 and args.log2n == 20) else (None, None)
         entry = {"metric": "bls12_381_%s_msm_points_per_sec" % cname, "value": world * nn * K / wall, "unit": "points/s",
                  "ms_per_msm": wall / K * 1e3, "step_times": st_msm.dist(),
-                 "points_per_gpu": nn, "total_points": world * nn, "scaling": "weak",
+                 "points_per_gpu": nn, "total_points": world * nn, "scaling": "weak", "window_plan": plan,
                  "multi_gpu": ("ncg_msm_sharded_dev: RCCL all-gather of grouped window sums + on-device add" if native_multi
                                else (("%s: ncg_msm_shard_local_dev -> torch.distributed all-gather of the slots (window-plan header + "
                                       "grouped window sums) -> ncg_msm_shard_combine (native header check, adding kernel, finish)"
                                       % ("host-staged exchange over gloo (ranks share GPUs)" if args.backend == "gloo" else "host-staged exchange (native RCCL communicator unavailable)"))
                                      if dist_on else "single GPU")),
-                 "roofline": {"bound": "hbm", "achieved": alg_b * nn / (wall / K) / 1e9, "peak": HBM_PEAK_GBS,
+                 "roofline": {"bound": "valu", "bound_note": BOUND_NOTE, "achieved": alg_b * nn / (wall / K) / 1e9, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": alg_b * nn / (wall / K) / 1e9 / HBM_PEAK_GBS,
                               "traffic": traffic, "traffic_source": tsrc,
                               "kernel": "k_msm_accum (dominant; achieved is for the whole MSM incl. the host finish, traffic for that kernel)",
@@ -710,6 +749,27 @@ def main():
     if args.workload in ("all", "msm_g2"):
         n2 = max(1, n >> 2)                                   # 2^18 at the default size (configs[4])
         msm2, sub2 = msm_workload(BLS12_381_G2, BlsG2, "g2", n2, 0x6D736D0000000004, 224.0, 3.0e5, "msm_g2")
+        if cpu_leg:
+            pts2_h, sc2_h = sub2["pts"].cpu().numpy(), sub2["sc"].cpu().numpy()
+            m2 = min(n2, 1 << 15)
+            t0 = time.perf_counter()
+            o_c2, _ = cport.pippenger("bls12_381_g2", pts2_h[:m2], sc2_h[:m2])
+            dt2 = time.perf_counter() - t0
+            g_s2, _ = eng.msm_dev(BLS12_381_G2, m2, dev_ptr(sub2["pts"]), dev_ptr(sub2["sc"]), stream)
+            assert np.array_equal(o_c2, g_s2), "G2 MSM sample mismatch vs oracle pippenger"
+            thr2 = os.cpu_count() or 1
+            rall2 = None
+            mm2 = min(m2, n2 // thr2) if thr2 > 1 else 0
+            if thr2 > 1 and mm2 >= 64:
+                from concurrent.futures import ThreadPoolExecutor
+                t0 = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=thr2) as ex:
+                    list(ex.map(lambda t: cport.pippenger("bls12_381_g2", pts2_h[t * mm2:(t + 1) * mm2], sc2_h[t * mm2:(t + 1) * mm2]), range(thr2)))
+                rall2 = thr2 * mm2 / (time.perf_counter() - t0)
+            msm2["cpu_baseline"] = baseline_entry(m2 / dt2, m2, rall2, thr2 * mm2 if rall2 else 0, thr2, "points/s",
+                                                  "first %d points of the same MSM through oracle/c pippenger over Fp2 (curve.ts:863-905, "
+                                                  "tower.ts:393-475 restated), result compared bit-exactly with the GPU MSM on the same subset; "
+                                                  "all_threads: one independent MSM of n/threads points per thread (points/s summed)")
         extra["msm_g2"] = msm2
         if dist_on:
             ns = n2 // world
@@ -807,7 +867,7 @@ def main():
                                            "(ncg_ed25519_verify_batch_msgs_dev); %d distinct key pairs, 32-byte messages, 1/64 corrupted "
                                            "(R, s or message), the reference's %d zip215.json cases appended; zip215 = true timed, "
                                            "strict mode verified once" % (tail, nz),
-                                   "roofline": {"bound": "hbm", "achieved": 161.0 * nv / (ev_ms / K * 1e-3) / 1e9,
+                                   "roofline": {"bound": "valu", "bound_note": BOUND_NOTE, "achieved": 161.0 * nv / (ev_ms / K * 1e-3) / 1e9,
                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                 "frac": 161.0 * nv / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "traffic": traffic, "traffic_source": tsrc,
@@ -868,7 +928,7 @@ def main():
                            "unit": "elements/s", "ms_per_transform": wall / K * 1e3, "log2n": bits,
                            "step_times": st_ntt.dist(),
                            "note": "FFT(roots, Fr).direct, natural in / natural out, one 2^%d transform per GPU" % bits,
-                           "roofline": {"bound": "hbm", "achieved": 64.0 * nn / (ev_ms / K * 1e-3) / 1e9,
+                           "roofline": {"bound": "valu", "bound_note": BOUND_NOTE, "achieved": 64.0 * nn / (ev_ms / K * 1e-3) / 1e9,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": 64.0 * nn / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "traffic": traffic, "traffic_source": tsrc,
@@ -891,8 +951,8 @@ def main():
         result["extra"] = extra
     if rank == 0:
         result["host"] = host
-        result["prewarm"] = ("%.0f ms of untimed steps before the W warm-up steps of every timed loop (boost-clock settling; "
-                             "the K timed steps are unchanged)" % (PREWARM_S * 1e3))
+        result["prewarm"] = (("%d untimed steps" % PREWARM_DIST_STEPS if dist_on else "%.0f ms of untimed steps" % (PREWARM_S * 1e3)) +
+                             " before the W warm-up steps of every timed loop (boost-clock settling; the K timed steps are unchanged)")
         result["pmc"] = "live rocprofv3 passes in this run" if live else "committed profile profiles/r02_pmc.json"
         print(json.dumps(result))
         if args.out:

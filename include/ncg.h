@@ -193,6 +193,9 @@ int ncg_mul_base_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* scalar
  * on the host, so the call returns after synchronising the stream. */
 int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const void* scalars,
             void* out_affine, uint8_t* out_is_inf);
+/* The window plan the MSM entry points use for n points (measurement / diagnostics): out4 = {window bits c,
+ * windows, buckets per window 2^(c-1) (signed digits), grouped window sums per window handed to the host finish}. */
+int ncg_msm_plan_info(int curve, size_t n, int* out4);
 int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev,
                 const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream);
 

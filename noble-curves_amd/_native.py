@@ -376,6 +376,15 @@ class Engine:
                                                  ctypes.byref(inf), stream))
         return out, bool(inf.value)
 
+    def msm_plan_info(self, curve, n):
+        """{c, nwin, nb, ngroups} of the window plan for an n-point MSM (ncg_msm_plan_info)."""
+        out = (ctypes.c_int * 4)()
+        fn = self.lib.ncg_msm_plan_info
+        fn.argtypes, fn.restype = [ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)], ctypes.c_int
+        if fn(curve, n, out) != 0:
+            raise NativeError("noble-gpu: msm_plan_info: bad arguments")
+        return {"c": out[0], "nwin": out[1], "nb": out[2], "ngroups": out[3]}
+
     def msm_shard_slot_bytes(self, curve):
         fn = self.lib.ncg_msm_shard_slot_bytes
         fn.argtypes, fn.restype = [ctypes.c_int], ctypes.c_size_t

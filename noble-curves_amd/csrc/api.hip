@@ -356,6 +356,18 @@ int ncg_mul_base_batch(ncg_ctx* ctx, int curve, size_t n, const void* scalars, v
   return NCG_OK;
 }
 
+// window plan the MSM entry points use for n points: out = {c, nwin, buckets per window, grouped sums per window}
+int ncg_msm_plan_info(int curve, size_t n, int* out4) {
+  if (!out4 || ncg_point_bytes(curve) == 0 || n == 0 || n > 0x7fffffffu) return NCG_ERR_INVALID_ARG;
+  ncg::MsmPlan pl;
+  if (ncg::msm_make_plan(curve, (int)n, 0, &pl) != 0) return NCG_ERR_INVALID_ARG;
+  out4[0] = pl.c;
+  out4[1] = pl.nwin;
+  out4[2] = pl.nb;
+  out4[3] = (int)(ncg::msm_fin_words(curve, pl) / ncg::msm_acc_words(curve) / (size_t)pl.nwin);
+  return NCG_OK;
+}
+
 int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev, const void* scalars_dev,
                 void* out_affine, uint8_t* out_is_inf, void* stream) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");

@@ -7,9 +7,12 @@
  * (double) and :834-880 (add), with a = 0 so mulA() returns 0 (:613) and b3 = 3*b (:612).
  *
  * Instantiate with:  #define NL 6 / #define PFX(x) bls_##x / #include "field_tmpl.h"
+ * With PT_ONLY defined only the group-law part is instantiated, over a field the includer supplies under the
+ * same names (PFX(fe) of NL * 8 wire bytes, PFX(ctx) with r1 and b3, is0 / add / sub / mul / neg / inv /
+ * tomont / frommont): bls12-381 G2 over Fp2 (src/abstract/tower.ts:393-475), see oracle.c.
  */
+#ifndef PT_ONLY
 typedef struct { uint64_t v[NL]; } PFX(fe);
-typedef struct { PFX(fe) X, Y, Z; } PFX(pt);
 typedef struct {
   PFX(fe) p, r1, r2, b3; /* modulus, R mod p, R^2 mod p, 3b (Montgomery form) */
   uint64_t inv;          /* -p^-1 mod 2^64 */
@@ -109,6 +112,9 @@ static void PFX(inv)(const PFX(ctx) * c, PFX(fe) * r, const PFX(fe) * a) {
   }
   *r = acc;
 }
+#endif /* PT_ONLY */
+
+typedef struct { PFX(fe) X, Y, Z; } PFX(pt);
 
 /* ZERO = (0, 1, 0), weierstrass.ts:687 */
 static void PFX(pt_zero)(const PFX(ctx) * c, PFX(pt) * r) {

@@ -28,6 +28,69 @@
 #undef NL
 #undef PFX
 
+/* ---- bls12-381 G2: the same group-law template over Fp2 = Fp[u] / (u^2 + 1) (src/abstract/tower.ts:393-475;
+ * curve constants src/bls12-381.ts:321-345: b = 4 + 4u).  Wire: c0 || c1, 48 bytes each. */
+static bls_ctx BLS;
+typedef struct { bls_fe c0, c1; } g2_fe;
+typedef struct { g2_fe r1, b3; } g2_ctx;
+static g2_ctx G2C;
+static inline int g2_is0(const g2_fe* a) { return bls_is0(&a->c0) && bls_is0(&a->c1); }
+static inline void g2_add(const g2_ctx* c, g2_fe* r, const g2_fe* a, const g2_fe* b) { /* tower.ts:404 */
+  (void)c;
+  bls_add(&BLS, &r->c0, &a->c0, &b->c0);
+  bls_add(&BLS, &r->c1, &a->c1, &b->c1);
+}
+static inline void g2_sub(const g2_ctx* c, g2_fe* r, const g2_fe* a, const g2_fe* b) { /* :413 */
+  (void)c;
+  bls_sub(&BLS, &r->c0, &a->c0, &b->c0);
+  bls_sub(&BLS, &r->c1, &a->c1, &b->c1);
+}
+static inline void g2_neg(const g2_ctx* c, g2_fe* r, const g2_fe* a) { /* :393 */
+  (void)c;
+  bls_neg(&BLS, &r->c0, &a->c0);
+  bls_neg(&BLS, &r->c1, &a->c1);
+}
+static inline void g2_mul(const g2_ctx* c, g2_fe* r, const g2_fe* a, const g2_fe* b) { /* :420-431, Karatsuba */
+  (void)c;
+  bls_fe t1, t2, s1, s2, m;
+  bls_mul(&BLS, &t1, &a->c0, &b->c0);
+  bls_mul(&BLS, &t2, &a->c1, &b->c1);
+  bls_add(&BLS, &s1, &a->c0, &a->c1);
+  bls_add(&BLS, &s2, &b->c0, &b->c1);
+  bls_mul(&BLS, &m, &s1, &s2);
+  bls_sub(&BLS, &r->c0, &t1, &t2);
+  bls_add(&BLS, &t1, &t1, &t2);
+  bls_sub(&BLS, &r->c1, &m, &t1);
+}
+static void g2_inv(const g2_ctx* c, g2_fe* r, const g2_fe* a) { /* :458-475 */
+  (void)c;
+  bls_fe n0, n1, f;
+  bls_mul(&BLS, &n0, &a->c0, &a->c0);
+  bls_mul(&BLS, &n1, &a->c1, &a->c1);
+  bls_add(&BLS, &n0, &n0, &n1);
+  bls_inv(&BLS, &f, &n0);
+  bls_mul(&BLS, &r->c0, &f, &a->c0);
+  bls_neg(&BLS, &n1, &a->c1);
+  bls_mul(&BLS, &r->c1, &f, &n1);
+}
+static void g2_tomont(const g2_ctx* c, g2_fe* r, const g2_fe* a) {
+  (void)c;
+  bls_tomont(&BLS, &r->c0, &a->c0);
+  bls_tomont(&BLS, &r->c1, &a->c1);
+}
+static void g2_frommont(const g2_ctx* c, g2_fe* r, const g2_fe* a) {
+  (void)c;
+  bls_frommont(&BLS, &r->c0, &a->c0);
+  bls_frommont(&BLS, &r->c1, &a->c1);
+}
+#define NL 12
+#define PFX(x) g2_##x
+#define PT_ONLY
+#include "field_tmpl.h"
+#undef PT_ONLY
+#undef NL
+#undef PFX
+
 /* ---- small multi-limb helpers (32-bit limbs, little endian) for the GLV split ---- */
 #define MPN 16
 typedef struct { uint32_t w[MPN]; int neg; } mp; /* sign-magnitude */
@@ -139,7 +202,6 @@ static void mp_from_hex(mp* a, const char* hex) {
 
 /* ---- constants ---- */
 static k1_ctx K1;
-static bls_ctx BLS;
 static k1_fe K1_BETA;
 static mp GLV_A1, GLV_B1, GLV_A2, GLV_B2, K1_N;
 static int inited = 0;
@@ -221,6 +283,11 @@ static void init_once(void) {
   memset(&u, 0, sizeof u);
   u.v[0] = 12; /* b3 = 3*4 */
   bls_tomont(&BLS, &BLS.b3, &u);
+  /* src/bls12-381.ts:321-345: G2 b = 4 + 4u, b3 = 12 + 12u; Montgomery one = (R mod p, 0) */
+  memset(&G2C, 0, sizeof G2C);
+  G2C.r1.c0 = BLS.r1;
+  G2C.b3.c0 = BLS.b3;
+  G2C.b3.c1 = BLS.b3;
   inited = 1;
 }
 
@@ -329,6 +396,66 @@ int orc_bls12_381_g1_multiply_unsafe(const uint8_t* pts, const uint8_t* scalars,
     if (is_zero_bytes(k, 32) || bls_is0(&p.Z)) bls_pt_zero(&BLS, &r);
     else bls_mul_add_unsafe(&BLS, &r, &p, k, 32, 1);
     out_inf[i] = (uint8_t)bls_pt_to_wire(&BLS, out + 96 * i, &r);
+  }
+  return 0;
+}
+
+/* bls12-381 G2 pippenger (curve.ts:863-905 over Fp2 points), Fn.BITS = 255; wire 192 bytes per point */
+int orc_bls12_381_g2_pippenger(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out, uint8_t* out_inf) {
+  init_once();
+  g2_pt* P = (g2_pt*)malloc((n ? n : 1) * sizeof(g2_pt));
+  for (size_t i = 0; i < n; i++) g2_pt_from_wire(&G2C, &P[i], pts + 192 * i);
+  g2_pt r;
+  g2_pippenger(&G2C, &r, P, scalars, n, 255);
+  free(P);
+  *out_inf = (uint8_t)g2_pt_to_wire(&G2C, out, &r);
+  return 0;
+}
+
+/* secp256k1 Point.multiply for a batch (weierstrass.ts:900-907 -> mulSecret curve.ts:741-750 -> mulCTBlinded
+ * :663-690 / mulCT :658-661 -> runCT :647-656 -> fixedWindowCT :707-729, the path of an un-precomputed point:
+ * BASELINE configs[0], benchmark/point.ts:31).  blinds: n x 16 bytes (the RNG output, big-endian as
+ * bytesToNumberBE reads it; top two bits forced to 10 as :683), or NULL for the unblinded mulCT shape.
+ * Scalars must satisfy 1 <= k < n (the caller's contract; weierstrass.ts:904). */
+int orc_secp256k1_multiply(const uint8_t* pts, const uint8_t* scalars, const uint8_t* blinds, uint8_t* out, uint8_t* out_inf,
+                           size_t n) {
+  init_once();
+  enum { W = 5, SIZE = 1 << W };
+  for (size_t i = 0; i < n; i++) {
+    k1_pt p, table[SIZE], acc, sel;
+    k1_pt_from_wire(&K1, &p, pts + 64 * i);
+    mp nn;
+    mp_zero(&nn);
+    for (int j = 0; j < 32; j++) nn.w[j >> 2] |= (uint32_t)scalars[32 * i + j] << (8 * (j & 3));
+    int bits = 256;
+    if (blinds) { /* n = scalar + blind * Fn.ORDER, bits = Fn.BITS + 128 (:670, :689) */
+      mp b, prod;
+      mp_zero(&b);
+      uint8_t bb[16];
+      memcpy(bb, blinds + 16 * i, 16);
+      bb[0] = (uint8_t)((bb[0] & 0x3f) | 0x80);
+      for (int j = 0; j < 16; j++) b.w[j >> 2] |= (uint32_t)bb[15 - j] << (8 * (j & 3));
+      mp_mul(&prod, &b, &K1_N);
+      mp_add(&nn, &nn, &prod);
+      bits = 256 + 128;
+    }
+    k1_pt_zero(&K1, &table[0]); /* flat table [O, P, 2P, ..., 31P] */
+    for (int t = 1; t < SIZE; t++) k1_pt_add(&K1, &table[t], &table[t - 1], &p);
+    const int windows = (bits + W - 1) / W;
+    k1_pt_zero(&K1, &acc);
+    for (int w = windows - 1; w >= 0; w--) {
+      if (w != windows - 1)
+        for (int d = 0; d < W; d++) k1_pt_double(&K1, &acc, &acc);
+      const int bit = w * W;
+      uint32_t digit = nn.w[bit >> 5] >> (bit & 31);
+      if ((bit & 31) > 32 - W && (bit >> 5) + 1 < MPN) digit |= nn.w[(bit >> 5) + 1] << (32 - (bit & 31));
+      digit &= SIZE - 1;
+      sel = table[0]; /* data-oblivious scan over every entry (:722-723) */
+      for (int t = 1; t < SIZE; t++)
+        if ((uint32_t)t == digit) sel = table[t];
+      k1_pt_add(&K1, &acc, &acc, &sel); /* one add per window, even for digit 0 */
+    }
+    out_inf[i] = (uint8_t)k1_pt_to_wire(&K1, out + 64 * i, &acc);
   }
   return 0;
 }

@@ -20,8 +20,9 @@ def lib():
         vp, sz = ctypes.c_void_p, ctypes.c_size_t
         for name in ("orc_secp256k1_multiply_unsafe", "orc_bls12_381_g1_multiply_unsafe"):
             getattr(L, name).argtypes = [vp, vp, vp, vp, sz]
-        for name in ("orc_bls12_381_g1_pippenger", "orc_secp256k1_pippenger"):
+        for name in ("orc_bls12_381_g1_pippenger", "orc_secp256k1_pippenger", "orc_bls12_381_g2_pippenger"):
             getattr(L, name).argtypes = [vp, vp, sz, vp, vp]
+        L.orc_secp256k1_multiply.argtypes = [vp, vp, vp, vp, vp, sz]
         L.orc_ed25519_verify_batch.argtypes = [vp, vp, vp, ctypes.c_int, vp, sz]
         L.orc_fft_fr.argtypes = [ctypes.c_int, vp, vp, vp, ctypes.c_int]
         _lib = L
@@ -43,8 +44,21 @@ def multiply_unsafe(curve_name, pts_wire, scalars_wire):
     return out, inf
 
 
+def multiply(pts_wire, scalars_wire, blinds=None):
+    """secp256k1 Point.multiply (constant-time fixed-window shape of the reference; blinds: uint8 [n, 16] = the
+    reference's randomBytes(16) per call, or None for the unblinded shape)."""
+    pts, sc = _u8(pts_wire, 64), _u8(scalars_wire, 32)
+    n = pts.shape[0]
+    out = np.zeros((n, 64), np.uint8)
+    inf = np.zeros((n,), np.uint8)
+    bl = None if blinds is None else _u8(blinds, 16)
+    lib().orc_secp256k1_multiply(pts.ctypes.data, sc.ctypes.data, None if bl is None else bl.ctypes.data, out.ctypes.data,
+                                 inf.ctypes.data, n)
+    return out, inf
+
+
 def pippenger(curve_name, pts_wire, scalars_wire):
-    pb = {"secp256k1": 64, "bls12_381_g1": 96}[curve_name]
+    pb = {"secp256k1": 64, "bls12_381_g1": 96, "bls12_381_g2": 192}[curve_name]
     pts, sc = _u8(pts_wire, pb), _u8(scalars_wire, 32)
     n = pts.shape[0]
     out = np.zeros((pb,), np.uint8)

@@ -5,10 +5,10 @@ import time
 import pytest
 
 from helpers import load_golden, points_to_wire, scalars_to_wire, wire_to_affine
-from noble_curves_amd._native import BLS12_381_G1, SECP256K1
+from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, SECP256K1
 from oracle import cport
 from oracle import curve as C
-from oracle.curves import BLS_R, BlsG1, SECP256K1_N, Secp256k1, makeRng
+from oracle.curves import BLS_R, BlsG1, BlsG2, SECP256K1_N, Secp256k1, makeRng
 
 
 def test_c_secp256k1_multiply_unsafe_vs_python_and_golden():
@@ -39,8 +39,29 @@ def test_c_g1_multiply_unsafe_vs_python():
         assert wire_to_affine(BLS12_381_G1, out[i]) == p.multiplyUnsafe(k).toAffine()
 
 
+def test_c_secp256k1_multiply_ct_shape_vs_python():
+    """Point.multiply through the fixed-window constant-time path (curve.ts:707-729), unblinded and with the 128-bit
+    blind n = k + r * ORDER (:663-690): the value never depends on the blind (test/point.test.ts:647-651)."""
+    import numpy as np
+    n = SECP256K1_N
+    rng = makeRng(0xC7)
+    ks = [1, 2, 31, 32, n - 1, n - 2, (1 << 180) - 15820, 1 << 255] + [rng.rndBelow(n - 1) + 1 for _ in range(40)]
+    pts = [Secp256k1.BASE.multiplyUnsafe(rng.rndBelow(n - 1) + 1) for _ in ks]
+    exp = [p.multiply(k).toAffine() for p, k in zip(pts, ks)]
+    pw, sw = points_to_wire(SECP256K1, pts), scalars_to_wire(ks)
+    out, inf = cport.multiply(pw, sw)
+    blinds = np.array([[(rng.rnd64() >> 8) & 0xFF for _ in range(16)] for _ in ks], dtype=np.uint8)
+    blinds[0] = 0          # rngMin-like (test/point.test.ts:586): the forced top bits make it 2^127
+    blinds[1] = 0xFF       # rngMax-like
+    outb, infb = cport.multiply(pw, sw, blinds)
+    for i in range(len(ks)):
+        assert wire_to_affine(SECP256K1, out[i]) == exp[i] and not inf[i]
+        assert wire_to_affine(SECP256K1, outb[i]) == exp[i] and not infb[i]
+
+
 @pytest.mark.parametrize("name,curve,Pt,n", [("bls12_381_g1", BLS12_381_G1, BlsG1, 200),
-                                             ("secp256k1", SECP256K1, Secp256k1, 150)])
+                                             ("secp256k1", SECP256K1, Secp256k1, 150),
+                                             ("bls12_381_g2", BLS12_381_G2, BlsG2, 40)])
 def test_c_pippenger_vs_python(name, curve, Pt, n):
     order = Pt.Fn.ORDER
     rng = makeRng(0xC2 + curve)
