@@ -397,13 +397,11 @@ static napi_value PackBigInts(napi_env env, napi_callback_info info) {
       napi_throw_type_error(env, nullptr, "noble-gpu: packBigInts: expected bigint");
       return nullptr;
     }
+    // `words` comes back as the count the value NEEDS (it may exceed the 8 fetched): a canonical BigInt with more
+    // words than the field holds is never zero (e.g. 1n << 512n has eight zero low words), and -0n does not exist
     if (sign != 0 || words > maxw) {
-      bool zero = true;
-      for (size_t k = 0; k < words && k < 8; k++) zero = zero && w[k] == 0;
-      if (!zero) {
-        napi_throw_range_error(env, nullptr, "noble-gpu: packBigInts: value out of range");
-        return nullptr;
-      }
+      napi_throw_range_error(env, nullptr, "noble-gpu: packBigInts: value out of range");
+      return nullptr;
     }
     memcpy(out + (size_t)i * blen, w, blen);  // little-endian host
   }

@@ -123,9 +123,25 @@ function uploadEncoded(c, bytes, zip215) {      // concatenated compressed encod
   if (!(bytes instanceof Uint8Array) || bytes.length % eb) throw new Error('noble-gpu: expected a Uint8Array of ' + eb + '-byte encodings');
   return new PointSet(c, id, native.uploadPoints(id, bytes, true, !!zip215), bytes.length / eb);
 }
+// packed scalars (32 bytes little-endian each) must satisfy the same rule as BigInt ones: 0 <= s < Fn.ORDER
+// (validateMSMScalars, curve.ts:398-404 / 'invalid scalar: out of range', weierstrass.ts:920) - checked here, on
+// the bytes, so that no entry point can reach the device with an unreduced scalar
+function checkPackedScalars(bytes, Fn) {
+  const order = Fn.ORDER;
+  const ob = new Uint8Array(32);
+  for (let i = 0, v = order; i < 32; i++, v >>= 8n) ob[i] = Number(v & 0xffn);
+  const n = bytes.length >>> 5;
+  for (let i = 0; i < n; i++) {
+    const o = i << 5;
+    let k = 31;
+    while (k >= 0 && bytes[o + k] === ob[k]) k--;
+    if (k < 0 || bytes[o + k] > ob[k]) throw new Error('invalid scalar at index ' + i);
+  }
+}
 function residentScalars(set, scalars) {
   if (scalars instanceof Uint8Array) {
     if (scalars.length !== 32 * set.length) throw new Error('arrays of points and scalars must have equal length');
+    checkPackedScalars(scalars, set.c.Fn);
     return scalars;
   }
   validateMSMScalars(scalars, set.c.Fn);

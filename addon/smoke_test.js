@@ -109,6 +109,14 @@ if (haveGpu) {
   }
   assert.throws(() => gpu.pippengerResident(set, ss.slice(1)), /arrays of points and scalars must have equal length/);
   assert.throws(() => gpu.pippengerResident(set, ss.map(() => N)), /invalid scalar at index 0/);
+  {  // packed scalars get the same range rule: the group order itself (and 2^256 - 1) must be refused, on every resident entry point
+    const bad1 = new Uint8Array(32 * ss.length), bad2 = new Uint8Array(32 * ss.length).fill(0);
+    { let t = N; for (let j = 0; j < 32; j++) { bad1[32 + j] = Number(t & 0xffn); t >>= 8n; } }
+    bad2.fill(0xff, 64, 96);
+    assert.throws(() => gpu.pippengerResident(set, bad1), /invalid scalar at index 1/);
+    assert.throws(() => gpu.multiplyUnsafeBatchResident(set, bad2), /invalid scalar at index 2/);
+  }
+  assert.throws(() => gpu.native.packBigInts([1n << 512n], 32), /out of range/);
   assert.throws(() => gpu.uploadEncoded(Point, Uint8Array.from(Array.from(enc[0]).concat(Array.from(bad)))), /invalid point encoding at index 1/);
   set.free(); setEnc.free();
   // interleavedMSMUnsafe (test/point.test.ts:309-317): 3G + 5*2G + 7*4G + 11*8G = 129G for every window size,

@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(256, NCG_DEC_G1_MINW) k_decode_g1(const uint8_
   ok[i] = g1_decode_lane(in + (size_t)i * 48, out + (size_t)i * 24, &f) ? 1 : 0;
   inf[i] = f;
 }
+#ifdef NCG_AB_BUILD  // one lane per point, decompression + subgroup test fused: 587 spilled registers; replaced by the two stages below
 __global__ void __launch_bounds__(128, NCG_DEC_G2_MINW) k_decode_g2(const uint8_t* __restrict__ in, uint32_t* __restrict__ out,
                                                    uint8_t* __restrict__ ok, uint8_t* __restrict__ inf, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -262,6 +263,7 @@ __global__ void __launch_bounds__(128, NCG_DEC_G2_MINW) k_decode_g2(const uint8_
   ok[i] = g2_decode_lane(in + (size_t)i * 96, out + (size_t)i * 48, &f) ? 1 : 0;
   inf[i] = f;
 }
+#endif
 // ---- split G2 decoder (device default): stage A decompresses (range rules, Fp2 square root, sort bit) one
 // point per lane in the unpaired form; stage B runs the subgroup test -[|x|]P == psi(P) (bls12-381.ts:599-601)
 // in the lane-paired form - half the registers per lane instead of 587 spilled ones - and clears rejected rows.
@@ -336,13 +338,15 @@ hipError_t decode_points_batch(int curve, const uint8_t* in, int flags, uint32_t
       hipLaunchKernelGGL(k_decode_g1, grid, block, 0, st, in, out, ok, inf, n);
       break;
     case CURVE_BLS12_381_G2: {
+#ifdef NCG_AB_BUILD  // the fused kernel (587 spilled registers) only exists in A/B builds
       static const int fused = [] { const char* e = std::getenv("NCG_DEC_G2_FUSED"); return e ? std::atoi(e) : 0; }();
       if (fused) {
         hipLaunchKernelGGL(k_decode_g2, dim3((n + 127) / 128), dim3(128), 0, st, in, out, ok, inf, n);
-      } else {
-        hipLaunchKernelGGL(k_decode_g2_stage_a, dim3((n + 127) / 128), dim3(128), 0, st, in, out, ok, inf, n);
-        hipLaunchKernelGGL(k_decode_g2_stage_b, dim3((unsigned)(((size_t)n * 2 + 63) / 64)), dim3(64), 0, st, out, ok, inf, n);
+        break;
       }
+#endif
+      hipLaunchKernelGGL(k_decode_g2_stage_a, dim3((n + 127) / 128), dim3(128), 0, st, in, out, ok, inf, n);
+      hipLaunchKernelGGL(k_decode_g2_stage_b, dim3((unsigned)(((size_t)n * 2 + 63) / 64)), dim3(64), 0, st, out, ok, inf, n);
       break;
     }
     default: return hipErrorInvalidValue;

@@ -412,8 +412,13 @@ size_t ed25519_verify_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * EdC
 hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
                                 int zip215, uint8_t* out_ok, int n, uint32_t* gtab, hipStream_t st) {
   if (n <= 0) return hipSuccess;
+#ifdef NCG_AB_BUILD
   static const int variant = [] { const char* e = std::getenv("NCG_ED_VARIANT"); return e ? std::atoi(e) : 3; }();
+#else
+  constexpr int variant = 3;  // 3 waves/SIMD (168 registers); 2 and 4 are A/B builds
+#endif
   if (gtab && variant > 0) {
+#ifdef NCG_AB_BUILD
     if (variant == 2)
       hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 2>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
                          zip215, out_ok, gtab, n);
@@ -421,6 +426,7 @@ hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const
       hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 4>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
                          zip215, out_ok, gtab, n);
     else
+#endif
       hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 3>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
                          zip215, out_ok, gtab, n);
     return hipGetLastError();

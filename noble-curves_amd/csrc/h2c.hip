@@ -355,7 +355,11 @@ hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t*
       hipLaunchKernelGGL(k_map_to_g1<false>, dim3((n + 127) / 128), dim3(128), 0, st, u, count, out, inf, n);
     }
   } else if (curve == CURVE_BLS12_381_G2) {
+#ifdef NCG_AB_BUILD
     static const int fused = [] { const char* e = std::getenv("NCG_H2C_G2_FUSED"); return e ? std::atoi(e) : 0; }();
+#else
+    constexpr int fused = 0;
+#endif
     if (jac_tmp && !fused) {
       // scratch layout: [n] output Jacobians, then [n * count] stage-1 Jacobians (map_to_curve_tmp_words)
       uint32_t* stage1 = jac_tmp + (size_t)n * 84;
@@ -364,10 +368,12 @@ hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t*
       hipLaunchKernelGGL(k_g2_map_stage2, dim3((unsigned)(((size_t)n * 2 + 63) / 64)), dim3(64), 0, st, stage1, count, jac_tmp, n);
       hipLaunchKernelGGL((k_jac_batch_affine<CurveG2P, 4>), dim3(((((n + 3) / 4) << 1) + 255) / 256), dim3(256), 0, st,
                          jac_tmp, out, inf, n);
+#ifdef NCG_AB_BUILD  // the fused kernel (1 871 spilled registers) only exists in A/B builds
     } else if (jac_tmp) {
       hipLaunchKernelGGL(k_map_to_g2<true>, dim3((n + 63) / 64), dim3(64), 0, st, u, count, jac_tmp, inf, n);
       hipLaunchKernelGGL((k_jac_batch_affine<CurveG2P, 4>), dim3(((((n + 3) / 4) << 1) + 255) / 256), dim3(256), 0, st,
                          jac_tmp, out, inf, n);
+#endif
     } else {
       hipLaunchKernelGGL(k_map_to_g2<false>, dim3((n + 63) / 64), dim3(64), 0, st, u, count, out, inf, n);
     }

@@ -139,6 +139,7 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
     // NCG_SECP_W / NCG_G1_W / NCG_G2_W select the alternatives: 1WM = table in device memory with
     // W-bit windows and M waves/SIMD requested, WM = table in LDS).
     case CURVE_SECP256K1: {
+#ifdef NCG_AB_BUILD  // the measured alternatives (tools/ab_secp.sh builds with -DNCG_AB_BUILD): not in the shipped library
       static const int w = [] { const char* e = std::getenv("NCG_SECP_W"); return e ? std::atoi(e) : 243; }();
       if (jac_tmp && w == 154) return launch_mul_var_gtab<CurveSecp, 5, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 153) return launch_mul_var_gtab<CurveSecp, 5, 3>(pts, scalars, out, out_inf, n, jac_tmp, st);
@@ -148,22 +149,33 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
       if (jac_tmp && w == 144) return launch_mul_var_gtab<CurveSecp, 4, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 133) return launch_mul_var_gtab<CurveSecp, 3, 3>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (w == 42) return launch_mul_var<CurveSecp, 4, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
+#else
+      if (jac_tmp) return mul_var_secp_inline(13, pts, scalars, out, out_inf, n, jac_tmp, st);  // W = 4, 3 waves/SIMD, multiply inlined
+#endif
       return launch_mul_var<CurveSecp, 3, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);  // LDS table (also without scratch)
     }
     case CURVE_ED25519: return ed25519_mul_var_batch(pts, scalars, out, out_inf, n, jac_tmp, st);
     case CURVE_BLS12_381_G1: {
+#ifdef NCG_AB_BUILD
       static const int w = [] { const char* e = std::getenv("NCG_G1_W"); return e ? std::atoi(e) : 142; }();
       if (jac_tmp && w == 141) return launch_mul_var_gtab<CurveG1, 4, 1>(pts, scalars, out, out_inf, n, jac_tmp, st);
-      if (jac_tmp && w == 142) return launch_mul_var_gtab<CurveG1, 4, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 152) return launch_mul_var_gtab<CurveG1, 5, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 151) return launch_mul_var_gtab<CurveG1, 5, 1>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 132) return launch_mul_var_gtab<CurveG1, 3, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
+      if (jac_tmp && w == 142) return launch_mul_var_gtab<CurveG1, 4, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
+#else
+      if (jac_tmp) return launch_mul_var_gtab<CurveG1, 4, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
+#endif
       return launch_mul_var<CurveG1, 3, 1, 8>(pts, scalars, out, out_inf, n, jac_tmp, st);
     }
     case CURVE_BLS12_381_G2: {
+#ifdef NCG_AB_BUILD
       static const int w = [] { const char* e = std::getenv("NCG_G2_W"); return e ? std::atoi(e) : 142; }();
-      if (jac_tmp && w == 142) return launch_mul_var_gtab<CurveG2P, 4, 2, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (w == 0) return launch_mul_var<CurveG2, 3, 1, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);  // unpaired
+      if (jac_tmp && w == 142) return launch_mul_var_gtab<CurveG2P, 4, 2, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
+#else
+      if (jac_tmp) return launch_mul_var_gtab<CurveG2P, 4, 2, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
+#endif
       return launch_mul_var<CurveG2P, 2, 2, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     }
     default: return hipErrorInvalidValue;

@@ -15,6 +15,10 @@ struct CurveSecpI : CurveSecp {};
 
 hipError_t mul_var_secp_inline(int minw, const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
                                uint32_t* jac_tmp, hipStream_t st) {
+#ifndef NCG_AB_BUILD
+  if (minw == 13) return launch_mul_var_gtab<CurveSecpI, 4, 3, 16>(pts, scalars, out, out_inf, n, jac_tmp, st);  // the shipped kernel
+  return hipErrorInvalidValue;
+#else
   static const int k = [] { const char* e = std::getenv("NCG_AFF_K"); return e ? std::atoi(e) : 16; }();
   switch (minw * 100 + k) {
     case 408: return launch_mul_var_gtab<CurveSecpI, 5, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
@@ -28,6 +32,7 @@ hipError_t mul_var_secp_inline(int minw, const uint32_t* pts, const uint32_t* sc
     case 1408: return launch_mul_var_gtab<CurveSecpI, 4, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     default: return hipErrorInvalidValue;
   }
+#endif
 }
 
 }  // namespace ncg

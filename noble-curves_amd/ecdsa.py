@@ -201,7 +201,14 @@ def recoverPublicKeyBatch(signatures, messages, prehash=True, isCompressed=True,
 def getSharedSecretBatch(secretKeys, publicKeys, isCompressed=True, engine=None):
     """[secp256k1.getSharedSecret(sk, pk, isCompressed) for each pair] (weierstrass.ts:1198-1210): the point
     s * Point.fromBytes(pk) as SEC1 bytes.  Secret keys: 32 big-endian bytes in [1, n) (Fn.fromBytes +
-    isValidNot0, else ValueError like the reference); a public key the reference's decoder rejects raises too."""
+    isValidNot0, else ValueError like the reference); a public key the reference's decoder rejects raises too.
+    NOT constant-time: the reference's getSharedSecret multiplies the secret key with the constant-time
+    Point.multiply (weierstrass.ts:1198-1210); this batch form runs the GPU's variable-time GLV ladder
+    (zero digits skipped, table index taken from the scalar digits), so its timing and memory-access pattern
+    depend on the secret scalars.  Use it only where that side channel is acceptable (DESIGN.md section 8:
+    the GPU path offers no constant-time multiplication); the reference's own getSharedSecret stays the
+    constant-time route.
+    """
     from . import curve as G
     K1 = G.secp256k1_Point
     n = len(secretKeys)
