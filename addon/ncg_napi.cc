@@ -508,6 +508,22 @@ static napi_value VerifySubgroup(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_create_int64(env, bad, &r));
   return r;
 }
+// precomputePoints(handle) -> boolean: interleavedMSMUnsafe's per-point tables in device form (ncg_points_precompute)
+static napi_value PrecomputePoints(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!need_ctx(env)) return nullptr;
+  ncg_points* h = argc >= 1 ? get_set(env, argv[0]) : nullptr;
+  if (!h) return nullptr;
+  if (ncg_points_precompute(g_ctx, h) != NCG_OK) {
+    napi_throw_error(env, nullptr, ncg_last_error(g_ctx));
+    return nullptr;
+  }
+  napi_value r;
+  NAPI_OK(napi_get_boolean(env, ncg_points_precomputed(h) != 0, &r));
+  return r;
+}
 static napi_value InSubgroup(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -718,7 +734,7 @@ NAPI_MODULE_INIT() {
              {"decodePoints", DecodePoints}, {"encodePoints", EncodePoints},
              {"aggregateEncoded", AggregateEncoded},
              {"ntt", Ntt},               {"mapToCurve", MapToCurve},
-             {"packBigInts", PackBigInts}, {"unpackBigInts", UnpackBigInts}, {"uploadPoints", UploadPoints}, {"freePoints", FreePoints}, {"verifySubgroup", VerifySubgroup}, {"inSubgroup", InSubgroup},
+             {"packBigInts", PackBigInts}, {"unpackBigInts", UnpackBigInts}, {"uploadPoints", UploadPoints}, {"freePoints", FreePoints}, {"verifySubgroup", VerifySubgroup}, {"precomputePoints", PrecomputePoints}, {"inSubgroup", InSubgroup},
              {"msmResident", MsmResident}, {"mulVarResident", MulVarResident},
              {"ed25519VerifyMsgs", Ed25519VerifyMsgs}, {"ecdsaVerify", EcdsaVerify}, {"secpVerifyMsgs", SecpVerifyMsgs}, {"ecdsaRecover", EcdsaRecover},
              {"version", Version}};

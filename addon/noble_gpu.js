@@ -172,6 +172,7 @@ function interleavedMSMUnsafe(c, points, windowSize) {
   validateMSMPoints(points, c);
   const n = points.length;
   const set = n ? uploadPoints(c, points) : null;
+  if (set) native.precomputePoints(set.handle);   // the reference builds its per-point tables here (curve.ts:948)
   return (scalars) => {
     validateMSMScalars(scalars, c.Fn);
     if (scalars.length > n) throw new Error('array of scalars must not be larger than array of points');

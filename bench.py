@@ -691,6 +691,25 @@ def main():
                 "verify_once_ms": verify_ms,
                 "note": "ncg_msm_resident_dev on a set that passed the reference's isTorsionFree test on every point "
                         "(bls12-381.ts:567-577 / :599-601) at upload; result compared bit-exactly with the generic MSM above"}
+            # the same set with interleavedMSMUnsafe's precomputation in device form (ncg_points_precompute: window-shifted
+            # copies, one shared bucket set; curve.ts:907-959 builds its per-point tables once too)
+            t0 = time.perf_counter()
+            pre_ok = res.precompute()
+            torch.cuda.synchronize()
+            pre_ms = (time.perf_counter() - t0) * 1e3
+            if pre_ok:
+                ph = {}
+
+                def pstep():
+                    ph["r"] = res.msm_dev(dev_ptr(sc), stream)
+
+                st_pre = time_steps(pstep, K, W, False)
+                assert np.array_equal(ph["r"][0], got), "precomputed-set MSM differs from the generic MSM"
+                entry["resident_subgroup_set"]["precomputed"] = {
+                    "value": nn * K / st_pre[0], "unit": "points/s", "ms_per_msm": st_pre[0] / K * 1e3, "step_times": st_pre.dist(),
+                    "precompute_once_ms": pre_ms,
+                    "note": "ncg_points_precompute on the verified set: shifted copies 2^(16 w) of every endomorphism image, all "
+                            "windows add into one bucket set (one fold, no Horner across windows); result compared bit-exactly"}
             res.free()
         sub = {"pts": pts, "sc": sc, "ks": ks, "pks": pks}
         return entry, sub

@@ -226,6 +226,15 @@ const void* ncg_points_dev(const ncg_points* pts); /* device address of the affi
  * set keeps using the generic path.  ncg_points_in_subgroup: 1 if the fast path is active.  On G1 a verified set
  * also makes ncg_mul_var_batch_resident use the GLV ladder (two 128-bit half-scalars, half the doublings). */
 int ncg_points_verify_subgroup(ncg_ctx* ctx, ncg_points* pts, int64_t* out_bad_index);
+/* The precomputation of interleavedMSMUnsafe (src/abstract/curve.ts:907-959: per-point tables built ONCE for a
+ * fixed point set) in device form: window-shifted copies 2^(16 w) P of every point (or of every endomorphism image
+ * of a verified set - call ncg_points_verify_subgroup first to get those), 16 / 8 / 4 copies of the set in device
+ * memory.  ncg_msm_resident* then adds every window into ONE bucket set: the bucket fold runs once instead of once
+ * per window and the serial combine across windows (curve.ts:901-902) disappears.  Same group element, bit for bit.
+ * Weierstrass curves, sets of >= 4096 points; otherwise (and when memory is short) the call succeeds and changes
+ * nothing.  ncg_points_precomputed: 1 if the shared-bucket path is active. */
+int ncg_points_precompute(ncg_ctx* ctx, ncg_points* pts);
+int ncg_points_precomputed(const ncg_points* pts);
 int ncg_points_in_subgroup(const ncg_points* pts);
 /* pippenger(c, <resident points>, scalars) and the batch multiplyUnsafe on them; scalars: host */
 int ncg_msm_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine,

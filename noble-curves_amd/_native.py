@@ -130,6 +130,8 @@ _OPTIONAL_PROTOS = {
     "ncg_ecdsa_verify_batch_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _i32, _vp, _vp],
     "ncg_points_verify_subgroup": [_vp, _vp, ctypes.POINTER(ctypes.c_int64)],
     "ncg_points_in_subgroup": [_vp],
+    "ncg_points_precompute": [_vp, _vp],
+    "ncg_points_precomputed": [_vp],
     "ncg_mul_var_batch_resident": [_vp, _vp, _vp, _vp, _vp],
     "ncg_field_check": [_vp, _i32, _i32, _i32, _sz, _vp, _vp, _vp],
     "ncg_comm_unique_id": [_vp],
@@ -633,6 +635,17 @@ class ResidentPoints:
         bad = ctypes.c_int64(-1)
         self.engine._check(self.engine.lib.ncg_points_verify_subgroup(self.engine.h, self.h, ctypes.byref(bad)))
         return int(bad.value)
+
+    def precompute(self):
+        """Build the window-shifted copies of the set once (ncg_points_precompute: the device form of
+        interleavedMSMUnsafe's per-point tables, curve.ts:907-959); later MSMs add every window into one bucket
+        set.  Returns True if the shared-bucket path is active afterwards (sets of >= 4096 Weierstrass points)."""
+        self.engine._check(self.engine.lib.ncg_points_precompute(self.engine.h, self.h))
+        return self.precomputed
+
+    @property
+    def precomputed(self):
+        return bool(self.engine.lib.ncg_points_precomputed(self.h)) if self.h else False
 
     @property
     def in_subgroup(self):

@@ -425,6 +425,11 @@ struct ncg_points {
   void* d_pts;
   void* d_endo = nullptr;  // endomorphism images (msm_endo_expand) once the set is known to lie in the subgroup
   void* d_stored = nullptr;  // the points in the accumulate kernel's storage format (built at the first generic MSM)
+  // window-shifted copies for the shared-bucket MSM (ncg_points_precompute, msm_precomp.hip): shift_nwin levels of
+  // shift_m stored points; shift_mode 1 = levels of the points themselves, 2 = of the endomorphism images
+  void* d_shift = nullptr;
+  int shift_c = 0, shift_nwin = 0, shift_mode = 0;
+  size_t shift_m = 0;
 };
 
 // The point of a resident set (curve.ts:907-918: precompute once, call with scalars): the wire -> storage
@@ -602,6 +607,52 @@ int ncg_points_verify_subgroup(ncg_ctx* ctx, ncg_points* h, int64_t* out_bad_ind
   return NCG_OK;
 }
 
+// interleavedMSMUnsafe's precomputation (curve.ts:907-959: tables once per point set) on the device: window-shifted
+// copies of the set, after which ncg_msm_resident* runs the shared-bucket MSM (one bucket fold, no Horner across
+// windows).  Uses the endomorphism images when the set is verified, the points themselves otherwise.  Sets below
+// 4096 points and ed25519 sets are left as they are (NCG_OK, nothing built).
+int ncg_points_precompute(ncg_ctx* ctx, ncg_points* h) {
+  if (!ctx || !h || h->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_precompute: handle does not belong to this context");
+  if (h->d_shift || h->n < 4096 || h->curve == NCG_ED25519) return NCG_OK;
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  static const bool no_endo = std::getenv("NCG_NO_ENDO") != nullptr;
+  const bool endo = h->d_endo && !no_endo;
+  ncg::MsmPlan pl;
+  const int c = 16;
+  if ((endo ? ncg::msm_make_plan_endo(h->curve, (int)h->n, c, &pl) : ncg::msm_make_plan(h->curve, (int)h->n, c, &pl)) != 0)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+  const size_t m = (size_t)pl.n, sw = ncg::msm_stored_words_per_point(h->curve);
+  if (m * (size_t)pl.nwin > 0x7fffffffu) return NCG_OK;  // entry index space: keep the per-window path
+  if (!endo) {
+    int rc = points_build_stored(ctx, h, ctx->stream);
+    if (rc) return rc;
+    if (!h->d_stored) return NCG_OK;
+  }
+  void *d = nullptr, *tmp = nullptr;
+  hipError_t e = hipMalloc(&d, m * (size_t)pl.nwin * sw * 4);
+  if (e == hipSuccess) e = hipMalloc(&tmp, ncg::msm_shift_tmp_bytes(h->curve, (int)m));
+  if (e != hipSuccess) {  // not fatal: the set keeps the per-window path
+    (void)hipGetLastError();
+    if (d) (void)hipFree(d);
+    return NCG_OK;
+  }
+  e = hipMemcpyAsync(d, endo ? h->d_endo : h->d_stored, m * sw * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = ncg::msm_shift_levels(h->curve, (uint32_t*)d, (int)m, pl.nwin, pl.c, tmp, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return set_err(ctx, NCG_ERR_HIP, "noble-gpu: points_precompute: %s", hipGetErrorString(e));
+  }
+  h->d_shift = d;
+  h->shift_c = pl.c;
+  h->shift_nwin = pl.nwin;
+  h->shift_mode = endo ? 2 : 1;
+  h->shift_m = m;
+  return NCG_OK;
+}
+int ncg_points_precomputed(const ncg_points* h) { return h && h->d_shift ? 1 : 0; }
+
 int ncg_points_in_subgroup(const ncg_points* h) { return h && h->d_endo ? 1 : 0; }
 
 void ncg_points_free(ncg_points* h) {
@@ -610,6 +661,7 @@ void ncg_points_free(ncg_points* h) {
   if (h->d_pts) (void)hipFree(h->d_pts);
   if (h->d_endo) (void)hipFree(h->d_endo);
   if (h->d_stored) (void)hipFree(h->d_stored);
+  if (h->d_shift) (void)hipFree(h->d_shift);
   delete h;
 }
 size_t ncg_points_count(const ncg_points* h) { return h ? h->n : 0; }
@@ -629,6 +681,26 @@ static int upload_scalars(ncg_ctx* ctx, PinSet& pins, size_t n, const void* scal
 static int msm_resident_core(ncg_ctx* ctx, const ncg_points* pts, const void* d_sc, void* out_affine, uint8_t* out_is_inf,
                              hipStream_t st) {
   static const bool no_endo = std::getenv("NCG_NO_ENDO") != nullptr;
+  static const bool no_shift = std::getenv("NCG_NO_PRECOMP") != nullptr;
+  if (pts->d_shift && !no_shift) {  // precomputed set: every window adds into one bucket set (msm.hpp `shared`)
+    ncg::MsmPlan pl;
+    const int prc = pts->shift_mode == 2 ? ncg::msm_make_plan_endo(pts->curve, (int)pts->n, pts->shift_c, &pl)
+                                         : ncg::msm_make_plan(pts->curve, (int)pts->n, pts->shift_c, &pl);
+    if (prc != 0 || pl.nwin != pts->shift_nwin || (size_t)pl.n != pts->shift_m)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: the precomputed levels do not match the window plan");
+    pl.shared = 1;
+    pl.pts_stored = 1;
+    int rc = msm_ensure_ws(ctx, pts->curve, pl);
+    if (rc) return rc;
+    uint32_t bad = 0xFFFFFFFFu;
+    uint8_t inf_local = 0;
+    NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, (const uint32_t*)pts->d_shift, (const uint32_t*)d_sc, ctx->msm_ws,
+                              (uint32_t*)out_affine, &inf_local, st, &bad));
+    if (bad != 0xFFFFFFFFu)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
+    if (out_is_inf) *out_is_inf = inf_local;
+    return NCG_OK;
+  }
   if (pts->d_endo && !no_endo) {  // verified subgroup set: endomorphism MSM on the expanded images (endo.hpp)
     ncg::MsmPlan pl;
     if (ncg::msm_make_plan_endo(pts->curve, (int)pts->n, 0, &pl) != 0)

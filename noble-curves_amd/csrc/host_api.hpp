@@ -85,6 +85,12 @@ hipError_t msm_sum_partials(int curve, uint32_t* d_gathered, int nparts, size_t 
 size_t msm_fin_words(int curve, const MsmPlan& pl);
 size_t msm_acc_words(int curve);
 
+// Window-shifted copies of a stored affine set for the shared-bucket MSM (msm_precomp.hip): d_levels holds nlev
+// levels of m points (level 0 = the set itself, filled by the caller); level w = 2^(c w) * level 0.  Weierstrass
+// curves only.  A plan with shared = 1 (and c, nwin = nlev) then takes d_levels as its point array.
+size_t msm_shift_tmp_bytes(int curve, int m);
+hipError_t msm_shift_levels(int curve, uint32_t* d_levels, int m, int nlev, int c, void* d_tmp, hipStream_t st);
+
 // G1 batch multiply on verified subgroup points (mulvar_endo.hip): GLV ladder with the phi endomorphism
 hipError_t mul_var_batch_g1_subgroup(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
                                      uint32_t* jac_tmp, hipStream_t st);

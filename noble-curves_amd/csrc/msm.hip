@@ -149,6 +149,31 @@ __global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ bucket
   if (t == T - 1) bs[pl.nb] = part[T - 1];
 }
 
+// Shared-bucket mode: bucket b of EVERY window is the same bucket.  T_b = sum_w size[w][b] (k_msm_shared_totals),
+// exclusive scan over b = the list position of the bucket (k_msm_scan on the one-window array shared_start), then
+// every window's share of the bucket gets its start: bucket_start[w][b] = S_b + sum_{w' < w} size[w'][b]
+// (k_msm_shared_starts).  shared_start[0 .. nb] = S_b are the accumulate view's starts.
+__global__ void __launch_bounds__(256) k_msm_shared_totals(const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ shared_start,
+                                                           MsmPlan pl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= pl.nb) return;
+  uint32_t tot = 0;
+  for (int w = 0; w < pl.nwin; w++) tot += bucket_start[(size_t)w * (pl.nb + 1) + b];
+  shared_start[b] = tot;
+}
+__global__ void __launch_bounds__(256) k_msm_shared_starts(uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ shared_start,
+                                                           MsmPlan pl) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= pl.nb) return;
+  uint32_t r = shared_start[b];
+  for (int w = 0; w < pl.nwin; w++) {
+    uint32_t* p = bucket_start + (size_t)w * (pl.nb + 1) + b;
+    const uint32_t size = *p;
+    *p = r;
+    r += size;
+  }
+}
+
 // sorted[w*n + pos] = point index | sign<<31, grouped by bucket within the window
 __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict__ digits,
                                                       const uint32_t* __restrict__ counts,
@@ -163,12 +188,15 @@ __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict_
   __syncthreads();
   const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
   const int16_t* dg = digits + (size_t)w * pl.n;
-  uint32_t* dst = sorted + (size_t)w * pl.n;
+  // shared-bucket mode: one list for all windows (the starts already include the other windows' shares), and the
+  // entry names the window's shifted copy of the point
+  uint32_t* dst = sorted + (pl.shared ? 0 : (size_t)w * pl.n);
+  const uint32_t level = pl.shared ? (uint32_t)w * (uint32_t)pl.n : 0u;
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     int d = dg[i];
     if (d != 0) {
       uint32_t pos = atomicAdd(&offs[(d < 0 ? -d : d) - 1], 1u);
-      dst[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+      dst[pos] = (level + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
     }
   }
 }
@@ -275,6 +303,7 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
 // cooperative operations it uses) gives each such run a whole workgroup: strided partial sums, then an LDS tree -
 // log depth in the run length.
 constexpr int MSM_RUN_SERIAL = 2;
+constexpr int MSM_RUN_SERIAL_SHARED = 8;
 constexpr int MSM_LONG_BLOCKS = 512;
 template <class C>
 __global__ void __launch_bounds__(256, TailMinWaves<C>::value) k_msm_fixup_merge(const uint32_t* __restrict__ part_pts,
@@ -457,6 +486,59 @@ __global__ void __launch_bounds__(MSM_TAIL_THREADS) k_msm_fixup_long(const uint3
 #endif
 }
 
+// The fix-up merge with one UNIT (cooperative group) per lane segment, for the shared-bucket mode: there every bucket is
+// cut into a handful of pieces (nwin * n / nb entries over lanes of `seg`), the owners are one lane in four or five and
+// each adds 4-5 heads - a dependent chain that the cooperative additions shorten 2-3x.  Same contract as
+// k_msm_fixup_merge (runs longer than run_serial heads go to the work list).
+template <class C, bool COOP>
+__global__ void __launch_bounds__(256) k_msm_fixup_merge_units(const uint32_t* __restrict__ part_pts, const int* __restrict__ part_meta,
+                                                               const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ buckets,
+                                                               MsmPlan pl, MsmSeg sg, uint32_t* __restrict__ long_runs, int run_serial) {
+#ifdef __HIP_DEVICE_COMPILE__
+  using T = TailOps<C, COOP>;
+  constexpr int XW = MsmGroup<C>::ACC_WORDS;
+  extern __shared__ __attribute__((aligned(16))) uint32_t merge_lds[];
+  const int unit = (int)(threadIdx.x >> T::UNIT_SHIFT);
+  uint32_t* lds = merge_lds + (size_t)unit * T::LDS_WORDS;
+  uint32_t* acc = lds + T::SCRATCH_WORDS;
+  // one unit per BUCKET (the owners are one lane in four or five: indexing by lane would spread them over every
+  // workgroup): the run of bucket tb starts in lane s = start / seg, whose tail slot names tb iff the bucket is cut
+  const int tb = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> T::UNIT_SHIFT), w = blockIdx.y;
+  if (tb >= pl.nb) return;
+  const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  const uint32_t b0 = bs[tb], b1 = bs[tb + 1];
+  if (b1 == b0) return;
+  const int s = (int)(b0 / (uint32_t)sg.seg);
+  if (part_meta[((size_t)w * sg.nseg + s) * 4 + 2] != tb) return;
+  const int s1 = (int)((b1 - 1) / (uint32_t)sg.seg);
+  const int heads = s1 - s;
+  if (heads > run_serial) {
+    if ((threadIdx.x & ((1u << T::UNIT_SHIFT) - 1u)) == 0) {
+      const uint32_t k = atomicAdd(long_runs, 1u);
+      uint32_t* e = long_runs + 4 + (size_t)k * 4;
+      e[0] = (uint32_t)w;
+      e[1] = (uint32_t)tb;
+      e[2] = (uint32_t)s;
+      e[3] = (uint32_t)s1;
+    }
+    return;
+  }
+  const uint32_t* pp = part_pts + (size_t)w * sg.nseg * 2 * XW;
+  uint32_t* dst = buckets + ((size_t)w * pl.nb + tb) * XW;
+  if (heads == 0) {
+    T::copy(pp + ((size_t)s * 2 + 1) * XW, dst);
+    return;
+  }
+  T::copy(pp + ((size_t)s * 2 + 1) * XW, acc);
+  T::sync();
+  for (int k = 1; k < heads; k++) {
+    T::add(lds, acc, pp + ((size_t)(s + k) * 2) * XW, acc);
+    T::sync();
+  }
+  T::add(lds, acc, pp + ((size_t)(s + heads) * 2) * XW, dst);
+#endif
+}
+
 // in: [narr][nwin][n_in] accumulators (read-only here: other workgroups read their windows from it);
 // s0 / s1: scratch, MSM_TAIL_REGION accumulators PER WINDOW each - a window's levels ping-pong inside its own
 // regions, laid out [array][n] (workgroups run at different levels, so they must not share a layout);
@@ -567,7 +649,7 @@ int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) { return msm_ma
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct MsmLayout {
-  size_t pts_mont, digits, counts, bucket_start, sorted, buckets, part_pts, part_meta, long_runs, bad, red0, red1, tail0, tail1, fin, total;
+  size_t pts_mont, digits, counts, bucket_start, sorted, shared_start, buckets, part_pts, part_meta, long_runs, bad, red0, red1, tail0, tail1, fin, total;
 };
 
 static MsmSeg msm_seg(const MsmPlan& pl) {
@@ -608,29 +690,31 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
     off = align256(off + bytes);
     return o;
   };
-  L.pts_mont = take((pl.endo || pl.pts_stored) ? 0 : (size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);  // else: the caller's array
+  L.pts_mont = take((pl.endo || pl.pts_stored || pl.shared) ? 0 : (size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);  // else: the caller's array
   L.digits = take((size_t)pl.nwin * pl.n * 2);
   L.counts = take((size_t)pl.nwin * pl.Q * pl.nb * 4);
   L.bucket_start = take((size_t)pl.nwin * (pl.nb + 1) * 4);
   L.sorted = take((size_t)pl.nwin * pl.n * 4);
-  L.buckets = take((size_t)pl.nwin * pl.nb * MsmGroup<C>::ACC_WORDS * 4);
-  MsmSeg sg = msm_seg(pl);
-  L.part_pts = take((size_t)pl.nwin * sg.nseg * 2 * MsmGroup<C>::ACC_WORDS * 4);
-  L.part_meta = take((size_t)pl.nwin * sg.nseg * 4 * 4);
+  L.shared_start = take((size_t)(pl.nb + 1) * 4);
+  const MsmPlan av = msm_acc_view(pl);   // one window of nwin * n entries in shared-bucket mode
+  L.buckets = take((size_t)av.nwin * av.nb * MsmGroup<C>::ACC_WORDS * 4);
+  MsmSeg sg = msm_seg(av);
+  L.part_pts = take((size_t)av.nwin * sg.nseg * 2 * MsmGroup<C>::ACC_WORDS * 4);
+  L.part_meta = take((size_t)av.nwin * sg.nseg * 4 * 4);
   // work list of the long runs: a counter + (window, bucket, first lane, last lane) per run of more than
   // MSM_RUN_SERIAL heads - such runs cover disjoint lane ranges, so there are at most nwin * nseg / MSM_RUN_SERIAL
-  L.long_runs = take(16 + ((size_t)pl.nwin * (sg.nseg / MSM_RUN_SERIAL + 1)) * 16);
+  L.long_runs = take(16 + ((size_t)av.nwin * (sg.nseg / MSM_RUN_SERIAL + 1)) * 16);
   L.bad = take(64);
   // fold ping-pong: level l output holds (l+1) * nwin * nb/2^l points <= nwin*nb (l = 1, 2)
-  size_t red = (size_t)pl.nwin * std::max(pl.nb, pl.c) * MsmGroup<C>::ACC_WORDS * 4;
+  size_t red = (size_t)av.nwin * std::max(av.nb, av.c) * MsmGroup<C>::ACC_WORDS * 4;
   L.red0 = take(red);
   L.red1 = take(red);
   // the tail workgroups' private ping-pong (levels that fit one workgroup per window: at most 2 * 512 additions
   // per window and level) and the grouped window sums
-  const size_t tail = (size_t)pl.nwin * MSM_TAIL_REGION * MsmGroup<C>::ACC_WORDS * 4;
+  const size_t tail = (size_t)av.nwin * MSM_TAIL_REGION * MsmGroup<C>::ACC_WORDS * 4;
   L.tail0 = take(tail);
   L.tail1 = take(tail);
-  L.fin = take((size_t)msm_ngroups(pl.c) * pl.nwin * MsmGroup<C>::ACC_WORDS * 4);
+  L.fin = take((size_t)msm_ngroups(av.c) * av.nwin * MsmGroup<C>::ACC_WORDS * 4);
   L.total = off;
   return L;
 }
@@ -666,7 +750,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     e = msm_endo_digits(pl, d_scalars, digits, bad, st);
     if (e != hipSuccess) return e;
   } else {
-    if (pl.pts_stored) {
+    if (pl.pts_stored || pl.shared) {
       pts_mont = const_cast<uint32_t*>(d_pts);
     } else if (side && side->stream) {  // beside the digits / sort kernels; joined in front of the accumulate kernel
       e = hipEventRecord(side->fork, st);
@@ -702,27 +786,48 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   const dim3 sort_grid = pl.xcd_map ? dim3((unsigned)(pl.Q * ((pl.nwin + 7) & ~7))) : dim3(pl.Q, pl.nwin);
   hipLaunchKernelGGL(k_msm_hist, sort_grid, dim3(1024), lds, st, digits, counts, pl);
   hipLaunchKernelGGL(k_msm_bucket_totals, dim3((pl.nb + 255) / 256, pl.nwin), dim3(256), 0, st, counts, bstart, pl);
-  hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), (size_t)(pl.nb + pl.nb / 32 + 1) * 4, st, bstart, pl);
+  uint32_t* shared_start = (uint32_t*)(base + L.shared_start);
+  if (pl.shared) {
+    hipLaunchKernelGGL(k_msm_shared_totals, dim3((pl.nb + 255) / 256), dim3(256), 0, st, bstart, shared_start, pl);
+    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), (size_t)(pl.nb + pl.nb / 32 + 1) * 4, st, shared_start, pl);  // window 0 of a 1-window array
+    hipLaunchKernelGGL(k_msm_shared_starts, dim3((pl.nb + 255) / 256), dim3(256), 0, st, bstart, shared_start, pl);
+  } else {
+    hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), (size_t)(pl.nb + pl.nb / 32 + 1) * 4, st, bstart, pl);
+  }
   hipLaunchKernelGGL(k_msm_scatter, sort_grid, dim3(1024), lds, st, digits, counts, bstart, sorted, pl);
+  // from here on: the accumulate view (shared-bucket mode: ONE window of nwin * n entries whose starts are shared_start)
+  const MsmPlan av = msm_acc_view(pl);
+  const uint32_t* acc_start = pl.shared ? shared_start : bstart;
   {
-    MsmSeg sg = msm_seg(pl);
+    MsmSeg sg = msm_seg(av);
     uint32_t* part_pts = (uint32_t*)(base + L.part_pts);
     int* part_meta = (int*)(base + L.part_meta);
-    e = hipMemsetAsync(buckets, 0, (size_t)pl.nwin * pl.nb * XW * 4, st);  // empty buckets = infinity
+    e = hipMemsetAsync(buckets, 0, (size_t)av.nwin * av.nb * XW * 4, st);  // empty buckets = infinity
     if (e != hipSuccess) return e;
-    dim3 grid((unsigned)((((size_t)sg.nseg << LS) + 255) / 256), pl.nwin);
+    dim3 grid((unsigned)((((size_t)sg.nseg << LS) + 255) / 256), av.nwin);
     if (forked) {
       e = hipStreamWaitEvent(st, side->join, 0);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_msm_accum<D>, grid, dim3(256), 0, st, pts_mont, sorted, bstart, buckets, part_pts, part_meta,
-                       pl, sg);
+    hipLaunchKernelGGL(k_msm_accum<D>, grid, dim3(256), 0, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta,
+                       av, sg);
     uint32_t* long_runs = (uint32_t*)(base + L.long_runs);
     e = hipMemsetAsync(long_runs, 0, 16, st);
     if (e != hipSuccess) return e;
     const int run_serial = [] { const char* e = std::getenv("NCG_MSM_RUN_SERIAL"); return e ? std::atoi(e) : MSM_RUN_SERIAL; }();
-    hipLaunchKernelGGL(k_msm_fixup_merge<D>, grid, dim3(256), 0, st, part_pts, part_meta, bstart, buckets, pl, sg, long_runs,
-                       std::max(run_serial, MSM_RUN_SERIAL));
+    // shared-bucket mode: every bucket holds nwin * n / nb entries, i.e. a handful of pieces - all of them, so their
+    // owners add them serially (fully parallel over the buckets), as cooperative groups where the curve has them;
+    // the work list is for the outliers only
+    if (pl.shared && CoopOK<D>::value) {
+      constexpr bool MCOOP = CoopOK<D>::value;
+      using K = TailOps<D, MCOOP>;
+      const dim3 mgrid((unsigned)((((size_t)av.nb << K::UNIT_SHIFT) + 255) / 256), av.nwin);
+      hipLaunchKernelGGL((k_msm_fixup_merge_units<D, MCOOP>), mgrid, dim3(256), (size_t)(256 >> K::UNIT_SHIFT) * K::LDS_WORDS * 4, st, part_pts,
+                         part_meta, acc_start, buckets, av, sg, long_runs, std::max(run_serial, MSM_RUN_SERIAL_SHARED));
+    } else {
+      hipLaunchKernelGGL(k_msm_fixup_merge<D>, grid, dim3(256), 0, st, part_pts, part_meta, acc_start, buckets, av, sg, long_runs,
+                         std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL));
+    }
     {
       constexpr bool LCOOP = CoopOK<D>::value;
       using K = TailOps<D, LCOOP>;
@@ -735,7 +840,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 16) attr_done[dev] = true;
       }
-      hipLaunchKernelGGL((k_msm_fixup_long<D, LCOOP>), dim3(MSM_LONG_BLOCKS), dim3(MSM_TAIL_THREADS), lds_b, st, part_pts, buckets, pl, sg,
+      hipLaunchKernelGGL((k_msm_fixup_long<D, LCOOP>), dim3(MSM_LONG_BLOCKS), dim3(MSM_TAIL_THREADS), lds_b, st, part_pts, buckets, av, sg,
                          long_runs);
     }
   }
@@ -749,7 +854,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   // lanes the chip keeps resident for these kernels (2 waves/SIMD): beyond that the cooperative form costs throughput
   const long coop_max_tasks = (65536L * 2) >> (LS + 2);
   const uint32_t* cur = buckets;
-  int narr = 1, n_in = pl.nb, flip = 0;
+  int narr = 1, n_in = av.nb, flip = 0;
   {
     static bool attr_done[16] = {};
     int dev = 0;
@@ -762,7 +867,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     }
   }
   while (n_in > 1 && (long)(narr + 1) * (n_in >> 1) > 2L * tail_units) {
-    const long total = (long)(narr + 1) * pl.nwin * (n_in >> 1);
+    const long total = (long)(narr + 1) * av.nwin * (n_in >> 1);
     bool done = false;
     if constexpr (CAN_COOP) {
       const bool coop_level = [] { const char* e = std::getenv("NCG_MSM_COOP_LEVEL"); return e ? std::atoi(e) != 0 : true; }();
@@ -770,26 +875,26 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
         using K = TailOps<D, true>;
         const size_t lds_b = (size_t)(256 >> K::UNIT_SHIFT) * COOP_SLOTS * G::FW * 4;
         hipLaunchKernelGGL(k_msm_reduce_level_coop<D>, dim3((unsigned)(((total << K::UNIT_SHIFT) + 255) / 256)), dim3(256), lds_b, st,
-                           cur, red[flip], narr, pl.nwin, n_in);
+                           cur, red[flip], narr, av.nwin, n_in);
         done = true;
       }
     }
     if (!done)
       hipLaunchKernelGGL(k_msm_reduce_level<D>, dim3((unsigned)(((total << LS) + 255) / 256)), dim3(256), 0, st, cur, red[flip],
-                         narr, pl.nwin, n_in);
+                         narr, av.nwin, n_in);
     cur = red[flip];
     flip ^= 1;
     narr++;
     n_in >>= 1;
   }
-  const int ng = msm_ngroups(pl.c);
+  const int ng = msm_ngroups(av.c);
   {
     uint32_t* t0 = (uint32_t*)(base + L.tail0);
     uint32_t* t1 = (uint32_t*)(base + L.tail1);
     uint32_t* fin = (uint32_t*)(base + L.fin);
     using K = TailOps<D, CAN_COOP>;
-    hipLaunchKernelGGL((k_msm_tail<D, CAN_COOP>), dim3(pl.nwin), dim3(MSM_TAIL_THREADS), (size_t)tail_units * K::LDS_WORDS * 4, st, cur,
-                       t0, t1, fin, narr, pl.nwin, n_in, MSM_GROUP, ng);
+    hipLaunchKernelGGL((k_msm_tail<D, CAN_COOP>), dim3(av.nwin), dim3(MSM_TAIL_THREADS), (size_t)tail_units * K::LDS_WORDS * 4, st, cur,
+                       t0, t1, fin, narr, av.nwin, n_in, MSM_GROUP, ng);
     cur = fin;
   }
   *d_fin = cur;
@@ -799,7 +904,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
 
 template <class C>
 static size_t msm_fin_words_t(const MsmPlan& pl) {
-  return (size_t)msm_ngroups(pl.c) * pl.nwin * MsmGroup<C>::ACC_WORDS;
+  return (size_t)msm_ngroups(pl.c) * msm_acc_view(pl).nwin * MsmGroup<C>::ACC_WORDS;
 }
 
 // Finish: the grouped window sums come to the host (one small copy), Horner, canonical affine output.
@@ -810,10 +915,11 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
   using G = MsmGroup<C>;
   constexpr int XW = G::ACC_WORDS;
   const int ng = msm_ngroups(pl.c);
+  const int fin_nwin = msm_acc_view(pl).nwin;  // shared-bucket mode: one window, no Horner across windows
   hipError_t e;
   // the surviving points land in a small pinned buffer (one per thread, reused): a pageable target
   // would go through the runtime's staging copy
-  const size_t fin_words = (size_t)ng * pl.nwin * XW;
+  const size_t fin_words = (size_t)ng * fin_nwin * XW;
   static thread_local uint32_t* pinned = nullptr;
   static thread_local size_t pinned_words = 0;
   if (pinned_words < fin_words) {
@@ -836,11 +942,11 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
   if (land != fin.data()) std::copy(land, land + fin_words, fin.begin());
   static const bool timing = std::getenv("NCG_TIMING") != nullptr;
   auto t0 = std::chrono::steady_clock::now();
-  msm_host_finish_any<C>(fin.data(), pl.c, pl.nwin, out_affine_host, out_inf_host);
+  msm_host_finish_any<C>(fin.data(), pl.c, fin_nwin, out_affine_host, out_inf_host);
   if (timing) {
     auto t1 = std::chrono::steady_clock::now();
     fprintf(stderr, "[ncg] msm host finish: %.1f us (c=%d nwin=%d)\n",
-            std::chrono::duration<double, std::micro>(t1 - t0).count(), pl.c, pl.nwin);
+            std::chrono::duration<double, std::micro>(t1 - t0).count(), pl.c, fin_nwin);
   }
   return hipSuccess;
 }

@@ -51,7 +51,21 @@ struct MsmPlan {
   int n_src = 0;
   int xcd_map = 0;  // sort kernels: window-major block ids so that a window's blocks share an XCD (one L2)
   int pts_stored = 0;  // the caller's points are already in the accumulate kernel's storage format (resident sets)
+  // shared-bucket mode (precomputed sets, msm_precomp.hip): the point array holds one window-shifted copy of the
+  // set per window, level w = 2^(c w) P at [w * n, (w + 1) * n), so every window adds into ONE bucket set: sorted
+  // entry = w * n + i, and everything after the sort runs as a single window of nwin * n entries
+  int shared = 0;
 };
+
+// the plan the kernels AFTER the sort see: the plan itself, or - shared-bucket mode - one window holding every entry
+inline MsmPlan msm_acc_view(const MsmPlan& pl) {
+  MsmPlan av = pl;
+  if (pl.shared) {
+    av.n = pl.n * pl.nwin;
+    av.nwin = 1;
+  }
+  return av;
+}
 
 // Group policy of the MSM kernels: how an input point is stored, what the bucket accumulator
 // is and the three operations on it.  Default: short-Weierstrass a = 0 (XYZZ buckets, affine

@@ -80,7 +80,24 @@ int msm_make_plan_endo(int curve, int n_src, int c_override, MsmPlan* pl) {
     const char* env = std::getenv("NCG_MSM_C_ENDO");
     if (env) c = std::atoi(env);
   }
-  if (c <= 0) c = ilog2u((unsigned)n) - (curve == CURVE_BLS12_381_G2 ? 3 : 4);
+  if (c <= 0) {
+    // as in msm_plan.hpp: the width also decides how full the TOP window is - 128-bit sub-scalars in 14-bit windows
+    // leave it 2 bits, i.e. a handful of buckets holding every entry of the window (very long fix-up runs; measured:
+    // G1 2^17 verified 1.67 ms at c = 14 against 1.06 ms for the generic path).  Take the width closest to
+    // log2(entries) - 4 (G2: - 3) whose top window is at least 80 % full.
+    const int c0 = std::max(3, std::min(16, ilog2u((unsigned)n) - (curve == CURVE_BLS12_381_G2 ? 3 : 4)));
+    int best = c0, best_d = 99;
+    for (int cc = std::max(3, c0 - 3); cc <= std::min(16, c0 + 3); cc++) {
+      const int nw = (bits + cc - 1) / cc, top = bits - (nw - 1) * cc;
+      if (top * 5 < cc * 4) continue;
+      const int d = cc > c0 ? cc - c0 : c0 - cc;
+      if (d < best_d) {
+        best_d = d;
+        best = cc;
+      }
+    }
+    c = best;
+  }
   // c >= 3 keeps |sub| + H' below 2^(c nwin) even when c nwin == bits: H' < 2^(c nwin - 1) (1 + 1/(2^c - 1))
   c = std::max(3, std::min(16, c));
   *pl = MsmPlan();

@@ -338,14 +338,17 @@ def interleavedMSMUnsafe(c, points, windowSize, engine=None):
     """curve.ts:938-959: MSM over a FIXED point set; returns the closure `scalars -> Point`.  Same
     argument checks and messages (window in [2..Fn.BITS], validateMSMPoints); the closure accepts at most
     len(points) scalars and treats omitted trailing ones as zero.  `windowSize` only sizes the reference's
-    per-point wNAF tables and does not change the result: here the set is uploaded once and every call
-    runs the bucket MSM on the resident points with only the scalars crossing."""
+    per-point wNAF tables and does not change the result: here the set is uploaded once, its precomputation is the
+    device's own (window-shifted copies of the points, ncg_points_precompute, for sets of >= 4096 points), and
+    every call runs the bucket MSM on the resident points with only the scalars crossing."""
     bits = c.Fn.BITS
     if not (isinstance(windowSize, int) and not isinstance(windowSize, bool) and 2 <= windowSize <= bits):
         raise ValueError("invalid window size, expected [2..%d], got W=%s" % (bits, windowSize))
     validateMSMPoints(points, c)
     n = len(points)
     pset = uploadPoints(c, points, engine) if n else None
+    if pset is not None:
+        pset.resident.precompute()          # the reference builds its per-point tables here too (curve.ts:948)
 
     def msm(scalars):
         validateMSMScalars(scalars, c.Fn)

@@ -78,6 +78,9 @@ def _worker(rank, world, port, curve_name, sizes, q, wrong_n_max):
 
 
 def _run(curve_name, sizes, wrong_n_max=False):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hosttest
+    hosttest.lib()           # (re)build the twin once, here, not inside the workers' time limit
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -52,8 +52,14 @@ for name, cid, O, top in (("g1", BLS12_381_G1, BlsG1, args.max), ("g2", BLS12_38
         if not args.no_resident:
             res = eng.upload_points(cid, pts[:n].cpu().numpy())
             timed(lambda: res.msm_dev(sc.data_ptr(), s), "resident")
+            if res.precompute():
+                timed(lambda: res.msm_dev(sc.data_ptr(), s), "resident_precomp")
+            res.free()
+            res = eng.upload_points(cid, pts[:n].cpu().numpy())
             assert res.verify_subgroup() == -1
             timed(lambda: res.msm_dev(sc.data_ptr(), s), "resident_verified")
+            if res.precompute():
+                timed(lambda: res.msm_dev(sc.data_ptr(), s), "verified_precomp")
             res.free()
         rows.append(row)
         print(json.dumps(row), flush=True)
