@@ -44,9 +44,9 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 16 lanes/clk/SIMD at the nominal 2.4 GHz = 3.93e13 lane-ops/s
 MAD_PEAK = 3.08e13                         # v_mad_u64_u32 ceiling measured on MI355X (profiles/r01_ubench_instr_rates.json,
                                            # profiles/r02_valu_rates.jsonl: ~2x the issue time of a plain 32-bit VALU op)
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 # FETCH_SIZE / WRITE_SIZE -> bytes, calibrated per access pattern with tools/pmc_calib on known byte counts
-# (profiles/r02_pmc.json "calibration"): item-major 64 B gathers count at face value, 16 B/lane coalesced
+# (profiles/r03_pmc.json "calibration"): item-major 64 B gathers count at face value, 16 B/lane coalesced
 # streams at half (MI355X_MICROARCH.md, HBM), writes at face value.
 FETCH_FACTOR = {"gather": 1.0, "stream": 2.0}
 KERNELS = {   # workload -> (kernel-name prefix in rocprofv3 output, FETCH access pattern)
@@ -117,7 +117,7 @@ def pmc_live(workload, log2n, budget_s=420.0):
 
 class Pmc:
     """HBM traffic and executed-VALU figures per kernel: live counters if this run collected them, else the
-    committed profile (profiles/r02_pmc.json, same command, earlier box)."""
+    committed profile (profiles/r03_pmc.json, same command, earlier box)."""
 
     def __init__(self, live):
         self.live = live
@@ -129,7 +129,7 @@ class Pmc:
             if v:
                 return v, "live"
         v = _pmc_lookup(self.committed, prefix)
-        return (v, "profiles/r02_pmc.json") if v else (None, None)
+        return (v, "profiles/r03_pmc.json") if v else (None, None)
 
     def traffic(self, workload, launches_per_unit=1):
         prefix, pattern = KERNELS[workload]
@@ -972,7 +972,7 @@ def main():
         result["host"] = host
         result["prewarm"] = (("%d untimed steps" % PREWARM_DIST_STEPS if dist_on else "%.0f ms of untimed steps" % (PREWARM_S * 1e3)) +
                              " before the W warm-up steps of every timed loop (boost-clock settling; the K timed steps are unchanged)")
-        result["pmc"] = "live rocprofv3 passes in this run" if live else "committed profile profiles/r02_pmc.json"
+        result["pmc"] = "live rocprofv3 passes in this run" if live else "committed profile profiles/r03_pmc.json"
         print(json.dumps(result))
         if args.out:
             with open(args.out, "w") as f:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Rewrites section 5 of BASELINE.md from the committed round profiles (profiles/r02_*), so the tables are
+"""Rewrites section 5 of BASELINE.md from the committed round profiles (profiles/r03_*, r02 beside them), so the tables are
 transcriptions of measured files, not hand-typed numbers.  python tools/make_baseline_tables.py"""
 import json
 import os
@@ -14,15 +14,16 @@ def load(name):
 
 
 def main():
-    b = load("r02_bench_line.json")
-    b1 = load("r01_bench_line.json")
+    b = load("r03_bench_line.json")
+    b1 = load("r02_bench_line.json")
     ex, ex1 = load("r02_bench_extra.json"), load("r01_bench_extra.json")
     e = b["extra"]
     host = b.get("host", {})
     out = []
-    out.append("## 5. Results table (round 2, one MI355X, `profiles/r02_bench_line.json`, `profiles/r02_bench_kernel_stats.csv`, `profiles/r02_pmc.json`)\n")
-    out.append("Throughput with inputs resident in HBM, one run of `python bench.py` (box-to-box variation of the pool: up to ~7 %% on the "
-               "long kernels, more on the MSM lines whose ≈45 launches + host finish are sensitive to the host).  Every result is verified "
+    out.append("## 5. Results table (round 3, one MI355X, the driver's command `python3 bench.py --gpus 1 --steps 20 --warmup 5`: `profiles/r03_bench_line.json`, `profiles/r03_bench_kernel_stats.csv`, `profiles/r03_pmc.json`)\n")
+    out.append("Throughput with inputs resident in HBM, one run of the driver's command on a fresh box (per-step event / wall distributions "
+               "are in the line: `step_times`; the same command on other boxes: `profiles/r03_driver_cmd_run*.json`; the driver's own "
+               "round-2 box read 12-80 %% slower than any box seen here, DESIGN.md section 7).  Every result is verified "
                "bit-exactly before it is printed (sample vs the CPU oracle's C restatement, full-size checksum / progression identity, "
                "ed25519 verdicts by construction + the reference's 196 zip215.json cases).  `hbm_frac` = algorithmic bytes ÷ 8 TB/s (the "
                "contract's figure; the path is VALU-bound, §2 caveat); `mad_frac` = executed `v_mad_u64_u32` (counted from the kernel's "
@@ -31,7 +32,7 @@ def main():
                "(FETCH_SIZE/WRITE_SIZE with the per-pattern calibration of `tools/pmc_calib`).  CPU baseline = `oracle/c` restatement of "
                "the reference algorithm on the GPU box's host (%s, %s logical cores; Node %s cannot run the TypeScript reference).\n"
                % (host.get("cpu_model"), host.get("logical_cores"), host.get("node_version")))
-    out.append("| config | N | time (r01 → r02) | throughput | hbm_frac | mad_frac | valu_issue | traffic / algorithmic | CPU port 1 thread / all threads | bit-exact |")
+    out.append("| config | N | time (r02 → r03) | throughput | hbm_frac | mad_frac | valu_issue | traffic / algorithmic | CPU port 1 thread / all threads | bit-exact |")
     out.append("|---|---|---|---|---|---|---|---|---|---|")
 
     def row(name, n, t1, t2, unit, entry, alg_bytes):
@@ -56,12 +57,13 @@ def main():
     row("bls12-381 Fr NTT (natural→natural)", "2²²", e1["ntt_fr"]["ms_per_transform"], e["ntt_fr"]["ms_per_transform"], "elements/s", e["ntt_fr"],
         64.0 * (1 << 22))
     ko = e["ed25519_verify"]["kernel_only"]
-    out.append("\ned25519 kernel-only (pre-hashed challenges, the r01 figure): %.2f ms → **%.2f ms** (%.3g verifies/s); the device hash adds "
+    out.append("\ned25519 kernel-only (pre-hashed challenges): %.2f ms → **%.2f ms** (%.3g verifies/s); the device hash adds "
                "%.2f ms per 2¹⁸ signatures.  Multi-GPU (2/4/8): measured by the driver's scaling run - `bench.py --gpus N` reports weak "
                "scaling per line, `extra.msm_g1_strong` / `msm_g2_strong` = one 2²⁰ / 2¹⁸-point MSM split over the N GPUs through "
-               "`ncg_msm_sharded_dev` (RCCL all-gather of ~18 KB per rank).\n"
+               "`ncg_msm_sharded_dev` (RCCL all-gather of one fixed-size slot per rank); `python bench.py --gpus N` launches its own ranks; strong-scaling budget: DESIGN.md section 6.\n"
                % (e1["ed25519_verify"]["ms_per_batch"], ko["ms_per_batch"], ko["value"], e["ed25519_verify"]["ms_per_batch"] - ko["ms_per_batch"]))
     r1, r2 = e["msm_g1"].get("resident_subgroup_set"), e["msm_g2"].get("resident_subgroup_set")
+    p1, p2 = (r1 or {}).get("precomputed"), (r2 or {}).get("precomputed")
     if r1 and r2:
         out.append("MSM on a RESIDENT point set verified once to lie in the prime-order subgroup (`ncg_points_verify_subgroup`, %.0f ms for "
                    "2²⁰ G1 points / %.0f ms for 2¹⁸ G2 points; sets decoded by `ncg_points_from_encoded` qualify without it) - the scalars "
@@ -69,6 +71,17 @@ def main():
                    "same run: G1 2²⁰ **%.2f ms** (%.3g points/s), G2 2¹⁸ **%.2f ms** (%.3g points/s).  The rows above are the generic "
                    "`pippenger` (arbitrary curve points, like the reference).\n"
                    % (r1["verify_once_ms"], r2["verify_once_ms"], r1["ms_per_msm"], r1["value"], r2["ms_per_msm"], r2["value"]))
+    if p1 and p2:
+        out.append("The same verified sets with `ncg_points_precompute` (interleavedMSMUnsafe's per-point tables in device form: window-"
+                   "shifted copies, built once in %.0f / %.0f ms; one shared bucket set, no combine across windows): G1 2²⁰ **%.2f ms**, "
+                   "G2 2¹⁸ **%.2f ms**; per size and path: `profiles/r03_msm_timing.json`.\n"
+                   % (p1["precompute_once_ms"], p2["precompute_once_ms"], p1["ms_per_msm"], p2["ms_per_msm"]))
+    c0 = e.get("configs0_point_multiply")
+    if c0:
+        out.append("BASELINE configs[0] (`benchmark/point.ts:20-32`, CPU plumbing; port, 1 core of the box's %s): `Point.multiply` "
+                   "%.0f ops/s (%.0f µs), `Point.multiplyUnsafe` %.0f ops/s (%.0f µs).\n"
+                   % (c0.get("cpu_model"), c0["Point_multiply"]["value"], c0["Point_multiply"]["us_per_op"],
+                      c0["Point_multiplyUnsafe"]["value"], c0["Point_multiplyUnsafe"]["us_per_op"]))
     out.append("Targets: ≥10⁷ secp256k1 scalar-mults/s per MI355X — met (%.1f×); \"≥40 %% HBM roofline\" for the 2²⁰ G1 MSM is not physically "
                "meaningful (§2 caveat): its dominant kernel runs at %.0f %% of the measured multiplier ceiling in EXECUTED multiplies.\n"
                % (b["value"] / 1e7, 100 * e["msm_g1"]["roofline"]["valu"]["mad_frac"]))
