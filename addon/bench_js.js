@@ -33,10 +33,16 @@ gpu.native.msm(0, pb, sb);
 const [tMsmN] = ms(() => gpu.native.msm(0, pb, sb));
 const [tMulN] = ms(() => gpu.native.mulVarBatch(0, pb, sb));
 // resident point set (uploadPoints once): only scalars cross - as BigInt[] (native 64-bit-word reads) and as packed bytes
+// packed columns (packPoints once, scalars as BigUint64Array): the reference-shaped call without per-value N-API work
+const packedPts = gpu.packPoints(Point, pts);
+const sc64 = new BigUint64Array(sb.buffer);
+const [tPacked, rPacked] = ms(() => gpu.pippenger(Point, packedPts, sc64));
+const rRef = gpu.pippenger(Point, pts, ss);
+if (rPacked.x !== rRef.x || rPacked.y !== rRef.y) throw new Error('packed pippenger differs');
 const set = gpu.uploadPoints(Point, pts);
 gpu.pippengerResident(set, ss);
 const [tResBig] = ms(() => gpu.pippengerResident(set, ss));
 const [tResBytes] = ms(() => gpu.pippengerResident(set, sb));
 set.free();
-console.log(JSON.stringify({ n, pippenger_resident_bigint_ms: tResBig, pippenger_resident_bytes_ms: tResBytes, pippenger_js_ms: tMsm, pippenger_native_ms: tMsmN, multiplyUnsafeBatch_js_ms: tMul,
+console.log(JSON.stringify({ n, pippenger_resident_bigint_ms: tResBig, pippenger_resident_bytes_ms: tResBytes, pippenger_js_ms: tMsm, pippenger_packed_columns_ms: tPacked, pippenger_native_ms: tMsmN, multiplyUnsafeBatch_js_ms: tMul,
   multiplyUnsafeBatch_native_ms: tMulN }));

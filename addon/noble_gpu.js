@@ -86,14 +86,36 @@ function curveId(c) {
   return id;
 }
 
+// Packed columns (SURVEY 8a gotcha 8; VERDICT r02 #9): every BigInt that crosses N-API costs ~100 ns
+// (napi_get_element + napi_get_value_bigint_words), i.e. 2^16 points + scalars = 196 608 values = most of an
+// end-to-end pippenger.  Callers that keep their data in columns skip that entirely:
+//   packPoints(c, points)  -> Uint8Array, affine x || y little-endian per point (the wire format of include/ncg.h;
+//                             Fp2 as c0 || c1) - marshal ONCE, reuse across calls (or uploadPoints for a resident set)
+//   packScalars(scalars)   -> Uint8Array, 32 bytes little-endian each; a BigUint64Array of 4 words per scalar is the
+//                             same bytes on a little-endian host and is accepted as is
+// pippenger / multiplyUnsafeBatch accept these in place of Point[] / BigInt[]; packed scalars are range-checked on the
+// bytes (same 'invalid scalar at index i'), packed points are trusted like fromAffine trusts its caller.
+function packPoints(c, points) { const id = curveId(c); validateMSMPoints(points, c); return marshalPoints(c, id, points); }
+function packScalars(scalars, Fn) { if (Fn) validateMSMScalars(scalars, Fn); return marshalScalars(scalars); }
+function asBytes(x) {
+  if (x instanceof Uint8Array) return x;
+  if (typeof BigUint64Array !== 'undefined' && x instanceof BigUint64Array) return new Uint8Array(x.buffer, x.byteOffset, x.byteLength);
+  return null;
+}
 function pippenger(c, points, scalars) {
   const id = curveId(c);
-  validateMSMPoints(points, c);
-  validateMSMScalars(scalars, c.Fn);
-  if (points.length !== scalars.length) throw new Error('arrays of points and scalars must have equal length');
-  if (points.length === 0) return c.ZERO;      // curve.ts:878
+  const pb = native.pointBytes(id);
+  const pBytes = asBytes(points), sBytes = asBytes(scalars);
+  if (pBytes === null) validateMSMPoints(points, c);
+  else if (pBytes.length % pb) throw new Error('noble-gpu: packed points: expected a multiple of ' + pb + ' bytes');
+  if (sBytes === null) validateMSMScalars(scalars, c.Fn);
+  else if (sBytes.length % 32) throw new Error('array of scalars expected');
+  const np = pBytes === null ? points.length : pBytes.length / pb, ns = sBytes === null ? scalars.length : sBytes.length / 32;
+  if (np !== ns) throw new Error('arrays of points and scalars must have equal length');
+  if (sBytes !== null) checkPackedScalars(sBytes, c.Fn);
+  if (np === 0) return c.ZERO;      // curve.ts:878
   init();
-  const out = native.msm(id, marshalPoints(c, id, points), marshalScalars(scalars));
+  const out = native.msm(id, pBytes === null ? marshalPoints(c, id, points) : pBytes, sBytes === null ? marshalScalars(scalars) : sBytes);
   return unmarshalPoint(c, id, out, 0, out[out.length - 1] === 1);
 }
 // ---- resident point sets (interleavedMSMUnsafe's pattern, curve.ts:907-959): upload once, then only the
@@ -131,7 +153,11 @@ function checkPackedScalars(bytes, Fn) {
   const ob = new Uint8Array(32);
   for (let i = 0, v = order; i < 32; i++, v >>= 8n) ob[i] = Number(v & 0xffn);
   const n = bytes.length >>> 5;
+  // fast path: the top 32-bit word decides for all but ~2^-32 of the scalars of a full-width order
+  const top = ((ob[31] << 24) | (ob[30] << 16) | (ob[29] << 8) | ob[28]) >>> 0;
+  const u32 = (bytes.byteOffset & 3) === 0 ? new Uint32Array(bytes.buffer, bytes.byteOffset, bytes.length >>> 2) : null;
   for (let i = 0; i < n; i++) {
+    if (u32 !== null && u32[8 * i + 7] < top) continue;
     const o = i << 5;
     let k = 31;
     while (k >= 0 && bytes[o + k] === ob[k]) k--;
@@ -424,6 +450,6 @@ function hashToCurveBatch(c, msgs, DST) {
   return unmarshalPoints(c, id, out, n, n * pb);
 }
 
-module.exports = { CURVE, init, initMulti, register, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
+module.exports = { CURVE, init, initMulti, register, packPoints, packScalars, pippenger, multiplyUnsafeBatch, multiplyBaseBatch, ed25519VerifyBatch,
                    PointSet, uploadPoints, uploadEncoded, interleavedMSMUnsafe, pippengerResident, multiplyUnsafeBatchResident, ed25519VerifyBatchDevice, ecdsaVerifyBatch, ecdsaVerifyBatchMsgs, schnorrVerifyBatch, ecdsaRecoverBatch,
                    fromBytesBatch, toBytesBatch, aggregateFromBytes, fftFr, hashToCurveBatch, native };

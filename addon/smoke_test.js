@@ -46,6 +46,14 @@ if (haveGpu) {
   const ss = ks.map((_, i) => BigInt(i * 7919 + 1));
   const tot = ks.reduce((a, k, i) => (a + k * ss[i]) % N, 0n);
   const msm = gpu.pippenger(Point, viaBase, ss);
+  {  // packed columns in place of Point[] / BigInt[]: same result, same scalar rule
+    const pp = gpu.packPoints(Point, viaBase), ps = gpu.packScalars(ss, Point.Fn);
+    const m2 = gpu.pippenger(Point, pp, ps), m3 = gpu.pippenger(Point, pp, new BigUint64Array(ps.buffer, ps.byteOffset, ps.length / 8));
+    assert.strictEqual(m2.x, msm.x); assert.strictEqual(m2.y, msm.y); assert.strictEqual(m3.x, msm.x); assert.strictEqual(m3.y, msm.y);
+    const badS = Uint8Array.from(ps); badS.fill(0xff, 0, 32);
+    assert.throws(() => gpu.pippenger(Point, pp, badS), /invalid scalar at index 0/);
+    assert.throws(() => gpu.pippenger(Point, pp.subarray(0, pp.length - 64), ps), /arrays of points and scalars must have equal length/);
+  }
   const ref = gpu.multiplyBaseBatch(Point, [tot])[0];
   assert.strictEqual(msm.x, ref.x); assert.strictEqual(msm.y, ref.y);
   assert.strictEqual(gpu.pippenger(Point, [Point.BASE, Point.BASE.negate(), Point.ZERO], [5n, 5n, 9n]), Point.ZERO);

@@ -91,18 +91,21 @@ def main():
     for k, v in ex.items():
         o = ex1.get(k)
         out.append("| %s | 2^%d | %s | %.2f ms | %.3g %s/s |" % (k, v["n"].bit_length() - 1, ("%.2f ms" % o["ms"]) if o else "—", v["ms"], v["per_s"], v["unit"]))
-    out.append("\n### End to end from JavaScript (`addon/bench_js.js`, Node 12 on the GPU box, secp256k1, `profiles/r02_js_bench.jsonl`)\n")
+    out.append("\n### End to end from JavaScript (`addon/bench_js.js`, Node 12 on the GPU box, secp256k1, `profiles/r03_js_bench.jsonl`)\n")
     out.append("BigInt marshalling + N-API + H2D/D2H + kernels.  `resident` = the point set was uploaded once (`uploadPoints`), only the scalars "
-               "cross per call - as `BigInt[]` read natively as 64-bit words, or as packed bytes (SURVEY 8a gotcha 8).\n")
-    out.append("| N | `pippenger` from JS | resident, BigInt[] scalars | resident, packed scalars | native call alone | `multiplyUnsafeBatch` from JS | native |")
-    out.append("|---|---|---|---|---|---|---|")
-    for line in open(P("r02_js_bench.jsonl")):
+               "cross per call - as `BigInt[]` read natively as 64-bit words, or as packed bytes (SURVEY 8a gotcha 8).  Every BigInt that crosses "
+               "N-API costs ~100 ns (`napi_get_element` + `napi_get_value_bigint_words`; handle scopes and JS-side conversions measured no "
+               "better), so the reference-shaped call with 2¹⁶ Point objects stays at ≈16 ms; `pippenger` / `multiplyUnsafeBatch` therefore also "
+               "take packed columns (`packPoints`, `packScalars`, `BigUint64Array`) in place of `Point[]` / `BigInt[]`.\n")
+    out.append("| N | `pippenger` from JS (Point[] / BigInt[]) | packed columns (`packPoints` once + BigUint64Array scalars) | resident, BigInt[] scalars | resident, packed scalars | native call alone | `multiplyUnsafeBatch` from JS | native |")
+    out.append("|---|---|---|---|---|---|---|---|")
+    for line in open(P("r03_js_bench.jsonl")):
         line = line.strip()
         if not line.startswith("{"):
             continue
         j = json.loads(line)
-        out.append("| 2^%d | %.1f ms | %.2f ms | %.2f ms | %.2f ms | %.1f ms | %.2f ms |" % (
-            j["n"].bit_length() - 1, j["pippenger_js_ms"], j["pippenger_resident_bigint_ms"], j["pippenger_resident_bytes_ms"],
+        out.append("| 2^%d | %.1f ms | %.2f ms | %.2f ms | %.2f ms | %.2f ms | %.1f ms | %.2f ms |" % (
+            j["n"].bit_length() - 1, j["pippenger_js_ms"], j.get("pippenger_packed_columns_ms", float("nan")), j["pippenger_resident_bigint_ms"], j["pippenger_resident_bytes_ms"],
             j["pippenger_native_ms"], j["multiplyUnsafeBatch_js_ms"], j["multiplyUnsafeBatch_native_ms"]))
     text = "\n".join(out) + "\n"
     path = os.path.join(ROOT, "BASELINE.md")
