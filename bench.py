@@ -490,7 +490,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist_on = world > 1
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    if dist_on and args.backend == "nccl" and torch.cuda.device_count() < world:
+    if dist_on and args.backend == "nccl" and torch.cuda.device_count() < world and not os.environ.get("NCG_BENCH_FORCE_NCCL"):
         # fewer GPUs than ranks (a 1-GPU box): RCCL refuses two ranks on one device, so the ranks share GPUs and
         # exchange through gloo - the native per-shard phase and the native combine still run (host-staged slots)
         args.backend = "gloo"

@@ -1,5 +1,6 @@
 // C ABI (include/ncg.h): context, workspace and dispatch.  No torch types cross here.
 #include <hip/hip_runtime.h>
+#include "knobs.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -615,7 +616,7 @@ int ncg_points_precompute(ncg_ctx* ctx, ncg_points* h) {
   if (!ctx || !h || h->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_precompute: handle does not belong to this context");
   if (h->d_shift || h->n < 4096 || h->curve == NCG_ED25519) return NCG_OK;
   NCG_HIP(ctx, hipSetDevice(ctx->device));
-  static const bool no_endo = std::getenv("NCG_NO_ENDO") != nullptr;
+  static const bool no_endo = ncg::knob_set("NCG_NO_ENDO");
   const bool endo = h->d_endo && !no_endo;
   ncg::MsmPlan pl;
   const int c = 16;
@@ -680,8 +681,8 @@ static int upload_scalars(ncg_ctx* ctx, PinSet& pins, size_t n, const void* scal
 // MSM on a resident set with the scalars already on the device
 static int msm_resident_core(ncg_ctx* ctx, const ncg_points* pts, const void* d_sc, void* out_affine, uint8_t* out_is_inf,
                              hipStream_t st) {
-  static const bool no_endo = std::getenv("NCG_NO_ENDO") != nullptr;
-  static const bool no_shift = std::getenv("NCG_NO_PRECOMP") != nullptr;
+  static const bool no_endo = ncg::knob_set("NCG_NO_ENDO");
+  static const bool no_shift = ncg::knob_set("NCG_NO_PRECOMP");
   if (pts->d_shift && !no_shift) {  // precomputed set: every window adds into one bucket set (msm.hpp `shared`)
     ncg::MsmPlan pl;
     const int prc = pts->shift_mode == 2 ? ncg::msm_make_plan_endo(pts->curve, (int)pts->n, pts->shift_c, &pl)
@@ -776,7 +777,7 @@ int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* 
   char* d_out = d_sc + sc_b;
   char* d_inf = d_out + out_b;
   NCG_HIP(ctx, pins.h2d(d_sc, scalars, n * 32));
-  static const bool no_endo = std::getenv("NCG_NO_ENDO") != nullptr;
+  static const bool no_endo = ncg::knob_set("NCG_NO_ENDO");
   if (pts->d_endo && pts->curve == NCG_BLS12_381_G1 && !no_endo) {  // verified subgroup set: GLV ladder (mulvar_endo.hip)
     rc = ensure_mul_ws(ctx, pts->curve, n, ctx->stream);
     if (rc) return rc;

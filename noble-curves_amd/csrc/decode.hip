@@ -13,6 +13,7 @@
 //   ed25519    32 bytes: Point.fromBytes(bytes, zip215) (src/abstract/edwards.ts:405-436)
 // out_ok[i] = 0 exactly where the reference throws; the affine output is then (0,0).
 #include <cstdlib>
+#include "knobs.hpp"
 #include <vector>
 
 #include "bls_lanes.hpp"
@@ -339,7 +340,7 @@ hipError_t decode_points_batch(int curve, const uint8_t* in, int flags, uint32_t
       break;
     case CURVE_BLS12_381_G2: {
 #ifdef NCG_AB_BUILD  // the fused kernel (587 spilled registers) only exists in A/B builds
-      static const int fused = [] { const char* e = std::getenv("NCG_DEC_G2_FUSED"); return e ? std::atoi(e) : 0; }();
+      static const int fused = knob("NCG_DEC_G2_FUSED", 0);
       if (fused) {
         hipLaunchKernelGGL(k_decode_g2, dim3((n + 127) / 128), dim3(128), 0, st, in, out, ok, inf, n);
         break;

@@ -17,6 +17,7 @@
 // window measured 1.7x slower for that reason) and 6 bits for B (32 precomputed affine Niels
 // multiples shared by every lane): 258 doublings, 129 + 43 additions.
 #include <cstdlib>
+#include "knobs.hpp"
 #include <mutex>
 #include <vector>
 
@@ -413,7 +414,7 @@ hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const
                                 int zip215, uint8_t* out_ok, int n, uint32_t* gtab, hipStream_t st) {
   if (n <= 0) return hipSuccess;
 #ifdef NCG_AB_BUILD
-  static const int variant = [] { const char* e = std::getenv("NCG_ED_VARIANT"); return e ? std::atoi(e) : 3; }();
+  static const int variant = knob("NCG_ED_VARIANT", 3);
 #else
   constexpr int variant = 3;  // 3 waves/SIMD (168 registers); 2 and 4 are A/B builds
 #endif

@@ -19,6 +19,7 @@
 //     F.2.1.1 ladder in Fp2 is several times the field work.  Either root is fine: SWU fixes the
 //     sign of y by sgn0(u) == sgn0(y) (:707-708).
 #include <cstdlib>
+#include "knobs.hpp"
 #include <vector>
 
 #include "bls_lanes.hpp"
@@ -323,23 +324,52 @@ __global__ void __launch_bounds__(64, NCG_H2C_G2_STAGE1_MINW) k_g2_map_stage1(co
   FieldIO<FeBls2>::store(o + 28, Q.Y);
   FieldIO<FeBls2>::store(o + 56, Q.Z);
 }
-__global__ void __launch_bounds__(64, 2) k_g2_map_stage2(const uint32_t* __restrict__ jac_in, int count, uint32_t* __restrict__ jac_out,
-                                                         int n) {
+// Stage 2, split by live points (round 3; one kernel kept P, t1, t2, t3 and the addition's temporaries alive and spilled
+// 635 registers): the cofactor clearing of bls12-381.ts:604-618,
+//     t1 = -[x]P;  t2 = psi(P);  t3 = psi^2(2P) - t2;  t2 = -[x](t1 + t2);  R = t3 + t2 - t1 - P,
+// as five launches with the points handed over in HBM (Jacobian, 84 words each: P, t1, u = t1 + psi(P), v = -[x]u):
+//     k_g2_cc_sum   P = Q0 (+ Q1)                      k_g2_cc_negmulx   out = -[x] in     (used twice)
+//     k_g2_cc_mid   u = t1 + psi(P)                    k_g2_cc_final     R = psi^2(2P) - psi(P) + v - t1 - P
+// each with at most two points live.  All lane-paired (two lanes per item).
+struct G2ccIO {
   using F = FeBls2P;
-  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;  // two lanes per item
+  static NCG_DI Jac<F> load(const uint32_t* p) { return {FieldIO<F>::load(p), FieldIO<F>::load(p + 28), FieldIO<F>::load(p + 56)}; }
+  static NCG_DI void store(uint32_t* o, Jac<F> R) {
+    if (R.is_inf()) R = Jac<F>::inf();
+    FieldIO<F>::store(o, R.X);
+    FieldIO<F>::store(o + 28, R.Y);
+    FieldIO<F>::store(o + 56, R.Z);
+  }
+};
+__global__ void __launch_bounds__(64, 2) k_g2_cc_sum(const uint32_t* __restrict__ jac_in, int count, uint32_t* __restrict__ P, int n) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (i >= n) return;
-  auto load = [&](size_t idx) -> Jac<F> {
-    const uint32_t* p = jac_in + idx * 84;
-    return {FieldIO<F>::load(p), FieldIO<F>::load(p + 28), FieldIO<F>::load(p + 56)};
-  };
-  Jac<F> acc = load((size_t)i * count);
-  if (count == 2) acc = jac_add(acc, load((size_t)i * 2 + 1));
-  Jac<F> R = g2p_clear_cofactor(acc);
-  if (R.is_inf()) R = Jac<F>::inf();
-  uint32_t* o = jac_out + (size_t)i * 84;
-  FieldIO<F>::store(o, R.X);
-  FieldIO<F>::store(o + 28, R.Y);
-  FieldIO<F>::store(o + 56, R.Z);
+  Jac<FeBls2P> acc = G2ccIO::load(jac_in + (size_t)i * count * 84);
+  if (count == 2) acc = jac_add(acc, G2ccIO::load(jac_in + ((size_t)i * 2 + 1) * 84));
+  G2ccIO::store(P + (size_t)i * 84, acc);
+}
+__global__ void __launch_bounds__(64, 2) k_g2_cc_negmulx(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int n) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (i >= n) return;
+  G2ccIO::store(out + (size_t)i * 84, jac_neg(bls_mul_by_x(G2ccIO::load(in + (size_t)i * 84))));
+}
+__global__ void __launch_bounds__(64, 2) k_g2_cc_mid(const uint32_t* __restrict__ P, const uint32_t* __restrict__ T1, uint32_t* __restrict__ U,
+                                                     int n) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (i >= n) return;
+  const Jac<FeBls2P> t2 = g2p_psi(G2ccIO::load(P + (size_t)i * 84));
+  G2ccIO::store(U + (size_t)i * 84, jac_add(G2ccIO::load(T1 + (size_t)i * 84), t2));
+}
+__global__ void __launch_bounds__(64, 2) k_g2_cc_final(const uint32_t* __restrict__ P, const uint32_t* __restrict__ T1,
+                                                       const uint32_t* __restrict__ V, uint32_t* __restrict__ out, int n) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (i >= n) return;
+  const Jac<FeBls2P> p = G2ccIO::load(P + (size_t)i * 84);
+  Jac<FeBls2P> t3 = g2p_psi2(jac_dbl(p));
+  t3 = jac_add(t3, jac_neg(g2p_psi(p)));
+  t3 = jac_add(t3, G2ccIO::load(V + (size_t)i * 84));
+  t3 = jac_add(t3, jac_neg(G2ccIO::load(T1 + (size_t)i * 84)));
+  G2ccIO::store(out + (size_t)i * 84, jac_add(t3, jac_neg(p)));
 }
 
 // jac_tmp: n * 3 * FW words of device scratch (then the affine conversion is batched), or nullptr
@@ -356,7 +386,7 @@ hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t*
     }
   } else if (curve == CURVE_BLS12_381_G2) {
 #ifdef NCG_AB_BUILD
-    static const int fused = [] { const char* e = std::getenv("NCG_H2C_G2_FUSED"); return e ? std::atoi(e) : 0; }();
+    static const int fused = knob("NCG_H2C_G2_FUSED", 0);
 #else
     constexpr int fused = 0;
 #endif
@@ -365,7 +395,17 @@ hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t*
       uint32_t* stage1 = jac_tmp + (size_t)n * 84;
       const int total = n * count;
       hipLaunchKernelGGL(k_g2_map_stage1, dim3((total + 63) / 64), dim3(64), 0, st, u, stage1, total);
-      hipLaunchKernelGGL(k_g2_map_stage2, dim3((unsigned)(((size_t)n * 2 + 63) / 64)), dim3(64), 0, st, stage1, count, jac_tmp, n);
+      // then [n] each: P, t1, u, v of the cofactor clearing (the mul_ws of G2 holds 1434 words per item: enough)
+      uint32_t* bP = stage1 + (size_t)total * 84;
+      uint32_t* bT1 = bP + (size_t)n * 84;
+      uint32_t* bU = bT1 + (size_t)n * 84;
+      uint32_t* bV = bU + (size_t)n * 84;
+      const dim3 g2((unsigned)(((size_t)n * 2 + 63) / 64));
+      hipLaunchKernelGGL(k_g2_cc_sum, g2, dim3(64), 0, st, stage1, count, bP, n);
+      hipLaunchKernelGGL(k_g2_cc_negmulx, g2, dim3(64), 0, st, bP, bT1, n);
+      hipLaunchKernelGGL(k_g2_cc_mid, g2, dim3(64), 0, st, bP, bT1, bU, n);
+      hipLaunchKernelGGL(k_g2_cc_negmulx, g2, dim3(64), 0, st, bU, bV, n);
+      hipLaunchKernelGGL(k_g2_cc_final, g2, dim3(64), 0, st, bP, bT1, bV, jac_tmp, n);
       hipLaunchKernelGGL((k_jac_batch_affine<CurveG2P, 4>), dim3(((((n + 3) / 4) << 1) + 255) / 256), dim3(256), 0, st,
                          jac_tmp, out, inf, n);
 #ifdef NCG_AB_BUILD  // the fused kernel (1 871 spilled registers) only exists in A/B builds

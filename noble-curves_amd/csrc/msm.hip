@@ -1,5 +1,6 @@
 // MSM kernels and the single-GPU driver (see msm.hpp for the pipeline).
 #include "msm.hpp"
+#include "knobs.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -654,9 +655,9 @@ struct MsmLayout {
 
 static MsmSeg msm_seg(const MsmPlan& pl) {
   MsmSeg sg;
-  const char* env = std::getenv("NCG_MSM_SEG");
-  if (env) {
-    sg.seg = std::max(1, std::atoi(env));
+  const int seg_knob = knob("NCG_MSM_SEG", 0);
+  if (seg_knob > 0) {
+    sg.seg = seg_knob;
   } else {
     // Every lane adds `seg` consecutive sorted entries, and the accumulate kernel keeps
     // cap = waves/SIMD x 1024 SIMDs x 64 lanes resident, so its time goes like rounds(seg) * seg with
@@ -814,7 +815,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     uint32_t* long_runs = (uint32_t*)(base + L.long_runs);
     e = hipMemsetAsync(long_runs, 0, 16, st);
     if (e != hipSuccess) return e;
-    const int run_serial = [] { const char* e = std::getenv("NCG_MSM_RUN_SERIAL"); return e ? std::atoi(e) : MSM_RUN_SERIAL; }();
+    const int run_serial = knob("NCG_MSM_RUN_SERIAL", MSM_RUN_SERIAL);
     // shared-bucket mode: every bucket holds nwin * n / nb entries, i.e. a handful of pieces - all of them, so their
     // owners add them serially (fully parallel over the buckets), as cooperative groups where the curve has them;
     // the work list is for the outliers only
@@ -870,7 +871,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     const long total = (long)(narr + 1) * av.nwin * (n_in >> 1);
     bool done = false;
     if constexpr (CAN_COOP) {
-      const bool coop_level = [] { const char* e = std::getenv("NCG_MSM_COOP_LEVEL"); return e ? std::atoi(e) != 0 : true; }();
+      const bool coop_level = knob("NCG_MSM_COOP_LEVEL", 1) != 0;
       if (coop && coop_level && total <= coop_max_tasks) {
         using K = TailOps<D, true>;
         const size_t lds_b = (size_t)(256 >> K::UNIT_SHIFT) * COOP_SLOTS * G::FW * 4;
@@ -940,7 +941,7 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
   if (land != fin.data()) std::copy(land, land + fin_words, fin.begin());
-  static const bool timing = std::getenv("NCG_TIMING") != nullptr;
+  static const bool timing = knob_set("NCG_TIMING");
   auto t0 = std::chrono::steady_clock::now();
   msm_host_finish_any<C>(fin.data(), pl.c, fin_nwin, out_affine_host, out_inf_host);
   if (timing) {

@@ -4,6 +4,7 @@
 // one-off subgroup verification of a raw point set.  Everything downstream of the digits (sort, bucket
 // accumulate, fold, finish) is the unchanged pipeline of msm.hip running on endo * n entries.
 #include <algorithm>
+#include "knobs.hpp"
 #include <cstdlib>
 
 #include "bls_lanes.hpp"
@@ -77,8 +78,7 @@ int msm_make_plan_endo(int curve, int n_src, int c_override, MsmPlan* pl) {
   const int n = n_src * E;
   int c = c_override;
   if (c <= 0) {
-    const char* env = std::getenv("NCG_MSM_C_ENDO");
-    if (env) c = std::atoi(env);
+    c = knob("NCG_MSM_C_ENDO", 0);
   }
   if (c <= 0) {
     // as in msm_plan.hpp: the width also decides how full the TOP window is - 128-bit sub-scalars in 14-bit windows
@@ -116,7 +116,7 @@ int msm_make_plan_endo(int curve, int n_src, int c_override, MsmPlan* pl) {
   }
   static const uint32_t BLS_R[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
   for (int i = 0; i < 8; i++) pl->order[i] = BLS_R[i];
-  static const int q_blocks = [] { const char* e = std::getenv("NCG_MSM_QBLOCKS"); return e ? std::max(64, std::atoi(e)) : 512; }();
+  static const int q_blocks = std::max(64, knob("NCG_MSM_QBLOCKS", 512));
   int Q = std::max(1, q_blocks / pl->nwin);
   Q = std::min(Q, std::max(1, n / 4096));
   pl->Q = Q;

@@ -5,6 +5,7 @@
 // curves (and NCG_MSM_HOST64=0, the A/B switch) run the device templates compiled for the host.
 #pragma once
 #include <cstdlib>
+#include "knobs.hpp"
 
 #include "bls_host64.hpp"
 #include "msm.hpp"
@@ -32,8 +33,7 @@ inline void msm_host_finish(const uint32_t* fin, int c, int nwin, uint32_t* out_
 }
 
 inline bool msm_host64_enabled() {
-  const char* e = std::getenv("NCG_MSM_HOST64");
-  return e ? std::atoi(e) != 0 : true;
+  return knob("NCG_MSM_HOST64", 1) != 0;
 }
 
 template <class C>

@@ -1,6 +1,7 @@
 // Window plan of the MSM (host side; shared by msm.hip, comm.hip and the CPU test twin).
 #pragma once
 #include <algorithm>
+#include "knobs.hpp"
 #include <cstdlib>
 
 #include "msm.hpp"
@@ -55,8 +56,7 @@ inline int ilog2(unsigned x) {
 inline int msm_make_plan_impl(int curve, int n, int c_override, MsmPlan* pl) {
   int c = c_override;
   if (c <= 0) {
-    const char* env = std::getenv("NCG_MSM_C");
-    if (env) c = std::atoi(env);
+    c = knob("NCG_MSM_C", 0);
   }
   if (c <= 0) {
     // accumulate cost nwin*n mixed adds vs fold cost ~2*nwin*2^(c-1) full adds: c ~ log2(n) - 4 - but the width also
@@ -87,12 +87,12 @@ inline int msm_make_plan_impl(int curve, int n, int c_override, MsmPlan* pl) {
   for (int i = 0; i < 8; i++) pl->order[i] = curve_order(curve)[i];
   // sort chunks: ~512 blocks per sort kernel (two per CU; measured 2 % faster than 1024 on the 2^20 G1 MSM,
   // tools/ab_q.sh: half the per-chunk count arrays to write, prefix and read), at least 4096 points per chunk
-  static const int q_blocks = [] { const char* e = std::getenv("NCG_MSM_QBLOCKS"); return e ? std::max(64, std::atoi(e)) : 512; }();
+  static const int q_blocks = std::max(64, knob("NCG_MSM_QBLOCKS", 512));
   int Q = std::max(1, q_blocks / pl->nwin);
   Q = std::min(Q, std::max(1, n / 4096));
   pl->Q = Q;
   pl->chunk = (n + Q - 1) / Q;
-  static const int xcd = [] { const char* e = std::getenv("NCG_MSM_XCD"); return e ? std::atoi(e) : 0; }();
+  static const int xcd = knob("NCG_MSM_XCD", 0);
   pl->xcd_map = xcd;
   return 0;
 }

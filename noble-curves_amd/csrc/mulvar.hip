@@ -1,5 +1,6 @@
 // Launchers for the batch variable-base multiply kernels (see mulvar.hpp).
 #include "mulvar.hpp"
+#include "knobs.hpp"
 #include "host_api.hpp"
 
 #include <cstdlib>
@@ -140,7 +141,7 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
     // W-bit windows and M waves/SIMD requested, WM = table in LDS).
     case CURVE_SECP256K1: {
 #ifdef NCG_AB_BUILD  // the measured alternatives (tools/ab_secp.sh builds with -DNCG_AB_BUILD): not in the shipped library
-      static const int w = [] { const char* e = std::getenv("NCG_SECP_W"); return e ? std::atoi(e) : 243; }();
+      static const int w = knob("NCG_SECP_W", 243);
       if (jac_tmp && w == 154) return launch_mul_var_gtab<CurveSecp, 5, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 153) return launch_mul_var_gtab<CurveSecp, 5, 3>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 152) return launch_mul_var_gtab<CurveSecp, 5, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
@@ -157,7 +158,7 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
     case CURVE_ED25519: return ed25519_mul_var_batch(pts, scalars, out, out_inf, n, jac_tmp, st);
     case CURVE_BLS12_381_G1: {
 #ifdef NCG_AB_BUILD
-      static const int w = [] { const char* e = std::getenv("NCG_G1_W"); return e ? std::atoi(e) : 142; }();
+      static const int w = knob("NCG_G1_W", 142);
       if (jac_tmp && w == 141) return launch_mul_var_gtab<CurveG1, 4, 1>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 152) return launch_mul_var_gtab<CurveG1, 5, 2>(pts, scalars, out, out_inf, n, jac_tmp, st);
       if (jac_tmp && w == 151) return launch_mul_var_gtab<CurveG1, 5, 1>(pts, scalars, out, out_inf, n, jac_tmp, st);
@@ -170,7 +171,7 @@ hipError_t mul_var_batch(int curve, const uint32_t* pts, const uint32_t* scalars
     }
     case CURVE_BLS12_381_G2: {
 #ifdef NCG_AB_BUILD
-      static const int w = [] { const char* e = std::getenv("NCG_G2_W"); return e ? std::atoi(e) : 142; }();
+      static const int w = knob("NCG_G2_W", 142);
       if (w == 0) return launch_mul_var<CurveG2, 3, 1, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);  // unpaired
       if (jac_tmp && w == 142) return launch_mul_var_gtab<CurveG2P, 4, 2, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
 #else

@@ -5,6 +5,7 @@
 // translation units ship their own code object.
 #define NCG_MUL_INLINE 1
 #include "mulvar.hpp"
+#include "knobs.hpp"
 #include "host_api.hpp"
 
 #include <cstdlib>
@@ -19,7 +20,7 @@ hipError_t mul_var_secp_inline(int minw, const uint32_t* pts, const uint32_t* sc
   if (minw == 13) return launch_mul_var_gtab<CurveSecpI, 4, 3, 16>(pts, scalars, out, out_inf, n, jac_tmp, st);  // the shipped kernel
   return hipErrorInvalidValue;
 #else
-  static const int k = [] { const char* e = std::getenv("NCG_AFF_K"); return e ? std::atoi(e) : 16; }();
+  static const int k = knob("NCG_AFF_K", 16);
   switch (minw * 100 + k) {
     case 408: return launch_mul_var_gtab<CurveSecpI, 5, 4>(pts, scalars, out, out_inf, n, jac_tmp, st);
     case 308: return launch_mul_var_gtab<CurveSecpI, 5, 3>(pts, scalars, out, out_inf, n, jac_tmp, st);

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs an A/B build of the library: make -C noble-curves_amd/csrc clean all EXTRA=-DNCG_AB_BUILD (the shipped library ignores the NCG_* variant switches, csrc/knobs.hpp)
 # A/B of the bls12-381 G1 batch-multiply variants (NCG_G1_W) on the GPU box: 2^18 multiplies
 for w in ${*:-141 142 151 152 132}; do
   NCG_G1_W=$w timeout 200 python - <<PY 2>/dev/null

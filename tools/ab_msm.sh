@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs an A/B build of the library: make -C noble-curves_amd/csrc clean all EXTRA=-DNCG_AB_BUILD (the shipped library ignores the NCG_* variant switches, csrc/knobs.hpp)
 # A/B of two libncg builds on the MSM workloads with per-kernel times: tools/ab_msm.sh <tag> <lib...>
 TAG=$1; shift
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs an A/B build of the library: make -C noble-curves_amd/csrc clean all EXTRA=-DNCG_AB_BUILD (the shipped library ignores the NCG_* variant switches, csrc/knobs.hpp)
 # A/B of the secp256k1 batch-multiply variants (NCG_SECP_W[:NCG_AFF_K]) on the GPU box
 mkdir -p gpurun_out/ab
 for v in ${*:-154 253 243 244 253:4 253:16}; do

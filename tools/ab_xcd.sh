@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs an A/B build of the library: make -C noble-curves_amd/csrc clean all EXTRA=-DNCG_AB_BUILD (the shipped library ignores the NCG_* variant switches, csrc/knobs.hpp)
 # A/B of the XCD-aware block mapping of the MSM sort kernels (NCG_MSM_XCD=0/1) on one box
 for rep in 1 2; do for x in 0 1; do
   for w in msm_g1 msm_g2; do

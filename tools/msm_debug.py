@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the MSM tail components on the GPU (one process; the NCG_MSM_* switches are read per call): which sizes
-still satisfy the progression identity (test/slow-curves.test.ts:185-252) under which switch, with wall times."""
+still satisfy the progression identity (test/slow-curves.test.ts:185-252) under which switch, with wall times.
+Needs an A/B build (make -C noble-curves_amd/csrc clean all EXTRA=-DNCG_AB_BUILD): the shipped library ignores these switches."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
