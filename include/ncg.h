@@ -223,8 +223,9 @@ const void* ncg_points_dev(const ncg_points* pts); /* device address of the affi
  * reference's subgroup test on every point); for uploaded affine points ncg_points_verify_subgroup runs the
  * test once - every point P must satisfy [z^2]P = -phi(P) resp. [z]P = -psi(P) - and enables the path only if
  * all pass.  A failing set is not an error: *out_bad_index names the first point outside the subgroup and the
- * set keeps using the generic path.  ncg_points_in_subgroup: 1 if the fast path is active.  On G1 a verified set
- * also makes ncg_mul_var_batch_resident use the GLV ladder (two 128-bit half-scalars, half the doublings). */
+ * set keeps using the generic path.  ncg_points_in_subgroup: 1 if the fast path is active.  A verified set also
+ * makes ncg_mul_var_batch_resident* use the endomorphism ladders (G1: two 128-bit half-scalars, half the doublings;
+ * G2: four 64-bit streams along psi, a quarter of the doublings) - same group elements as the generic ladder. */
 int ncg_points_verify_subgroup(ncg_ctx* ctx, ncg_points* pts, int64_t* out_bad_index);
 /* The precomputation of interleavedMSMUnsafe (src/abstract/curve.ts:907-959: per-point tables built ONCE for a
  * fixed point set) in device form: window-shifted copies 2^(16 w) P of every point (or of every endomorphism image
@@ -243,6 +244,9 @@ int ncg_msm_resident_dev(ncg_ctx* ctx, const ncg_points* pts, const void* scalar
                          uint8_t* out_is_inf, void* stream); /* scalars: device, 32 B LE each */
 int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars,
                                void* out_affine, uint8_t* out_is_inf);
+/* the same with scalars (32 B LE each), results and infinity flags (all required) in device memory */
+int ncg_mul_var_batch_resident_dev(ncg_ctx* ctx, const ncg_points* pts, const void* scalars_dev,
+                                   void* out_affine_dev, uint8_t* out_is_inf_dev, void* stream);
 
 /* ---- multi-GPU MSM ---------------------------------------------------------------------
  * pippenger is a sum over points (src/abstract/curve.ts:863-905; its last step is the chain

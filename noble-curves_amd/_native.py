@@ -133,6 +133,7 @@ _OPTIONAL_PROTOS = {
     "ncg_points_precompute": [_vp, _vp],
     "ncg_points_precomputed": [_vp],
     "ncg_mul_var_batch_resident": [_vp, _vp, _vp, _vp, _vp],
+    "ncg_mul_var_batch_resident_dev": [_vp, _vp, _vp, _vp, _vp, _vp],
     "ncg_field_check": [_vp, _i32, _i32, _i32, _sz, _vp, _vp, _vp],
     "ncg_comm_unique_id": [_vp],
     "ncg_comm_init": [_vp, _i32, _i32, _vp],
@@ -693,6 +694,10 @@ class ResidentPoints:
             self.engine._check(self.engine.lib.ncg_mul_var_batch_resident(self.engine.h, self.h, scalars.ctypes.data,
                                                                           out.ctypes.data, inf.ctypes.data))
         return out, inf
+
+    def mul_var_batch_dev(self, d_scalars, d_out, d_inf, stream=None):
+        """The same with scalars, results and infinity flags in device memory (raw pointers)."""
+        self.engine._check(self.engine.lib.ncg_mul_var_batch_resident_dev(self.engine.h, self.h, d_scalars, d_out, d_inf, stream))
 
 
 class MultiEngine:

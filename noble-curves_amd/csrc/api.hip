@@ -761,6 +761,35 @@ int ncg_msm_resident_dev(ncg_ctx* ctx, const ncg_points* pts, const void* scalar
   return msm_resident_core(ctx, pts, scalars_dev, out_affine, out_is_inf, stream ? (hipStream_t)stream : ctx->stream);
 }
 
+// batch multiply on a resident set, device buffers: a verified subgroup set takes the endomorphism ladders of
+// mulvar_endo.hip (G1: two 128-bit streams along phi; G2: four 64-bit streams along psi), any other set the generic kernel
+static int mul_var_resident_core(ncg_ctx* ctx, const ncg_points* pts, const void* d_sc, void* d_out, uint8_t* d_inf, hipStream_t st) {
+  const size_t n = pts->n;
+  static const bool no_endo = ncg::knob_set("NCG_NO_ENDO");
+  const bool bls = pts->curve == NCG_BLS12_381_G1 || pts->curve == NCG_BLS12_381_G2;
+  if (pts->d_endo && bls && !no_endo) {
+    int rc = ensure_mul_ws(ctx, pts->curve, n, st);
+    if (rc) return rc;
+    if (pts->curve == NCG_BLS12_381_G1)
+      NCG_HIP(ctx, ncg::mul_var_batch_g1_subgroup((const uint32_t*)pts->d_pts, (const uint32_t*)d_sc, (uint32_t*)d_out, d_inf, (int)n,
+                                                  (uint32_t*)ctx->mul_ws, st));
+    else
+      NCG_HIP(ctx, ncg::mul_var_batch_g2_subgroup((const uint32_t*)pts->d_pts, (const uint32_t*)d_sc, (uint32_t*)d_out, d_inf, (int)n,
+                                                  (uint32_t*)ctx->mul_ws, st));
+    return NCG_OK;
+  }
+  return ncg_mul_var_batch_dev(ctx, pts->curve, n, pts->d_pts, d_sc, d_out, d_inf, st);
+}
+
+int ncg_mul_var_batch_resident_dev(ncg_ctx* ctx, const ncg_points* pts, const void* scalars_dev, void* out_affine_dev,
+                                   uint8_t* out_is_inf_dev, void* stream) {
+  if (!ctx || !pts || pts->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch_resident: handle does not belong to this context");
+  if (pts->n == 0) return NCG_OK;
+  if (!scalars_dev || !out_affine_dev || !out_is_inf_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch_resident: NULL buffer");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  return mul_var_resident_core(ctx, pts, scalars_dev, out_affine_dev, out_is_inf_dev, stream ? (hipStream_t)stream : ctx->stream);
+}
+
 int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine,
                                uint8_t* out_is_inf) {
   if (!ctx || !pts || pts->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: mul_var_batch_resident: handle does not belong to this context");
@@ -777,16 +806,8 @@ int ncg_mul_var_batch_resident(ncg_ctx* ctx, const ncg_points* pts, const void* 
   char* d_out = d_sc + sc_b;
   char* d_inf = d_out + out_b;
   NCG_HIP(ctx, pins.h2d(d_sc, scalars, n * 32));
-  static const bool no_endo = ncg::knob_set("NCG_NO_ENDO");
-  if (pts->d_endo && pts->curve == NCG_BLS12_381_G1 && !no_endo) {  // verified subgroup set: GLV ladder (mulvar_endo.hip)
-    rc = ensure_mul_ws(ctx, pts->curve, n, ctx->stream);
-    if (rc) return rc;
-    NCG_HIP(ctx, ncg::mul_var_batch_g1_subgroup((const uint32_t*)pts->d_pts, (const uint32_t*)d_sc, (uint32_t*)d_out, (uint8_t*)d_inf,
-                                                (int)n, (uint32_t*)ctx->mul_ws, ctx->stream));
-  } else {
-    rc = ncg_mul_var_batch_dev(ctx, pts->curve, n, pts->d_pts, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
-    if (rc) return rc;
-  }
+  rc = mul_var_resident_core(ctx, pts, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
+  if (rc) return rc;
   NCG_HIP(ctx, pins.d2h(out_affine, d_out, n * (size_t)pb));
   std::vector<uint8_t> inf_tmp;
   uint8_t* inf_dst = out_is_inf;

@@ -94,6 +94,10 @@ hipError_t msm_shift_levels(int curve, uint32_t* d_levels, int m, int nlev, int 
 // G1 batch multiply on verified subgroup points (mulvar_endo.hip): GLV ladder with the phi endomorphism
 hipError_t mul_var_batch_g1_subgroup(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
                                      uint32_t* jac_tmp, hipStream_t st);
+// G2 likewise: four 64-bit streams along psi; jac_tmp holds mul_var_g2_subgroup_tmp_bytes(n) bytes
+hipError_t mul_var_batch_g2_subgroup(const uint32_t* pts, const uint32_t* scalars, uint32_t* out, uint8_t* out_inf, int n,
+                                     uint32_t* jac_tmp, hipStream_t st);
+size_t mul_var_g2_subgroup_tmp_bytes(int n);
 
 // secp256k1 ECDSA batch verify, scalar side (ecdsa.hip): sig = r || s (big-endian), hash = 32 bytes.
 hipError_t ecdsa_prepare(const uint8_t* d_sig, const uint8_t* d_hash, int n, bool low_s, uint32_t* d_u1, uint32_t* d_u2,

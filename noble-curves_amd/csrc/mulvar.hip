@@ -1,4 +1,5 @@
 // Launchers for the batch variable-base multiply kernels (see mulvar.hpp).
+#include <algorithm>
 #include "mulvar.hpp"
 #include "knobs.hpp"
 #include "host_api.hpp"
@@ -127,7 +128,9 @@ size_t mul_var_tmp_bytes(int curve, int n) {
     // Jacobian scratch + the per-item window table of the widest variant (k_mul_var_gtab)
     case CURVE_SECP256K1: return pad64(n) * (3 * FieldIO<CurveSecp::F>::WORDS + gtab_words_per_item<CurveSecp, 5>()) * 4;
     case CURVE_BLS12_381_G1: return pad64(n) * (3 * FieldIO<CurveG1::F>::WORDS + gtab_words_per_item<CurveG1, 5>()) * 4;
-    case CURVE_BLS12_381_G2: return pad64(n) * (3 * FieldIO<CurveG2::F>::WORDS + 2 * gtab_words_per_item<CurveG2P, 4>()) * 4;
+    case CURVE_BLS12_381_G2:  // the verified-set ladder (mulvar_endo.hip) keeps a second table per lane
+      return std::max(pad64(n) * (3 * FieldIO<CurveG2::F>::WORDS + 2 * gtab_words_per_item<CurveG2P, 4>()) * 4,
+                      mul_var_g2_subgroup_tmp_bytes(n));
     case CURVE_ED25519: return ed25519_tmp_words(n) * 4;  // (X, Y, Z) + per-item window tables
     default: return 0;
   }

@@ -104,13 +104,14 @@ def test_large_verified_set_against_generic_path(c, Pt, log2n):
     fast.free(); plain.free()
 
 
-def test_g1_verified_set_batch_multiply_uses_the_glv_ladder():
-    """multiplyUnsafeBatch on a verified G1 set (ncg_mul_var_batch_resident -> mulvar_endo.hip) against the
-    oracle and against the generic ladder on the same set: edge scalars, ZERO, 3000 rows (full waves)."""
-    c, Pt = G.bls12_381_G1_Point, BlsG1
-    rng = makeRng(0x61F)
+@pytest.mark.parametrize("c,Pt", CASES)
+def test_verified_set_batch_multiply_uses_the_endomorphism_ladder(c, Pt):
+    """multiplyUnsafeBatch on a verified set (ncg_mul_var_batch_resident -> mulvar_endo.hip: G1 two streams along
+    phi, G2 four streams along psi) against the oracle and against the generic ladder on the same set: edge
+    scalars of the split (multiples of z^e, half-way values, r - 1), ZERO, full waves."""
+    rng = makeRng(0x61F + c.CURVE_ID)
     edges = edge_scalars()
-    n = 3000
+    n = 3000 if c is G.bls12_381_G1_Point else 1100
     a = [rng.rndBelow(BLS_R - 1) + 1 for _ in range(n)]
     pts = G.multiplyBaseBatch(c, a)
     pts[7] = c.ZERO
@@ -122,6 +123,27 @@ def test_g1_verified_set_batch_multiply_uses_the_glv_ladder():
     for i in list(range(len(edges))) + [n - 1, n - 2]:
         exp = Pt.ZERO if i == 7 else Pt.BASE.multiplyUnsafe(a[i] * sc[i] % BLS_R)
         assert rf[i].toAffine() == exp.toAffine(), i
+    fast.free(); plain.free()
+
+
+@pytest.mark.parametrize("c,Pt", CASES)
+def test_verified_set_batch_multiply_out_of_range_scalars_at_the_c_abi(c, Pt):
+    """The shims reject k >= r before crossing (weierstrass.ts:915-928); the C ABI takes any 256-bit value like the
+    generic ladder does: the endomorphism ladders must hand those lanes to the complete ladder, not mis-split them."""
+    import numpy as np
+    rng = makeRng(0xAB1 + c.CURVE_ID)
+    ks = [BLS_R, BLS_R + 1, BLS_R + Z ** 3, 2 * BLS_R - 1, 2 ** 255, 2 ** 256 - 1, 2 ** 256 - BLS_R, 5, 0]
+    ks += [rng.rndBelow(2 ** 256) for _ in range(130 - len(ks))]
+    a = [rng.rndBelow(BLS_R - 1) + 1 for _ in range(len(ks))]
+    pts = G.multiplyBaseBatch(c, a)
+    fast, plain = G.uploadPoints(c, pts, checkSubgroup=True), G.uploadPoints(c, pts)
+    wire = np.frombuffer(b"".join(k.to_bytes(32, "little") for k in ks), np.uint8).reshape(-1, 32)
+    (of, inf_f), (op, inf_p) = fast.resident.mul_var_batch(wire), plain.resident.mul_var_batch(wire)
+    assert np.array_equal(of, op) and np.array_equal(inf_f, inf_p)
+    for i in (0, 1, 2, 5, 8, 20):
+        exp = Pt.BASE.multiplyUnsafe(a[i] * ks[i] % BLS_R)
+        got = c._from_wire(of[i], bool(inf_f[i]))
+        assert got.toAffine() == exp.toAffine(), i
     fast.free(); plain.free()
 
 

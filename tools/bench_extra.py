@@ -185,6 +185,14 @@ def main():
     g1, _ = bench.gen_points(eng, BLS12_381_G1, BlsG1, m, a, b, dev, s)
     g1o = torch.empty((m, 96), dtype=torch.uint8, device=dev)
     rate("bls12-381 G1 variable-base multiply", m, timeit(lambda: eng.mul_var_batch_dev(BLS12_381_G1, m, P(g1), P(gsc), P(g1o), P(inf), s), 2), "scalar-mults")
+    rs1 = eng.upload_points(BLS12_381_G1, g1.cpu().numpy())
+    assert rs1.verify_subgroup() == -1 and rs1.in_subgroup
+    ref1 = g1o.clone()
+    rs1.mul_var_batch_dev(P(gsc), P(g1o), P(inf), s)
+    torch.cuda.synchronize()
+    assert bool((g1o == ref1).all().item()), "G1 verified-set ladder mismatch"
+    rate("bls12-381 G1 variable-base multiply, verified set (GLV ladder)", m, timeit(lambda: rs1.mul_var_batch_dev(P(gsc), P(g1o), P(inf), s), 2), "scalar-mults")
+    rs1.free()
     rate("bls12-381 G1 fixed-base multiply", m, timeit(lambda: eng.mul_base_batch_dev(BLS12_381_G1, m, P(gsc), P(g1o), P(inf), s), 2), "scalar-mults")
     genc = torch.empty((m, 48), dtype=torch.uint8, device=dev)              # compressed: x big-endian + flags
     fenc = lambda: eng._check(eng.lib.ncg_encode_points_batch_dev(eng.h, BLS12_381_G1, m, P(g1), P(genc), P(ok), s))  # noqa: E731
@@ -197,6 +205,14 @@ def main():
     g2, _ = bench.gen_points(eng, BLS12_381_G2, BlsG2, m, a, b, dev, s)
     g2o = torch.empty((m, 192), dtype=torch.uint8, device=dev)
     rate("bls12-381 G2 variable-base multiply", m, timeit(lambda: eng.mul_var_batch_dev(BLS12_381_G2, m, P(g2), P(gsc), P(g2o), P(inf), s), 2), "scalar-mults")
+    rs2 = eng.upload_points(BLS12_381_G2, g2.cpu().numpy())
+    assert rs2.verify_subgroup() == -1 and rs2.in_subgroup
+    ref2 = g2o.clone()
+    rs2.mul_var_batch_dev(P(gsc), P(g2o), P(inf), s)
+    torch.cuda.synchronize()
+    assert bool((g2o == ref2).all().item()), "G2 verified-set ladder mismatch"
+    rate("bls12-381 G2 variable-base multiply, verified set (psi ladder)", m, timeit(lambda: rs2.mul_var_batch_dev(P(gsc), P(g2o), P(inf), s), 2), "scalar-mults")
+    rs2.free()
     g2enc = torch.empty((m, 96), dtype=torch.uint8, device=dev)
     eng._check(eng.lib.ncg_encode_points_batch_dev(eng.h, BLS12_381_G2, m, P(g2), P(g2enc), P(ok), s))
     fg2 = lambda: eng._check(eng.lib.ncg_decode_points_batch_dev(eng.h, BLS12_381_G2, m, P(g2enc), 0, P(g2o), P(ok), P(inf), s))  # noqa: E731

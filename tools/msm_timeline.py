@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel timeline of the LAST MSM of each (curve, shape) in a rocprofv3 --kernel-trace CSV:
-    python tools/msm_timeline.py <dir with *kernel_trace.csv>
-An MSM is the kernel sequence from k_msm_digits* to k_msm_tail*."""
+    python tools/msm_timeline.py <dir with *kernel_trace.csv> [--seq]
+(--seq: every launch in order with its start offset and duration instead of the per-kernel sums.)  An MSM is the kernel sequence from k_msm_digits* to k_msm_tail*."""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
@@ -25,6 +25,10 @@ for m in msms:
     last[(tag, len(m["k"]), round((m["t1"] - m["t0"]) / 2e4))] = m
 for (tag, nk, _), m in last.items():
     print("%s  %d launches  span %.1f us" % (tag, nk, (m["t1"] - m["t0"]) / 1e3))
+    if "--seq" in sys.argv:
+        for nm, t0, t1 in m["k"]:
+            print("   +%8.1f us  %-58s %9.1f us" % ((t0 - m["t0"]) / 1e3, nm[:58], (t1 - t0) / 1e3))
+        continue
     agg = {}
     for nm, t0, t1 in m["k"]:
         a = agg.setdefault(nm, [0, 0.0]); a[0] += 1; a[1] += (t1 - t0) / 1e3

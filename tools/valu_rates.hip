@@ -117,6 +117,14 @@ __global__ void __launch_bounds__(256) k_rate(uint64_t* __restrict__ tstamps, ui
 #define X(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x[i]) : "v"(a));
       REP8(X) REP8(X)
 #undef X
+    } else if constexpr (KIND == 20) {  // v_fma_f64 (the DFMA big-integer product of Emmart et al. would be made of these)
+#define X(i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(r[i]) : "v"(r[(i + 1) & 7]), "v"(r[(i + 2) & 7]));
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (KIND == 21) {  // v_add_f64
+#define X(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 7]));
+      REP8(X) REP8(X)
+#undef X
     } else if constexpr (KIND == 19) {  // v_subb_co_u32 chain + cndmask (conditional subtract shape)
       asm volatile(
           "v_sub_co_u32 %0, vcc, %0, %8\n\tv_subb_co_u32 %1, vcc, %1, %8, vcc\n\tv_subb_co_u32 %2, vcc, %2, %8, vcc\n\t"
@@ -185,7 +193,8 @@ int main() {
       {"v_mul_hi_u32", 6, 16}, {"v_lshrrev_b64", 7, 16}, {"v_lshl_add_u64", 8, 16}, {"v_and_b32", 9, 16},
       {"v_cndmask_b32", 10, 16}, {"v_add3_u32", 11, 16}, {"v_mad_u32_u24", 12, 16}, {"v_mad_i64_i32", 13, 16},
       {"v_alignbit_b32", 14, 16}, {"v_mov_b32 dpp quad_perm", 15, 16}, {"v_sub_u32 + v_add_u32", 16, 16},
-      {"4 mad + and + lshr64 column", 17, 48}, {"v_mul_u32_u24", 18, 16}, {"v_sub_co/v_subb_co x8 + cndmask x8", 19, 16}};
+      {"4 mad + and + lshr64 column", 17, 48}, {"v_mul_u32_u24", 18, 16}, {"v_sub_co/v_subb_co x8 + cndmask x8", 19, 16},
+      {"v_fma_f64", 20, 16}, {"v_add_f64", 21, 16}};
   int rc = 0;
   rc |= run<0>(rows[0], d_ts, d_sink); rc |= run<1>(rows[1], d_ts, d_sink); rc |= run<2>(rows[2], d_ts, d_sink);
   rc |= run<3>(rows[3], d_ts, d_sink); rc |= run<4>(rows[4], d_ts, d_sink); rc |= run<5>(rows[5], d_ts, d_sink);
@@ -194,5 +203,6 @@ int main() {
   rc |= run<12>(rows[12], d_ts, d_sink); rc |= run<13>(rows[13], d_ts, d_sink); rc |= run<14>(rows[14], d_ts, d_sink);
   rc |= run<15>(rows[15], d_ts, d_sink); rc |= run<16>(rows[16], d_ts, d_sink); rc |= run<17>(rows[17], d_ts, d_sink);
   rc |= run<18>(rows[18], d_ts, d_sink); rc |= run<19>(rows[19], d_ts, d_sink);
+  rc |= run<20>(rows[20], d_ts, d_sink); rc |= run<21>(rows[21], d_ts, d_sink);
   return rc;
 }
