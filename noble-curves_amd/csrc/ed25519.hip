@@ -8,20 +8,26 @@
 //   s = LE(sig[32:64]) must be < L (BASE.multiplyUnsafe(s) throws otherwise)       (:962, :971, :573)
 //   strict mode only: A.isSmallOrder() rejects                                     (:980)
 //   accept iff [8](R + [k]A - [s]B) == O                                           (:985-988)
-// The reference computes [s]B with its cached window table (44 adds) and [k]A with a wNAF walk;
-// here both share ONE doubling chain (Straus).  Default (EdCfgGtab): signed-odd 4-bit windows for
-// -A (8-entry per-lane table of projective Niels points in device memory, 1 KB per item) and 8-bit
-// windows for B (128 precomputed affine Niels multiples shared by every lane): 264 doublings,
-// 66 + 33 additions, 4 waves/SIMD.  Fallback without scratch (EdCfgLds): 2-bit windows for -A (2-entry
-// per-lane table in LDS, projective Niels form: 16 KB per wave, so 8-10 waves fit a CU - a 3-bit
-// window measured 1.7x slower for that reason) and 6 bits for B (32 precomputed affine Niels
-// multiples shared by every lane): 258 doublings, 129 + 43 additions.
+// The reference computes [s]B with its cached window table (44 adds) and [k]A with a wNAF walk; here all
+// streams share ONE doubling chain (Straus), and the default path first halves the scalars (ed_halve.hpp:
+// u k = v mod L with |u|, v < 2^127 from a truncated Euclidean algorithm, the verdict is unchanged):
+//   default (EdCfgHalf, ed25519_verify_lane_half): accept iff [8]([|u| s mod L]B -+ [v]A - [|u|]R) == O - 128
+//     doublings; signed-odd 4-bit windows for -A and -R (two 8-entry per-lane tables of projective Niels points in
+//     device memory, 2.3 KB per item), 8-bit windows for the two 128-bit halves of |u| s mod L on the shared tables
+//     of B and 2^128 B (2 x 128 precomputed affine Niels multiples): 32 + 32 + 16 + 16 additions, 3 waves/SIMD.
+//     2^18 verifications: 2.84 ms against 3.58 ms for the full-size form below (MI355X).
+//   full-size scalars, table in device memory (EdCfgGtab, A/B builds only): 4-bit windows for -A, 8-bit for B:
+//     264 doublings, 66 + 33 additions.
+//   fallback without scratch (EdCfgLds): 2-bit windows for -A (2-entry per-lane table in LDS, projective Niels
+//     form: 16 KB per wave, so 8-10 waves fit a CU - a 3-bit window measured 1.7x slower for that reason) and
+//     6 bits for B (32 precomputed affine Niels multiples shared by every lane): 258 doublings, 129 + 43 additions.
 #include <cstdlib>
 #include "knobs.hpp"
 #include <mutex>
 #include <vector>
 
 #include "ec_te.hpp"
+#include "ed_halve.hpp"
 #include "host_api.hpp"
 #include "scalar.hpp"
 #include "sha512.hpp"
@@ -37,7 +43,7 @@ constexpr int ED_FW = FieldIO<FEd>::WORDS;        // stored words per field elem
 constexpr int ED_NIELS_WORDS = 4 * ED_FW;          // projective Niels entry (Y+X, Y-X, Z, 2dT)
 constexpr int ED_AFF_NIELS_WORDS = 3 * ED_FW;      // affine Niels entry (y+x, y-x, 2dxy)
 constexpr int ED_PROJ_WORDS = 3 * ED_FW;           // (X, Y, Z) hand-off to the batched inversion
-static_assert(ED25519_BTAB_WORDS == 128 * ED_AFF_NIELS_WORDS, "base table size in host_api.hpp");
+static_assert(ED25519_BTAB_WORDS == 256 * ED_AFF_NIELS_WORDS, "base table size in host_api.hpp");
 
 template <int WA_, int WB_, int BITS_>
 struct EdCfg {
@@ -45,10 +51,12 @@ struct EdCfg {
   static constexpr int MA = BITS / WA, MB = BITS / WB;
   static constexpr int TA = 1 << (WA - 1), TB = 1 << (WB - 1);
   static constexpr int LDS_WORDS = TA * ED_NIELS_WORDS * 64;
-  static_assert(WA * MA == BITS && WB * MB == BITS && WB % WA == 0 && BITS >= 254 && TB <= 128, "window tiling");
+  static_assert(WA * MA == BITS && WB * MB == BITS && WB % WA == 0 && TB <= 128, "window tiling");
 };
 using EdCfgLds = EdCfg<2, 6, 258>;
 using EdCfgGtab = EdCfg<4, 8, 264>;
+// halved scalars (ed_halve.hpp): 128-bit streams for -A and -R, two 128-bit halves of u s mod L on B and 2^128 B
+using EdCfgHalf = EdCfg<4, 8, 128>;
 
 NCG_DI bool ed_scalar_lt_L(const uint32_t (&s)[8]) {
   uint32_t bw = 0;
@@ -98,6 +106,7 @@ NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t
                                 const uint32_t* __restrict__ kscal, const uint32_t* __restrict__ btab, bool zip215,
                                 TABPTR tab, const int stride) {
   using F = FEd;
+  static_assert(CFG::BITS >= 254, "full-size scalars");
   uint32_t aw[8], rw[8], s[8], k[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -155,6 +164,88 @@ NCG_DI bool ed25519_verify_lane(const uint32_t* __restrict__ sig, const uint32_t
   return ok && ed_is_identity(acc);
 }
 
+// The same verdict from half-size scalars (ed_halve.hpp): (u, v) with u k == v (mod L), then
+//     accept iff [8]([|u| s mod L] B -+ [v] A - [|u|] R) == O        (upper sign for u > 0)
+// on ONE 128-step doubling chain: 4-bit signed-odd windows for -A and -R (two per-lane tables of TA projective
+// Niels entries), 8-bit windows for the two halves of |u| s mod L on the shared tables of B and 2^128 B
+// (btab: 2 x 128 affine Niels entries).  128 doublings and 32 + 32 + 16 + 16 additions instead of 264 and 66 + 33.
+template <class CFG, class TABPTR>
+NCG_DI bool ed25519_verify_lane_half(const uint32_t* __restrict__ sig, const uint32_t* __restrict__ pk,
+                                     const uint32_t* __restrict__ kscal, const uint32_t* __restrict__ btab, bool zip215,
+                                     TABPTR tab, const int stride) {
+  using F = FEd;
+  static_assert(CFG::BITS == 128 && CFG::WB == 2 * CFG::WA, "two windows of the point streams per base window");
+  uint32_t aw[8], rw[8], s[8], k[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    aw[i] = pk[i];
+    rw[i] = sig[i];
+    s[i] = sig[8 + i];
+    k[i] = kscal[i];
+  }
+  F ax, ay, rx, ry;
+  bool ok = ed_decompress(aw, zip215, ax, ay);
+  ok = ed_decompress(rw, zip215, rx, ry) && ok;
+  ok = ok && ed_scalar_lt_L(s);
+  const F d2 = EdConsts::d2();
+  // tables [1,3,..,2 TA - 1] (-A) at entries 0.., [1,3,..](-R) at entries TA..
+  auto build = [&](const F& x, const F& y, int base, bool check_small) {
+    EdExt<F> nP{f_neg(x), y, F::one(), f_neg(x * y)};
+    EdExt<F> dbl = ed_dbl(nP);
+    if (check_small) {  // strict: reject small-order A  (isSmallOrder: [8]A == O)
+      if (ed_is_identity(ed_dbl(ed_dbl(dbl)))) ok = false;
+    }
+    EdNielsProj<F> n2 = ed_to_niels(dbl, d2);
+    EdExt<F> cur = nP;
+    ed_store_niels(tab, stride, base, ed_to_niels(cur, d2));
+#pragma unroll 1
+    for (int j = 1; j < CFG::TA; j++) {
+      cur = ed_add_niels(cur, n2, false);
+      ed_store_niels(tab, stride, base + j, ed_to_niels(cur, d2));
+    }
+  };
+  build(ax, ay, 0, !zip215);
+  build(rx, ry, CFG::TA, false);
+  const EdHalf hv = ed_halve_scalar(k);
+  uint32_t w[8];
+  ed_mul_mod_l(w, hv.u, s);
+  const uint32_t wlo[4] = {w[0], w[1], w[2], w[3]}, whi[4] = {w[4], w[5], w[6], w[7]};
+  SignedOddWindows<4, CFG::WA, CFG::MA> wa, wr;
+  SignedOddWindows<4, CFG::WB, CFG::MB> wb0, wb1;
+  wa.template init<4>(hv.v);
+  wr.template init<4>(hv.u);
+  wb0.template init<4>(wlo);
+  wb1.template init<4>(whi);
+  const uint32_t* btab1 = btab + 128 * ED_AFF_NIELS_WORDS;
+
+  EdExt<F> acc = EdExt<F>::identity();
+#pragma unroll 1
+  for (int i = CFG::MA - 1; i >= 0; i--) {
+    if (i != CFG::MA - 1) {
+#pragma unroll(NCG_MUL_INLINE ? 1 : CFG::WA)
+      for (int d = 0; d < CFG::WA - 1; d++) acc = ed_dbl_no_t(acc);
+      acc = ed_dbl(acc);
+    }
+    const int dA = wa.pop();
+    acc = ed_add_niels(acc, ed_load_niels(tab, stride, ((dA < 0 ? -dA : dA) - 1) >> 1), (dA < 0) != hv.uneg);
+    const int dR = wr.pop();
+    acc = ed_add_niels(acc, ed_load_niels(tab, stride, CFG::TA + (((dR < 0 ? -dR : dR) - 1) >> 1)), dR < 0);
+    if ((i & 1) == 0) {
+      const int d0 = wb0.pop();
+      acc = ed_madd_niels(acc, ed_load_aff_niels(btab + (((d0 < 0 ? -d0 : d0) - 1) >> 1) * ED_AFF_NIELS_WORDS), d0 < 0);
+      const int d1 = wb1.pop();
+      acc = ed_madd_niels(acc, ed_load_aff_niels(btab1 + (((d1 < 0 ? -d1 : d1) - 1) >> 1) * ED_AFF_NIELS_WORDS), d1 < 0);
+    }
+  }
+  // even scalars were bumped by one: take the extra points back out
+  if (wa.was_even) acc = ed_add_niels(acc, ed_load_niels(tab, stride, 0), !hv.uneg);
+  if (wr.was_even) acc = ed_add_niels(acc, ed_load_niels(tab, stride, CFG::TA), true);
+  if (wb0.was_even) acc = ed_madd_niels(acc, ed_load_aff_niels(btab), true);
+  if (wb1.was_even) acc = ed_madd_niels(acc, ed_load_aff_niels(btab1), true);
+  acc = ed_dbl(ed_dbl(ed_dbl(acc)));
+  return ok && ed_is_identity(acc);
+}
+
 // GTAB: per-lane table in device memory at gtab + idx * TA * 32 (item-major, stride 1), no LDS
 template <class CFG, bool GTAB, int MINW>
 __global__ void __launch_bounds__(64, MINW)
@@ -172,6 +263,19 @@ k_ed25519_verify(const uint32_t* __restrict__ sigs, const uint32_t* __restrict__
   else
     ok = ed25519_verify_lane<CFG>(sigs + (size_t)src * 16, pks + (size_t)src * 8, ks + (size_t)src * 8, btab, zip215 != 0,
                                   lds + lane, 64);
+  if (idx < n) out_ok[idx] = ok ? 1 : 0;
+}
+
+// halved scalars: two per-lane tables (-A, -R) in device memory at gtab + idx * 2 TA * 36
+template <class CFG, int MINW>
+__global__ void __launch_bounds__(64, MINW)
+k_ed25519_verify_half(const uint32_t* __restrict__ sigs, const uint32_t* __restrict__ pks, const uint32_t* __restrict__ ks,
+                      const uint32_t* __restrict__ btab, int zip215, uint8_t* __restrict__ out_ok,
+                      uint32_t* __restrict__ gtab, int n) {
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  const int src = idx < n ? idx : n - 1;
+  const bool ok = ed25519_verify_lane_half<CFG>(sigs + (size_t)src * 16, pks + (size_t)src * 8, ks + (size_t)src * 8, btab,
+                                                zip215 != 0, gtab + (size_t)idx * (2 * CFG::TA * ED_NIELS_WORDS), 1);
   if (idx < n) out_ok[idx] = ok ? 1 : 0;
 }
 
@@ -393,43 +497,57 @@ void ed25519_build_fixed_table(uint32_t* out) {
   }
 }
 
-// ---- base-point table [1,3,..,63]*B in affine Niels form (host-computed with the same templates)
+// ---- base-point tables [1,3,..,255] B and [1,3,..,255] (2^128 B) in affine Niels form (host-computed with the
+// same templates); the second half serves the high half of the halved-scalar verification's fixed-base scalar
 void ed25519_build_base_table(uint32_t* out /* ED25519_BTAB_WORDS */) {
   using F = FEd;
   const F d2 = EdConsts::d2();
   EdExt<F> B = ed_base_point();
-  EdNielsProj<F> n2 = ed_to_niels(ed_dbl(B), d2);
-  EdExt<F> cur = B;
-  for (int j = 0; j < 128; j++) {
-    if (j > 0) cur = ed_add_niels(cur, n2, false);
-    F zi = f_inv(cur.Z);
-    F x = cur.X * zi, y = cur.Y * zi;
-    ed_store_aff_niels(out + j * ED_AFF_NIELS_WORDS, ed_affine_to_niels(x, y, d2));
+  for (int half = 0; half < 2; half++) {
+    EdNielsProj<F> n2 = ed_to_niels(ed_dbl(B), d2);
+    EdExt<F> cur = B;
+    for (int j = 0; j < 128; j++) {
+      if (j > 0) cur = ed_add_niels(cur, n2, false);
+      F zi = f_inv(cur.Z);
+      F x = cur.X * zi, y = cur.Y * zi;
+      ed_store_aff_niels(out + (half * 128 + j) * ED_AFF_NIELS_WORDS, ed_affine_to_niels(x, y, d2));
+    }
+    for (int d = 0; d < 128; d++) B = ed_dbl(B);
   }
 }
 
-// gtab: n_pad * TA * 32 words of device scratch for the per-item tables, or nullptr (LDS variant)
-size_t ed25519_verify_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * EdCfgGtab::TA * ED_NIELS_WORDS; }
+// gtab: ed25519_verify_tmp_words(n) words of device scratch for the per-item tables, or nullptr (LDS variant, full-size
+// scalars)
+size_t ed25519_verify_tmp_words(int n) { return ((size_t)n + 63) / 64 * 64 * 2 * EdCfgHalf::TA * ED_NIELS_WORDS; }
 hipError_t ed25519_verify_batch(const uint32_t* sigs, const uint32_t* pks, const uint32_t* ks, const uint32_t* btab,
                                 int zip215, uint8_t* out_ok, int n, uint32_t* gtab, hipStream_t st) {
   if (n <= 0) return hipSuccess;
 #ifdef NCG_AB_BUILD
-  static const int variant = knob("NCG_ED_VARIANT", 3);
+  static const int variant = knob("NCG_ED_VARIANT", 5);
 #else
-  constexpr int variant = 3;  // 3 waves/SIMD (168 registers); 2 and 4 are A/B builds
+  constexpr int variant = 5;  // halved scalars, 3 waves/SIMD; 2-4: full-size scalars at 2-4 waves/SIMD (A/B builds)
 #endif
   if (gtab && variant > 0) {
 #ifdef NCG_AB_BUILD
     if (variant == 2)
       hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 2>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
                          zip215, out_ok, gtab, n);
+    else if (variant == 3)
+      hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 3>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
+                         zip215, out_ok, gtab, n);
     else if (variant == 4)
       hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 4>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
                          zip215, out_ok, gtab, n);
+    else if (variant == 6)
+      hipLaunchKernelGGL((k_ed25519_verify_half<EdCfgHalf, 2>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab, zip215,
+                         out_ok, gtab, n);
+    else if (variant == 7)
+      hipLaunchKernelGGL((k_ed25519_verify_half<EdCfgHalf, 4>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab, zip215,
+                         out_ok, gtab, n);
     else
 #endif
-      hipLaunchKernelGGL((k_ed25519_verify<EdCfgGtab, true, 3>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab,
-                         zip215, out_ok, gtab, n);
+      hipLaunchKernelGGL((k_ed25519_verify_half<EdCfgHalf, 3>), dim3((n + 63) / 64), dim3(64), 0, st, sigs, pks, ks, btab, zip215,
+                         out_ok, gtab, n);
     return hipGetLastError();
   }
   size_t lds = (size_t)EdCfgLds::LDS_WORDS * 4;
@@ -472,8 +590,8 @@ void ed25519_challenge_host(const uint8_t* sig, const uint8_t* pk, const uint8_t
 
 // host-only: run the lane function on the CPU (unit tests through hosttest.hip)
 bool ed25519_verify_host(const uint32_t* sig, const uint32_t* pk, const uint32_t* k, const uint32_t* btab, bool zip215) {
-  std::vector<uint32_t> tab(EdCfgGtab::TA * ED_NIELS_WORDS);
-  return ed25519_verify_lane<EdCfgGtab>(sig, pk, k, btab, zip215, tab.data(), 1);
+  std::vector<uint32_t> tab(2 * EdCfgHalf::TA * ED_NIELS_WORDS);
+  return ed25519_verify_lane_half<EdCfgHalf>(sig, pk, k, btab, zip215, tab.data(), 1);
 }
 
 }  // namespace ncg

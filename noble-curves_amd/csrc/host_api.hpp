@@ -132,7 +132,7 @@ hipError_t msm_endo_verify(int curve, const uint32_t* d_mult, const uint8_t* d_m
 void msm_endo_verify_scalar(int curve, uint32_t (&k)[8]);
 
 // ed25519 batch verify (ed25519.hip).  btab: device copy of the table built by ed25519_build_base_table.
-constexpr int ED25519_BTAB_WORDS = 128 * 27;  // [1,3,..,255]B, affine Niels, 3 x 9 stored words each
+constexpr int ED25519_BTAB_WORDS = 256 * 27;  // [1,3,..,255] B then [1,3,..,255] 2^128 B, affine Niels, 3 x 9 stored words each
 void ed25519_build_base_table(uint32_t* out_words);
 size_t ed25519_verify_tmp_words(int n);
 size_t ed25519_tmp_words(int n);

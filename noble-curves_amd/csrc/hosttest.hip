@@ -307,6 +307,24 @@ int ht_ed25519_verify(const uint32_t* sig, const uint32_t* pk, const uint32_t* k
   return ed25519_verify_host(sig, pk, k, btab, zip215 != 0) ? 1 : 0;
 }
 
+// the scalar side of the halved ed25519 verification (ed_halve.hpp): out = u[4] | v[4] | uneg | w[8], w = u s mod L
+int ht_ed_halve(const uint32_t* k, const uint32_t* s, uint32_t* out) {
+  uint32_t kk[8], ss[8], w[8];
+  for (int i = 0; i < 8; i++) {
+    kk[i] = k[i];
+    ss[i] = s[i];
+  }
+  const EdHalf h = ed_halve_scalar(kk);
+  ed_mul_mod_l(w, h.u, ss);
+  for (int i = 0; i < 4; i++) {
+    out[i] = h.u[i];
+    out[4 + i] = h.v[i];
+  }
+  out[8] = h.uneg ? 1u : 0u;
+  for (int i = 0; i < 8; i++) out[9 + i] = w[i];
+  return 0;
+}
+
 size_t ht_msm_shard_slot_bytes(int curve) { return msm_shard_slot_bytes(curve); }
 int ht_msm_shard_local(int curve, int n_local, int n_max, const uint32_t* pts_wire, const uint32_t* scalars, uint8_t* slot) {
 #define CALL(C) ht_shard_local_t<C>(curve, n_local, n_max, pts_wire, scalars, slot)

@@ -93,16 +93,7 @@ NCG_DI void sha512_ram(uint64_t (&h)[8], const uint8_t* __restrict__ r32, const 
 
 // k = LE(digest) mod L as 8 LE limbs.  L = 2^252 + DELTA: fold 2^252 = -DELTA three times (the third
 // fold multiplies at most 6 bits), then bring the signed remainder into [0, L).
-NCG_DI void sha512_digest_mod_l(uint32_t (&k)[8], const uint64_t (&h)[8]) {
-  // digest bytes are the big-endian words h[0..7]; as a little-endian integer, limb j (32-bit) is
-  // bytes 4j..4j+3: byte-swapped halves of h[j/2]
-  uint32_t x[16];
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const uint32_t hi = (uint32_t)(h[i] >> 32), lo = (uint32_t)h[i];
-    x[2 * i] = __builtin_bswap32(hi);
-    x[2 * i + 1] = __builtin_bswap32(lo);
-  }
+NCG_DI void mod_l_512(uint32_t (&k)[8], const uint32_t (&x)[16]) {  // k = x mod L, x < 2^512 as 16 LE limbs
   uint32_t delta[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) delta[i] = Sha512Consts::DELTA[i];
@@ -166,6 +157,18 @@ NCG_DI void sha512_digest_mod_l(uint32_t (&k)[8], const uint64_t (&h)[8]) {
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) k[i] = r[i];
+}
+NCG_DI void sha512_digest_mod_l(uint32_t (&k)[8], const uint64_t (&h)[8]) {
+  // digest bytes are the big-endian words h[0..7]; as a little-endian integer, limb j (32-bit) is
+  // bytes 4j..4j+3: byte-swapped halves of h[j/2]
+  uint32_t x[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t hi = (uint32_t)(h[i] >> 32), lo = (uint32_t)h[i];
+    x[2 * i] = __builtin_bswap32(hi);
+    x[2 * i + 1] = __builtin_bswap32(lo);
+  }
+  mod_l_512(k, x);
 }
 
 }  // namespace ncg

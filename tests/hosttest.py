@@ -70,6 +70,20 @@ def glv_split(k):
     return bool(out[10]), k1, bool(out[11]), k2
 
 
+def ed_halve(k, s):
+    """(u, v, w) of the halved ed25519 verification: u signed, u k == v (mod L), w = |u| s mod L."""
+    K = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).copy()
+    S = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8).copy()
+    out = np.zeros(17, dtype=np.uint32)
+    f = lib().ht_ed_halve
+    f.argtypes = [ctypes.c_void_p] * 3
+    assert f(K.ctypes.data, S.ctypes.data, out.ctypes.data) == 0
+    u = sum(int(out[i]) << (32 * i) for i in range(4))
+    v = sum(int(out[4 + i]) << (32 * i) for i in range(4))
+    w = sum(int(out[9 + i]) << (32 * i) for i in range(8))
+    return (-u if out[8] else u), v, w
+
+
 def ed25519_verify(sig, pk, k, zip215):
     S = np.frombuffer(bytes(sig), dtype=np.uint8).copy()
     P = np.frombuffer(bytes(pk), dtype=np.uint8).copy()

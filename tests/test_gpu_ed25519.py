@@ -54,3 +54,52 @@ def test_wycheproof_old_vectors_gpu():
     for r, v in zip(good, got):
         assert v == (r["result"] in ("valid", "acceptable")), r["comment"]
     assert all(r["result"] == "invalid" for r in rows if len(r["sig"]) != 128)
+
+
+def test_chosen_challenges_exercise_the_scalar_halving():
+    """ncg_ed25519_verify_batch takes the challenge k as data: signatures built for chosen k (edges of the
+    truncated Euclidean algorithm of ed_halve.hpp: tiny, around 2^127, L - 1, values >= L, the golden-ratio worst
+    case, k with one long quotient) must verify, corrupted ones must not, and a torsion component added to R or A
+    keeps the cofactored verdict - all against the equation [8](sB - kA - R) == O evaluated by the oracle."""
+    from decimal import Decimal, getcontext
+    import numpy as np
+    from noble_curves_amd import get_engine
+    from oracle.curves import ED25519_L as L, makeRng
+    getcontext().prec = 120
+    gold = int(Decimal(L) * (Decimal(5).sqrt() - 1) / 2)
+    rng = makeRng(0x1A1F)
+    B = Ed25519.BASE
+    ks = [0, 1, 2, 3, 2 ** 127 - 1, 2 ** 127, 2 ** 127 + 1, 2 ** 126, 2 ** 128 + 1, 2 ** 200 + 1, L - 1, L - 2, L // 2, L // 3, gold,
+          L - gold, L, L + 5, 2 ** 255 + 19, 2 ** 256 - 1, 2 ** 252]
+    ks += [rng.rndBelow(L) for _ in range(107)]
+    tors = []                                       # 8-torsion points: [L]P for curve points P outside the subgroup
+    for y in range(2, 60):
+        try:
+            P = Ed25519.fromBytes(y.to_bytes(32, "little"))
+        except Exception:
+            continue
+        T = P.multiplyUnsafe(L - 1).add(P)
+        if not T.is0():
+            tors.append(T)
+    assert len(tors) >= 4
+    sigs, pks, kw, exp = [], [], [], []
+    for i, k in enumerate(ks):
+        a, r = rng.rndBelow(L - 1) + 1, rng.rndBelow(L - 1) + 1
+        A, R = B.multiplyUnsafe(a), B.multiplyUnsafe(r)
+        s = (r + k * a) % L
+        mode = i % 4 if i >= 21 else 0
+        if mode == 1:
+            s = (s + 1) % L                         # wrong s
+        elif mode == 2 and tors:
+            R = R.add(tors[i % len(tors)])          # torsion on R: still valid under the cofactored equation
+        elif mode == 3 and tors:
+            A = A.add(tors[i % len(tors)])          # torsion on A: [8][k]A unchanged
+        lhs = B.multiplyUnsafe(s).subtract(A.multiplyUnsafe(k % L)).subtract(R)
+        exp.append(lhs.clearCofactor().is0())
+        sigs.append(R.toBytes() + s.to_bytes(32, "little"))
+        pks.append(A.toBytes())
+        kw.append(k.to_bytes(32, "little"))
+    got = get_engine().ed25519_verify_batch(np.frombuffer(b"".join(sigs), np.uint8), np.frombuffer(b"".join(pks), np.uint8),
+                                            np.frombuffer(b"".join(kw), np.uint8), zip215=True)
+    assert list(got) == exp
+    assert sum(exp) > 90 and not all(exp)

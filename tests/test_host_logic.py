@@ -96,6 +96,26 @@ def _ed_cases():
     return cases
 
 
+def test_ed25519_halved_scalars():
+    """ed_halve.hpp: u k == v (mod L) with 0 < |u| < 2^126, 0 <= v < 2^127 and w = |u| s mod L - edge challenges
+    (0, 1, around 2^127, L - 1, any 256-bit value, the golden-ratio worst case of the Euclidean algorithm) and
+    random ones."""
+    from decimal import Decimal, getcontext
+    from oracle.curves import ED25519_L as L, makeRng
+    getcontext().prec = 120
+    gold = int(Decimal(L) * (Decimal(5).sqrt() - 1) / 2)
+    rng = makeRng(0xED)
+    ks = [0, 1, 2, 3, 2 ** 127 - 1, 2 ** 127, 2 ** 127 + 1, 2 ** 126, L - 1, L - 2, L // 2, (L + 1) // 2, L // 3, gold, L - gold,
+          L, L + 1, 2 ** 255, 2 ** 256 - 1, 2 ** 252, 2 ** 251, 2 ** 200 + 1]
+    ks += [rng.rndBelow(L) for _ in range(300)]
+    for i, k in enumerate(ks):
+        s = [0, 1, L - 1, 2 ** 256 - 1][i] if i < 4 else rng.rndBelow(L)
+        u, v, w = hosttest.ed_halve(k, s)
+        assert 0 < abs(u) < 2 ** 126 and 0 <= v < 2 ** 127, (k, u, v)
+        assert (u * k - v) % L == 0, k
+        assert w == abs(u) * s % L, (k, s)
+
+
 def test_ed25519_verify_lane_matches_oracle_both_modes():
     from oracle.curves import Ed25519
     from oracle.edwards import eddsa_hash_k, eddsa_verify
