@@ -131,7 +131,8 @@ size_t mul_var_tmp_bytes(int curve, int n) {
     case CURVE_BLS12_381_G2:  // the verified-set ladder (mulvar_endo.hip) keeps a second table per lane
       return std::max(pad64(n) * (3 * FieldIO<CurveG2::F>::WORDS + 2 * gtab_words_per_item<CurveG2P, 4>()) * 4,
                       mul_var_g2_subgroup_tmp_bytes(n));
-    case CURVE_ED25519: return ed25519_tmp_words(n) * 4;  // (X, Y, Z) + per-item window tables
+    case CURVE_ED25519:  // (X, Y, Z) + per-item window table of the multiply; the two tables per item of the verification
+      return std::max(ed25519_tmp_words(n), ed25519_verify_tmp_words(n)) * 4;
     default: return 0;
   }
 }

@@ -103,3 +103,20 @@ def test_chosen_challenges_exercise_the_scalar_halving():
                                             np.frombuffer(b"".join(kw), np.uint8), zip215=True)
     assert list(got) == exp
     assert sum(exp) > 90 and not all(exp)
+
+
+def test_fresh_context_sizes_its_own_scratch():
+    """A context whose FIRST call is a large ed25519 verification must size the per-item table scratch for it (two
+    8-entry tables per item) - not inherit a buffer that an earlier, larger call happened to leave behind."""
+    import numpy as np
+    from noble_curves_amd._native import Engine
+    rows = load_golden("ed25519_vectors.json")[:64]
+    reps = 128
+    sigs = np.frombuffer(b"".join(bytes.fromhex(r["sig"]) for r in rows), np.uint8).reshape(-1, 64)
+    pks = np.frombuffer(b"".join(bytes.fromhex(r["pk"]) for r in rows), np.uint8).reshape(-1, 32)
+    msgs = [bytes.fromhex(r["msg"]) for r in rows]
+    blob = np.frombuffer(b"".join(msgs) * reps, np.uint8)
+    off = np.cumsum([0] + [len(m) for m in msgs] * reps).astype(np.uint64)
+    eng = Engine(0)
+    ok = eng.ed25519_verify_batch_msgs(np.tile(sigs, (reps, 1)), np.tile(pks, (reps, 1)), blob, off, zip215=True)
+    assert ok.all() and ok.shape[0] == 64 * reps
