@@ -16,7 +16,7 @@ def load(name):
 def main():
     b = load("r03_bench_line.json")
     b1 = load("r02_bench_line.json")
-    ex, ex1 = load("r02_bench_extra.json"), load("r01_bench_extra.json")
+    ex, ex1 = load("r03_bench_extra.json"), load("r02_bench_extra.json")
     e = b["extra"]
     host = b.get("host", {})
     out = []
@@ -85,8 +85,8 @@ def main():
     out.append("Targets: ≥10⁷ secp256k1 scalar-mults/s per MI355X — met (%.1f×); \"≥40 %% HBM roofline\" for the 2²⁰ G1 MSM is not physically "
                "meaningful (§2 caveat): its dominant kernel runs at %.0f %% of the measured multiplier ceiling in EXECUTED multiplies.\n"
                % (b["value"] / 1e7, 100 * e["msm_g1"]["roofline"]["valu"]["mad_frac"]))
-    out.append("### Other entry points (one MI355X, `tools/bench_extra.py`, `profiles/r02_bench_extra.json`; r01 beside it)\n")
-    out.append("| entry point | N | r01 | r02 | throughput |")
+    out.append("### Other entry points (one MI355X, `tools/bench_extra.py`, `profiles/r03_bench_extra.json`; r02 beside it)\n")
+    out.append("| entry point | N | r02 | r03 | throughput |")
     out.append("|---|---|---|---|---|")
     for k, v in ex.items():
         o = ex1.get(k)
