@@ -1048,30 +1048,32 @@ static int ensure_ntt_table(ncg_ctx* ctx, int log2n, const uint32_t* omega) {
   }
   uint32_t* d_omega = (uint32_t*)tmp;
   uint32_t* d_small = d_omega + 8;
-  uint32_t probe[8] = {0};
+  alignas(16) uint32_t probe[16] = {0}, expect_tw[16] = {0};
+  const int tww = ncg::ntt_tw_words();
   e = hipMemcpyAsync(d_omega, omega, 32, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = ncg::ntt_build_table(log2n, d_omega, d_small, tab, ctx->stream);
-  // primitive-root check: omega^(N/2) == -1 (N = 1: omega == 1); table entries are in Montgomery form
+  // primitive-root check: omega^(N/2) == -1 (N = 1: omega == 1); table entries are x 2^261 mod r
   const size_t probe_idx = log2n ? ((size_t)1 << (log2n - 1)) : 0;
-  if (e == hipSuccess) e = hipMemcpyAsync(probe, tab + probe_idx * 8, 32, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(probe, tab + probe_idx * tww, (size_t)tww * 4, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(tmp);
   if (e != hipSuccess) {
     (void)hipFree(tab);
     return set_err(ctx, NCG_ERR_HIP, "noble-gpu: ntt table build failed: %s", hipGetErrorString(e));
   }
-  uint32_t expect[8];  // R mod r for +1, r - (R mod r) for -1
+  uint32_t expect[8];  // entries are x 2^261 mod r (ntt.hip): K261 for +1, r - K261 for -1
   if (log2n == 0) {
-    for (int i = 0; i < 8; i++) expect[i] = ncg::ParamsBlsR::R1[i];
+    for (int i = 0; i < 8; i++) expect[i] = ncg::Fr29PR::K261[i];
   } else {
     uint64_t bw = 0;
     for (int i = 0; i < 8; i++) {
-      uint64_t d = (uint64_t)ncg::ParamsBlsR::P[i] - ncg::ParamsBlsR::R1[i] - bw;
+      uint64_t d = (uint64_t)ncg::ParamsBlsR::P[i] - ncg::Fr29PR::K261[i] - bw;
       expect[i] = (uint32_t)d;
       bw = (d >> 32) & 1;
     }
   }
-  if (memcmp(probe, expect, 32) != 0) {
+  ncg::ntt_tw_from_canonical(expect, expect_tw);
+  if (memcmp(probe, expect_tw, (size_t)tww * 4) != 0) {
     (void)hipFree(tab);
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: omega is not a primitive 2^%d-th root of unity", log2n);
   }

@@ -44,11 +44,13 @@ void map_to_curve_host(int curve, const uint32_t* u, int count, uint32_t* out, u
 
 // radix-2 NTT over bls12-381 Fr (ntt.hip)
 size_t ntt_table_bytes(int n);
+int ntt_tw_words();
+void ntt_tw_from_canonical(const uint32_t (&w)[8], uint32_t* out);
 size_t ntt_small_bytes(int n);
 hipError_t ntt_build_table(int n, const uint32_t* d_omega, uint32_t* d_small, uint32_t* d_tab, hipStream_t st);
 hipError_t ntt_run(int n, size_t batch, const uint32_t* src, uint32_t* dst, uint32_t* ws, const uint32_t* tab,
                    int tab_log, int flags, hipStream_t st);
-void ntt_host(int n, const uint32_t* omega_wire, const uint32_t* src, uint32_t* dst, int flags);
+int ntt_host(int n, const uint32_t* omega_wire, const uint32_t* src, uint32_t* dst, int flags, int t0max = 10, int tmax = 8);
 
 struct MsmPlan;
 // Optional second stream of a context: the wire -> storage conversion of the points has no consumer before

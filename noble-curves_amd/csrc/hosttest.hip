@@ -247,8 +247,48 @@ int ht_map_to_curve(int curve, const uint32_t* u, int count, uint32_t* out, uint
 
 // NTT over Fr on the CPU through the device field code (butterflies + table walk of ntt.hip)
 int ht_ntt(int n, const uint32_t* omega, const uint32_t* in, uint32_t* out, int flags) {
-  ntt_host(n, omega, in, out, flags);
-  return 0;
+  return ntt_host(n, omega, in, out, flags);  // number of column / limb overflows seen by the host checks
+}
+// the same with smaller passes (first pass of at most t0max stages, the others of at most tmax)
+int ht_ntt_small_passes(int n, const uint32_t* omega, const uint32_t* in, uint32_t* out, int flags, int t0max, int tmax) {
+  if (t0max < 1 || tmax < 1 || 1 + (n - (n < t0max ? n : t0max) + tmax - 1) / tmax > 8) return -1;
+  return ntt_host(n, omega, in, out, flags, t0max, tmax);
+}
+// fr29.hpp on RAW limbs (9 words each).  op 0: mont(a, b) -> 9 limbs; 1: a + b; 2: a + 3r - b; 3: weak(a);
+// 4: reduce256(a); 5: cond_sub(a); 6: from_words(a[0..7]); 7: to_words(a) -> 8 words.
+// Returns the overflow count of the call.
+int ht_fr29_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* r) {
+  Fr29 x, y, z;
+  for (int i = 0; i < 9; i++) {
+    x.v[i] = a[i];
+    y.v[i] = b ? b[i] : 0;
+    z.v[i] = 0;
+  }
+  fr29_overflows() = 0;
+  switch (op) {
+    case 0: z = fr29_mont(x, y); break;
+    case 1: z = fr29_add(x, y); break;
+    case 2: z = fr29_sub(x, y); break;
+    case 3: z = fr29_weak(x); break;
+    case 4: z = fr29_reduce256(x); break;
+    case 5: z = fr29_cond_sub(x); break;
+    case 6: {
+      uint32_t w[8];
+      for (int i = 0; i < 8; i++) w[i] = a[i];
+      z = fr29_from_words(w);
+      break;
+    }
+    case 7: {
+      uint32_t w[8];
+      fr29_to_words(w, x);
+      for (int i = 0; i < 8; i++) z.v[i] = w[i];
+      z.v[8] = 0;
+      break;
+    }
+    default: return -1;
+  }
+  for (int i = 0; i < 9; i++) r[i] = z.v[i];
+  return fr29_overflows();
 }
 // the pass planner of ntt_run: writes s_lo/T pairs, returns the number of passes
 int ht_ntt_plan(int n, int* out) {

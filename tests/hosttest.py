@@ -29,6 +29,8 @@ def lib():
         _lib.ht_map_to_curve.argtypes = [i32, vp, i32, vp, vp, i32]
         _lib.ht_ntt.argtypes = [i32, vp, vp, vp, i32]
         _lib.ht_ntt_plan.argtypes = [i32, vp]
+        _lib.ht_ntt_small_passes.argtypes = [i32, vp, vp, vp, i32, i32, i32]
+        _lib.ht_fr29_op.argtypes = [i32, vp, vp, vp]
         _lib.ht_fe9_op.argtypes = [i32, i32, i32, vp, vp, vp]
         _lib.ht_ed25519_challenge.argtypes = [vp, vp, vp, ctypes.c_uint64, vp]
         _lib.ht_bls_endo_split.argtypes = [i32, vp, vp]
@@ -128,15 +130,31 @@ def encode_points(curve, affine, enc_bytes):
     return out, ok.astype(bool)
 
 
-def ntt(log2n, values, omega, flags):
-    """values: list of ints (one polynomial); returns list of ints."""
+def ntt(log2n, values, omega, flags, passes=None):
+    """values: list of ints (one polynomial); returns list of ints.  passes = (t0max, tmax) shrinks the
+    passes of the schedule (the device uses 10 / 8).  Asserts that the host checks of fr29.hpp saw no
+    64-bit column or 32-bit limb overflow."""
     n = 1 << log2n
     a = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in values), dtype=np.uint8).copy()
     om = np.frombuffer(int(omega).to_bytes(32, "little"), dtype=np.uint8).copy()
     out = np.zeros(n * 32, dtype=np.uint8)
-    assert lib().ht_ntt(log2n, om.ctypes.data, a.ctypes.data, out.ctypes.data, flags) == 0
+    if passes is None:
+        assert lib().ht_ntt(log2n, om.ctypes.data, a.ctypes.data, out.ctypes.data, flags) == 0
+    else:
+        assert lib().ht_ntt_small_passes(log2n, om.ctypes.data, a.ctypes.data, out.ctypes.data, flags,
+                                         passes[0], passes[1]) == 0
     b = out.tobytes()
     return [int.from_bytes(b[32 * i:32 * i + 32], "little") for i in range(n)]
+
+
+def fr29_op(op, a_limbs, b_limbs=None):
+    """fr29.hpp op on raw 9-limb operands -> (9 result words, overflow count)."""
+    A = np.array(list(a_limbs) + [0] * (9 - len(a_limbs)), dtype=np.uint32)
+    B = np.array(b_limbs if b_limbs is not None else [0] * 9, dtype=np.uint32)
+    R = np.zeros(9, dtype=np.uint32)
+    ovf = lib().ht_fr29_op(op, A.ctypes.data, B.ctypes.data, R.ctypes.data)
+    assert ovf >= 0
+    return [int(x) for x in R], ovf
 
 
 def ntt_plan(log2n):

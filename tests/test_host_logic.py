@@ -349,6 +349,90 @@ def test_ntt_lane_code_matches_oracle_all_orderings():
             assert hosttest.ntt(bits, x, roots.omega(bits), flags) == exp, (bits, flags)
 
 
+def _fr29_val(limbs):
+    return sum(int(x) << (29 * i) for i, x in enumerate(limbs))
+
+
+def _fr29_limbs(x):
+    return [(x >> (29 * i)) & ((1 << 29) - 1) for i in range(8)] + [x >> 232]
+
+
+def test_fr29_butterfly_arithmetic_at_the_bounds():
+    """fr29.hpp (the NTT butterflies' radix-2^29 lazy form of Fr, modular.ts:940-982 values at the pass
+    boundaries): Montgomery product with the left operand at the loosest limbs it admits (6 * 2^29, limb 8
+    all ones) and the right one at r - 1 / all-ones limbs, the fold below 2^256 from 33 r, the final
+    conditional subtraction and the word <-> limb conversions, against big-int arithmetic; the host
+    twin counts every 64-bit column and 32-bit limb overflow (must be none)."""
+    from oracle.curves import Fr_bls
+    r = Fr_bls.ORDER
+    M = (1 << 29) - 1
+    rinv = pow(1 << 261, -1, r)
+    rng = makeRng(0xF29)
+    for trial in range(120):
+        a = [rng.rndBelow(6 << 29) for _ in range(8)] + [rng.rndBelow(1 << 32)]
+        w = _fr29_limbs(rng.rndBelow(r))
+        if trial == 0:
+            a = [(6 << 29) - 1] * 8 + [(1 << 32) - 1]
+        if trial < 2:
+            w = _fr29_limbs(r - 1)
+        if trial == 2:
+            a, w = [(6 << 29) - 1] * 8 + [(1 << 32) - 1], [M] * 8 + [(1 << 23) - 1]
+        out, ovf = hosttest.fr29_op(0, a, w)
+        assert ovf == 0
+        assert _fr29_val(out) % r == _fr29_val(a) * _fr29_val(w) * rinv % r
+        assert all(x <= M for x in out[:8]) and _fr29_val(out) < _fr29_val(a) * _fr29_val(w) // (1 << 261) + r + 1
+    for trial in range(120):
+        v = rng.rndBelow(33 * r) if trial else 33 * r - 1
+        out, ovf = hosttest.fr29_op(4, _fr29_limbs(v))
+        assert ovf == 0 and _fr29_val(out) % r == v % r and _fr29_val(out) < (1 << 256) and all(x <= M for x in out[:8])
+        a = [rng.rndBelow(7 << 29) for _ in range(8)] + [rng.rndBelow(1 << 28)]     # loose limbs, value < 33 r
+        out, ovf = hosttest.fr29_op(4, a)
+        assert ovf == 0 and _fr29_val(out) % r == _fr29_val(a) % r and _fr29_val(out) < (1 << 256)
+    for trial in range(60):
+        v = [0, r - 1, r, 2 * r - 1][trial] if trial < 4 else rng.rndBelow(2 * r)
+        out, _ = hosttest.fr29_op(5, _fr29_limbs(v))
+        assert _fr29_val(out) == v % r
+        out, _ = hosttest.fr29_op(6, [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [0])
+        assert _fr29_val(out) == v and all(x <= M for x in out[:8])
+        out, _ = hosttest.fr29_op(7, _fr29_limbs(v))
+        assert sum(x << (32 * i) for i, x in enumerate(out[:8])) == v
+    # a - t through the 3 r bias, a + t, and the weak normalisation keep the value
+    for trial in range(60):
+        a = [rng.rndBelow(5 << 29) for _ in range(8)] + [rng.rndBelow(1 << 28)]
+        t = _fr29_limbs(rng.rndBelow(29 * r // 10) if trial else (0x015BC8F4 << 232) + (1 << 232) - 1)  # limb 8 at BIAS[8]
+        d, ovf = hosttest.fr29_op(2, a, t)
+        assert ovf == 0 and _fr29_val(d) == _fr29_val(a) + 3 * r - _fr29_val(t)
+        sm, ovf = hosttest.fr29_op(1, a, t)
+        assert ovf == 0 and _fr29_val(sm) == _fr29_val(a) + _fr29_val(t)
+        wk, ovf = hosttest.fr29_op(3, d)
+        assert ovf == 0 and _fr29_val(wk) == _fr29_val(d) and all(x < (1 << 29) + 8 for x in wk[:8])
+
+
+def test_ntt_multi_pass_schedules_and_full_size_passes():
+    """The device pass schedule on the host twin with the passes shrunk so that small transforms run three and
+    more passes (tiles with a contiguous run of 4, the fold of the bit reversal through the workspace, the
+    1/N scale on the last pass), and with the real 10-stage passes at 2^10 / 2^11 on random and all-(r - 1)
+    input (the largest lazy values a pass can build up) - every ordering against the oracle FFT
+    (fft.ts:518-577), no column or limb overflow."""
+    from oracle.curves import Fr_bls
+    from oracle.fft import FFT, RootsOfUnity
+    r = Fr_bls.ORDER
+    roots = RootsOfUnity(Fr_bls, 11)
+    f = FFT(roots, Fr_bls)
+    rng = makeRng(0x1729)
+    for bits, passes in ((7, (3, 2)), (6, (2, 2)), (5, (2, 1)), (7, (4, 3)), (8, (2, 1)), (9, (3, 3))):
+        x = [rng.rndBelow(r) for _ in range(1 << bits)]
+        x[0], x[1] = 0, r - 1
+        for flags in range(8):
+            inv, bi, bo = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+            assert hosttest.ntt(bits, x, roots.omega(bits), flags, passes) == (f.inverse if inv else f.direct)(x, bi, bo), (bits, passes, flags)
+    for bits in (10, 11):
+        for x in ([rng.rndBelow(r) for _ in range(1 << bits)], [r - 1] * (1 << bits)):
+            for flags in (0, 3, 6) if bits == 11 else (0, 1, 2, 5, 7):
+                inv, bi, bo = bool(flags & 1), bool(flags & 2), bool(flags & 4)
+                assert hosttest.ntt(bits, x, roots.omega(bits), flags) == (f.inverse if inv else f.direct)(x, bi, bo), (bits, flags)
+
+
 def test_ntt_pass_plan_covers_every_stage_once():
     for n in range(1, 29):
         plan = hosttest.ntt_plan(n)

@@ -202,6 +202,23 @@ def main():
     # bls12-381 scalar field Fr as a Montgomery field for the NTT (src/bls12-381.ts bls12_381_Fr;
     # src/abstract/fft.ts).  INV2 = 1/2 for the 1/N scale of the inverse transform.
     out += field("ParamsBlsR", bls_r, 8, {"INV2": (bls_r + 1) // 2})
+    # Fr in radix 2^29 for the NTT butterflies (fr29.hpp): R = 2^261, r = 1 (mod 2^29) so -r^-1 = -1 and
+    # the Montgomery quotient digit is the negated low limb; C255 = 2^255 - r folds the bits at and above
+    # 2^255; BIAS = 3 r with limbs 0..7 in [2^29, 2^30) for the subtraction a + BIAS - t; K261 = 2^261 mod r
+    # (plain 8 x 32-bit integer) moves the twiddle table from R = 2^256 to R = 2^261.
+    assert bls_r % (1 << 29) == 1
+    m29 = (1 << 29) - 1
+    low = sum(1 << (29 * i + 29) for i in range(8))
+    rest = 3 * bls_r - low
+    assert rest > 0
+    bias = [((rest >> (29 * i)) & m29) + (1 << 29) for i in range(8)] + [rest >> 232]
+    assert sum(b << (29 * i) for i, b in enumerate(bias)) == 3 * bls_r
+    out += "struct Fr29PR {\n"
+    out += arr29("P", bls_r, 9) + arr29("C255", (1 << 255) - bls_r, 9)
+    out += "  static constexpr uint32_t BIAS[9] = {%s};  // 3 r\n" % ", ".join("0x%08xu" % b for b in bias)
+    out += arr("K261", (1 << 261) % bls_r, 8)
+    out += arr29("ONE", (1 << 261) % bls_r, 9)
+    out += "};\n\n"
     out += "// group orders (Fn.ORDER of the reference's curves), 8 LE limbs\nstruct Orders {\n"
     out += arr("SECP_N", kn, 8) + arr("ED_L", ed_l, 8) + arr("BLS_R", bls_r, 8)
     out += "};\n\n"
