@@ -44,6 +44,8 @@ struct NttPass {
   int brp_store;  // store to the bit-reversed index
   int scale;      // multiply by 1/N on store
   int canon;      // last pass: store canonical residues
+  int colhi;      // the 2^logC columns of the tile are the TOP index bits (rows = the low T bits): the lowest pass
+                  // of a natural -> natural transform, whose bit-reversed store then writes runs of 2^logC elements
   int tshift;     // log2(table size) - n
 };
 
@@ -75,11 +77,22 @@ NCG_DI NttTile ntt_tile(const NttPass& ps, uint32_t bx, uint32_t by) {
   t.C = 1 << ps.logC;
   t.L = ps.s_lo - 1;  // index bits below the tile rows
   t.N = (size_t)1 << ps.n;
+  t.poly = (size_t)by * t.N * 8;
+  if (ps.colhi) {  // s_lo == 1: element (row, col) is index col << (n - logC) | bx << T | row
+    t.lochunk = 0;
+    t.hi = bx;
+    t.base = (size_t)bx << ps.T;
+    return t;
+  }
   t.lochunk = bx & ((1u << (t.L - ps.logC)) - 1u);
   t.hi = bx >> (t.L - ps.logC);
-  t.poly = (size_t)by * t.N * 8;
   t.base = ((size_t)t.hi << (t.L + ps.T)) | ((size_t)t.lochunk << ps.logC);
   return t;
+}
+// global index of tile element e
+NCG_DI size_t ntt_tile_index(const NttPass& ps, const NttTile& t, int e) {
+  if (ps.colhi) return t.base | ((size_t)(e & (t.C - 1)) << (ps.n - ps.logC)) | (size_t)(e >> ps.logC);
+  return t.base | ((size_t)(e >> ps.logC) << t.L) | (size_t)(e & (t.C - 1));
 }
 NCG_DI uint32_t ntt_brev32(uint32_t x) {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -146,7 +159,7 @@ NCG_DI void ntt_pass_load(LDS lds, int tid, const uint32_t* __restrict__ src, co
   for (int k = 0; k < 2; k++) {
     const int e = ntt_own_elem(tid, k);
     if (e < E) {
-      const size_t g = t.base | ((size_t)(e >> ps.logC) << t.L) | (size_t)(e & (t.C - 1));
+      const size_t g = ntt_tile_index(ps, t, e);
       fr29_store_l<E>(lds, e, fr29_load_g(src + t.poly + g * 8));
     }
   }
@@ -168,10 +181,11 @@ NCG_DI NttBf ntt_bf_index(const NttPass& ps, const NttTile& t, int b, int st) {
   r.e1 = r.e0 + (1 << (q + logC));
   uint32_t pos;
   if (ps.dit) {  // j = i0 mod m/2; rootPos = j * (N >> s)  (fft.ts:463-467)
-    const uint32_t j = (low << t.L) | (t.lochunk << logC) | c;
+    const uint32_t j = ps.colhi ? low : (low << t.L) | (t.lochunk << logC) | c;
     pos = j << (ps.n - s);
   } else {  // block = i0 >> s (n - s bits), exponent brev(block) * m/2; s == n is the trivial stage
-    const uint32_t blk = (t.hi << (ps.T - 1 - q)) | (bm >> q);
+    uint32_t blk = (t.hi << (ps.T - 1 - q)) | (bm >> q);
+    if (ps.colhi) blk |= c << (ps.n - logC - s);  // the column is the top of the index
     pos = s == ps.n ? 0u : (ntt_brev32(blk) >> (32 - (ps.n - s))) << (s - 1);
   }
   pos <<= ps.tshift;
@@ -204,7 +218,7 @@ NCG_DI void ntt_pass_store(LDS lds, int tid, uint32_t* __restrict__ dst, const u
   for (int k = 0; k < 2; k++) {
     const int e = ntt_own_elem(tid, k);
     if (e < E) {
-      size_t g = t.base | ((size_t)(e >> ps.logC) << t.L) | (size_t)(e & (t.C - 1));
+      size_t g = ntt_tile_index(ps, t, e);
       Fr29 v = fr29_load_l<E>(lds, e);
       if (ps.scale) v = fr29_mont(v, ninv);  // fft.ts:568-570; below 1.5 r
       else v = fr29_reduce256(v);            // below 1.29 * 2^255 = 1.42 r
@@ -360,16 +374,21 @@ NttSchedule ntt_schedule(int n, int tab_log, int flags, int t0max = 10, int tmax
   const bool inverse = flags & 1, brp_in = flags & 2, brp_out = flags & 4;
   NttSchedule sc;
   int s_lo[8], T[8];
-  sc.np = ntt_plan(n, s_lo, T, t0max, tmax);
   const bool dit = brp_in;
   const bool fold_brp = brp_in == brp_out;  // (0,0): natural-order butterflies then BR;  (1,1): DIT then BR
+  // (0,0) in several passes: the bit-reversed store falls to the lowest pass, whose contiguous tile would scatter
+  // single 32-byte elements; give it 4 columns from the top of the index instead (8 + 2 bits per tile)
+  const bool colhi = fold_brp && !dit && n > t0max;
+  if (colhi && t0max > 8) t0max = 8;
+  sc.np = ntt_plan(n, s_lo, T, t0max, tmax);
   for (int k = 0; k < sc.np; k++) {
     const int g = dit ? k : sc.np - 1 - k;  // DIT ascends the stages, the natural-input order descends
     NttPass& ps = sc.ps[k];
     ps.n = n;
     ps.s_lo = s_lo[g];
     ps.T = T[g];
-    ps.logC = s_lo[g] == 1 ? 0 : 2;
+    ps.colhi = colhi && s_lo[g] == 1;
+    ps.logC = s_lo[g] == 1 && !ps.colhi ? 0 : 2;
     ps.dit = dit;
     ps.inverse = inverse;
     ps.brp_store = fold_brp && k == sc.np - 1;
