@@ -5,21 +5,11 @@
 
 namespace ncg {
 
-NCG_DI Fe29<2> fe29_pow_words12(const Fe29<2>& a, const uint32_t* e) {  // square-and-multiply, MSB first
-  Fe29<2> r = Fe29<1>::one();
-  bool started = false;
-  for (int w = 11; w >= 0; w--) {
-    const uint32_t word = e[w];
-    for (int bit = 31; bit >= 0; bit--) {
-      if (started) r = f_sqr(r);
-      if ((word >> bit) & 1u) {
-        r = started ? r * a : a;
-        started = true;
-      }
-    }
-  }
-  return r;
-}
+// a^((p - 3) / 4): the shared power of the 3 mod 4 square roots (modular.ts:205-215 sqrt3mod4 value; the
+// Fp2 root of bls_lanes / h2c runs two of them).  Sliding windows over the compile-time schedule of fe29.hpp.
+NCG_DI Fe29<2> fe29_pow_sqrt_m1(const Fe29<2>& a) { return fe29_pow_sched(a, BlsPowSched<NCG_POW_W>::SQRT_M1); }
+// a^((p + 1) / 4): the candidate root itself (the G1 decoder)
+NCG_DI Fe29<2> fe29_pow_sqrt(const Fe29<2>& a) { return fe29_pow_sched(a, BlsPowSched<NCG_POW_W>::SQRT); }
 
 // [x]P for the BLS parameter x = 0xd201000000010000 (Jacobian double-and-add; x is public and
 // identical for every lane)
@@ -94,12 +84,12 @@ NCG_DI Jac<FeBls2P> g2p_psi(const Jac<FeBls2P>& P) {
 NCG_DI bool fe29x2_sqrt(const Fe29x2<2>& num, Fe29x2<2>& root) {
   const Fe29<1> half = fe29_const(ParamsBls29::HALF);
   Fe29<2> norm = (f_sqr(num.c0) + f_sqr(num.c1)) * Fe29<1>::one();
-  Fe29<2> a = fe29_pow_words12(norm, BlsFpConsts::SQRT_EXP_M1) * norm;
+  Fe29<2> a = fe29_pow_sqrt_m1(norm) * norm;
   bool ok = f_eq(f_sqr(a), norm);
   const bool c1_zero = f_eqz(num.c1);
   Fe29<2> d = (a + num.c0) * half;
   if (c1_zero) d = num.c0;
-  Fe29<2> t = fe29_pow_words12(d, BlsFpConsts::SQRT_EXP_M1);
+  Fe29<2> t = fe29_pow_sqrt_m1(d);
   Fe29<2> s = t * d;
   const bool residue = f_eq(f_sqr(s), d);
   Fe29<2> o = num.c1 * half * t;  // c1 / (2 s) up to the sign fixed below

@@ -109,7 +109,7 @@ NCG_DI bool g1_decode_lane(const uint8_t* __restrict__ in, uint32_t* __restrict_
 #pragma unroll
   for (int i = 0; i < 14; i++) four.v[i] = ParamsBls29::FOUR[i];
   Fe29<2> rhs = (f_sqr(x) * x + four) * Fe29<1>::one();  // x^3 + 4, bound back to 2
-  Fe29<2> y = fe29_pow_words12(rhs, BlsFpConsts::SQRT_EXP);
+  Fe29<2> y = fe29_pow_sqrt(rhs);
   ok = ok && f_eq(f_sqr(y), rhs);  // Fp.sqrt throws when there is no root
   // sort bit: canonical y > (p-1)/2
   uint32_t yw[12];

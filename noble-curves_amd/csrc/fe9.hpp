@@ -257,12 +257,19 @@ NCG_DI Fe9<PR, A + B> operator+(const Fe9<PR, A>& a, const Fe9<PR, B>& b) {
   for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
   return r;
 }
-// a - b = a + BIAS[B] - b, BIAS[B] a multiple of p with every limb in [B*U, (B+1)*U)
+// a - b = a + BIAS[B] - b, BIAS[B] a multiple of p with every limb in [B*U, (B+1)*U): one v_sad_u32 per limb
+// (|BIAS - b| + a, the bias in an SGPR; BIAS >= b by the limb bound) instead of a subtract and an add
 template <class PR, int A, int B>
 NCG_DI Fe9<PR, A + B + 1> operator-(const Fe9<PR, A>& a, const Fe9<PR, B>& b) {
   Fe9<PR, A + B + 1> r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + (PR::BIAS[B][i] - b.v[i]);
+  for (int i = 0; i < 9; i++) {
+#ifdef __HIP_DEVICE_COMPILE__
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r.v[i]) : "s"(PR::BIAS[B][i]), "v"(b.v[i]), "v"(a.v[i]));
+#else
+    r.v[i] = a.v[i] + (PR::BIAS[B][i] - b.v[i]);
+#endif
+  }
   return r;
 }
 template <class PR, int A>

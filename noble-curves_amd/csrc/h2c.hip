@@ -96,7 +96,7 @@ NCG_DI Jac<FeBls> g1_map(const Fe29<2>& u) {
   // sqrt_ratio_3mod4(gx, tv6)  (hash-to-curve.ts:629-645)
   Fe29<2> t2 = gx * tv6;
   Fe29<2> t1 = f_sqr(tv6) * t2;
-  Fe29<2> y1 = fe29_pow_words12(t1, BlsFpConsts::SQRT_EXP_M1) * t2;
+  Fe29<2> y1 = fe29_pow_sqrt_m1(t1) * t2;
   const bool isQR = f_eq(f_sqr(y1) * tv6, gx);
   Fe29<2> value = isQR ? y1 : y1 * fe29_const(BlsH2c::SWU1_C2);
   Fe29<2> y = tv1 * u * value;                                 // 19-20
@@ -134,7 +134,7 @@ NCG_DI Jac<FeBls> g1_clear_cofactor(const Jac<FeBls>& P) {  // bls12-381.ts:578-
 NCG_DI bool fe29x2_sqrt_or_zsqrt(const Fe29x2<2>& w, const Fe29x2<2>& zw, Fe29x2<2>& root) {
   const Fe29<1> half = fe29_const(ParamsBls29::HALF);
   Fe29<2> norm = (f_sqr(w.c0) + f_sqr(w.c1)) * Fe29<1>::one();
-  Fe29<2> a1 = fe29_pow_words12(norm, BlsFpConsts::SQRT_EXP_M1) * norm;
+  Fe29<2> a1 = fe29_pow_sqrt_m1(norm) * norm;
   const bool isQR = f_eq(f_sqr(a1), norm);
   Fe29<2> aK = a1 * fe29_const(BlsH2c::SWU2_K);
   const Fe29x2<2> t = isQR ? w : zw;
@@ -142,7 +142,7 @@ NCG_DI bool fe29x2_sqrt_or_zsqrt(const Fe29x2<2>& w, const Fe29x2<2>& zw, Fe29x2
   const bool c1_zero = f_eqz(t.c1);
   Fe29<2> d = (a + t.c0) * half;
   if (c1_zero) d = t.c0;
-  Fe29<2> tt = fe29_pow_words12(d, BlsFpConsts::SQRT_EXP_M1);
+  Fe29<2> tt = fe29_pow_sqrt_m1(d);
   Fe29<2> s = tt * d;
   const bool residue = f_eq(f_sqr(s), d);
   Fe29<2> o = t.c1 * half * tt;
