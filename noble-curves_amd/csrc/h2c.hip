@@ -13,9 +13,9 @@
 // The map is a function of u alone, so the device is free in HOW it evaluates it:
 //   * the isogeny lands directly in Jacobian coordinates (Z = xd yd), no inversion;
 //   * G1 sqrt_ratio is the reference's 3 mod 4 variant (one power);
-//   * G2 sqrt_ratio(u, v) = sqrt(u / v) or sqrt(Z u / v) through the norm-based Fp2 square root
-//     (both candidates share its first power, fe29x2_sqrt_or_zsqrt) and the inverse of tv4 that
-//     SWU needs anyway (v = tv4^3): 3 exponentiations in Fp per map; the reference's generic
+//   * G2 sqrt_ratio(u, v) = sqrt(u / v) or sqrt(Z u / v) through the norm-based Fp2 square root of the
+//     FRACTION (both candidates share its first power; fe29x2_sqrt_ratio_or_z), x stays over tv4 through
+//     the isogeny: 2 exponentiations in Fp per map and no inversion; the reference's generic
 //     F.2.1.1 ladder in Fp2 is several times the field work.  Either root is fine: SWU fixes the
 //     sign of y by sgn0(u) == sgn0(y) (:707-708).
 #include <cstdlib>
@@ -60,6 +60,18 @@ template <int N>
 NCG_DI Fe29x2<7> horner2(const uint32_t (&k)[N][2][14], const Fe29x2<2>& x) {
   Fe29x2<7> acc = fe29x2_const(k[N - 1]);
   for (int i = N - 2; i >= 0; i--) acc = acc * x + fe29x2_const(k[i]);
+  return acc;
+}
+
+// Homogeneous Horner over Fp2: D^(N-1) * sum_i k[i] (X/D)^i, no division
+template <int N>
+NCG_DI Fe29x2<12> horner2_hom(const uint32_t (&k)[N][2][14], const Fe29x2<2>& X, const Fe29x2<2>& D) {
+  Fe29x2<12> acc = fe29x2_const(k[N - 1]);
+  Fe29x2<6> dpow = D;
+  for (int i = N - 2; i >= 0; i--) {
+    acc = acc * X + fe29x2_const(k[i]) * dpow;
+    if (i) dpow = dpow * D;
+  }
   return acc;
 }
 
@@ -125,27 +137,41 @@ NCG_DI Jac<FeBls> g1_clear_cofactor(const Jac<FeBls>& P) {  // bls12-381.ts:578-
 }
 
 // ------------------------------------------------------------------------------------- G2
-// sqrt_ratio core for Fp2: returns whether w is a square and a square root of w (if it is) or of
-// zw = Z w (if it is not; Z is the non-square SWU constant, so exactly one of the two is a
-// square).  The first power is shared: a1 = norm(w)^((p+1)/4) squares to +-norm(w); "+" means w is
-// a square with sqrt(norm(w)) = a1, "-" means it is not and sqrt(norm(Z w)) = a1 K with
-// K = sqrt(-norm(Z)) - so both cases continue with ONE more power (fe29x2_sqrt, bls_lanes.hpp, is
-// the same algorithm for a single candidate).
-NCG_DI bool fe29x2_sqrt_or_zsqrt(const Fe29x2<2>& w, const Fe29x2<2>& zw, Fe29x2<2>& root) {
-  const Fe29<1> half = fe29_const(ParamsBls29::HALF);
-  Fe29<2> norm = (f_sqr(w.c0) + f_sqr(w.c1)) * Fe29<1>::one();
-  Fe29<2> a1 = fe29_pow_sqrt_m1(norm) * norm;
-  const bool isQR = f_eq(f_sqr(a1), norm);
-  Fe29<2> aK = a1 * fe29_const(BlsH2c::SWU2_K);
-  const Fe29x2<2> t = isQR ? w : zw;
-  const Fe29<2> a = isQR ? a1 : aK;
-  const bool c1_zero = f_eqz(t.c1);
-  Fe29<2> d = (a + t.c0) * half;
-  if (c1_zero) d = t.c0;
-  Fe29<2> tt = fe29_pow_sqrt_m1(d);
-  Fe29<2> s = tt * d;
-  const bool residue = f_eq(f_sqr(s), d);
-  Fe29<2> o = t.c1 * half * tt;
+// sqrt_ratio core for Fp2 WITHOUT an inversion: for w = n / d (d != 0) returns whether w is a square and a
+// square root of w (if it is) or of Z w (if it is not; Z is the non-square SWU constant, so exactly one of the
+// two is a square) - the true field element, not a fraction, so sgn0 can be read from it.
+//   w = M / nd with M = n conj(d), nd = norm(d) in Fp; norm(w) = norm(M) / nd^2 is a square iff nM = norm(M) is.
+//   First power: s1 = nM^((p+1)/4) squares to +-nM; "+": w is a square and sqrt(norm(w)) = s1 / nd, "-": it is
+//   not and sqrt(norm(Z w)) = K s1 / nd with K = sqrt(-norm(Z)).  Either sign of that root of the norm works.
+//   Norm-based root of t = T / nd (T = M or Z M): dq = (sqrt(norm(t)) + t0) / 2 = dn / dd with dn = S + T0,
+//   dd = 2 nd (dn = T0, dd = nd when T1 = 0).  Second power: P = (dn dd^3)^((p-3)/4); since dd^(p-1) = 1,
+//   dq^((p-3)/4) = P dd^2, so s = dq^((p+1)/4) = P dd dn and t1 / (2 s) -> o = T1 P dd.  s^2 = +-dq picks
+//   (s, o) or (-o, s) as in fe29x2_sqrt (bls_lanes.hpp).
+// Two exponentiations in Fp; the form with the inverse of d took three.
+NCG_DI bool fe29x2_sqrt_ratio_or_z(const Fe29x2<2>& n, const Fe29x2<2>& d, Fe29x2<2>& root) {
+  const Fe29x2<1> Z = fe29x2_const(BlsH2c::SWU2_Z);
+  const Fe29x2<2> cd{d.c0, f_neg(d.c1)};
+  const Fe29<2> nd = (f_sqr(d.c0) + f_sqr(d.c1)) * Fe29<1>::one();
+  const Fe29x2<2> M = nrm(n * cd);
+  const Fe29x2<2> MZ = nrm(M * Z);
+  const Fe29<2> nM = (f_sqr(M.c0) + f_sqr(M.c1)) * Fe29<1>::one();
+  const Fe29<2> s1 = fe29_pow_sqrt_m1(nM) * nM;
+  const bool isQR = f_eq(f_sqr(s1), nM);
+  const Fe29<2> sK = s1 * fe29_const(BlsH2c::SWU2_K);
+  const Fe29x2<2> T = isQR ? M : MZ;
+  const Fe29<2> S = isQR ? s1 : sK;
+  const bool c1_zero = f_eqz(T.c1);
+  Fe29<4> dn = S + T.c0, dd = nd + nd;
+  if (c1_zero) {
+    dn = T.c0;
+    dd = nd;
+  }
+  const Fe29<2> dd3 = f_sqr(dd) * dd;
+  const Fe29<2> P = fe29_pow_sqrt_m1(dn * dd3);
+  const Fe29<2> q = P * dd;
+  const Fe29<2> s = q * dn;
+  const Fe29<2> o = q * T.c1;
+  const bool residue = f_eq(f_sqr(s) * dd, dn);
   if (residue) {
     root = {s, o};
   } else {
@@ -165,25 +191,29 @@ NCG_DI Jac<FeBls2> g2_map(const Fe29x2<2>& u) {  // mapToG2 (bls12-381.ts:859-86
   auto gxn = (f_sqr(tv3) + tv6 * A) * tv3;
   tv6 = nrm(tv6 * tv4);
   Fe29x2<2> gx = nrm(gxn + tv6 * B);
-  Fe29x2<2> x = nrm(tv1 * tv3);
-  // sqrt_ratio(gx, tv6), tv6 = tv4^3: w = gx / tv6 through the inverse of tv4
-  Fe29x2<2> inv4 = f_inv(tv4);
-  Fe29x2<2> w = nrm(gx * (f_sqr(inv4) * inv4));
+  // sqrt_ratio(gx, tv6), tv6 = tv4^3 != 0 (A != 0 and Z, -tv2 != 0)
   Fe29x2<2> value;
-  const bool isQR = fe29x2_sqrt_or_zsqrt(w, nrm(w * Z), value);  // Z is a non-square: w or Z w is a square
+  const bool isQR = fe29x2_sqrt_ratio_or_z(gx, tv6, value);  // Z is a non-square: gx / tv6 or Z gx / tv6 is a square
+  Fe29x2<2> x = nrm(tv1 * tv3);
   Fe29x2<2> y = nrm(tv1 * u * value);
   if (isQR) {
     x = tv3;
     y = value;
   }
   if (sgn0(u) != sgn0(y)) y = nrm(f_neg(y));
-  x = nrm(x * inv4);
-  // 3-isogeny E' -> E
-  auto xn = horner2(BlsH2c::ISO2_XNUM, x), xd = horner2(BlsH2c::ISO2_XDEN, x);
-  auto yn = horner2(BlsH2c::ISO2_YNUM, x), yd = horner2(BlsH2c::ISO2_YDEN, x);
-  if (f_eqz(xd) || f_eqz(yd)) return Jac<FeBls2>::inf();
-  Fe29x2<2> Zj = nrm(xd * yd);
-  return {xn * yd * Zj, y * yn * xd * f_sqr(Zj), Zj};
+  // x = x / tv4 is NOT carried out: the 3-isogeny E' -> E (isogenyMap hash-to-curve.ts:381-410) is evaluated
+  // homogeneously in (X : D) = (x : tv4), as g1_map does.  With XN = D^3 xnum, XD = D^2 xden, YN = D^3 ynum, YD = D^3 yden:
+  //   x' = XN / (XD D),  y' = y YN / YD  ->  Z = XD D YD,  X = XN (XD D) YD^2,  Y = y YN YD^2 (XD D)^3;
+  // a zero denominator is the identity (:404-408).
+  static_assert(BlsH2c::ISO2_XNUM_N == 4 && BlsH2c::ISO2_XDEN_N == 3 && BlsH2c::ISO2_YNUM_N == 4 && BlsH2c::ISO2_YDEN_N == 4,
+                "degrees of the homogeneous form");
+  const Fe29x2<2> D = tv4;
+  auto XN = horner2_hom(BlsH2c::ISO2_XNUM, x, D), XD = horner2_hom(BlsH2c::ISO2_XDEN, x, D);
+  auto YN = horner2_hom(BlsH2c::ISO2_YNUM, x, D), YD = horner2_hom(BlsH2c::ISO2_YDEN, x, D);
+  if (f_eqz(XD) || f_eqz(YD)) return Jac<FeBls2>::inf();
+  Fe29x2<2> Aq = nrm(XD * D), YD2 = f_sqr(YD);
+  auto A3 = f_sqr(Aq) * Aq;
+  return {XN * Aq * YD2, y * YN * YD2 * A3, Aq * YD};
 }
 
 // psi / psi^2 on Jacobian coordinates: conjugation commutes with x = X/Z^2, y = Y/Z^3
