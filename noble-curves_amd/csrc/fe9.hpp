@@ -41,6 +41,16 @@ NCG_DI void fe9_mac(uint64_t& acc, uint32_t a, uint32_t b) {
   acc += (uint64_t)a * b;
 #endif
 }
+// acc = a * b: the first product of a chain, the addend is the inline constant 0 (saves clearing the pair)
+NCG_DI uint64_t fe9_mul64(uint32_t a, uint32_t b) {
+#ifdef __HIP_DEVICE_COMPILE__
+  uint64_t acc;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b) : "vcc");
+  return acc;
+#else
+  return (uint64_t)a * b;
+#endif
+}
 // acc += a * k for a wave-uniform constant k (kept in an SGPR)
 NCG_DI void fe9_mac_k(uint64_t& acc, uint32_t a, uint32_t k) {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -99,12 +109,12 @@ NCG_DI void fe9_tail(uint32_t (&r)[9], uint32_t (&t)[9], uint64_t c, uint32_t dt
 template <class PR>
 NCG_DI void fe9_mul_limbs(uint32_t (&r)[9], const uint32_t (&a)[9], const uint32_t (&b)[9]) {
   constexpr uint32_t C0 = PR::C0, C1 = PR::C1;
-  uint64_t d = 0;  // high chain: columns 8, 9, ..., 16
+  uint64_t d = fe9_mul64(a[0], b[8]);  // high chain: columns 8, 9, ..., 16
 #pragma unroll
-  for (int i = 0; i < 9; i++) fe9_mac(d, a[i], b[8 - i]);
+  for (int i = 1; i < 9; i++) fe9_mac(d, a[i], b[8 - i]);
   const uint32_t t8 = (uint32_t)d & FE9_MASK;
   d >>= 29;
-  uint64_t c = 0;  // low chain: columns 0..8 plus the folded high limbs
+  uint64_t c = fe9_mul64(a[0], b[0]);  // low chain: columns 0..8 plus the folded high limbs
   uint32_t t[9];
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -112,7 +122,7 @@ NCG_DI void fe9_mul_limbs(uint32_t (&r)[9], const uint32_t (&a)[9], const uint32
     // accumulators (back-to-back dependent multiply-adds cost a wait state each)
 #pragma unroll
     for (int j = 0; j < 9; j++) {
-      if (j <= k) fe9_mac(c, a[j], b[k - j]);
+      if (j <= k && (j | k)) fe9_mac(c, a[j], b[k - j]);
       if (j + k + 1 < 9) fe9_mac(d, a[j + k + 1], b[8 - j]);
     }
     const uint32_t u = (uint32_t)d & FE9_MASK;
@@ -133,19 +143,18 @@ NCG_DI void fe9_sqr_limbs(uint32_t (&r)[9], const uint32_t (&a)[9]) {
 #pragma unroll
   for (int i = 0; i < 9; i++) a2[i] = a[i] << 1;
   // column k = sum_{i<j, i+j=k} 2 a_i a_j + [k even] a_{k/2}^2
-  uint64_t d = 0;
-  fe9_mac(d, a[4], a[4]);
+  uint64_t d = fe9_mul64(a[4], a[4]);
 #pragma unroll
   for (int i = 0; i < 4; i++) fe9_mac(d, a2[i], a[8 - i]);
   const uint32_t t8 = (uint32_t)d & FE9_MASK;
   d >>= 29;
-  uint64_t c = 0;
+  uint64_t c = fe9_mul64(a[0], a[0]);
   uint32_t t[9];
 #pragma unroll
   for (int k = 0; k < 8; k++) {
 #pragma unroll
     for (int i = 0; 2 * i < k; i++) fe9_mac(c, a2[i], a[k - i]);
-    if ((k & 1) == 0) fe9_mac(c, a[k / 2], a[k / 2]);
+    if ((k & 1) == 0 && k) fe9_mac(c, a[k / 2], a[k / 2]);
     const int kk = 9 + k;
 #pragma unroll
     for (int i = k + 1; 2 * i < kk; i++) fe9_mac(d, a2[i], a[kk - i]);
