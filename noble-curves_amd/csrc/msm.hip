@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 
 #include "host_api.hpp"
@@ -815,7 +816,15 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     uint32_t* long_runs = (uint32_t*)(base + L.long_runs);
     e = hipMemsetAsync(long_runs, 0, 16, st);
     if (e != hipSuccess) return e;
-    const int run_serial = knob("NCG_MSM_RUN_SERIAL", MSM_RUN_SERIAL);
+    // How many heads the owner of a run adds itself.  A bucket of m entries cut by lanes of `seg` entries has up to
+    // ceil(m / seg) heads; m is n / nb on average and rarely above m + 4 sqrt(m).  The seg that fills the chip in one
+    // round can be a third of that (verified G1 set of 2^17 points: 64 entries per bucket, seg 20), and with a fixed
+    // limit of 2 EVERY bucket went to the work list - 40 000 runs through 512 workgroups, 2.9 ms against 1.0 ms for the
+    // generic path.  A serial head costs one dependent addition (3 us); the work list is for real outliers (equal
+    // scalars, a short top window).
+    const double m_avg = (double)av.n / (double)av.nb;
+    const int heads_typ = (int)std::ceil((m_avg + 4.0 * std::sqrt(m_avg) + 1.0) / (double)sg.seg);
+    const int run_serial = std::max(knob("NCG_MSM_RUN_SERIAL", MSM_RUN_SERIAL), std::min(8, heads_typ));
     // shared-bucket mode: every bucket holds nwin * n / nb entries, i.e. a handful of pieces - all of them, so their
     // owners add them serially (fully parallel over the buckets), as cooperative groups where the curve has them;
     // the work list is for the outliers only
