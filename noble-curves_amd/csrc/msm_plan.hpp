@@ -78,8 +78,8 @@ inline int msm_make_plan_impl(int curve, int n, int c_override, MsmPlan* pl) {
   c = std::max(2, std::min(16, c));
   pl->n = n;
   pl->ls = curve == CURVE_BLS12_381_G2 ? 1 : 0;  // lane-paired kernels: 2 lanes per item
-  // waves/SIMD the accumulate kernel runs at (registers): 4 for the 256-bit fields, 2 for bls12-381
-  pl->accum_waves = (curve == CURVE_SECP256K1 || curve == CURVE_ED25519) ? 4 : 2;
+  // waves/SIMD the accumulate kernel runs at (registers): 4 for the 256-bit fields, 2 for bls12-381 G1, 1 for G2
+  pl->accum_waves = (curve == CURVE_SECP256K1 || curve == CURVE_ED25519) ? 4 : curve == CURVE_BLS12_381_G2 ? 1 : 2;
   pl->c = c;
   pl->nb = 1 << (c - 1);
   pl->nwin = plan_windows(c, curve_order(curve), pl->hconst);

@@ -237,20 +237,33 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
 // Batched Jacobian -> affine (the reference's normalizeZ / FpInvertBatch, src/abstract/curve.ts:
 // 311-326, src/abstract/modular.ts:728-760): each lane runs Montgomery's trick over K
 // consecutive points - one field inversion per K points instead of one per point.
-template <class C, int K>
-__global__ void __launch_bounds__(256) k_jac_batch_affine(const uint32_t* __restrict__ jac,
-                                                          uint32_t* __restrict__ out_wire,
-                                                          uint8_t* __restrict__ out_inf, int n) {
+// PRE_LDS: the K prefix products live in LDS (64-thread blocks, limb-major, lane-minor) instead of a per-lane array.
+// In the translation units that inline the field multiply the array is not promoted to registers and ends up in
+// scratch memory (592 bytes per lane for secp256k1, K = 16) - global-memory round trips in a dependent chain, which cost
+// this kernel 0.22 ms per 2^20 on most boxes and 0.42 ms on the boxes of the pool with a slow memory path.
+template <class C, int K, bool PRE_LDS = false>
+__global__ void __launch_bounds__(PRE_LDS ? 64 : 256) k_jac_batch_affine(const uint32_t* __restrict__ jac,
+                                                                         uint32_t* __restrict__ out_wire,
+                                                                         uint8_t* __restrict__ out_inf, int n) {
   using F = typename C::F;
-  constexpr int FW = FieldIO<F>::WORDS, WW = FieldWire<F>::WORDS;
+  constexpr int FW = FieldIO<F>::WORDS, WW = FieldWire<F>::WORDS, TW = FieldIO<F>::LANE_WORDS;
+  extern __shared__ __attribute__((aligned(16))) uint32_t pre_lds[];
   const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> LaneShift<C>::value;
   const int i0 = t * K;
   if (i0 >= n) return;
-  F pre[K];   // pre[j] = product of the non-zero Z of points i0..i0+j-1
+  F pre[PRE_LDS ? 1 : K];   // pre[j] = product of the non-zero Z of points i0..i0+j-1
+  auto pre_put = [&](int j, const F& v) {
+    if constexpr (PRE_LDS) FieldIO<F>::store_strided(pre_lds + threadIdx.x + (size_t)j * TW * 64, 64, v);
+    else pre[j] = v;
+  };
+  auto pre_get = [&](int j) -> F {
+    if constexpr (PRE_LDS) return FieldIO<F>::load_strided(pre_lds + threadIdx.x + (size_t)j * TW * 64, 64);
+    else return pre[j];
+  };
   F acc = F::one();
 #pragma unroll
   for (int j = 0; j < K; j++) {
-    pre[j] = acc;
+    pre_put(j, acc);
     if (i0 + j < n) {
       F z = FieldIO<F>::load(jac + ((size_t)(i0 + j) * 3 + 2) * FW);
       if (!z.is_zero()) acc = acc * z;
@@ -265,7 +278,7 @@ __global__ void __launch_bounds__(256) k_jac_batch_affine(const uint32_t* __rest
       const bool inf = z.is_zero();
       Affine<F> A{F::zero(), F::zero()};
       if (!inf) {
-        F zi = inv * pre[j];
+        F zi = inv * pre_get(j);
         inv = inv * z;
         auto zi2 = f_sqr(zi);
         A = {FieldIO<F>::load(p) * zi2, FieldIO<F>::load(p + FW) * zi2 * zi};
@@ -370,7 +383,8 @@ inline hipError_t launch_mul_var_gtab(const uint32_t* pts, const uint32_t* scala
   hipLaunchKernelGGL((k_mul_var_gtab<C, W, MINW, true>), dim3(blocks), dim3(64), 0, st, pts, scalars, jac_tmp, out_inf,
                      gtab, n);
   int threads = ((n + K - 1) / K) << LS;
-  hipLaunchKernelGGL((k_jac_batch_affine<C, K>), dim3((threads + 255) / 256), dim3(256), 0, st, jac_tmp, out, out_inf, n);
+  constexpr size_t pre_bytes = (size_t)K * FieldIO<typename C::F>::LANE_WORDS * 64 * 4;   // 36 KB for secp256k1, K = 16
+  hipLaunchKernelGGL((k_jac_batch_affine<C, K, true>), dim3((threads + 63) / 64), dim3(64), pre_bytes, st, jac_tmp, out, out_inf, n);
   return hipGetLastError();
 }
 
