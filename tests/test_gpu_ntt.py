@@ -81,6 +81,36 @@ def test_ntt_three_pass_size_matches_oracle():
     assert f.direct(bitReversalPermutation(x), True) == y
 
 
+def test_ntt_extreme_values_at_the_bench_size():
+    """2^22 (the bench's size: 8 + 7 + 7 stages natural -> natural, 10 + 6 + 6 otherwise) on the inputs that build up the
+    largest lazily reduced values the fr29 butterflies can meet - every coefficient r - 1, and r - 1 / 0 alternating - whose
+    transforms are known in closed form: N (r - 1) at index 0 (and N/2 (r - 1) at 0 and N/2), zero elsewhere.  Raw arrays
+    in and out; natural and bit-reversed output, inverse round trip."""
+    eng = get_engine()
+    bits = 22
+    n = 1 << bits
+    roots = G.rootsOfUnity(G.bls12_381_Fr, 7)
+    om = roots.omega(bits)
+    top = np.frombuffer((R - 1).to_bytes(32, "little"), dtype=np.uint8)
+    x = np.tile(top, (n, 1))
+    for flags_out in (False, True):
+        y = eng.ntt(bits, x, om, brp_output=flags_out)
+        assert int.from_bytes(y[0].tobytes(), "little") == n * (R - 1) % R
+        assert not y[1:].any()
+    x2 = x.copy()
+    x2[1::2] = 0
+    y = eng.ntt(bits, x2, om)
+    half = (n // 2) * (R - 1) % R
+    assert int.from_bytes(y[0].tobytes(), "little") == half and int.from_bytes(y[n // 2].tobytes(), "little") == half
+    y[0] = 0
+    y[n // 2] = 0
+    assert not y.any()
+    yb = eng.ntt(bits, x2, om, brp_output=True)            # bit-reversed: index N/2 lands at 1
+    assert int.from_bytes(yb[0].tobytes(), "little") == half and int.from_bytes(yb[1].tobytes(), "little") == half
+    back = eng.ntt(bits, yb, om, inverse=True, brp_input=True)
+    assert (back == x2).all()
+
+
 def test_ntt_batch_and_raw_arrays():
     """a batch of polynomials in one call == the transforms one by one; uint8 arrays pass through"""
     eng = get_engine()
