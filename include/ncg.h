@@ -19,6 +19,8 @@
  * addresses valid on the context's GPU; all others are host pointers.  `stream` is a
  * hipStream_t passed as void* (NULL = the context's own stream); *_dev calls are
  * asynchronous on that stream, host-pointer calls return after the result is in host memory.
+ * Device buffers must be 16-byte aligned (any hipMalloc / torch allocation is, and so is any whole-record
+ * offset into one: records are 32 bytes or more); the kernels read and write them with 16-byte accesses.
  *
  * Threading and memory: a context is not thread-safe - use it from one host thread at a time (the
  * reference is single-threaded); several contexts per process are fine.  The context

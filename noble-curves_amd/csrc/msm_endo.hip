@@ -23,8 +23,12 @@ __global__ void __launch_bounds__(256) k_msm_digits_endo(const uint32_t* __restr
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= pl.n_src) return;
   uint32_t k[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) k[j] = scalars[(size_t)i * 8 + j];
+  {
+    const uint4* kp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+    const uint4 lo = kp[0], hi = kp[1];
+    k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w;
+    k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+  }
   {
     uint32_t bw = 0;
 #pragma unroll
