@@ -187,20 +187,36 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
 #pragma unroll(NCG_MUL_INLINE ? 1 : W)
       for (int d = 0; d < W; d++) R = jac_dbl(R);
     }
-    // one mixed addition per stream.  With the field multiply inlined the two additions of the GLV pair are ONE loop
-    // body run twice (the window body - 4 doublings through one rolled body + this - then fits the 64 KB instruction
-    // cache; as straight-line code it was 69 KB and re-fetched every window)
-#pragma unroll(NCG_MUL_INLINE ? 1 : 2)
-    for (int e = 0; e < (C::GLV ? 2 : 1); e++) {
-      const int d = e == 0 ? w1.pop() : w2.pop();
-      const bool ng = e == 0 ? neg1 : neg2;
-      const int idx = ((d < 0 ? -d : d) - 1) >> 1;
-      F qx = FieldIO<F>::load_strided(tab + (idx * 2 * TW) * stride, stride);
-      const F qy = FieldIO<F>::load_strided(tab + (idx * 2 * TW + TW) * stride, stride);
-      if constexpr (C::GLV) {
+    // one mixed addition per stream
+    if constexpr (NCG_MUL_INLINE && C::GLV) {
+      // field multiply inlined: the two additions of the GLV pair are ONE loop body run twice (the window body - 4
+      // doublings through one rolled body + this - then fits the 64 KB instruction cache; as straight-line code it
+      // was 69 KB and re-fetched every window)
+#pragma unroll 1
+      for (int e = 0; e < 2; e++) {
+        const int d = e == 0 ? w1.pop() : w2.pop();
+        const bool ng = e == 0 ? neg1 : neg2;
+        const int idx = ((d < 0 ? -d : d) - 1) >> 1;
+        F qx = FieldIO<F>::load_strided(tab + (idx * 2 * TW) * stride, stride);
+        const F qy = FieldIO<F>::load_strided(tab + (idx * 2 * TW + TW) * stride, stride);
         if (e == 1) qx = qx * beta;
+        R = jac_madd_q(R, qx, f_cneg(qy, (d < 0) != ng));
       }
-      R = jac_madd_q(R, qx, f_cneg(qy, (d < 0) != ng));
+    } else {
+      {
+        int d1 = w1.pop();
+        int e = ((d1 < 0 ? -d1 : d1) - 1) >> 1;
+        const F qx = FieldIO<F>::load_strided(tab + (e * 2 * TW) * stride, stride);
+        const F qy = FieldIO<F>::load_strided(tab + (e * 2 * TW + TW) * stride, stride);
+        R = jac_madd_q(R, qx, f_cneg(qy, (d1 < 0) != neg1));
+      }
+      if constexpr (C::GLV) {
+        int d2 = w2.pop();
+        int e = ((d2 < 0 ? -d2 : d2) - 1) >> 1;
+        const auto qx = FieldIO<F>::load_strided(tab + (e * 2 * TW) * stride, stride) * beta;
+        const F qy = FieldIO<F>::load_strided(tab + (e * 2 * TW + TW) * stride, stride);
+        R = jac_madd_q(R, qx, f_cneg(qy, (d2 < 0) != neg2));
+      }
     }
   }
   // even scalars were bumped by one: take the extra point back out
