@@ -226,15 +226,22 @@ NCG_DI bool ed25519_verify_lane_half(const uint32_t* __restrict__ sig, const uin
       for (int d = 0; d < CFG::WA - 1; d++) acc = ed_dbl_no_t(acc);
       acc = ed_dbl(acc);
     }
-    const int dA = wa.pop();
-    acc = ed_add_niels(acc, ed_load_niels(tab, stride, ((dA < 0 ? -dA : dA) - 1) >> 1), (dA < 0) != hv.uneg);
-    const int dR = wr.pop();
-    acc = ed_add_niels(acc, ed_load_niels(tab, stride, CFG::TA + (((dR < 0 ? -dR : dR) - 1) >> 1)), dR < 0);
+    // the additions of the two point streams (-A, -R) are one loop body run twice, and so are the two of the base
+    // streams: the window body is 40 KB of code instead of 62 KB (the instruction cache holds 64 KB)
+#pragma unroll 1
+    for (int e = 0; e < 2; e++) {
+      const int dP = e == 0 ? wa.pop() : wr.pop();
+      const bool ngP = e == 0 ? ((dP < 0) != hv.uneg) : (dP < 0);
+      const int ent = (e == 0 ? 0 : CFG::TA) + (((dP < 0 ? -dP : dP) - 1) >> 1);
+      acc = ed_add_niels(acc, ed_load_niels(tab, stride, ent), ngP);
+    }
     if ((i & 1) == 0) {
-      const int d0 = wb0.pop();
-      acc = ed_madd_niels(acc, ed_load_aff_niels(btab + (((d0 < 0 ? -d0 : d0) - 1) >> 1) * ED_AFF_NIELS_WORDS), d0 < 0);
-      const int d1 = wb1.pop();
-      acc = ed_madd_niels(acc, ed_load_aff_niels(btab1 + (((d1 < 0 ? -d1 : d1) - 1) >> 1) * ED_AFF_NIELS_WORDS), d1 < 0);
+#pragma unroll 1
+      for (int e = 0; e < 2; e++) {
+        const int dB = e == 0 ? wb0.pop() : wb1.pop();
+        const uint32_t* bt = e == 0 ? btab : btab1;
+        acc = ed_madd_niels(acc, ed_load_aff_niels(bt + (((dB < 0 ? -dB : dB) - 1) >> 1) * ED_AFF_NIELS_WORDS), dB < 0);
+      }
     }
   }
   // even scalars were bumped by one: take the extra points back out
