@@ -388,6 +388,24 @@ int ht_msm_finish(int curve, int c, int nwin, const uint32_t* fin, uint32_t* out
   HT_CURVE_DISPATCH(curve, CALL)
 #undef CALL
 }
+// bls_host64.hpp on raw operands: op 0: Montgomery product of two canonical residues given as 6 x 64-bit words (result
+// 6 words); op 1: from_fe29 of 14 stored limbs (result 6 words, Montgomery form R = 2^384)
+int ht_h64_op(int op, const uint64_t* a, const uint64_t* b, const uint32_t* limbs, uint64_t* r) {
+  h64::Fp x, y, z;
+  if (op == 0) {
+    for (int i = 0; i < 6; i++) {
+      x.v[i] = a[i];
+      y.v[i] = b[i];
+    }
+    z = h64::mul(x, y);
+  } else if (op == 1) {
+    z = h64::from_fe29(limbs);
+  } else {
+    return -1;
+  }
+  for (int i = 0; i < 6; i++) r[i] = z.v[i];
+  return 0;
+}
 int ht_msm_plan(int curve, int n, int* out) {  // c, nwin, ngroups, acc words
   MsmPlan pl;
   if (msm_make_plan_impl(curve, n, 0, &pl) != 0) return -1;

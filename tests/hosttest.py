@@ -41,6 +41,7 @@ def lib():
         _lib.ht_msm_shard_combine.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32]
         _lib.ht_msm_finish.argtypes = [i32, i32, i32, vp, vp, vp, i32]
         _lib.ht_msm_plan.argtypes = [i32, i32, vp]
+        _lib.ht_h64_op.argtypes = [i32, vp, vp, vp, vp]
     return _lib
 
 
@@ -155,6 +156,22 @@ def fr29_op(op, a_limbs, b_limbs=None):
     ovf = lib().ht_fr29_op(op, A.ctypes.data, B.ctypes.data, R.ctypes.data)
     assert ovf >= 0
     return [int(x) for x in R], ovf
+
+
+def h64_mul(a, b):
+    """bls_host64.hpp Montgomery product (R = 2^384) of two residues below p -> integer"""
+    A = np.array([(a >> (64 * i)) & (2 ** 64 - 1) for i in range(6)], dtype=np.uint64)
+    B = np.array([(b >> (64 * i)) & (2 ** 64 - 1) for i in range(6)], dtype=np.uint64)
+    R = np.zeros(6, dtype=np.uint64)
+    assert lib().ht_h64_op(0, A.ctypes.data, B.ctypes.data, None, R.ctypes.data) == 0
+    return sum(int(x) << (64 * i) for i, x in enumerate(R))
+
+
+def h64_from_fe29(limbs):
+    L = np.array(limbs, dtype=np.uint32)
+    R = np.zeros(6, dtype=np.uint64)
+    assert lib().ht_h64_op(1, None, None, L.ctypes.data, R.ctypes.data) == 0
+    return sum(int(x) << (64 * i) for i, x in enumerate(R))
 
 
 def ntt_plan(log2n):

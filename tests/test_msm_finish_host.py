@@ -94,3 +94,26 @@ def test_plan_twin_matches_expectation():
     assert p["c"] == 16 and p["nwin"] == 16 and p["ngroups"] == 5 and p["acc_words"] == 56
     assert hosttest.msm_shard_slot_bytes(BLS12_381_G1) % 256 == 0
     assert hosttest.msm_shard_slot_bytes(BLS12_381_G2) >= 2 * hosttest.msm_shard_slot_bytes(BLS12_381_G1) - 256
+
+
+def test_host64_product_and_limb_import_at_the_edges():
+    """bls_host64.hpp: the fused one-pass Montgomery product (R = 2^384) on 0, 1, p - 1, values with all-ones words, and
+    the import of device elements (14 limbs of 29 bits, R = 2^406, lazily reduced up to 64 p) through the 22-bit Montgomery
+    step - against big-int arithmetic (modular.ts:956 value of mul on Montgomery representatives)."""
+    rng = makeRng(0x64F1)
+    p = BLS_P
+    rinv = pow(1 << 384, -1, p)
+    edge = [0, 1, 2, p - 1, p - 2, (1 << 380) - 1, (1 << 381) - 1 - ((1 << 381) - 1) // p * 0]
+    edge = [e % p for e in edge] + [((1 << 64) - 1) << (64 * i) for i in range(5)]
+    vals = edge + [rng.rndBelow(p) for _ in range(40)]
+    for a in vals:
+        for b in (vals[:8] + vals[-6:]):
+            assert hosttest.h64_mul(a % p, b % p) == (a % p) * (b % p) * rinv % p
+    for trial in range(200):
+        x = rng.rndBelow(p) if trial > 2 else [0, 1, p - 1][trial]
+        k = rng.rndBelow(64) if trial % 3 else 63
+        m = x * R29 % p + k * p
+        if m >= 64 * p:
+            m -= p
+        limbs = [(m >> (29 * i)) & ((1 << 29) - 1) for i in range(13)] + [m >> (29 * 13)]
+        assert hosttest.h64_from_fe29(limbs) == x * (1 << 384) % p
