@@ -343,24 +343,29 @@ hipError_t ntt_build_table(int n, const uint32_t* d_omega, uint32_t* d_small, ui
   return hipGetLastError();
 }
 
-// Stage groups, lowest first: the lowest covers up to 10 stages on contiguous 2^T tiles, the rest
-// are split evenly into groups of at most 8 stages on 2^T x 4 tiles.
+// Stage groups, lowest first: the lowest covers up to t0max (10) stages on contiguous 2^T tiles, the others up to tmax (8)
+// on 2^T x 4 tiles.  The stages are spread evenly over the fewest passes that hold them (12 = 6 + 6, not 10 + 2: a
+// 2-stage pass runs tiles of 16 elements on 64-thread blocks).
 int ntt_plan(int n, int (&s_lo)[8], int (&T)[8], int t0max = 10, int tmax = 8) {
   if (n == 0) return 0;
-  int np = 0;
-  const int t0 = n < t0max ? n : t0max;
-  s_lo[np] = 1;
-  T[np++] = t0;
+  int np = 1;
+  if (n > t0max) np = 1 + (n - t0max + tmax - 1) / tmax;
+  int t0 = (n + np - 1) / np;  // even share, within the lowest pass's limit
+  if (t0 > t0max) t0 = t0max;
+  if (n - t0 > (np - 1) * tmax) t0 = n - (np - 1) * tmax;
+  int cnt = 0;
+  s_lo[cnt] = 1;
+  T[cnt++] = t0;
   int rem = n - t0, s = t0 + 1;
-  const int groups = (rem + tmax - 1) / tmax;
+  const int groups = np - 1;
   for (int g = 0; g < groups; g++) {
     int t = (rem + (groups - g) - 1) / (groups - g);
-    s_lo[np] = s;
-    T[np++] = t;
+    s_lo[cnt] = s;
+    T[cnt++] = t;
     s += t;
     rem -= t;
   }
-  return np;
+  return cnt;
 }
 
 // The passes of one transform in execution order.  flags: bit 0 inverse, bit 1 brpInput, bit 2 brpOutput.
