@@ -200,6 +200,15 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
 int ncg_msm_plan_info(int curve, size_t n, int* out4);
 int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev,
                 const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream);
+/* Diagnostics of the MSM pipeline on one context.  ncg_msm_set_tuning overrides two internals that decide HOW buckets are
+ * cut, never the result: `seg` = sorted entries per accumulate lane (lane boundaries cut buckets into pieces), `run_serial`
+ * = how many following pieces the owner of a cut bucket adds itself before the run goes to the long-run work list
+ * (k_msm_fixup_long); seg <= 0 / run_serial < 0 restore the measured defaults.  ncg_msm_last_plan reports what the last MSM
+ * launch on the context ran with: out8 = {window bits c, windows run, buckets per window, first window, windows of the whole
+ * plan, seg, run_serial, runs that went to the work list}; it synchronises the device.  (tests/test_gpu_msm.py uses the pair
+ * to cut buckets in every possible way and to prove that the requested cut was the one executed.) */
+int ncg_msm_set_tuning(ncg_ctx* ctx, int seg, int run_serial);
+int ncg_msm_last_plan(ncg_ctx* ctx, int* out8);
 
 /* ---- resident point sets --------------------------------------------------------------------
  * Upload a point set once, multiply many times with only the scalars crossing - the usage pattern of
@@ -278,8 +287,10 @@ int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max,
                         uint8_t* out_is_inf, void* stream);
 /* The same sharded MSM with a HOST-STAGED exchange, for transports other than RCCL (gloo, MPI, sockets; also how
  * two ranks sharing one GPU are tested): ncg_msm_shard_local_dev runs this rank's per-shard phase and writes its
- * slot - a 16-byte header (window plan) + the grouped window sums, ncg_msm_shard_slot_bytes(curve) bytes, zero
- * padded - to host memory; the caller gathers the slots of all ranks (rank order) and any rank calls
+ * slot - a 32-byte header (window plan, window range, mode, scalar-range verdict) + the grouped window sums,
+ * ncg_msm_shard_slot_bytes(curve) bytes, zero padded - to host memory; a scalar outside the group order does NOT fail
+ * this call: the verdict travels in the header and fails ncg_msm_shard_combine on EVERY rank (so no rank leaves the
+ * exchange early); the caller gathers the slots of all ranks (rank order) and any rank calls
  * ncg_msm_shard_combine on the concatenation: upload, header check, adding kernel, finish - the code
  * ncg_msm_sharded_dev runs after its all-gather.  n_max as above (the same value on every rank and in combine). */
 size_t ncg_msm_shard_slot_bytes(int curve);
@@ -287,6 +298,44 @@ int ncg_msm_shard_local_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_ma
                             const void* scalars_dev, void* slot_out, void* stream);
 int ncg_msm_shard_combine(ncg_ctx* ctx, int curve, size_t n_max, int nparts, const void* slots, void* out_affine,
                           uint8_t* out_is_inf, void* stream);
+/* WINDOW-sharded mode (strong scaling of ONE MSM; round 4).  pippenger's windows are independent until its final
+ * double-and-add chain (src/abstract/curve.ts:886-902), so when every rank holds ALL n points and scalars - a replicated
+ * array, or a resident set uploaded on every GPU (the fixed bases of a prover) - rank r of G runs only a contiguous range of
+ * the windows (2 of 16 at G = 8 for 2^20 bls12-381 G1 points): digits, sort, accumulate and the throughput part of the
+ * bucket fold all divide by G, where point sharding leaves every rank the full fold and tail.  The slots hold the ranks'
+ * grouped window sums; they are CONCATENATED (no group additions) and every rank runs the Horner chain.  On a
+ * precomputed resident set (ncg_points_precompute) the rank's windows add into ONE bucket set and the slots are added.
+ * Pass points_affine_dev (n points, device) or `resident` (then curve / n / points_affine_dev are ignored); scalars_dev:
+ * all n scalars.  Collective over the context's communicator like ncg_msm_sharded_dev; without one it is a single-GPU MSM.
+ * Host-staged twin: ncg_msm_shard_windows_local_dev (part r of nparts) -> any all-gather -> ncg_msm_shard_combine (which
+ * reads the mode from the slot headers). */
+int ncg_msm_sharded_windows_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev, const ncg_points* resident,
+                                const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream);
+int ncg_msm_shard_windows_local_dev(ncg_ctx* ctx, int curve, size_t n, int part, int nparts, const void* points_affine_dev,
+                                    const ncg_points* resident, const void* scalars_dev, void* slot_out, void* stream);
+/* the window-sharded pipeline on ONE GPU: the parts run in turn, then the same concatenation / finish */
+int ncg_msm_split_windows_dev(ncg_ctx* ctx, int curve, size_t n, int parts, const void* points_affine_dev,
+                              const ncg_points* resident, const void* scalars_dev, void* out_affine, uint8_t* out_is_inf,
+                              void* stream);
+/* Several MSMs in flight (round 4).  A context has ncg_msm_async_lanes() lanes; each owns a stream, a workspace and a
+ * pinned landing area.  ncg_msm_async_submit enqueues one MSM on a lane and returns at once (`stream`, if given, is the
+ * stream the inputs were produced on; the lane waits for it); ncg_msm_async_collect waits for that MSM, runs the host
+ * finish and frees the lane.  Used in turn, the lanes overlap the dependent tail of one MSM (narrow fold levels, per-window
+ * tail, D2H, host Horner: latency, not throughput) with the sort / accumulate kernels of the next - the steady-state time
+ * per MSM is the throughput part alone.  Points: device array or `resident` (as above).  flags: NCG_MSM_ASYNC_WINDOWS =
+ * window-sharded over the context's communicator (collective: all ranks submit / collect the same lanes in the same order).
+ * Errors of the MSM itself (scalar outside the group order, plans that disagree) are reported by collect. */
+#define NCG_MSM_ASYNC_WINDOWS 1
+/* ONE part of a window-sharded MSM on a lane (part p of P, no communicator): its slot comes back through
+ * ncg_msm_async_collect_slot and goes, with the other parts' slots, to ncg_msm_shard_combine.  This is the host-staged
+ * exchange with several parts in flight - and how one GPU measures a rank's share of a G-GPU MSM (bench.py). */
+#define NCG_MSM_ASYNC_PART_FLAG 2
+#define NCG_MSM_ASYNC_PART(p, P) (NCG_MSM_ASYNC_PART_FLAG | ((p) << 8) | ((P) << 20))
+int ncg_msm_async_collect_slot(ncg_ctx* ctx, int lane, void* slot_out);
+int ncg_msm_async_lanes(void);
+int ncg_msm_async_submit(ncg_ctx* ctx, int lane, int curve, size_t n, const void* points_affine_dev, const ncg_points* resident,
+                         const void* scalars_dev, int flags, void* stream);
+int ncg_msm_async_collect(ncg_ctx* ctx, int lane, void* out_affine, uint8_t* out_is_inf);
 /* The sharded pipeline on ONE GPU (self-check, shard-plan A/B): the points are cut into `parts` slices,
  * each runs the per-shard phase in turn, the slices' window sums go through the multi-GPU combine kernel
  * and finish - everything of ncg_msm_sharded_dev except the all-gather. */

@@ -144,6 +144,14 @@ _OPTIONAL_PROTOS = {
     "ncg_msm_split_dev": [_vp, _i32, _sz, _i32, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_msm_shard_local_dev": [_vp, _i32, _sz, _sz, _vp, _vp, _vp, _vp],
     "ncg_msm_shard_combine": [_vp, _i32, _sz, _i32, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
+    "ncg_msm_sharded_windows_dev": [_vp, _i32, _sz, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
+    "ncg_msm_shard_windows_local_dev": [_vp, _i32, _sz, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "ncg_msm_split_windows_dev": [_vp, _i32, _sz, _i32, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
+    "ncg_msm_async_submit": [_vp, _i32, _i32, _sz, _vp, _vp, _vp, _i32, _vp],
+    "ncg_msm_async_collect": [_vp, _i32, _vp, ctypes.POINTER(ctypes.c_uint8)],
+    "ncg_msm_async_collect_slot": [_vp, _i32, _vp],
+    "ncg_msm_set_tuning": [_vp, _i32, _i32],
+    "ncg_msm_last_plan": [_vp, ctypes.POINTER(ctypes.c_int)],
     "ncg_multi_init": [ctypes.POINTER(_i32), _i32, ctypes.POINTER(_vp)],
     "ncg_multi_devices": [_vp],
     "ncg_msm_multi": [_vp, _i32, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8)],
@@ -420,6 +428,76 @@ class Engine:
         self._check(self.lib.ncg_msm_split_dev(self.h, curve, n, parts, d_points, d_scalars, out.ctypes.data,
                                                ctypes.byref(inf), stream))
         return out, bool(inf.value)
+
+    # ---- window-sharded MSM (include/ncg.h "WINDOW-sharded mode"): every rank holds all points and scalars ----
+    @staticmethod
+    def _res_handle(resident):
+        return resident.h if resident is not None else None
+
+    def msm_sharded_windows_dev(self, curve, n, d_points, d_scalars, stream=None, resident=None):
+        """Collective: rank r runs its range of the windows of ONE n-point MSM; the slots are concatenated (precomputed
+        sets: added).  `resident`: a ResidentPoints of this engine instead of d_points."""
+        pb = POINT_BYTES[resident.curve if resident is not None else curve]
+        out = np.zeros((pb,), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self._check(self.lib.ncg_msm_sharded_windows_dev(self.h, curve, n, d_points, self._res_handle(resident), d_scalars,
+                                                         out.ctypes.data, ctypes.byref(inf), stream))
+        return out, bool(inf.value)
+
+    def msm_shard_windows_local_dev(self, curve, n, part, nparts, d_points, d_scalars, stream=None, resident=None):
+        """Part `part` of `nparts` of a window-sharded MSM with a host-staged exchange: the slot as a uint8 array."""
+        c = resident.curve if resident is not None else curve
+        slot = np.zeros((self.msm_shard_slot_bytes(c),), dtype=np.uint8)
+        self._check(self.lib.ncg_msm_shard_windows_local_dev(self.h, curve, n, part, nparts, d_points, self._res_handle(resident),
+                                                             d_scalars, slot.ctypes.data, stream))
+        return slot
+
+    def msm_split_windows_dev(self, curve, n, parts, d_points, d_scalars, stream=None, resident=None):
+        """The window-sharded pipeline on this one GPU: the parts in turn, then the concatenation / finish."""
+        pb = POINT_BYTES[resident.curve if resident is not None else curve]
+        out = np.zeros((pb,), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self._check(self.lib.ncg_msm_split_windows_dev(self.h, curve, n, parts, d_points, self._res_handle(resident), d_scalars,
+                                                       out.ctypes.data, ctypes.byref(inf), stream))
+        return out, bool(inf.value)
+
+    # ---- several MSMs in flight (include/ncg.h "Several MSMs in flight") --------------------------------------
+    ASYNC_WINDOWS = 1
+
+    def msm_async_lanes(self):
+        fn = self.lib.ncg_msm_async_lanes
+        fn.argtypes, fn.restype = [], ctypes.c_int
+        return int(fn())
+
+    def msm_async_submit(self, lane, curve, n, d_points, d_scalars, stream=None, resident=None, flags=0):
+        self._check(self.lib.ncg_msm_async_submit(self.h, lane, curve, n, d_points, self._res_handle(resident), d_scalars, flags, stream))
+
+    def msm_async_collect(self, lane, curve):
+        pb = POINT_BYTES[curve]
+        out = np.zeros((pb,), dtype=np.uint8)
+        inf = ctypes.c_uint8(0)
+        self._check(self.lib.ncg_msm_async_collect(self.h, lane, out.ctypes.data, ctypes.byref(inf)))
+        return out, bool(inf.value)
+
+    @staticmethod
+    def async_part(part, nparts):
+        """flags for msm_async_submit: ONE part of a window-sharded MSM (NCG_MSM_ASYNC_PART)."""
+        return 2 | (part << 8) | (nparts << 20)
+
+    def msm_async_collect_slot(self, lane, curve):
+        slot = np.zeros((self.msm_shard_slot_bytes(curve),), dtype=np.uint8)
+        self._check(self.lib.ncg_msm_async_collect_slot(self.h, lane, slot.ctypes.data))
+        return slot
+
+    def msm_set_tuning(self, seg=0, run_serial=-1):
+        """Diagnostics: entries per accumulate lane / serial pieces per cut bucket (0 / -1 = defaults)."""
+        self._check(self.lib.ncg_msm_set_tuning(self.h, seg, run_serial))
+
+    def msm_last_plan(self):
+        out = (ctypes.c_int * 8)()
+        self._check(self.lib.ncg_msm_last_plan(self.h, out))
+        keys = ("c", "nwin", "nb", "w0", "nwin_total", "seg", "run_serial", "long_runs")
+        return dict(zip(keys, [int(v) for v in out]))
 
     # ---- ed25519 batch verify --------------------------------------------------------------------
     def ed25519_verify_batch(self, sigs, pks, ks, zip215=True):

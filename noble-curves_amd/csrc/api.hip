@@ -76,26 +76,43 @@ static int ensure_scratch(ncg_ctx* ctx, size_t bytes) {
 }
 
 // window plan for an n-point MSM (c_override > 0 fixes the window width) and a workspace big enough for it
-static int msm_ensure_ws(ncg_ctx* ctx, int curve, const ncg::MsmPlan& pl);
+static int msm_ensure_ws(ncg_ctx* ctx, int curve, ncg::MsmPlan& pl);
 int ncg_msm_plan_ws(ncg_ctx* ctx, int curve, size_t n, int c_override, ncg::MsmPlan* pl) {
   if (ncg::msm_make_plan(curve, (int)n, c_override, pl) != 0)
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
   return msm_ensure_ws(ctx, curve, *pl);
 }
-static int msm_ensure_ws(ncg_ctx* ctx, int curve, const ncg::MsmPlan& pl_ref) {
-  const ncg::MsmPlan* pl = &pl_ref;
-  size_t need = ncg::msm_workspace_bytes(curve, *pl);
-  if (ctx->msm_ws_bytes < need) {
-    if (ctx->msm_ws) (void)hipFree(ctx->msm_ws);
-    ctx->msm_ws = nullptr;
-    ctx->msm_ws_bytes = 0;
-    hipError_t e = hipMalloc(&ctx->msm_ws, need);
+// the context's tuning overrides and trace slot go into the plan (every MSM entry point passes through here or
+// through ncg_msm_ensure_buf), then the workspace grows if the plan needs more
+static void msm_apply_ctx(ncg_ctx* ctx, ncg::MsmPlan& pl) {
+  pl.seg_override = ctx->msm_seg_override;
+  pl.run_serial_override = ctx->msm_run_serial_override;
+  pl.trace = &ctx->msm_trace;
+}
+int ncg_msm_ensure_buf(ncg_ctx* ctx, int curve, ncg::MsmPlan& pl, void** ws, size_t* ws_bytes) {
+  msm_apply_ctx(ctx, pl);
+  size_t need = ncg::msm_workspace_bytes(curve, pl);
+  if (*ws_bytes < need) {
+    if (*ws) (void)hipFree(*ws);
+    *ws = nullptr;
+    *ws_bytes = 0;
+    hipError_t e = hipMalloc(ws, need);
     if (e != hipSuccess)
       return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: msm workspace hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
-    ctx->msm_ws_bytes = need;
+    *ws_bytes = need;
   }
   return NCG_OK;
 }
+static int msm_ensure_ws(ncg_ctx* ctx, int curve, ncg::MsmPlan& pl) { return ncg_msm_ensure_buf(ctx, curve, pl, &ctx->msm_ws, &ctx->msm_ws_bytes); }
+int ncg_msm_plan_ws_windows(ncg_ctx* ctx, int curve, size_t n, int w0, int cnt, ncg::MsmPlan* pl, void** ws, size_t* ws_bytes) {
+  if (ncg::msm_make_plan(curve, (int)n, 0, pl) != 0)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+  if (w0 < 0 || cnt < 0 || w0 + cnt > pl->nwin) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: window range outside the plan");
+  ncg::msm_plan_take_windows(*pl, w0, cnt);
+  return ncg_msm_ensure_buf(ctx, curve, *pl, ws ? ws : &ctx->msm_ws, ws_bytes ? ws_bytes : &ctx->msm_ws_bytes);
+}
+// device buffers are read with 16-byte accesses (ncg.h "Conventions"): refuse a misaligned pointer instead of faulting
+static inline bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 
 // only the C ABI of include/ncg.h is exported (the objects are built with -fvisibility=hidden)
 #pragma GCC visibility push(default)
@@ -132,7 +149,7 @@ int ncg_init(int device_id, ncg_ctx** out_ctx) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->msm_side.join, hipEventDisableTiming);
   if (e != hipSuccess) {
     int rc = set_err(nullptr, NCG_ERR_HIP, "noble-gpu: cannot create stream on device %d: %s", device_id, hipGetErrorString(e));
-    delete ctx;
+    ncg_destroy(ctx);  // releases whichever streams / events were created before the failure
     return rc;
   }
   *out_ctx = ctx;
@@ -157,6 +174,19 @@ void ncg_destroy(ncg_ctx* ctx) {
   if (ctx->ntt_ws) (void)hipFree(ctx->ntt_ws);
   (void)ncg_comm_destroy(ctx);
   if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
+  if (ctx->sync_land) (void)hipHostFree(ctx->sync_land);
+  for (ncg_msm_lane& ln : ctx->lanes) {
+    if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+    if (ln.ws) (void)hipFree(ln.ws);
+    if (ln.comm_buf) (void)hipFree(ln.comm_buf);
+    if (ln.land) (void)hipHostFree(ln.land);
+    if (ln.done) (void)hipEventDestroy(ln.done);
+    if (ln.input_ready) (void)hipEventDestroy(ln.input_ready);
+    if (ln.side.fork) (void)hipEventDestroy(ln.side.fork);
+    if (ln.side.join) (void)hipEventDestroy(ln.side.join);
+    if (ln.side.stream) (void)hipStreamDestroy(ln.side.stream);
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
+  }
   if (ctx->msm_side.fork) (void)hipEventDestroy(ctx->msm_side.fork);
   if (ctx->msm_side.join) (void)hipEventDestroy(ctx->msm_side.join);
   if (ctx->msm_side.stream) (void)hipStreamDestroy(ctx->msm_side.stream);
@@ -369,6 +399,30 @@ int ncg_msm_plan_info(int curve, size_t n, int* out4) {
   return NCG_OK;
 }
 
+// Tuning overrides of the MSM on this context (diagnostics / tests: the lane segment decides how the accumulate kernel
+// cuts buckets, run_serial which cut buckets go to the long-run work list).  seg <= 0 and run_serial < 0 restore the defaults.
+int ncg_msm_set_tuning(ncg_ctx* ctx, int seg, int run_serial) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (seg > (1 << 24) || run_serial > (1 << 24)) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_set_tuning: value out of range");
+  ctx->msm_seg_override = seg > 0 ? seg : 0;
+  ctx->msm_run_serial_override = run_serial >= 0 ? run_serial : -1;
+  return NCG_OK;
+}
+// What the last MSM launch on this context ran with: out8 = {c, local windows, buckets per window, first window, windows of
+// the whole plan, entries per accumulate lane (seg), run_serial, runs that went to the long-run work list}.  Synchronises.
+int ncg_msm_last_plan(ncg_ctx* ctx, int* out8) {
+  if (!ctx || !out8) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_last_plan: NULL argument");
+  const ncg::MsmTrace& tr = ctx->msm_trace;
+  if (tr.c == 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_last_plan: no MSM has run on this context");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  NCG_HIP(ctx, hipDeviceSynchronize());
+  uint32_t runs = 0;
+  if (tr.d_long_runs) NCG_HIP(ctx, hipMemcpy(&runs, tr.d_long_runs, 4, hipMemcpyDeviceToHost));
+  out8[0] = tr.c; out8[1] = tr.nwin; out8[2] = tr.nb; out8[3] = tr.w0; out8[4] = tr.nwin_total;
+  out8[5] = tr.seg; out8[6] = tr.run_serial; out8[7] = (int)runs;
+  return NCG_OK;
+}
+
 int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev, const void* scalars_dev,
                 void* out_affine, uint8_t* out_is_inf, void* stream) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
@@ -384,6 +438,8 @@ int ncg_msm_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev
   }
   if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: too many points");
   if (!points_affine_dev || !scalars_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: NULL buffer");
+  if (misaligned16(points_affine_dev) || misaligned16(scalars_dev))
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: device buffers must be 16-byte aligned");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   ncg::MsmPlan pl;
   int prc = ncg_msm_plan_ws(ctx, curve, n, 0, &pl);
@@ -419,19 +475,6 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
 
 // ---- resident point sets: upload once, multiply many (interleavedMSMUnsafe's usage pattern,
 // src/abstract/curve.ts:907-959; SURVEY 8a gotcha 8: marshalling dominates an end-to-end call)
-struct ncg_points {
-  ncg_ctx* ctx;
-  int curve;
-  size_t n;
-  void* d_pts;
-  void* d_endo = nullptr;  // endomorphism images (msm_endo_expand) once the set is known to lie in the subgroup
-  void* d_stored = nullptr;  // the points in the accumulate kernel's storage format (built at the first generic MSM)
-  // window-shifted copies for the shared-bucket MSM (ncg_points_precompute, msm_precomp.hip): shift_nwin levels of
-  // shift_m stored points; shift_mode 1 = levels of the points themselves, 2 = of the endomorphism images
-  void* d_shift = nullptr;
-  int shift_c = 0, shift_nwin = 0, shift_mode = 0;
-  size_t shift_m = 0;
-};
 
 // The point of a resident set (curve.ts:907-918: precompute once, call with scalars): the wire -> storage
 // conversion of the points is paid at the first MSM, every later call starts at the digits.
@@ -615,6 +658,8 @@ int ncg_points_verify_subgroup(ncg_ctx* ctx, ncg_points* h, int64_t* out_bad_ind
 int ncg_points_precompute(ncg_ctx* ctx, ncg_points* h) {
   if (!ctx || !h || h->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: points_precompute: handle does not belong to this context");
   if (h->d_shift || h->n < 4096 || h->curve == NCG_ED25519) return NCG_OK;
+  static const bool no_shift = ncg::knob_set("NCG_NO_PRECOMP");
+  if (no_shift) return NCG_OK;  // the levels would never be used: pay neither the build nor the memory
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   static const bool no_endo = ncg::knob_set("NCG_NO_ENDO");
   const bool endo = h->d_endo && !no_endo;
@@ -630,6 +675,11 @@ int ncg_points_precompute(ncg_ctx* ctx, ncg_points* h) {
     if (!h->d_stored) return NCG_OK;
   }
   void *d = nullptr, *tmp = nullptr;
+  {  // the levels are nwin copies of the set: leave room for the MSM workspace and whatever else the process allocates
+    size_t free_b = 0, total_b = 0;
+    const size_t want = m * (size_t)pl.nwin * sw * 4 + ncg::msm_shift_tmp_bytes(h->curve, (int)m);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) return NCG_OK;  // keep the per-window path
+  }
   hipError_t e = hipMalloc(&d, m * (size_t)pl.nwin * sw * 4);
   if (e == hipSuccess) e = hipMalloc(&tmp, ncg::msm_shift_tmp_bytes(h->curve, (int)m));
   if (e != hipSuccess) {  // not fatal: the set keeps the per-window path
@@ -644,6 +694,10 @@ int ncg_points_precompute(ncg_ctx* ctx, ncg_points* h) {
   if (e != hipSuccess) {
     (void)hipFree(d);
     return set_err(ctx, NCG_ERR_HIP, "noble-gpu: points_precompute: %s", hipGetErrorString(e));
+  }
+  if (!endo && h->d_stored) {  // level 0 of the copies IS the stored set: the separate array is a duplicate now
+    (void)hipFree(h->d_stored);
+    h->d_stored = nullptr;
   }
   h->d_shift = d;
   h->shift_c = pl.c;
@@ -678,66 +732,68 @@ static int upload_scalars(ncg_ctx* ctx, PinSet& pins, size_t n, const void* scal
   return NCG_OK;
 }
 
-// MSM on a resident set with the scalars already on the device
-static int msm_resident_core(ncg_ctx* ctx, const ncg_points* pts, const void* d_sc, void* out_affine, uint8_t* out_is_inf,
-                             hipStream_t st) {
+}  // extern "C"
+#pragma GCC visibility pop
+// Which window plan and which device point array an MSM on a resident set uses: the precomputed levels (shared-bucket
+// mode), the endomorphism images of a verified set, the stored form of the points, or - if that cache could not be
+// allocated - the wire points.  The stored form is built on first use (on `st`).
+int ncg_resident_plan(ncg_ctx* ctx, const ncg_points* pts, ncg::MsmPlan* pl, const uint32_t** d_pts, hipStream_t st) {
   static const bool no_endo = ncg::knob_set("NCG_NO_ENDO");
   static const bool no_shift = ncg::knob_set("NCG_NO_PRECOMP");
   if (pts->d_shift && !no_shift) {  // precomputed set: every window adds into one bucket set (msm.hpp `shared`)
-    ncg::MsmPlan pl;
-    const int prc = pts->shift_mode == 2 ? ncg::msm_make_plan_endo(pts->curve, (int)pts->n, pts->shift_c, &pl)
-                                         : ncg::msm_make_plan(pts->curve, (int)pts->n, pts->shift_c, &pl);
-    if (prc != 0 || pl.nwin != pts->shift_nwin || (size_t)pl.n != pts->shift_m)
+    const int prc = pts->shift_mode == 2 ? ncg::msm_make_plan_endo(pts->curve, (int)pts->n, pts->shift_c, pl)
+                                         : ncg::msm_make_plan(pts->curve, (int)pts->n, pts->shift_c, pl);
+    if (prc != 0 || pl->nwin != pts->shift_nwin || (size_t)pl->n != pts->shift_m)
       return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: the precomputed levels do not match the window plan");
-    pl.shared = 1;
-    pl.pts_stored = 1;
-    int rc = msm_ensure_ws(ctx, pts->curve, pl);
-    if (rc) return rc;
-    uint32_t bad = 0xFFFFFFFFu;
-    uint8_t inf_local = 0;
-    NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, (const uint32_t*)pts->d_shift, (const uint32_t*)d_sc, ctx->msm_ws,
-                              (uint32_t*)out_affine, &inf_local, st, &bad));
-    if (bad != 0xFFFFFFFFu)
-      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
-    if (out_is_inf) *out_is_inf = inf_local;
+    pl->shared = 1;
+    pl->pts_stored = 1;
+    *d_pts = (const uint32_t*)pts->d_shift;
     return NCG_OK;
   }
   if (pts->d_endo && !no_endo) {  // verified subgroup set: endomorphism MSM on the expanded images (endo.hpp)
-    ncg::MsmPlan pl;
-    if (ncg::msm_make_plan_endo(pts->curve, (int)pts->n, 0, &pl) != 0)
+    if (ncg::msm_make_plan_endo(pts->curve, (int)pts->n, 0, pl) != 0)
       return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
-    int rc = msm_ensure_ws(ctx, pts->curve, pl);
-    if (rc) return rc;
-    uint32_t bad = 0xFFFFFFFFu;
-    uint8_t inf_local = 0;
-    NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, (const uint32_t*)pts->d_endo, (const uint32_t*)d_sc, ctx->msm_ws,
-                              (uint32_t*)out_affine, &inf_local, st, &bad));
-    if (bad != 0xFFFFFFFFu)
-      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
-    if (out_is_inf) *out_is_inf = inf_local;
+    *d_pts = (const uint32_t*)pts->d_endo;
     return NCG_OK;
   }
-  if (pts->n <= 0x7fffffffu) {
-    int rc = points_build_stored(ctx, const_cast<ncg_points*>(pts), st);  // a cache inside the handle
-    if (rc) return rc;
+  if (ncg::msm_make_plan(pts->curve, (int)pts->n, 0, pl) != 0)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+  if (pts->d_shift && pts->shift_mode == 1) {  // level 0 of the copies is the stored set
+    pl->pts_stored = 1;
+    *d_pts = (const uint32_t*)pts->d_shift;
+    return NCG_OK;
   }
+  int rc = points_build_stored(ctx, const_cast<ncg_points*>(pts), st);  // a cache inside the handle
+  if (rc) return rc;
   if (pts->d_stored) {
-    ncg::MsmPlan pl;
-    if (ncg::msm_make_plan(pts->curve, (int)pts->n, 0, &pl) != 0)
-      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
-    pl.pts_stored = 1;
-    int rc = msm_ensure_ws(ctx, pts->curve, pl);
-    if (rc) return rc;
-    uint32_t bad = 0xFFFFFFFFu;
-    uint8_t inf_local = 0;
-    NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, (const uint32_t*)pts->d_stored, (const uint32_t*)d_sc, ctx->msm_ws,
-                              (uint32_t*)out_affine, &inf_local, st, &bad));
-    if (bad != 0xFFFFFFFFu)
-      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
-    if (out_is_inf) *out_is_inf = inf_local;
-    return NCG_OK;
+    pl->pts_stored = 1;
+    *d_pts = (const uint32_t*)pts->d_stored;
+  } else {
+    *d_pts = (const uint32_t*)pts->d_pts;  // wire points: converted per call
   }
-  return ncg_msm_dev(ctx, pts->curve, pts->n, pts->d_pts, d_sc, out_affine, out_is_inf, st);
+  return NCG_OK;
+}
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+// MSM on a resident set with the scalars already on the device
+static int msm_resident_core(ncg_ctx* ctx, const ncg_points* pts, const void* d_sc, void* out_affine, uint8_t* out_is_inf,
+                             hipStream_t st) {
+  ncg::MsmPlan pl;
+  const uint32_t* d_pts = nullptr;
+  int rc = ncg_resident_plan(ctx, pts, &pl, &d_pts, st);
+  if (rc) return rc;
+  rc = msm_ensure_ws(ctx, pts->curve, pl);
+  if (rc) return rc;
+  uint32_t bad = 0xFFFFFFFFu;
+  uint8_t inf_local = 0;
+  NCG_HIP(ctx, ncg::msm_run(pts->curve, pl, d_pts, (const uint32_t*)d_sc, ctx->msm_ws, (uint32_t*)out_affine, &inf_local, st, &bad,
+                            pl.pts_stored || pl.endo ? nullptr : &ctx->msm_side));
+  if (bad != 0xFFFFFFFFu)
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
+  if (out_is_inf) *out_is_inf = inf_local;
+  return NCG_OK;
 }
 
 int ncg_msm_resident(ncg_ctx* ctx, const ncg_points* pts, const void* scalars, void* out_affine, uint8_t* out_is_inf) {
@@ -757,6 +813,7 @@ int ncg_msm_resident_dev(ncg_ctx* ctx, const ncg_points* pts, const void* scalar
   if (!ctx || !pts || pts->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_resident: handle does not belong to this context");
   if (pts->n == 0) return ncg_msm_dev(ctx, pts->curve, 0, nullptr, nullptr, out_affine, out_is_inf, nullptr);
   if (!scalars_dev || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_resident: NULL buffer");
+  if (misaligned16(scalars_dev)) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_resident: device buffers must be 16-byte aligned");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   return msm_resident_core(ctx, pts, scalars_dev, out_affine, out_is_inf, stream ? (hipStream_t)stream : ctx->stream);
 }

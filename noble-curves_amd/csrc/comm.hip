@@ -91,83 +91,191 @@ const Rccl* rccl() {
     }                                                                                         \
   } while (0)
 
-int ensure_comm_buf(ncg_ctx* ctx, size_t bytes) {
-  if (ctx->comm_buf_bytes >= bytes) return NCG_OK;
-  if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
-  ctx->comm_buf = nullptr;
-  ctx->comm_buf_bytes = 0;
-  hipError_t e = hipMalloc(&ctx->comm_buf, bytes);
+// ---- one sharded MSM job on one rank ----------------------------------------------------------------------------
+// The resources a job runs on: the context's own (synchronous entry points, caller's stream) or one of its lanes
+// (asynchronous entry points: several MSMs in flight).
+struct JobRes {
+  hipStream_t st;
+  const ncg::MsmSide* side;
+  void** ws;
+  size_t* ws_bytes;
+  void** comm_buf;       // device: nparts slots, then the packed payloads + their sum (point / shared modes)
+  size_t* comm_buf_bytes;
+  uint32_t** land;       // pinned host: the gathered slots, then the summed payload
+  size_t* land_words;
+};
+// what finish needs to know about an enqueued job
+struct JobState {
+  int curve = 0, nparts = 1;
+  uint32_t mode = ncg::SHARD_POINTS;
+  int c = 0, nwin = 0;   // the WHOLE plan
+  size_t stride = 0, sum_words = 0;
+  bool identity = false;  // nothing to do: the result is the identity (curve.ts:878)
+};
+struct ShardJob {
+  int curve = 0;
+  uint32_t mode = ncg::SHARD_POINTS;
+  size_t n_local = 0, n_plan = 0;      // SHARD_POINTS: this rank's slice and the largest slice of any rank; window modes: n both
+  const void* d_pts = nullptr;         // device wire points (or NULL with `resident`)
+  const ncg_points* resident = nullptr;
+  const void* d_sc = nullptr;
+  int part = 0, nparts = 1;            // this rank's place in the exchange
+};
+
+int ensure_dev_buf(ncg_ctx* ctx, void** p, size_t* have, size_t bytes) {
+  if (*have >= bytes) return NCG_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *have = 0;
+  hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-  ctx->comm_buf_bytes = bytes;
+  *have = bytes;
   return NCG_OK;
 }
+int ensure_land(ncg_ctx* ctx, uint32_t** p, size_t* have_words, size_t words) {
+  if (*have_words >= words) return NCG_OK;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  *have_words = 0;
+  hipError_t e = hipHostMalloc((void**)p, words * 4, hipHostMallocPortable);
+  if (e != hipSuccess) return set_err(ctx, NCG_ERR_NOMEM, "noble-gpu: hipHostMalloc(%zu) failed: %s", words * 4, hipGetErrorString(e));
+  *have_words = words;
+  return NCG_OK;
+}
+size_t comm_buf_need(size_t stride, size_t fin_words, int nparts) {
+  return stride * (size_t)nparts + ((size_t)nparts + 1) * fin_words * 4 + 256;
+}
 
-// Window plan shared by all shards of one MSM: every rank must cut the same windows, so the width is
-// chosen for the LARGEST shard (the caller passes it) - which also re-tunes c for the shard size:
-// the bucket fold costs ~2^c per window whatever the shard holds.  Slot format: msm_shard.hpp.
-size_t comm_buf_need(size_t stride, size_t fin_words, int nparts);
-
-// this rank's contribution = header + grouped window sums, written at comm_buf + rank * stride
-int local_phase(ncg_ctx* ctx, int curve, size_t n_local, size_t n_plan, const void* d_pts, const void* d_sc, int slot,
-                int nslots, ncg::MsmPlan* pl_out, size_t* stride_out, hipStream_t st, const uint32_t** d_bad_out = nullptr) {
-  if (d_bad_out) *d_bad_out = nullptr;
-  ncg::MsmPlan pl;
-  int rc = ncg_msm_plan_ws(ctx, curve, n_plan, 0, &pl);
+// This rank's part: header + grouped window sums into slot `slot_idx` of the gather buffer.  Returns the whole plan.
+// Window plan shared by all ranks of one MSM: every rank must cut the same windows, so in SHARD_POINTS the width is chosen
+// for the LARGEST slice (the caller passes it) - which also re-tunes c for the slice size: the bucket fold costs ~2^c per
+// window whatever the slice holds; in the window modes every rank holds all n points and derives the same plan.
+int job_local_phase(ncg_ctx* ctx, const JobRes& R, const ShardJob& J, int slot_idx, int nslots, JobState* S) {
+  const int curve = J.curve;
+  ncg::MsmPlan whole, local;
+  const uint32_t* d_pts = (const uint32_t*)J.d_pts;
+  uint32_t mode = J.mode;
+  int rc;
+  if (J.resident) {
+    rc = ncg_resident_plan(ctx, J.resident, &whole, &d_pts, R.st);
+    if (rc) return rc;
+    if (whole.shared && mode == ncg::SHARD_WINDOWS) mode = ncg::SHARD_WINDOWS_SHARED;
+  } else {
+    if (ncg::msm_make_plan(curve, (int)J.n_plan, 0, &whole) != 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+  }
+  local = whole;
+  int w0 = 0, cnt = whole.nwin;
+  if (mode == ncg::SHARD_POINTS) {
+    if (J.n_local != J.n_plan && J.n_local > 0) {  // same windows, this slice's size
+      if (ncg::msm_make_plan(curve, (int)J.n_local, whole.c, &local) != 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+    }
+  } else {
+    ncg::msm_shard_window_range(whole.nwin, J.part, J.nparts, &w0, &cnt);
+    ncg::msm_plan_take_windows(local, w0, cnt);
+  }
+  const size_t xw = ncg::msm_acc_words(curve);
+  const size_t ng = (size_t)ncg::msm_ngroups(whole.c);
+  const size_t fin_words = ng * (mode == ncg::SHARD_WINDOWS_SHARED ? 1 : (size_t)cnt) * xw;
+  const size_t stride = ncg::msm_shard_slot_bytes(curve);  // the same on every rank, whatever its plan
+  rc = ensure_dev_buf(ctx, R.comm_buf, R.comm_buf_bytes, comm_buf_need(stride, ncg::msm_shard_max_fin_words(curve), nslots));
   if (rc) return rc;
-  const int c = pl.c;
-  if (n_local != n_plan && n_local > 0) {
-    rc = ncg_msm_plan_ws(ctx, curve, n_local, c, &pl);  // same windows, this shard's size
+  const bool work = J.n_local > 0 && cnt > 0;
+  if (work) {
+    rc = ncg_msm_ensure_buf(ctx, curve, local, R.ws, R.ws_bytes);
     if (rc) return rc;
   }
-  const size_t fin_bytes = ncg::msm_fin_words(curve, pl) * 4;
-  const size_t stride = ncg::msm_shard_slot_bytes(curve);  // the same on every rank, whatever its plan
-  rc = ensure_comm_buf(ctx, comm_buf_need(stride, ncg::msm_shard_max_fin_words(curve), nslots));
+  char* mine = (char*)*R.comm_buf + stride * (size_t)slot_idx;
+  FinHeader h{(uint32_t)whole.c, (uint32_t)whole.nwin, (uint32_t)fin_words, (uint32_t)curve, (uint32_t)w0, (uint32_t)cnt, mode, ncg::SHARD_NO_BAD};
+  // (the header is read by the copy engine before this function's frame dies only if the source is pinned: stage it in `land`)
+  static_assert(sizeof(FinHeader) % 4 == 0, "header words");
+  rc = ensure_land(ctx, R.land, R.land_words, (stride * (size_t)nslots + ncg::msm_shard_max_fin_words(curve) * 4) / 4 + 64);
   if (rc) return rc;
-  char* mine = (char*)ctx->comm_buf + stride * (size_t)slot;
-  FinHeader h{(uint32_t)pl.c, (uint32_t)pl.nwin, (uint32_t)(fin_bytes / 4), (uint32_t)curve};
-  NCG_HIP(ctx, hipMemcpyAsync(mine, &h, sizeof h, hipMemcpyHostToDevice, st));
-  if (n_local == 0) {  // an empty shard contributes identities (all-zero accumulators decode as such)
-    NCG_HIP(ctx, hipMemsetAsync(mine + sizeof h, 0, fin_bytes, st));
+  FinHeader* hstage = (FinHeader*)(*R.land) + slot_idx;  // first bytes of the landing area; overwritten by the gather's D2H later
+  *hstage = h;
+  NCG_HIP(ctx, hipMemcpyAsync(mine, hstage, sizeof h, hipMemcpyHostToDevice, R.st));
+  if (!work) {  // an empty slice / no windows: identities (all-zero accumulators decode as such)
+    if (fin_words) NCG_HIP(ctx, hipMemsetAsync(mine + sizeof h, 0, fin_words * 4, R.st));
   } else {
     const uint32_t *d_fin = nullptr, *d_bad = nullptr;
-    NCG_HIP(ctx, ncg::msm_device_phase(curve, pl, (const uint32_t*)d_pts, (const uint32_t*)d_sc, ctx->msm_ws, &d_fin, st, &d_bad, &ctx->msm_side));
-    if (d_bad_out) *d_bad_out = d_bad;
-    NCG_HIP(ctx, hipMemcpyAsync(mine + sizeof h, d_fin, fin_bytes, hipMemcpyDeviceToDevice, st));
+    NCG_HIP(ctx, ncg::msm_device_phase(curve, local, d_pts, (const uint32_t*)J.d_sc, *R.ws, &d_fin, R.st, &d_bad,
+                                       (local.pts_stored || local.endo) ? nullptr : R.side));
+    NCG_HIP(ctx, hipMemcpyAsync(mine + sizeof h, d_fin, fin_words * 4, hipMemcpyDeviceToDevice, R.st));
+    NCG_HIP(ctx, hipMemcpyAsync(mine + offsetof(FinHeader, bad), d_bad, 4, hipMemcpyDeviceToDevice, R.st));  // the verdict travels with the slot
   }
-  *pl_out = pl;
-  *stride_out = stride;
+  S->curve = curve;
+  S->mode = mode;
+  S->c = whole.c;
+  S->nwin = whole.nwin;
+  S->stride = stride;
   return NCG_OK;
 }
 
-// after the gather: check the headers, add the nparts arrays, finish.  comm_buf layout: nparts slots of
-// `stride` bytes, then one more slot for the sum.
-int combine_and_finish(ncg_ctx* ctx, int curve, const ncg::MsmPlan& pl, size_t stride, int nparts, void* out_affine,
-                       uint8_t* out_is_inf, hipStream_t st) {
-  const size_t fin_words = ncg::msm_fin_words(curve, pl);
-  char* base = (char*)ctx->comm_buf;
-  // the headers travel to the host (checked after the stream is drained); the payloads are compacted into a
-  // contiguous [nparts][fin_words] scratch behind the slots, which the adding kernel reduces in place
+// After the gather (or with all slots written locally): what can be enqueued without looking at the data - the slots
+// travel to the host; in the adding modes the payloads are packed, summed on the device (pairwise tree, cooperative
+// additions) and the sum follows the slots.
+int job_enqueue_combine(ncg_ctx* ctx, const JobRes& R, JobState* S, int nparts) {
+  S->nparts = nparts;
+  const int curve = S->curve;
+  char* base = (char*)*R.comm_buf;
+  const size_t stride = S->stride;
+  uint32_t* land = *R.land;
+  NCG_HIP_DRAIN(ctx, R.st, hipMemcpyAsync(land, base, stride * (size_t)nparts, hipMemcpyDeviceToHost, R.st));
+  S->sum_words = 0;
+  if (S->mode != ncg::SHARD_WINDOWS) {
+    const size_t xw = ncg::msm_acc_words(curve);
+    const size_t fin_words = (size_t)ncg::msm_ngroups(S->c) * (S->mode == ncg::SHARD_WINDOWS_SHARED ? 1 : (size_t)S->nwin) * xw;
+    const uint32_t* sum = (const uint32_t*)(base + sizeof(FinHeader));
+    if (nparts > 1) {  // pack payloads: [nparts][fin_words] behind the slots (sized by comm_buf_need), reduced in place by the adding kernel
+      uint32_t* packed = (uint32_t*)(base + stride * (size_t)nparts);
+      for (int r = 0; r < nparts; r++)
+        NCG_HIP_DRAIN(ctx, R.st, hipMemcpyAsync(packed + (size_t)r * fin_words, base + stride * (size_t)r + sizeof(FinHeader), fin_words * 4,
+                                                hipMemcpyDeviceToDevice, R.st));
+      uint32_t* dsum = packed + (size_t)nparts * fin_words;
+      NCG_HIP_DRAIN(ctx, R.st, ncg::msm_sum_partials(curve, packed, nparts, fin_words / xw, dsum, R.st));
+      sum = dsum;
+    }
+    NCG_HIP_DRAIN(ctx, R.st, hipMemcpyAsync(land + stride * (size_t)nparts / 4, sum, fin_words * 4, hipMemcpyDeviceToHost, R.st));
+    S->sum_words = fin_words;
+  }
+  return NCG_OK;
+}
+
+// With the stream drained: header check, scalar verdict of all ranks, window assembly, host Horner.
+int job_finish_host(ncg_ctx* ctx, const JobRes& R, const JobState& S, void* out_affine, uint8_t* out_is_inf) {
+  const int nparts = S.nparts, curve = S.curve;
+  const uint8_t* slots = (const uint8_t*)*R.land;
   std::vector<FinHeader> hs(nparts);
-  for (int r = 0; r < nparts; r++)
-    NCG_HIP_DRAIN(ctx, st, hipMemcpyAsync(&hs[r], base + stride * (size_t)r, sizeof(FinHeader), hipMemcpyDeviceToHost, st));
-  // pack payloads: [nparts][fin_words] behind the slots (sized by comm_buf_need)
-  uint32_t* packed = (uint32_t*)(base + stride * (size_t)nparts);
-  for (int r = 0; r < nparts; r++)
-    NCG_HIP_DRAIN(ctx, st, hipMemcpyAsync(packed + (size_t)r * fin_words, base + stride * (size_t)r + sizeof(FinHeader), fin_words * 4,
-                                          hipMemcpyDeviceToDevice, st));
-  uint32_t* sum = packed + (size_t)nparts * fin_words;
-  const size_t npoints = fin_words / ncg::msm_acc_words(curve);
-  NCG_HIP_DRAIN(ctx, st, ncg::msm_sum_partials(curve, packed, nparts, npoints, sum, st));
+  for (int r = 0; r < nparts; r++) memcpy(&hs[r], slots + S.stride * (size_t)r, sizeof(FinHeader));
+  ncg::MsmPlan pl;  // only c and nwin matter from here on
+  pl.c = S.c;
+  pl.nwin = S.nwin;
+  char msg[400];
+  if (ncg::msm_shard_check(hs.data(), nparts, curve, pl, S.mode, msg, sizeof msg) >= 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "%s", msg);
+  uint32_t bad_idx = 0;
+  const int bad_rank = ncg::msm_shard_first_bad(hs.data(), nparts, &bad_idx);
+  if (bad_rank >= 0) {
+    if (S.mode == ncg::SHARD_POINTS && nparts > 1)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: invalid scalar at index %u of shard %d (not below the group order)", bad_idx, bad_rank);
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad_idx);
+  }
   uint8_t inf_local = 0;
-  NCG_HIP_DRAIN(ctx, st, ncg::msm_finish(curve, pl, sum, (uint32_t*)out_affine, &inf_local, st));  // synchronises st
-  char msg[320];
-  if (ncg::msm_shard_check(hs.data(), nparts, curve, pl, fin_words, msg, sizeof msg) >= 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "%s", msg);
+  if (S.mode == ncg::SHARD_WINDOWS) {
+    std::vector<uint32_t> fin((size_t)ncg::msm_ngroups(S.c) * S.nwin * ncg::msm_acc_words(curve));
+    ncg::msm_shard_assemble_windows(slots, S.stride, hs.data(), nparts, curve, pl, fin.data());
+    ncg::msm_finish_host(curve, S.c, S.nwin, fin.data(), (uint32_t*)out_affine, &inf_local);
+  } else {
+    const uint32_t* sum = *R.land + S.stride * (size_t)nparts / 4;
+    ncg::msm_finish_host(curve, S.c, S.mode == ncg::SHARD_WINDOWS_SHARED ? 1 : S.nwin, sum, (uint32_t*)out_affine, &inf_local);
+  }
   if (out_is_inf) *out_is_inf = inf_local;
   return NCG_OK;
 }
 
-size_t comm_buf_need(size_t stride, size_t fin_words, int nparts) {
-  return stride * (size_t)nparts + ((size_t)nparts + 1) * fin_words * 4 + 256;
+JobRes ctx_res(ncg_ctx* ctx, hipStream_t st) {
+  return JobRes{st, &ctx->msm_side, &ctx->msm_ws, &ctx->msm_ws_bytes, &ctx->comm_buf, &ctx->comm_buf_bytes, &ctx->sync_land, &ctx->sync_land_words};
+}
+JobRes lane_res(ncg_msm_lane& ln) {
+  return JobRes{ln.stream, &ln.side, &ln.ws, &ln.ws_bytes, &ln.comm_buf, &ln.comm_buf_bytes, &ln.land, &ln.land_words};
 }
 
 int identity_out(int curve, void* out_affine, uint8_t* out_is_inf) {
@@ -177,6 +285,46 @@ int identity_out(int curve, void* out_affine, uint8_t* out_is_inf) {
   if (out_is_inf) *out_is_inf = 1;
   return NCG_OK;
 }
+
+// local phase (+ the all-gather over the context's communicator when it has one) + the combine that needs no host decision
+int job_enqueue(ncg_ctx* ctx, const JobRes& R, const ShardJob& J, bool collective, JobState* S) {
+  const int G = collective && ctx->comm ? ctx->comm_size : 1;
+  ShardJob job = J;
+  if (collective) {
+    job.part = ctx->comm ? ctx->comm_rank : 0;
+    job.nparts = G;
+  }
+  int rc = job_local_phase(ctx, R, job, collective ? job.part : 0, G, S);
+  if (rc) return rc;
+  if (G > 1) {
+    const Rccl* r = rccl();
+    if (!r) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: librccl.so not found");
+    char* base = (char*)*R.comm_buf;
+    // in place: rank r's slot already sits at offset r * stride of the receive buffer
+    NCG_NCCL(ctx, r, r->AllGather(base + S->stride * (size_t)ctx->comm_rank, base, S->stride, ncclUint8, (ncclComm_t)ctx->comm, R.st));
+  }
+  return job_enqueue_combine(ctx, R, S, G);
+}
+
+int job_run_sync(ncg_ctx* ctx, const ShardJob& J, bool collective, void* out_affine, uint8_t* out_is_inf, hipStream_t st) {
+  JobRes R = ctx_res(ctx, st);
+  JobState S;
+  int rc = job_enqueue(ctx, R, J, collective, &S);
+  if (rc) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
+  NCG_HIP(ctx, hipStreamSynchronize(st));
+  return job_finish_host(ctx, R, S, out_affine, out_is_inf);
+}
+
+int check_common(ncg_ctx* ctx, int curve, const void* out_affine, const char* who) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (ncg_point_bytes(curve) == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: %s: unsupported curve %d", who, curve);
+  if (!out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: %s: NULL output", who);
+  return NCG_OK;
+}
+inline bool misaligned16(const void* p) { return ((uintptr_t)p & 15u) != 0; }
 
 }  // namespace
 
@@ -233,130 +381,351 @@ int ncg_comm_rank(ncg_ctx* ctx) { return ctx ? ctx->comm_rank : -1; }
 
 int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max, const void* points_affine_dev,
                         const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream) {
-  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
-  if (ncg_point_bytes(curve) == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm_sharded: unsupported curve %d", curve);
-  if (!out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: NULL output");
+  int rc = check_common(ctx, curve, out_affine, "msm_sharded");
+  if (rc) return rc;
   if (n_max == 0) n_max = n_local;
   if (n_local > n_max || n_max > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: n_local > n_max");
   if (n_local && (!points_affine_dev || !scalars_dev)) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: NULL buffer");
-  const int G = ctx->comm ? ctx->comm_size : 1;
+  if (n_local && (misaligned16(points_affine_dev) || misaligned16(scalars_dev)))
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: device buffers must be 16-byte aligned");
   if (n_max == 0) return identity_out(curve, out_affine, out_is_inf);  // every shard empty (curve.ts:878)
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  ncg::MsmPlan pl;
-  size_t stride = 0;
-  {  // size the gather buffer before anything is enqueued
-    int rc = ensure_comm_buf(ctx, comm_buf_need(ncg::msm_shard_slot_bytes(curve), ncg::msm_shard_max_fin_words(curve), G));
-    if (rc) return rc;
+  ShardJob J;
+  J.curve = curve;
+  J.mode = ncg::SHARD_POINTS;
+  J.n_local = n_local;
+  J.n_plan = n_max;
+  J.d_pts = points_affine_dev;
+  J.d_sc = scalars_dev;
+  return job_run_sync(ctx, J, true, out_affine, out_is_inf, st);
+}
+
+// ---- window-sharded mode: every rank holds ALL n points and scalars, rank r runs a contiguous range of the windows ----
+static int windows_job(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev, const ncg_points* resident, const void* scalars_dev,
+                       ShardJob* J, const char* who) {
+  if (resident) {
+    if (resident->ctx != ctx) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: %s: handle does not belong to this context", who);
+    curve = resident->curve;
+    n = resident->n;
   }
-  const uint32_t* d_bad = nullptr;
-  int rc = local_phase(ctx, curve, n_local, n_max, points_affine_dev, scalars_dev, ctx->comm ? ctx->comm_rank : 0, G, &pl, &stride, st,
-                       &d_bad);
-  if (rc) return rc;
-  if (ctx->comm && G > 1) {
-    const Rccl* r = rccl();
-    if (!r) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: librccl.so not found");
-    char* base = (char*)ctx->comm_buf;
-    // in place: rank r's slot already sits at offset r * stride of the receive buffer
-    NCG_NCCL(ctx, r, r->AllGather(base + stride * (size_t)ctx->comm_rank, base, stride, ncclUint8, (ncclComm_t)ctx->comm, st));
-  }
-  uint32_t bad = 0xFFFFFFFFu;  // this rank's scalar-range verdict (validateMSMScalars, curve.ts:398-404); read in stream order
-  if (d_bad) NCG_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
-  rc = combine_and_finish(ctx, curve, pl, stride, G, out_affine, out_is_inf, st);  // drains st on every path
-  if (rc) return rc;
-  if (bad != 0xFFFFFFFFu)
-    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: invalid scalar at index %u of this rank's shard (not below the group order)", bad);
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: %s: too many points", who);
+  if (n && ((!points_affine_dev && !resident) || !scalars_dev)) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: %s: NULL buffer", who);
+  if (n && ((points_affine_dev && misaligned16(points_affine_dev)) || misaligned16(scalars_dev)))
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: %s: device buffers must be 16-byte aligned", who);
+  J->curve = curve;
+  J->mode = ncg::SHARD_WINDOWS;
+  J->n_local = J->n_plan = n;
+  J->d_pts = resident ? nullptr : points_affine_dev;
+  J->resident = resident;
+  J->d_sc = scalars_dev;
   return NCG_OK;
 }
 
+int ncg_msm_sharded_windows_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_affine_dev, const ncg_points* resident,
+                                const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream) {
+  if (resident) curve = resident->curve;
+  int rc = check_common(ctx, curve, out_affine, "msm_sharded_windows");
+  if (rc) return rc;
+  ShardJob J;
+  rc = windows_job(ctx, curve, n, points_affine_dev, resident, scalars_dev, &J, "msm_sharded_windows");
+  if (rc) return rc;
+  if (J.n_plan == 0) return identity_out(J.curve, out_affine, out_is_inf);
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  return job_run_sync(ctx, J, true, out_affine, out_is_inf, stream ? (hipStream_t)stream : ctx->stream);
+}
+
 // ---- host-staged exchange: the same sharded MSM for transports other than RCCL (gloo, MPI, sockets) --------
-// ncg_msm_shard_local_dev runs this rank's phase and returns its slot (header + grouped window sums,
-// ncg_msm_shard_slot_bytes(curve) bytes) in host memory; the caller moves the slots of all ranks by whatever
-// means it has and hands them to ncg_msm_shard_combine on any rank, which uploads them and runs the same
-// header check, adding kernel and finish that ncg_msm_sharded_dev runs after its all-gather.
+// ncg_msm_shard_local_dev / ncg_msm_shard_windows_local_dev run this rank's phase and return its slot (header + grouped
+// window sums, ncg_msm_shard_slot_bytes(curve) bytes) in host memory; the caller moves the slots of all ranks by whatever
+// means it has and hands them to ncg_msm_shard_combine on any rank, which uploads them and runs the same header check,
+// combine and finish that the RCCL entry points run after their all-gather.  A scalar outside the group order does NOT
+// fail the local call: the verdict travels in the slot header and fails the combine on EVERY rank (a rank that raised
+// before the exchange would leave the others waiting in it).
 size_t ncg_msm_shard_slot_bytes(int curve) { return ncg_point_bytes(curve) ? ncg::msm_shard_slot_bytes(curve) : 0; }
+
+static int local_to_host(ncg_ctx* ctx, const ShardJob& J, void* slot_out, hipStream_t st) {
+  JobRes R = ctx_res(ctx, st);
+  JobState S;
+  int rc = job_local_phase(ctx, R, J, 0, 1, &S);
+  if (rc) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
+  NCG_HIP_DRAIN(ctx, st, hipMemcpyAsync(*R.land, *R.comm_buf, S.stride, hipMemcpyDeviceToHost, st));
+  NCG_HIP(ctx, hipStreamSynchronize(st));
+  FinHeader h;
+  memcpy(&h, *R.land, sizeof h);
+  memset(slot_out, 0, S.stride);
+  memcpy(slot_out, *R.land, sizeof h + (size_t)h.words * 4);
+  return NCG_OK;
+}
 
 int ncg_msm_shard_local_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max, const void* points_affine_dev,
                             const void* scalars_dev, void* slot_out, void* stream) {
-  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
-  if (ncg_point_bytes(curve) == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm_shard_local: unsupported curve %d", curve);
-  if (!slot_out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_local: NULL output");
+  int rc = check_common(ctx, curve, slot_out, "msm_shard_local");
+  if (rc) return rc;
   if (n_max == 0) n_max = n_local;
   if (n_local > n_max || n_max > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_local: n_local > n_max");
   if (n_local && (!points_affine_dev || !scalars_dev)) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_local: NULL buffer");
-  const size_t slot_bytes = ncg::msm_shard_slot_bytes(curve);
-  memset(slot_out, 0, slot_bytes);
+  if (n_local && (misaligned16(points_affine_dev) || misaligned16(scalars_dev)))
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_local: device buffers must be 16-byte aligned");
+  memset(slot_out, 0, ncg::msm_shard_slot_bytes(curve));
   if (n_max == 0) return NCG_OK;  // every shard empty: an all-zero slot (combine returns the identity for n_max = 0)
   NCG_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  ncg::MsmPlan pl;
-  size_t stride = 0;
-  const uint32_t* d_bad = nullptr;
-  int rc = local_phase(ctx, curve, n_local, n_max, points_affine_dev, scalars_dev, 0, 1, &pl, &stride, st, &d_bad);
+  ShardJob J;
+  J.curve = curve;
+  J.mode = ncg::SHARD_POINTS;
+  J.n_local = n_local;
+  J.n_plan = n_max;
+  J.d_pts = points_affine_dev;
+  J.d_sc = scalars_dev;
+  return local_to_host(ctx, J, slot_out, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int ncg_msm_shard_windows_local_dev(ncg_ctx* ctx, int curve, size_t n, int part, int nparts, const void* points_affine_dev,
+                                    const ncg_points* resident, const void* scalars_dev, void* slot_out, void* stream) {
+  if (resident) curve = resident->curve;
+  int rc = check_common(ctx, curve, slot_out, "msm_shard_windows_local");
   if (rc) return rc;
-  uint32_t bad = 0xFFFFFFFFu;
-  if (d_bad) NCG_HIP_DRAIN(ctx, st, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
-  NCG_HIP_DRAIN(ctx, st, hipMemcpyAsync(slot_out, ctx->comm_buf, sizeof(FinHeader) + ncg::msm_fin_words(curve, pl) * 4, hipMemcpyDeviceToHost, st));
-  NCG_HIP(ctx, hipStreamSynchronize(st));
-  if (bad != 0xFFFFFFFFu)
-    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: invalid scalar at index %u of this rank's shard (not below the group order)", bad);
-  return NCG_OK;
+  if (nparts < 1 || nparts > 4096 || part < 0 || part >= nparts) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_windows_local: bad part %d / %d", part, nparts);
+  ShardJob J;
+  rc = windows_job(ctx, curve, n, points_affine_dev, resident, scalars_dev, &J, "msm_shard_windows_local");
+  if (rc) return rc;
+  memset(slot_out, 0, ncg::msm_shard_slot_bytes(J.curve));
+  if (J.n_plan == 0) return NCG_OK;
+  J.part = part;
+  J.nparts = nparts;
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  return local_to_host(ctx, J, slot_out, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int ncg_msm_shard_combine(ncg_ctx* ctx, int curve, size_t n_max, int nparts, const void* slots, void* out_affine, uint8_t* out_is_inf,
                           void* stream) {
-  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
-  if (ncg_point_bytes(curve) == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm_shard_combine: unsupported curve %d", curve);
-  if (!out_affine || !slots || nparts < 1 || nparts > 4096) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_combine: bad arguments");
+  int rc = check_common(ctx, curve, out_affine, "msm_shard_combine");
+  if (rc) return rc;
+  if (!slots || nparts < 1 || nparts > 4096) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_combine: bad arguments");
   if (n_max > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_combine: too many points");
   if (n_max == 0) return identity_out(curve, out_affine, out_is_inf);  // every shard empty (curve.ts:878)
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  ncg::MsmPlan pl;
-  if (ncg::msm_make_plan(curve, (int)n_max, 0, &pl) != 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
   const size_t stride = ncg::msm_shard_slot_bytes(curve);
-  int rc = ensure_comm_buf(ctx, comm_buf_need(stride, ncg::msm_shard_max_fin_words(curve), nparts));
+  FinHeader h0;
+  memcpy(&h0, slots, sizeof h0);
+  JobRes R = ctx_res(ctx, st);
+  JobState S;
+  S.curve = curve;
+  S.stride = stride;
+  S.mode = h0.mode;
+  if (h0.mode == ncg::SHARD_POINTS) {  // the plan this rank derives from n_max must be the one every slot was made with
+    ncg::MsmPlan pl;
+    if (ncg::msm_make_plan(curve, (int)n_max, 0, &pl) != 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+    S.c = pl.c;
+    S.nwin = pl.nwin;
+  } else if (h0.mode == ncg::SHARD_WINDOWS || h0.mode == ncg::SHARD_WINDOWS_SHARED) {
+    // window modes: the plan may be a resident set's own (endomorphism / precomputed): slot 0 names it, the check compares the rest
+    if (h0.c < 2 || h0.c > 16 || h0.nwin < 1 || h0.nwin > 200) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_combine: malformed slot header");
+    S.c = (int)h0.c;
+    S.nwin = (int)h0.nwin;
+  } else {
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_combine: malformed slot header (mode %u)", h0.mode);
+  }
+  rc = ensure_dev_buf(ctx, R.comm_buf, R.comm_buf_bytes, comm_buf_need(stride, ncg::msm_shard_max_fin_words(curve), nparts));
   if (rc) return rc;
-  NCG_HIP(ctx, hipMemcpyAsync(ctx->comm_buf, slots, stride * (size_t)nparts, hipMemcpyHostToDevice, st));
-  return combine_and_finish(ctx, curve, pl, stride, nparts, out_affine, out_is_inf, st);
+  rc = ensure_land(ctx, R.land, R.land_words, (stride * (size_t)nparts + ncg::msm_shard_max_fin_words(curve) * 4) / 4 + 64);
+  if (rc) return rc;
+  // bound the payload sizes the device-side packing will read BEFORE trusting them (the full check runs in job_finish_host)
+  for (int r = 0; r < nparts; r++) {
+    FinHeader h;
+    memcpy(&h, (const char*)slots + stride * (size_t)r, sizeof h);
+    if ((size_t)h.words * 4 + sizeof h > stride) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_shard_combine: malformed slot %d - all ranks must pass the same curve and n_max", r);
+  }
+  NCG_HIP(ctx, hipMemcpyAsync(*R.comm_buf, slots, stride * (size_t)nparts, hipMemcpyHostToDevice, st));
+  rc = job_enqueue_combine(ctx, R, &S, nparts);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipStreamSynchronize(st));
+  return job_finish_host(ctx, R, S, out_affine, out_is_inf);
 }
 
-// The sharded pipeline on ONE GPU (self-check and A/B of the shard-size plan): the point set is cut into
-// `parts` slices, each runs the per-shard phase in turn, and the slices' window sums go through the same
-// combine kernel and finish that G GPUs use - everything of ncg_msm_sharded_dev except the all-gather.
-int ncg_msm_split_dev(ncg_ctx* ctx, int curve, size_t n, int parts, const void* points_affine_dev, const void* scalars_dev,
-                      void* out_affine, uint8_t* out_is_inf, void* stream) {
-  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
-  const int pb = ncg_point_bytes(curve);
-  if (pb == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm_split: unsupported curve %d", curve);
-  if (!out_affine || parts < 1 || parts > 64) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: bad arguments");
-  if (n == 0) return identity_out(curve, out_affine, out_is_inf);
-  if (!points_affine_dev || !scalars_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: NULL buffer");
-  NCG_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+// The sharded pipelines on ONE GPU (self-check, shard-plan A/B, per-rank share measurements): the work is cut into
+// `parts` as G ranks would cut it - slices of the points (ncg_msm_split_dev) or ranges of the windows
+// (ncg_msm_split_windows_dev) - each part runs its local phase in turn, and the parts' slots go through the same combine
+// and finish that G GPUs run after their all-gather.
+static int split_run(ncg_ctx* ctx, ShardJob J, int parts, size_t n, int pb, void* out_affine, uint8_t* out_is_inf, hipStream_t st) {
+  JobRes R = ctx_res(ctx, st);
+  JobState S;
   const size_t per = (n + parts - 1) / parts;
-  if (per > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: too many points");
-  ncg::MsmPlan pl;
-  int rc = ensure_comm_buf(ctx, comm_buf_need(ncg::msm_shard_slot_bytes(curve), ncg::msm_shard_max_fin_words(curve), parts));
-  if (rc) return rc;
-  size_t stride = 0;
+  const char* pts0 = (const char*)J.d_pts;
+  const char* sc0 = (const char*)J.d_sc;
   for (int g = 0; g < parts; g++) {
-    const size_t lo = std::min(n, per * (size_t)g), cnt = std::min(n, lo + per) - lo;
-    ncg::MsmPlan plg;
-    const uint32_t* d_bad = nullptr;
-    rc = local_phase(ctx, curve, cnt, per, (const char*)points_affine_dev + lo * (size_t)pb, (const char*)scalars_dev + lo * 32, g,
-                     parts, &plg, &stride, st, &d_bad);
-    if (rc) return rc;
-    if (g == 0) pl = plg;
-    if (d_bad) {  // the workspace (and its flag) is reused by the next slice: read it now
-      uint32_t bad = 0xFFFFFFFFu;
-      NCG_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
-      NCG_HIP(ctx, hipStreamSynchronize(st));
-      if (bad != 0xFFFFFFFFu)
-        return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: invalid scalar at index %zu (not below the group order)", lo + bad);
+    if (J.mode == ncg::SHARD_POINTS) {
+      const size_t lo = std::min(n, per * (size_t)g), cnt = std::min(n, lo + per) - lo;
+      J.n_local = cnt;
+      J.n_plan = per;
+      J.d_pts = pts0 + lo * (size_t)pb;
+      J.d_sc = sc0 + lo * 32;
+    } else {
+      J.part = g;
+      J.nparts = parts;
+    }
+    int rc = job_local_phase(ctx, R, J, g, parts, &S);
+    if (rc) {
+      (void)hipStreamSynchronize(st);
+      return rc;
     }
   }
-  return combine_and_finish(ctx, curve, pl, stride, parts, out_affine, out_is_inf, st);
+  int rc = job_enqueue_combine(ctx, R, &S, parts);
+  if (rc) return rc;
+  NCG_HIP(ctx, hipStreamSynchronize(st));
+  return job_finish_host(ctx, R, S, out_affine, out_is_inf);
+}
+
+int ncg_msm_split_dev(ncg_ctx* ctx, int curve, size_t n, int parts, const void* points_affine_dev, const void* scalars_dev,
+                      void* out_affine, uint8_t* out_is_inf, void* stream) {
+  int rc = check_common(ctx, curve, out_affine, "msm_split");
+  if (rc) return rc;
+  const int pb = ncg_point_bytes(curve);
+  if (parts < 1 || parts > 64) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: bad arguments");
+  if (n == 0) return identity_out(curve, out_affine, out_is_inf);
+  if (!points_affine_dev || !scalars_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: NULL buffer");
+  if (misaligned16(points_affine_dev) || misaligned16(scalars_dev))
+    return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: device buffers must be 16-byte aligned");
+  if ((n + parts - 1) / parts > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split: too many points");
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  ShardJob J;
+  J.curve = curve;
+  J.mode = ncg::SHARD_POINTS;
+  J.d_pts = points_affine_dev;
+  J.d_sc = scalars_dev;
+  return split_run(ctx, J, parts, n, pb, out_affine, out_is_inf, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int ncg_msm_split_windows_dev(ncg_ctx* ctx, int curve, size_t n, int parts, const void* points_affine_dev, const ncg_points* resident,
+                              const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream) {
+  if (resident) curve = resident->curve;
+  int rc = check_common(ctx, curve, out_affine, "msm_split_windows");
+  if (rc) return rc;
+  if (parts < 1 || parts > 64) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_split_windows: bad arguments");
+  ShardJob J;
+  rc = windows_job(ctx, curve, n, points_affine_dev, resident, scalars_dev, &J, "msm_split_windows");
+  if (rc) return rc;
+  if (J.n_plan == 0) return identity_out(J.curve, out_affine, out_is_inf);
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  return split_run(ctx, J, parts, J.n_plan, ncg_point_bytes(J.curve), out_affine, out_is_inf, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+// ---- several MSMs in flight ----------------------------------------------------------------------------------
+// A lane owns a stream, a workspace, a gather buffer and a pinned landing area.  submit enqueues one MSM on the lane and
+// returns; collect waits for it and runs the host finish.  With two or more lanes used in turn, the dependent tail of
+// one MSM (narrow fold levels, per-window tail, D2H, host Horner - latency, not throughput) overlaps the sort and
+// accumulate kernels of the next.  flags: NCG_MSM_ASYNC_WINDOWS = window-sharded over the context's communicator (a
+// collective: every rank submits the same sequence of lanes).
+static int lane_init(ncg_ctx* ctx, ncg_msm_lane& ln) {
+  if (ln.stream) return NCG_OK;
+  hipError_t e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.side.stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.side.fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.side.join, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.input_ready, hipEventDisableTiming);
+  if (e != hipSuccess) return set_err(ctx, NCG_ERR_HIP, "noble-gpu: msm_async: cannot create the lane's stream: %s", hipGetErrorString(e));
+  return NCG_OK;
+}
+
+int ncg_msm_async_lanes(void) { return NCG_MSM_LANES; }
+
+int ncg_msm_async_submit(ncg_ctx* ctx, int lane, int curve, size_t n, const void* points_affine_dev, const ncg_points* resident,
+                         const void* scalars_dev, int flags, void* stream) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (lane < 0 || lane >= NCG_MSM_LANES) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: lane %d out of range (0..%d)", lane, NCG_MSM_LANES - 1);
+  if (resident) curve = resident->curve;
+  if (ncg_point_bytes(curve) == 0) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: msm_async: unsupported curve %d", curve);
+  ncg_msm_lane& ln = ctx->lanes[lane];
+  if (ln.busy) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: lane %d has an MSM in flight - collect it first", lane);
+  ShardJob J;
+  int rc = windows_job(ctx, curve, n, points_affine_dev, resident, scalars_dev, &J, "msm_async");
+  if (rc) return rc;
+  NCG_HIP(ctx, hipSetDevice(ctx->device));
+  rc = lane_init(ctx, ln);
+  if (rc) return rc;
+  ln.curve = J.curve;
+  ln.state_identity = J.n_plan == 0;
+  if (ln.state_identity) {
+    ln.busy = true;
+    return NCG_OK;
+  }
+  if (stream) {  // the inputs are produced on the caller's stream
+    NCG_HIP(ctx, hipEventRecord(ln.input_ready, (hipStream_t)stream));
+    NCG_HIP(ctx, hipStreamWaitEvent(ln.stream, ln.input_ready, 0));
+  }
+  JobRes R = lane_res(ln);
+  JobState S;
+  const bool collective = (flags & NCG_MSM_ASYNC_WINDOWS) != 0;
+  ln.part_only = (flags & NCG_MSM_ASYNC_PART_FLAG) != 0;
+  if (ln.part_only) {  // one part of a window-sharded MSM; its slot comes back through ncg_msm_async_collect_slot
+    J.part = (flags >> 8) & 0xFFF;
+    J.nparts = (flags >> 20) & 0x7FF;
+    if (collective || J.nparts < 1 || J.part >= J.nparts) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: bad part %d / %d", J.part, J.nparts);
+    rc = job_local_phase(ctx, R, J, 0, 1, &S);
+    if (rc == NCG_OK) {
+      hipError_t e = hipMemcpyAsync(*R.land, *R.comm_buf, S.stride, hipMemcpyDeviceToHost, ln.stream);
+      if (e != hipSuccess) rc = set_err(ctx, NCG_ERR_HIP, "noble-gpu: msm_async: %s", hipGetErrorString(e));
+    }
+  } else {
+    rc = job_enqueue(ctx, R, J, collective, &S);  // not collective: one part holding every window
+  }
+  if (rc) {
+    (void)hipStreamSynchronize(ln.stream);
+    return rc;
+  }
+  NCG_HIP_DRAIN(ctx, ln.stream, hipEventRecord(ln.done, ln.stream));
+  ln.mode = (int)S.mode;
+  ln.nparts = S.nparts;
+  ln.c = S.c;
+  ln.nwin = S.nwin;
+  ln.stride = S.stride;
+  ln.busy = true;
+  return NCG_OK;
+}
+
+int ncg_msm_async_collect(ncg_ctx* ctx, int lane, void* out_affine, uint8_t* out_is_inf) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (lane < 0 || lane >= NCG_MSM_LANES) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: lane %d out of range", lane);
+  if (!out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: NULL output");
+  ncg_msm_lane& ln = ctx->lanes[lane];
+  if (!ln.busy) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: nothing was submitted on lane %d", lane);
+  if (ln.part_only) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: lane %d holds one part of a sharded MSM - use ncg_msm_async_collect_slot", lane);
+  ln.busy = false;
+  if (ln.state_identity) return identity_out(ln.curve, out_affine, out_is_inf);
+  NCG_HIP(ctx, hipEventSynchronize(ln.done));
+  JobRes R = lane_res(ln);
+  JobState S;
+  S.curve = ln.curve;
+  S.mode = (uint32_t)ln.mode;
+  S.nparts = ln.nparts;
+  S.c = ln.c;
+  S.nwin = ln.nwin;
+  S.stride = ln.stride;
+  return job_finish_host(ctx, R, S, out_affine, out_is_inf);
+}
+
+int ncg_msm_async_collect_slot(ncg_ctx* ctx, int lane, void* slot_out) {
+  if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
+  if (lane < 0 || lane >= NCG_MSM_LANES) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: lane %d out of range", lane);
+  if (!slot_out) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: NULL output");
+  ncg_msm_lane& ln = ctx->lanes[lane];
+  if (!ln.busy || !ln.part_only) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: no part of a sharded MSM was submitted on lane %d", lane);
+  ln.busy = false;
+  ln.part_only = false;
+  const size_t stride = ncg::msm_shard_slot_bytes(ln.curve);
+  memset(slot_out, 0, stride);
+  if (ln.state_identity) return NCG_OK;
+  NCG_HIP(ctx, hipEventSynchronize(ln.done));
+  FinHeader h;
+  memcpy(&h, ln.land, sizeof h);
+  if ((size_t)h.words * 4 + sizeof h > stride) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_async: malformed slot");
+  memcpy(slot_out, ln.land, sizeof h + (size_t)h.words * 4);
+  return NCG_OK;
 }
 
 /* ---- one process, several GPUs ---------------------------------------------------------------- */
@@ -420,19 +789,14 @@ int ncg_msm_multi(ncg_multi* m, int curve, size_t n, const void* points_affine, 
   const int G = m->n_dev;
   const size_t per = (n + G - 1) / G;
   if (per > 0x7fffffffu) return fail(set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: msm_multi: too many points"));
-  ncg::MsmPlan pl;
-  size_t stride = 0;
   const Rccl* r = G > 1 ? rccl() : nullptr;
   if (G > 1 && !r) return fail(set_err(nullptr, NCG_ERR_UNSUPPORTED, "noble-gpu: librccl.so not found"));
-  std::vector<const uint32_t*> d_bads(G, nullptr);
-  std::vector<uint32_t> bads(G, 0xFFFFFFFFu);
+  std::vector<JobState> states(G);
   // 1. every device: upload its slice and run the device phase (all asynchronous, one host thread)
   for (int g = 0; g < G; g++) {
     ncg_ctx* ctx = m->ctx[g];
     const size_t lo = std::min(n, per * (size_t)g), cnt = std::min(n, lo + per) - lo;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(set_err(ctx, NCG_ERR_HIP, "noble-gpu: hipSetDevice failed"));
-    int rc = ensure_comm_buf(ctx, comm_buf_need(ncg::msm_shard_slot_bytes(curve), ncg::msm_shard_max_fin_words(curve), G));
-    if (rc) return fail(rc);
     const size_t pts_b = cnt * (size_t)pb, sc_b = cnt * 32;
     const size_t pts_al = (pts_b + 255) & ~(size_t)255;
     if (ctx->scratch_bytes < pts_al + sc_b + 512) {
@@ -450,12 +814,18 @@ int ncg_msm_multi(ncg_multi* m, int curve, size_t n, const void* points_affine, 
           hipMemcpyAsync(d_sc, (const char*)scalars + lo * 32, sc_b, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return fail(set_err(ctx, NCG_ERR_HIP, "noble-gpu: msm_multi: upload failed on device %d", ctx->device));
     }
-    ncg::MsmPlan plg;
-    rc = local_phase(ctx, curve, cnt, per, d_pts, d_sc, g, G, &plg, &stride, ctx->stream, &d_bads[g]);
+    ShardJob J;
+    J.curve = curve;
+    J.mode = ncg::SHARD_POINTS;
+    J.n_local = cnt;
+    J.n_plan = per;
+    J.d_pts = d_pts;
+    J.d_sc = d_sc;
+    int rc = job_local_phase(ctx, ctx_res(ctx, ctx->stream), J, g, G, &states[g]);
     if (rc) return fail(rc);
-    if (g == 0) pl = plg;
   }
   // 2. one grouped all-gather over the device set
+  const size_t stride = states[0].stride;
   if (G > 1) {
     ncclResult_t nr = r->GroupStart();
     for (int g = 0; g < G && nr == ncclSuccess; g++) {
@@ -468,20 +838,19 @@ int ncg_msm_multi(ncg_multi* m, int curve, size_t n, const void* points_affine, 
       return fail(set_err(nullptr, NCG_ERR_RCCL, "noble-gpu: msm_multi: RCCL all-gather failed (%s)",
                           r->GetErrorString(nr != ncclSuccess ? nr : ne)));
   }
-  // 3. device 0 adds the partial arrays and finishes; the others only drain their streams
+  // 3. device 0 adds the partial arrays and finishes (the scalar verdicts of all devices travel in the slot headers);
+  //    the others only drain their streams
   if (hipSetDevice(m->ctx[0]->device) != hipSuccess) return fail(set_err(m->ctx[0], NCG_ERR_HIP, "noble-gpu: hipSetDevice failed"));
-  int rc = combine_and_finish(m->ctx[0], curve, pl, stride, G, out_affine, out_is_inf, m->ctx[0]->stream);
+  JobRes R0 = ctx_res(m->ctx[0], m->ctx[0]->stream);
+  int rc = job_enqueue_combine(m->ctx[0], R0, &states[0], G);
   for (int g = 0; g < G; g++) {
     (void)hipSetDevice(m->ctx[g]->device);
-    if (d_bads[g]) (void)hipMemcpyAsync(&bads[g], d_bads[g], 4, hipMemcpyDeviceToHost, m->ctx[g]->stream);
     (void)hipStreamSynchronize(m->ctx[g]->stream);
   }
   (void)hipSetDevice(m->ctx[0]->device);
   if (rc) return fail(rc);
-  for (int g = 0; g < G; g++)
-    if (bads[g] != 0xFFFFFFFFu)
-      return fail(set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: msm_multi: invalid scalar at index %zu (not below the group order)",
-                          per * (size_t)g + bads[g]));
+  rc = job_finish_host(m->ctx[0], R0, states[0], out_affine, out_is_inf);
+  if (rc) return fail(rc);
   return NCG_OK;
 }
 

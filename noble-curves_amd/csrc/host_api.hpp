@@ -84,6 +84,12 @@ hipError_t msm_finish(int curve, const MsmPlan& pl, const uint32_t* d_fin, uint3
                       uint8_t* out_inf_host, hipStream_t st);
 hipError_t msm_sum_partials(int curve, uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
                             hipStream_t st);  // d_gathered is scratch: reduced in place
+// asynchronous form: device phase + D2H of the grouped sums and the scalar-range flag into `land` (pinned host memory,
+// msm_fin_words + 1 words), nothing synchronised; msm_finish_host is the host half of msm_finish on a host array of
+// [ngroups(c)][nwin] grouped sums (also what the window-sharded multi-GPU mode assembles from the ranks' slots)
+hipError_t msm_enqueue(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws, uint32_t* land,
+                       hipStream_t st, const MsmSide* side = nullptr);
+void msm_finish_host(int curve, int c, int nwin, const uint32_t* fin_host, uint32_t* out_affine_host, uint8_t* out_inf_host);
 size_t msm_fin_words(int curve, const MsmPlan& pl);
 size_t msm_acc_words(int curve);
 

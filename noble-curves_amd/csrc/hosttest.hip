@@ -98,22 +98,29 @@ static int ht_fe9_t(int op, int variant, const uint32_t* a, const uint32_t* b, u
 // ---- sharded MSM twin (tests/test_distributed_cpu.py): the per-shard grouped window sums computed naively with the
 // group-law templates, then the REAL slot format, header check, partial-sum order and finish of comm.hip / msm_finish.hpp
 template <class C>
-static int ht_shard_local_t(int curve, int n_local, int n_max, const uint32_t* pts_wire, const uint32_t* scalars, uint8_t* slot) {
+static int ht_shard_local_t(int curve, int n_local, int n_max, const uint32_t* pts_wire, const uint32_t* scalars, uint8_t* slot, int mode,
+                            int part, int nparts) {
   using G = MsmGroup<C>;
   constexpr int XW = G::ACC_WORDS;
   MsmPlan pl;
   if (msm_make_plan_impl(curve, n_max, 0, &pl) != 0) return -1;
   const int ng = msm_ngroups(pl.c);
-  const size_t fin_words = (size_t)ng * pl.nwin * XW;
+  int w0 = 0, cnt = pl.nwin;
+  if (mode == SHARD_WINDOWS) msm_shard_window_range(pl.nwin, part, nparts, &w0, &cnt);
+  const size_t fin_words = (size_t)ng * cnt * XW;
   memset(slot, 0, msm_shard_slot_bytes(curve));
-  FinHeader h{(uint32_t)pl.c, (uint32_t)pl.nwin, (uint32_t)fin_words, (uint32_t)curve};
-  memcpy(slot, &h, sizeof h);
+  FinHeader h{(uint32_t)pl.c, (uint32_t)pl.nwin, (uint32_t)fin_words, (uint32_t)curve, (uint32_t)w0, (uint32_t)cnt, (uint32_t)mode, SHARD_NO_BAD};
   uint32_t* fin = (uint32_t*)(slot + sizeof h);
   std::vector<typename G::Acc> win(pl.nwin, G::identity());
   std::vector<uint32_t> st(G::AFF_WORDS);
   const uint32_t mask = (1u << pl.c) - 1u;
   const int half = 1 << (pl.c - 1);
   for (int i = 0; i < n_local; i++) {
+    {  // scalar >= group order: the smallest such index travels in the header (k_msm_digits)
+      uint32_t bw = 0;
+      for (int j = 0; j < 8; j++) (void)__builtin_subc(scalars[(size_t)i * 8 + j], pl.order[j], bw, &bw);
+      if (bw == 0 && h.bad == SHARD_NO_BAD) h.bad = (uint32_t)i;
+    }
     G::wire_to_storage(pts_wire + (size_t)i * G::WIRE_AFF, st.data());
     const typename G::Aff P = G::aff_load(st.data());
     uint32_t my[11];
@@ -122,7 +129,7 @@ static int ht_shard_local_t(int curve, int n_local, int n_max, const uint32_t* p
     my[8] = __builtin_addc(0u, pl.hconst[8], cy, &cy);
     my[9] = pl.hconst[9] + cy;
     my[10] = 0;
-    for (int w = 0; w < pl.nwin; w++) {
+    for (int w = w0; w < w0 + cnt; w++) {
       const int bp = w * pl.c, limb = bp >> 5, sft = bp & 31;
       const uint64_t two = ((uint64_t)my[limb + 1] << 32) | my[limb];
       const int d = (int)((uint32_t)(two >> sft) & mask) - half;
@@ -136,9 +143,12 @@ static int ht_shard_local_t(int curve, int n_local, int n_max, const uint32_t* p
       win[w] = G::add(win[w], t);
     }
   }
-  for (int w = 0; w < pl.nwin; w++) G::acc_store(fin + (size_t)w * XW, win[w]);  // V_0 = W_w; V_j = identity for j >= 1
+  memcpy(slot, &h, sizeof h);
+  for (int w = 0; w < cnt; w++) G::acc_store(fin + (size_t)w * XW, win[w0 + w]);  // V_0 = W_w; V_j = identity for j >= 1
   return 0;
 }
+// the host half of comm.hip's job_finish_host around a naive term-by-term sum: header check, the scalar verdict of all
+// ranks, window assembly (SHARD_WINDOWS) or the sum of the slots (SHARD_POINTS), host Horner
 template <class C>
 static int ht_shard_combine_t(int curve, int n_max, int nparts, const uint8_t* slots, uint32_t* out, uint8_t* out_inf, char* err, int errlen) {
   using G = MsmGroup<C>;
@@ -146,20 +156,31 @@ static int ht_shard_combine_t(int curve, int n_max, int nparts, const uint8_t* s
   MsmPlan pl;
   if (msm_make_plan_impl(curve, n_max, 0, &pl) != 0) return -1;
   const size_t stride = msm_shard_slot_bytes(curve);
-  const size_t fin_words = (size_t)msm_ngroups(pl.c) * pl.nwin * XW;
   std::vector<FinHeader> hs(nparts);
   for (int r = 0; r < nparts; r++) memcpy(&hs[r], slots + stride * r, sizeof(FinHeader));
-  char msg[320];
-  if (msm_shard_check(hs.data(), nparts, curve, pl, fin_words, msg, sizeof msg) >= 0) {
+  const uint32_t mode = hs[0].mode;
+  char msg[400];
+  if (msm_shard_check(hs.data(), nparts, curve, pl, mode, msg, sizeof msg) >= 0) {
     if (err && errlen > 0) snprintf(err, errlen, "%s", msg);
     return 1;
   }
-  const size_t npoints = fin_words / XW;
+  uint32_t bad_idx = 0;
+  const int bad_rank = msm_shard_first_bad(hs.data(), nparts, &bad_idx);
+  if (bad_rank >= 0) {
+    if (err && errlen > 0) snprintf(err, errlen, "noble-gpu: msm_sharded: invalid scalar at index %u of shard %d (not below the group order)", bad_idx, bad_rank);
+    return 2;
+  }
+  const size_t fin_words = (size_t)msm_ngroups(pl.c) * pl.nwin * XW;
   std::vector<uint32_t> sum(fin_words);
-  for (size_t t = 0; t < npoints; t++) {
-    typename G::Acc acc = G::acc_load((const uint32_t*)(slots + sizeof(FinHeader)) + t * XW);
-    for (int r = 1; r < nparts; r++) acc = G::add(acc, G::acc_load((const uint32_t*)(slots + stride * r + sizeof(FinHeader)) + t * XW));
-    G::acc_store(sum.data() + t * XW, acc);
+  if (mode == SHARD_WINDOWS) {
+    msm_shard_assemble_windows(slots, stride, hs.data(), nparts, curve, pl, sum.data());
+  } else {
+    const size_t npoints = fin_words / XW;
+    for (size_t t = 0; t < npoints; t++) {
+      typename G::Acc acc = G::acc_load((const uint32_t*)(slots + sizeof(FinHeader)) + t * XW);
+      for (int r = 1; r < nparts; r++) acc = G::add(acc, G::acc_load((const uint32_t*)(slots + stride * r + sizeof(FinHeader)) + t * XW));
+      G::acc_store(sum.data() + t * XW, acc);
+    }
   }
   msm_host_finish_any<C>(sum.data(), pl.c, pl.nwin, out, out_inf);
   return 0;
@@ -366,8 +387,13 @@ int ht_ed_halve(const uint32_t* k, const uint32_t* s, uint32_t* out) {
 }
 
 size_t ht_msm_shard_slot_bytes(int curve) { return msm_shard_slot_bytes(curve); }
+int ht_msm_shard_windows_local(int curve, int n, int part, int nparts, const uint32_t* pts_wire, const uint32_t* scalars, uint8_t* slot) {
+#define CALL(C) ht_shard_local_t<C>(curve, n, n, pts_wire, scalars, slot, SHARD_WINDOWS, part, nparts)
+  HT_CURVE_DISPATCH(curve, CALL)
+#undef CALL
+}
 int ht_msm_shard_local(int curve, int n_local, int n_max, const uint32_t* pts_wire, const uint32_t* scalars, uint8_t* slot) {
-#define CALL(C) ht_shard_local_t<C>(curve, n_local, n_max, pts_wire, scalars, slot)
+#define CALL(C) ht_shard_local_t<C>(curve, n_local, n_max, pts_wire, scalars, slot, SHARD_POINTS, 0, 1)
   HT_CURVE_DISPATCH(curve, CALL)
 #undef CALL
 }

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
     const uint32_t mask = (1u << pl.c) - 1u;
     const int half = 1 << (pl.c - 1);
     for (int w = 0; w < pl.nwin; w++) {
-      int bp = w * pl.c;
+      int bp = (w + pl.w0) * pl.c;
       int limb = bp >> 5, sft = bp & 31;
       uint64_t two = ((uint64_t)my[limb + 1] << 32) | my[limb];
       uint32_t v = (uint32_t)(two >> sft) & mask;
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict_
   // shared-bucket mode: one list for all windows (the starts already include the other windows' shares), and the
   // entry names the window's shifted copy of the point
   uint32_t* dst = sorted + (pl.shared ? 0 : (size_t)w * pl.n);
-  const uint32_t level = pl.shared ? (uint32_t)w * (uint32_t)pl.n : 0u;
+  const uint32_t level = pl.shared ? (uint32_t)(w + pl.w0) * (uint32_t)pl.n : 0u;  // the window's shifted copy (global window index)
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     int d = dg[i];
     if (d != 0) {
@@ -665,7 +665,7 @@ struct MsmLayout {
 
 static MsmSeg msm_seg(const MsmPlan& pl) {
   MsmSeg sg;
-  const int seg_knob = knob("NCG_MSM_SEG", 0);
+  const int seg_knob = pl.seg_override > 0 ? pl.seg_override : knob("NCG_MSM_SEG", 0);
   if (seg_knob > 0) {
     sg.seg = seg_knob;
   } else {
@@ -714,7 +714,8 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
   L.part_meta = take((size_t)av.nwin * sg.nseg * 4 * 4);
   // work list of the long runs: a counter + (window, bucket, first lane, last lane) per run of more than
   // MSM_RUN_SERIAL heads - such runs cover disjoint lane ranges, so there are at most nwin * nseg / MSM_RUN_SERIAL
-  L.long_runs = take(16 + ((size_t)av.nwin * (sg.nseg / MSM_RUN_SERIAL + 1)) * 16);
+  // (with a run_serial override below 2 - tests - adjacent runs share a lane: at most one run per lane)
+  L.long_runs = take(16 + ((size_t)av.nwin * (sg.nseg + 1)) * 16);
   L.bad = take(64);
   // fold ping-pong: level l output holds (l+1) * nwin * nb/2^l points <= nwin*nb (l = 1, 2)
   size_t red = (size_t)av.nwin * std::max(av.nb, av.c) * MsmGroup<C>::ACC_WORDS * 4;
@@ -753,6 +754,15 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   hipError_t e;
 
   bool forked = false;
+  // error paths between the fork and the join must not return while the side-stream kernel is still writing into the
+  // workspace (the caller may free or re-size it): drain the side stream unless the join has been enqueued on `st`
+  struct SideGuard {
+    const MsmSide* side;
+    bool armed = false;
+    ~SideGuard() {
+      if (armed && side && side->stream) (void)hipStreamSynchronize(side->stream);
+    }
+  } side_guard{side};
   uint32_t* bad = (uint32_t*)(base + L.bad);
   e = hipMemsetAsync(bad, 0xFF, 4, st);
   if (e != hipSuccess) return e;
@@ -769,6 +779,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, side->stream,
                          d_pts, pts_mont, n);
+      side_guard.armed = true;
       e = hipEventRecord(side->join, side->stream);
       if (e != hipSuccess) return e;
       forked = true;
@@ -819,6 +830,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     if (forked) {
       e = hipStreamWaitEvent(st, side->join, 0);
       if (e != hipSuccess) return e;
+      side_guard.armed = false;
     }
     hipLaunchKernelGGL(k_msm_accum<D>, grid, dim3(256), 0, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta,
                        av, sg);
@@ -833,7 +845,16 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     // scalars, a short top window).
     const double m_avg = (double)av.n / (double)av.nb;
     const int heads_typ = (int)std::ceil((m_avg + 4.0 * std::sqrt(m_avg) + 1.0) / (double)sg.seg);
-    const int run_serial = std::max(knob("NCG_MSM_RUN_SERIAL", MSM_RUN_SERIAL), std::min(8, heads_typ));
+    const int run_serial_auto = std::max(knob("NCG_MSM_RUN_SERIAL", MSM_RUN_SERIAL), std::min(8, heads_typ));
+    const bool rs_forced = pl.run_serial_override >= 0;  // ncg_msm_set_tuning: exactly this many (tests force the work list)
+    const int run_serial = rs_forced ? pl.run_serial_override : run_serial_auto;
+    if (pl.trace) {
+      MsmTrace& tr = *pl.trace;
+      tr.c = pl.c; tr.nwin = pl.nwin; tr.nb = pl.nb; tr.seg = sg.seg; tr.nseg = sg.nseg; tr.w0 = pl.w0;
+      tr.nwin_total = pl.nwin_total ? pl.nwin_total : pl.nwin;
+      tr.run_serial = rs_forced ? run_serial : std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL);
+      tr.d_long_runs = (const uint32_t*)(base + L.long_runs);
+    }
     // shared-bucket mode: every bucket holds nwin * n / nb entries, i.e. a handful of pieces - all of them, so their
     // owners add them serially (fully parallel over the buckets), as cooperative groups where the curve has them;
     // the work list is for the outliers only
@@ -842,10 +863,10 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       using K = TailOps<D, MCOOP>;
       const dim3 mgrid((unsigned)((((size_t)av.nb << K::UNIT_SHIFT) + 255) / 256), av.nwin);
       hipLaunchKernelGGL((k_msm_fixup_merge_units<D, MCOOP>), mgrid, dim3(256), (size_t)(256 >> K::UNIT_SHIFT) * K::LDS_WORDS * 4, st, part_pts,
-                         part_meta, acc_start, buckets, av, sg, long_runs, std::max(run_serial, MSM_RUN_SERIAL_SHARED));
+                         part_meta, acc_start, buckets, av, sg, long_runs, rs_forced ? run_serial : std::max(run_serial, MSM_RUN_SERIAL_SHARED));
     } else {
       hipLaunchKernelGGL(k_msm_fixup_merge<D>, grid, dim3(256), 0, st, part_pts, part_meta, acc_start, buckets, av, sg, long_runs,
-                         std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL));
+                         rs_forced ? run_serial : std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL));
     }
     {
       constexpr bool LCOOP = CoopOK<D>::value;
@@ -970,6 +991,21 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
   return hipSuccess;
 }
 
+// Asynchronous form (several MSMs in flight, api.hip `ncg_msm_async_*`): the device phase, then the grouped sums and the
+// scalar-range flag travel to `land` (pinned host memory: fin words, then one flag word) on the same stream.  Nothing is
+// synchronised here; the caller waits on its own event and runs msm_finish_host on `land`.
+template <class C>
+static hipError_t msm_enqueue_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws, uint32_t* land,
+                                hipStream_t st, const MsmSide* side) {
+  const uint32_t *d_fin = nullptr, *d_bad = nullptr;
+  hipError_t e = msm_device_t<C>(pl, d_pts, d_scalars, ws, &d_fin, st, &d_bad, side);
+  if (e != hipSuccess) return e;
+  const size_t fin_words = msm_fin_words_t<C>(pl);
+  e = hipMemcpyAsync(land, d_fin, fin_words * 4, hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return e;
+  return hipMemcpyAsync(land + fin_words, d_bad, 4, hipMemcpyDeviceToHost, st);
+}
+
 template <class C>
 static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws,
                             uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index,
@@ -1016,6 +1052,22 @@ hipError_t msm_sum_partials(int curve, uint32_t* d_gathered, int nparts, size_t 
 #define CALL(C) msm_sum_partials_t<C>(d_gathered, nparts, npoints, d_out, st)
   NCG_MSM_DISPATCH(curve, CALL)
 #undef CALL
+}
+hipError_t msm_enqueue(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws, uint32_t* land,
+                       hipStream_t st, const MsmSide* side) {
+#define CALL(C) msm_enqueue_t<C>(pl, d_pts, d_scalars, ws, land, st, side)
+  NCG_MSM_DISPATCH(curve, CALL)
+#undef CALL
+}
+// Horner over [ngroups(c)][nwin] grouped window sums in HOST memory (device storage format) + canonical affine output
+void msm_finish_host(int curve, int c, int nwin, const uint32_t* fin_host, uint32_t* out_affine_host, uint8_t* out_inf_host) {
+  switch (curve) {
+    case CURVE_SECP256K1: return msm_host_finish_any<CurveSecp>(fin_host, c, nwin, out_affine_host, out_inf_host);
+    case CURVE_BLS12_381_G1: return msm_host_finish_any<CurveG1>(fin_host, c, nwin, out_affine_host, out_inf_host);
+    case CURVE_BLS12_381_G2: return msm_host_finish_any<CurveG2>(fin_host, c, nwin, out_affine_host, out_inf_host);
+    case CURVE_ED25519: return msm_host_finish_any<CurveEd>(fin_host, c, nwin, out_affine_host, out_inf_host);
+    default: return;
+  }
 }
 size_t msm_fin_words(int curve, const MsmPlan& pl) {
   switch (curve) {

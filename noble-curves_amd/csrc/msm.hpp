@@ -33,6 +33,7 @@
 
 namespace ncg {
 
+struct MsmTrace;
 struct MsmPlan {
   int n = 0;       // points
   int c = 0;       // window bits
@@ -55,7 +56,34 @@ struct MsmPlan {
   // set per window, level w = 2^(c w) P at [w * n, (w + 1) * n), so every window adds into ONE bucket set: sorted
   // entry = w * n + i, and everything after the sort runs as a single window of nwin * n entries
   int shared = 0;
+  // window subset (window-sharded multi-GPU mode, comm.hip): this plan runs windows [w0, w0 + nwin) of a full plan of
+  // nwin_total windows; the digit kernels cut bit position c (w0 + w), everything after them sees nwin local windows
+  int w0 = 0;
+  int nwin_total = 0;  // 0 = the plan is whole (nwin_total == nwin)
+  // per-context tuning overrides (ncg_msm_set_tuning; 0 / -1 = the measured defaults): entries per accumulate lane, and
+  // how many following pieces the owner of a cut bucket adds itself before the run goes to the work list
+  int seg_override = 0;
+  int run_serial_override = -1;
+  MsmTrace* trace = nullptr;  // host side: what the last launch actually used (ncg_msm_last_plan)
 };
+
+// what the device phase actually ran with (host memory, filled by msm_device_phase when the plan names one)
+struct MsmTrace {
+  int c = 0, nwin = 0, nb = 0, seg = 0, nseg = 0, run_serial = 0, w0 = 0, nwin_total = 0;
+  const uint32_t* d_long_runs = nullptr;  // device: word 0 = number of runs that went to the work list
+};
+
+// restrict a whole plan to windows [w0, w0 + cnt): the sort chunking is re-derived for the smaller window count
+inline void msm_plan_take_windows(MsmPlan& pl, int w0, int cnt, int q_blocks = 512) {
+  pl.nwin_total = pl.nwin_total ? pl.nwin_total : pl.nwin;
+  pl.w0 += w0;
+  pl.nwin = cnt;
+  int Q = cnt > 0 ? (q_blocks / cnt > 1 ? q_blocks / cnt : 1) : 1;
+  const int cap = pl.n / 4096 > 1 ? pl.n / 4096 : 1;
+  if (Q > cap) Q = cap;
+  pl.Q = Q;
+  pl.chunk = (pl.n + Q - 1) / Q;
+}
 
 // the plan the kernels AFTER the sort see: the plan itself, or - shared-bucket mode - one window holding every entry
 inline MsmPlan msm_acc_view(const MsmPlan& pl) {

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) k_msm_digits_endo(const uint32_t* __restr
     my[6] = 0;
     my[7] = 0;
     for (int w = 0; w < pl.nwin; w++) {
-      const int bp = w * pl.c;
+      const int bp = (w + pl.w0) * pl.c;
       const int limb = bp >> 5, sft = bp & 31;
       const uint64_t two = ((uint64_t)my[limb + 1] << 32) | my[limb];
       const uint32_t v = (uint32_t)(two >> sft) & mask;

@@ -13,6 +13,9 @@
   grouped window sums, a fixed size per curve), torch.distributed all-gathers the slots, and
   `ncg_msm_shard_combine` runs the header check, the adding kernel and the finish that the RCCL path runs
   after its own all-gather.
+* Strong scaling of ONE MSM: `msm_sharded_windows` - every rank holds all points (replicated array or a resident set
+  per GPU) and runs a range of the WINDOWS (curve.ts:886-902: windows are independent until the final chain); the
+  slots are concatenated instead of added.  Same two transports.
 * `n_max` (the largest shard, which fixes the window plan on every rank) is found with one MAX all-reduce
   when the caller does not pass it, so ragged shards always agree on the plan.
 """
@@ -143,8 +146,45 @@ def msm_sharded(engine, curve, n_local, d_points, d_scalars, stream=None, device
         n_max = _agree_n_max(n_local, device)
     if init_comm(engine, device):
         return engine.msm_sharded_dev(curve, n_local, d_points, d_scalars, stream, n_max)
-    slot = engine.msm_shard_local_dev(curve, n_local, d_points, d_scalars, stream, n_max)
-    return engine.msm_shard_combine(curve, n_max, all_gather_slots(slot, device), stream)
+    return _staged_exchange(engine, curve, n_max, device, stream,
+                            lambda: engine.msm_shard_local_dev(curve, n_local, d_points, d_scalars, stream, n_max))
+
+
+def _staged_exchange(engine, curve, n_plan, device, stream, local_phase):
+    """Host-staged exchange: local phase -> all-gather of the fixed-size slots -> combine on every rank.  A rank whose
+    local phase fails must still enter the all-gather (the others are already waiting in it): it posts a poisoned slot,
+    which fails the header check of every rank's combine, and re-raises its own error afterwards.  A scalar outside the
+    group order is not such a failure: the native local phase records it in the slot header and EVERY rank's combine
+    raises 'invalid scalar' (the reference's validateMSMScalars fails the whole call, curve.ts:398-404)."""
+    err = None
+    try:
+        slot = local_phase()
+    except Exception as e:  # noqa: BLE001 - re-raised below, after the collective
+        err = e
+        slot = np.full((engine.msm_shard_slot_bytes(curve),), 0xFF, dtype=np.uint8)
+    slots = all_gather_slots(slot, device)
+    if err is not None:
+        raise err
+    return engine.msm_shard_combine(curve, n_plan, slots, stream)
+
+
+def msm_sharded_windows(engine, curve, n, d_points, d_scalars, stream=None, device=None, resident=None):
+    """ONE n-point MSM cut by WINDOWS over the ranks (strong scaling): every rank holds all n points - `d_points`, or
+    `resident` (a ResidentPoints of this rank's engine holding the same set) - and all n scalars; rank r runs its range
+    of the windows, the slots are concatenated (precomputed sets: added), every rank returns the same (bytes, is_inf).
+    RCCL backend: inside the C ABI (ncg_msm_sharded_windows_dev); otherwise the host-staged exchange."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        if resident is not None:
+            return resident.msm_dev(d_scalars, stream)
+        return engine.msm_dev(curve, n, d_points, d_scalars, stream)
+    if init_comm(engine, device):
+        return engine.msm_sharded_windows_dev(curve, n, d_points, d_scalars, stream, resident)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    c = resident.curve if resident is not None else curve
+    n_all = len(resident) if resident is not None else n
+    return _staged_exchange(engine, c, n_all, device, stream,
+                            lambda: engine.msm_shard_windows_local_dev(curve, n, rank, world, d_points, d_scalars, stream, resident))
 
 
 def msm_sharded_host(engine, curve, points_wire, scalars_wire, device=None):

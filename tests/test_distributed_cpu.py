@@ -34,9 +34,48 @@ class HostTwinEngine:
     def msm_shard_local_dev(self, curve, n_local, d_points, d_scalars, stream=None, n_max=0):
         return self.ht.msm_shard_local(curve, n_local, n_max or n_local, d_points, d_scalars)
 
+    def msm_shard_slot_bytes(self, curve):
+        return self.ht.msm_shard_slot_bytes(curve)
+
+    def msm_shard_windows_local_dev(self, curve, n, part, nparts, d_points, d_scalars, stream=None, resident=None):
+        return self.ht.msm_shard_windows_local(curve, n, part, nparts, d_points, d_scalars)
+
     def msm_shard_combine(self, curve, n_max, slots, stream=None):
         from noble_curves_amd._native import POINT_BYTES
         return self.ht.msm_shard_combine(curve, n_max, slots, POINT_BYTES[curve])
+
+
+def _worker_windows(rank, world, port, curve_name, n, q, bad_at):
+    """window-sharded mode: every rank holds ALL n points and scalars, rank r computes its range of the windows."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import ORACLE_CURVE, points_to_wire, scalars_to_wire, wire_to_affine
+    from noble_curves_amd import _native
+    from noble_curves_amd.distributed import msm_sharded_windows
+    curve = getattr(_native, curve_name)
+    Pt = ORACLE_CURVE[curve]
+    order = Pt.Fn.ORDER
+    from oracle.curves import makeRng
+    rng = makeRng(0x57A6)
+    ks = [rng.rndBelow(order - 1) + 1 for _ in range(n)]
+    sc = [0 if i % 5 == 0 else (order - 1 if i % 7 == 0 else rng.rndBelow(order)) for i in range(n)]
+    if bad_at is not None:
+        sc[bad_at] = order          # outside the contract: EVERY rank must fail (validateMSMScalars, curve.ts:398-404)
+    pts_w = points_to_wire(curve, [Pt.BASE.multiplyUnsafe(k) for k in ks])
+    sc_w = scalars_to_wire(sc)
+    eng = HostTwinEngine()
+    exp = Pt.BASE.multiplyUnsafe(sum(k * s for k, s in zip(ks, sc)) % order).toAffine()
+    try:
+        out, inf = msm_sharded_windows(eng, curve, n, pts_w.ctypes.data, sc_w.ctypes.data)
+        q.put((rank, wire_to_affine(curve, out) == exp, inf, None))
+    except ValueError as e:
+        q.put((rank, False, False, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _worker(rank, world, port, curve_name, sizes, q, wrong_n_max):
@@ -75,6 +114,26 @@ def _worker(rank, world, port, curve_name, sizes, q, wrong_n_max):
         q.put((rank, False, False, str(e)))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _run_windows(curve_name, n, world, bad_at=None):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hosttest
+    hosttest.lib()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_windows, args=(r, world, port, curve_name, n, q, bad_at)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    return res
 
 
 def _run(curve_name, sizes, wrong_n_max=False):
@@ -127,3 +186,25 @@ def test_msm_sharded_rejects_disagreeing_plans():
     path, not a collective with mismatched counts: the slot size does not depend on the plan)."""
     res = _run("BLS12_381_G1", (20, 20), wrong_n_max=True)
     assert all((not r[1]) and r[3] and "all ranks must pass the same curve and n_max" in r[3] for r in res), res
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("curve_name,n,world", [
+    ("BLS12_381_G1", 40, 2),          # c = 2: 128 windows, 64 per rank
+    ("SECP256K1", 24, 3),             # uneven ranges
+    ("ED25519", 11, 2),
+])
+def test_msm_window_sharded_ranks_gloo_native_assembly_twin(curve_name, n, world):
+    """Strong-scaling mode: rank r computes windows [w0, w0 + cnt) of ALL points, the slots are concatenated by the
+    shipped assembly (csrc/msm_shard.hpp) and every rank runs the Horner finish (curve.ts:886-902)."""
+    res = _run_windows(curve_name, n, world)
+    assert all(r[1] for r in res), res
+    assert not any(r[2] for r in res)
+
+
+@pytest.mark.timeout(300)
+def test_out_of_range_scalar_fails_every_rank_not_only_the_owner():
+    """the verdict of validateMSMScalars travels in the slot header, so no rank leaves the exchange early
+    and all of them raise - window mode (all ranks see the scalar) and point mode (only the owner of the slice does)."""
+    res = _run_windows("BLS12_381_G1", 20, 2, bad_at=13)
+    assert all((not r[1]) and r[3] and "invalid scalar at index 13" in r[3] for r in res), res

@@ -84,22 +84,70 @@ def test_msm_non_normalised_inputs_and_window_override(monkeypatch):
         assert gpu_msm(BLS12_381_G1, pts, sc) == exp.toAffine()
 
 
-@pytest.mark.parametrize("seg", ["1", "3", "64", "100000"])
-def test_msm_segment_lengths_and_skewed_buckets(monkeypatch, seg):
-    """Lane-segment boundaries cutting buckets in every possible way, including one bucket that
-    holds every entry (all scalars equal) and many empty buckets."""
-    monkeypatch.setenv("NCG_MSM_SEG", seg)
+@pytest.mark.parametrize("seg,run_serial", [(1, 0), (1, 2), (3, 0), (3, 1), (64, -1), (100000, -1), (7, 50)])
+def test_msm_segment_lengths_and_skewed_buckets(monkeypatch, seg, run_serial):
+    """Lane-segment boundaries cutting buckets in every possible way, including one bucket that holds every entry (all
+    scalars equal) and many empty buckets; with run_serial 0 / 1 every cut bucket takes the long-run work list
+    (k_msm_fixup_long), with 50 none does (k_msm_fixup_merge adds every piece serially).  The segment is set through
+    ncg_msm_set_tuning and ncg_msm_last_plan proves that the launch used it (the NCG_MSM_SEG environment
+    knob is honoured by A/B builds only, so the old form of this test ran one configuration four times)."""
     monkeypatch.setenv("NCG_MSM_C", "6")
+    eng = get_engine()
     Pt = ORACLE_CURVE[BLS12_381_G1]
     pts, sc, exp = progression(Pt, 900, 0x5E6)
-    assert gpu_msm(BLS12_381_G1, pts, sc) == exp.toAffine()
-    order = Pt.Fn.ORDER
     k = 0x1F                                            # every point lands in the same low bucket
-    same = [k] * 900
-    ks_exp = Pt.BASE.multiplyUnsafe(1).toAffine()
     tot = C.normalizeZ(Pt, [sum_points(Pt, pts)])[0]
-    assert gpu_msm(BLS12_381_G1, pts, same) == tot.multiplyUnsafe(k).toAffine()
-    assert ks_exp is not None and order > 0
+    try:
+        eng.msm_set_tuning(seg, run_serial)
+        assert gpu_msm(BLS12_381_G1, pts, sc) == exp.toAffine()
+        lp = eng.msm_last_plan()
+        assert lp["seg"] == seg and lp["c"] == 6 and lp["nb"] == 32
+        if run_serial >= 0:
+            assert lp["run_serial"] == run_serial
+        if seg <= 3 and run_serial in (0, 1):           # 900 entries over 32 buckets: every bucket spans many lanes
+            assert lp["long_runs"] >= 32, lp
+        if run_serial == 50:
+            assert lp["long_runs"] == 0, lp
+        assert gpu_msm(BLS12_381_G1, pts, [k] * 900) == tot.multiplyUnsafe(k).toAffine()
+        lp = eng.msm_last_plan()
+        assert lp["seg"] == seg
+        if seg < 900 and run_serial in (0, 1, 2):
+            assert lp["long_runs"] >= 1, lp             # the one bucket of window 0 is a single long run
+        # the other pipelines under the same cut: sharded by points and by windows, shared-bucket sets need >= 4096 points
+        pw, sw = points_to_wire(BLS12_381_G1, pts), scalars_to_wire(sc)
+        import torch
+        dp, ds = torch.from_numpy(pw).cuda(), torch.from_numpy(sw).cuda()
+        for parts in (2, 5):
+            got, _ = eng.msm_split_windows_dev(BLS12_381_G1, 900, parts, dp.data_ptr(), ds.data_ptr())
+            assert wire_to_affine(BLS12_381_G1, got) == exp.toAffine(), ("windows", parts)
+            got, _ = eng.msm_split_dev(BLS12_381_G1, 900, parts, dp.data_ptr(), ds.data_ptr())
+            assert wire_to_affine(BLS12_381_G1, got) == exp.toAffine(), ("points", parts)
+    finally:
+        eng.msm_set_tuning(0, -1)
+    gpu_msm(BLS12_381_G1, pts[:50], sc[:50])
+    assert eng.msm_last_plan()["seg"] != 100000          # the defaults are back
+
+
+def test_msm_refuses_misaligned_device_buffers():
+    """include/ncg.h: device buffers are read with 16-byte accesses; a 4- or 8-byte-aligned pointer is an
+    NCG_ERR_INVALID_ARG, not a memory fault."""
+    import torch
+    eng = get_engine()
+    Pt = ORACLE_CURVE[BLS12_381_G1]
+    pts, sc, exp = progression(Pt, 40, 0xA11)
+    pw, sw = points_to_wire(BLS12_381_G1, pts), scalars_to_wire(sc)
+    buf = torch.zeros(pw.size + sw.size + 64, dtype=torch.uint8, device="cuda")
+    for off in (4, 8):
+        p = buf.data_ptr() + off
+        with pytest.raises(Exception, match="16-byte aligned"):
+            eng.msm_dev(BLS12_381_G1, 40, p, buf.data_ptr() + 8192)
+        with pytest.raises(Exception, match="16-byte aligned"):
+            eng.msm_dev(BLS12_381_G1, 40, buf.data_ptr(), p)
+        with pytest.raises(Exception, match="16-byte aligned"):
+            eng.msm_split_dev(BLS12_381_G1, 40, 2, p, buf.data_ptr())
+        with pytest.raises(Exception, match="16-byte aligned"):
+            eng.msm_split_windows_dev(BLS12_381_G1, 40, 2, buf.data_ptr(), p)
+    assert gpu_msm(BLS12_381_G1, pts, sc) == exp.toAffine()      # the context keeps working
 
 
 def sum_points(Pt, pts):

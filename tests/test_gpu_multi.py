@@ -138,6 +138,112 @@ def test_host_staged_exchange_native_combine(curve):
     assert inf
 
 
+@pytest.mark.parametrize("curve", [SECP256K1, ED25519, BLS12_381_G1, BLS12_381_G2])
+def test_window_sharded_pipeline_matches_oracle(curve):
+    """Strong-scaling mode (include/ncg.h "WINDOW-sharded mode"): part r runs a range of the windows of ALL points
+    (curve.ts:886-902), the slots are concatenated, every part count incl. more parts than windows; the host-staged
+    twin in one process; resident sets in their generic, endomorphism and precomputed plans."""
+    eng = get_engine()
+    n = 150 if curve != BLS12_381_G2 else 70
+    pw, sw, exp = _case(curve, n, 0x77AD + curve)
+    dp, ds = _dev(pw), _dev(sw)
+    for parts in (1, 2, 3, 8, 64):
+        got, inf = eng.msm_split_windows_dev(curve, n, parts, dp.data_ptr(), ds.data_ptr())
+        assert wire_to_affine(curve, got) == exp.toAffine(), parts
+        assert inf == exp.is0()
+        assert eng.msm_last_plan()["nwin_total"] >= eng.msm_last_plan()["nwin"]
+    for nparts in (2, 5):
+        slots = [eng.msm_shard_windows_local_dev(curve, n, r, nparts, dp.data_ptr(), ds.data_ptr()) for r in range(nparts)]
+        got, inf = eng.msm_shard_combine(curve, n, np.stack(slots))
+        assert wire_to_affine(curve, got) == exp.toAffine() and inf == exp.is0(), nparts
+        with pytest.raises(Exception, match="all ranks must pass the same curve and n_max"):
+            eng.msm_shard_combine(curve, n, np.stack(slots[:-1]))                 # a window range is missing
+        with pytest.raises(Exception, match="all ranks must pass the same curve and n_max"):
+            eng.msm_shard_combine(curve, n, np.stack(slots[::-1]))                # ranges out of rank order
+    rs = eng.upload_points(curve, pw)
+    got, _ = eng.msm_split_windows_dev(curve, n, 3, 0, ds.data_ptr(), resident=rs)
+    assert wire_to_affine(curve, got) == exp.toAffine()
+    rs.free()
+    got, inf = eng.msm_split_windows_dev(curve, 0, 4, 0, 0)
+    assert inf
+
+
+def test_out_of_range_scalar_travels_in_the_slot_header():
+    """the local phase of the rank that owns a scalar >= the group order returns its slot (so the
+    rank still takes part in the exchange), and the combine fails on EVERY rank - here: with every slot order."""
+    eng = get_engine()
+    Pt = ORACLE_CURVE[BLS12_381_G1]
+    pw, sw, exp = _case(BLS12_381_G1, 64, 0xBAD5)
+    sw = sw.copy()
+    sw[40] = np.frombuffer(int(Pt.Fn.ORDER).to_bytes(32, "little"), dtype=np.uint8)
+    dp, ds = _dev(pw), _dev(sw)
+    a = eng.msm_shard_local_dev(BLS12_381_G1, 32, dp.data_ptr(), ds.data_ptr(), None, 32)
+    b = eng.msm_shard_local_dev(BLS12_381_G1, 32, dp.data_ptr() + 32 * 96, ds.data_ptr() + 32 * 32, None, 32)   # holds index 40
+    with pytest.raises(Exception, match="invalid scalar at index 8 of shard 1"):
+        eng.msm_shard_combine(BLS12_381_G1, 32, np.stack([a, b]))
+    with pytest.raises(Exception, match="invalid scalar at index 8 of shard 0"):
+        eng.msm_shard_combine(BLS12_381_G1, 32, np.stack([b, a]))
+    with pytest.raises(Exception, match="invalid scalar at index 40"):
+        eng.msm_split_windows_dev(BLS12_381_G1, 64, 4, dp.data_ptr(), ds.data_ptr())
+    with pytest.raises(Exception, match="invalid scalar at index 8 of shard 1"):
+        eng.msm_split_dev(BLS12_381_G1, 64, 2, dp.data_ptr(), ds.data_ptr())
+    with pytest.raises(Exception, match="invalid scalar at index 40"):
+        eng.msm_dev(BLS12_381_G1, 64, dp.data_ptr(), ds.data_ptr())
+    eng.msm_async_submit(0, BLS12_381_G1, 64, dp.data_ptr(), ds.data_ptr())
+    with pytest.raises(Exception, match="invalid scalar at index 40"):
+        eng.msm_async_collect(0, BLS12_381_G1)
+
+
+def test_several_msms_in_flight():
+    """ncg_msm_async_submit / _collect: four MSMs of different curves and sizes enqueued on the four lanes before any is
+    collected; collected in another order; lanes reused; a busy lane and an idle lane are refused."""
+    eng = get_engine()
+    assert eng.msm_async_lanes() >= 2
+    jobs = []
+    for lane, (curve, n) in enumerate([(BLS12_381_G1, 300), (SECP256K1, 111), (BLS12_381_G2, 60), (ED25519, 77)]):
+        pw, sw, exp = _case(curve, n, 0xA5 + lane)
+        dp, ds = _dev(pw), _dev(sw)
+        jobs.append((lane, curve, n, dp, ds, exp))
+    for rnd in range(3):
+        for lane, curve, n, dp, ds, exp in jobs:
+            eng.msm_async_submit(lane, curve, n, dp.data_ptr(), ds.data_ptr())
+        with pytest.raises(Exception, match="has an MSM in flight"):
+            eng.msm_async_submit(2, BLS12_381_G1, 10, jobs[0][3].data_ptr(), jobs[0][4].data_ptr())
+        for lane, curve, n, dp, ds, exp in (jobs[::-1] if rnd % 2 else jobs):
+            got, inf = eng.msm_async_collect(lane, curve)
+            assert wire_to_affine(curve, got) == exp.toAffine() and inf == exp.is0(), (rnd, lane)
+    with pytest.raises(Exception, match="nothing was submitted"):
+        eng.msm_async_collect(1, SECP256K1)
+    # resident sets (incl. a precomputed one) and the empty MSM on a lane
+    pw, sw, exp = _case(BLS12_381_G1, 5000, 0x5E7)
+    rs = eng.upload_points(BLS12_381_G1, pw)
+    ds = _dev(sw)
+    for stage in range(3):
+        if stage == 1:
+            assert rs.verify_subgroup() == -1
+        if stage == 2:
+            assert rs.precompute()
+        eng.msm_async_submit(0, BLS12_381_G1, 0, 0, ds.data_ptr(), resident=rs)
+        eng.msm_async_submit(1, BLS12_381_G1, 0, 0, ds.data_ptr(), resident=rs)
+        for lane in (0, 1):
+            got, inf = eng.msm_async_collect(lane, BLS12_381_G1)
+            assert wire_to_affine(BLS12_381_G1, got) == exp.toAffine(), stage
+        got, _ = eng.msm_split_windows_dev(BLS12_381_G1, 0, 8, 0, ds.data_ptr(), resident=rs)
+        assert wire_to_affine(BLS12_381_G1, got) == exp.toAffine(), stage
+        # the parts of ONE window-sharded MSM in flight on the lanes, their slots combined (NCG_MSM_ASYNC_PART)
+        for r in range(4):
+            eng.msm_async_submit(r, BLS12_381_G1, 0, 0, ds.data_ptr(), resident=rs, flags=eng.async_part(r, 4))
+        with pytest.raises(Exception, match="use ncg_msm_async_collect_slot"):
+            eng.msm_async_collect(0, BLS12_381_G1)
+        slots = [eng.msm_async_collect_slot(r, BLS12_381_G1) for r in range(4)]
+        got, _ = eng.msm_shard_combine(BLS12_381_G1, 5000, np.stack(slots))
+        assert wire_to_affine(BLS12_381_G1, got) == exp.toAffine(), stage
+    rs.free()
+    eng.msm_async_submit(3, BLS12_381_G1, 0, 0, 0)
+    got, inf = eng.msm_async_collect(3, BLS12_381_G1)
+    assert inf and not got.any()
+
+
 def test_multi_engine_one_device():
     m = MultiEngine([0])
     try:
