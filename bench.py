@@ -386,6 +386,43 @@ def time_steps(fn, steps, warmup, dist_on):
                      [(ts[i + 1] - ts[i]) * 1e3 for i in range(steps)])
 
 
+def time_pipelined(submit, collect, depth, steps, warmup, dist_on, check=None):
+    """The K-step contract for MSMs IN FLIGHT: W warm-up steps, barrier + synchronize, then exactly K MSMs submitted
+    over `depth` lanes (lane i % depth is collected - result on the host, host finish done - just before it is reused)
+    and the last `depth` collected, synchronize + barrier.  Every collected result goes through `check`.
+    Returns (wall seconds for the K MSMs, per-MSM completion intervals in ms)."""
+    import torch.distributed as dist
+    def run(k, timed):
+        done = []
+        t0 = time.perf_counter()
+        for i in range(k):
+            if i >= depth:
+                r = collect(i % depth)
+                done.append(time.perf_counter())
+                if check:
+                    check(r)
+            submit(i % depth, i)
+        for i in range(k, k + min(depth, k)):
+            r = collect(i % depth)
+            done.append(time.perf_counter())
+            if check:
+                check(r)
+        return t0, done
+    run(max(warmup, depth) + (PREWARM_DIST_STEPS if dist_on else 4), False)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0, done = run(steps, True)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    marks = [t0] + done
+    return wall, [round((marks[i + 1] - marks[i]) * 1e3, 4) for i in range(len(done))]
+
+
 def max_over_ranks(x, dist_on, device):
     if not dist_on:
         return x
@@ -680,6 +717,50 @@ def main():
                               "valu": valu_block(pmc, key, wall / K, ref_mac_pt * nn,
                                                  (g1_msm_mads_per_point(nwin, nn, 1 << (c - 1), True) * (3 if curve == BLS12_381_G2 else 1)) * nn)}}
         if not dist_on:
+            # several MSMs in flight (ncg_msm_async_submit / _collect): the dependent tail of one MSM (narrow fold levels,
+            # per-window tail, D2H, host Horner) overlaps the sort / accumulate kernels of the next
+            def chk(r):
+                assert np.array_equal(r[0], got), "pipelined MSM differs from the synchronous one"
+            pipe = {}
+            for depth in (2, 3):
+                pw, iv = time_pipelined(lambda lane, i: eng.msm_async_submit(lane, curve, nn, dev_ptr(pts), dev_ptr(sc), stream),
+                                        lambda lane: eng.msm_async_collect(lane, curve), depth, K, W, False, chk)
+                pipe["depth%d" % depth] = {"value": nn * K / pw, "unit": "points/s", "ms_per_msm": pw / K * 1e3, "completion_intervals_ms": iv}
+            entry["pipelined"] = dict(pipe, note="K MSMs submitted over `depth` lanes (own stream / workspace / pinned landing area each), lane "
+                                                 "i % depth collected before reuse; every result compared with the synchronous MSM; same K-step "
+                                                 "contract (barrier + synchronize around the K MSMs)")
+            # ONE rank's share of this MSM in the window-sharded multi-GPU mode, emulated on this GPU:
+            # part r of G runs windows [w0, w0 + cnt) of ALL points; `latency` = part 0 synchronously + the combine / finish
+            # every rank runs on the G gathered slots; `pipelined` = the parts of successive MSMs in flight on the lanes
+            # (average over all G parts).  The G slots are combined and checked, so the timed path is the shipped one.
+            # Not included: the all-gather of G x 29 KB (58 KB on G2) over xGMI.
+            shares = {}
+            for G in (2, 4, 8):
+                slots = [eng.msm_shard_windows_local_dev(curve, nn, r, G, dev_ptr(pts), dev_ptr(sc), stream) for r in range(G)]
+                stack = np.stack(slots)
+                cg, _ = eng.msm_shard_combine(curve, nn, stack, stream)
+                assert np.array_equal(cg, got), "window-sharded MSM (%d parts) differs from the single-GPU MSM" % G
+                st_l = time_steps(lambda: eng.msm_shard_windows_local_dev(curve, nn, 0, G, dev_ptr(pts), dev_ptr(sc), stream), K, W, False)
+                st_c = time_steps(lambda: eng.msm_shard_combine(curve, nn, stack, stream), K, W, False)
+                coll = {}
+
+                def sub(lane, i, G=G):
+                    eng.msm_async_submit(lane, curve, nn, dev_ptr(pts), dev_ptr(sc), stream, None, eng.async_part(i % G, G))
+                    coll[lane] = i % G
+
+                def col(lane):
+                    return coll[lane], eng.msm_async_collect_slot(lane, curve)
+                seen = {}
+                pw, _ = time_pipelined(sub, col, 3, G * max(2, (K + G - 1) // G), W, False, lambda r: seen.__setitem__(r[0], r[1]))
+                jobs = G * max(2, (K + G - 1) // G)
+                cg2, _ = eng.msm_shard_combine(curve, nn, np.stack([seen[r] for r in range(G)]), stream)
+                assert np.array_equal(cg2, got), "window-sharded MSM (%d parts, pipelined) differs from the single-GPU MSM" % G
+                lat = (st_l[0] + st_c[0]) / K * 1e3
+                shares["G%d" % G] = {"latency_ms": lat, "local_part0_ms": st_l[0] / K * 1e3, "combine_finish_ms": st_c[0] / K * 1e3,
+                                     "pipelined_part_ms": pw / jobs * 1e3, "speedup_latency": (wall / K * 1e3) / lat,
+                                     "speedup_pipelined": (wall / K * 1e3) / (pw / jobs * 1e3)}
+            entry["window_share"] = dict(shares, note="per-rank share of ONE %d-point MSM cut by windows over G ranks, emulated on one GPU; speedup_* = "
+                                                      "this run's single-GPU ms_per_msm / share; the xGMI all-gather (~30 us) is not included" % nn)
             # the same MSM on a resident set verified to lie in the prime-order subgroup (ncg_points_verify_subgroup,
             # once per set): the scalars are split along the curve endomorphism (csrc/endo.hpp) - same group
             # element, half (G1) / a quarter (G2) of the windows.  pippenger itself accepts arbitrary curve
@@ -725,6 +806,45 @@ def main():
         sub = {"pts": pts, "sc": sc, "ks": ks, "pks": pks}
         return entry, sub
 
+    def strong_by_windows(curve, Pt, nn, seed):
+        """configs[3] / [4] as written - ONE nn-point MSM on all GPUs - in the window-sharded mode: every rank holds the same
+        nn points (a replicated / resident set: the fixed bases of a prover) and all nn scalars, rank r runs its range of the
+        windows (digits, sort, accumulate and the throughput part of the fold divide by the rank count), ONE all-gather of
+        the grouped window sums, concatenation, Horner on every rank.  Timed synchronously (latency of one MSM) and with 3
+        MSMs in flight per rank (sustained rate)."""
+        from noble_curves_amd.distributed import msm_sharded_windows
+        rng = makeRng(seed)                                   # the SAME set on every rank
+        a, b = rng.rndBelow(BLS_R - 1) + 1, rng.rndBelow(BLS_R - 1) + 1
+        pts, pks = gen_points(eng, curve, Pt, nn, a, b, device, stream)
+        sc = gen_scalars(nn, 254, 4242 + seed % 1000, device)
+        sc[::17] = 0
+        ks = scalars_to_ints(sc)
+        exp = Pt.BASE.multiplyUnsafe(sum(k * p for k, p in zip(ks, pks)) % BLS_R).toAffine()
+        res = eng.upload_points(curve, pts.cpu().numpy())     # resident on every GPU (stored form built once)
+        hs = {}
+
+        def step_w():
+            hs["r"] = msm_sharded_windows(eng, curve, nn, 0, dev_ptr(sc), stream, device, res)
+
+        st_w = time_steps(step_w, K, W, dist_on)
+        wall_w = max_over_ranks(st_w[0], dist_on, device)
+        assert wire_to_affine(curve, hs["r"][0]) == exp, "window-sharded MSM mismatch"
+        out = {"metric": "bls12_381_%s_msm_points_per_sec" % ("g1" if curve == BLS12_381_G1 else "g2"), "value": nn * K / wall_w, "unit": "points/s",
+               "ms_per_msm": wall_w / K * 1e3, "total_points": nn, "scaling": "strong", "mode": "windows", "step_times": st_w.dist(),
+               "window_plan": eng.msm_plan_info(curve, nn),
+               "transport": "ncg_msm_sharded_windows_dev (RCCL all-gather inside the C ABI)" if native_multi else "host-staged slots over torch.distributed (%s)" % args.backend,
+               "note": "every rank holds all %d points (resident set) and scalars; rank r runs windows [w0, w0 + cnt); slots concatenated" % nn}
+        if native_multi:
+            def chk(r):
+                assert wire_to_affine(curve, r[0]) == exp, "pipelined window-sharded MSM mismatch"
+            pwall, iv = time_pipelined(lambda lane, i: eng.msm_async_submit(lane, curve, nn, 0, dev_ptr(sc), stream, res, eng.ASYNC_WINDOWS),
+                                       lambda lane: eng.msm_async_collect(lane, curve), 3, K, W, dist_on, chk)
+            pwall = max_over_ranks(pwall, dist_on, device)
+            out["pipelined"] = {"value": nn * K / pwall, "unit": "points/s", "ms_per_msm": pwall / K * 1e3, "depth": 3, "completion_intervals_ms": iv,
+                                "note": "3 window-sharded MSMs in flight per rank (ncg_msm_async_submit with NCG_MSM_ASYNC_WINDOWS); every result checked"}
+        res.free()
+        return out
+
     if args.workload in ("all", "msm_g1"):
         msm, sub = msm_workload(BLS12_381_G1, BlsG1, "g1", n, 0x6D736D0000000003, 128.0, 9.45e4, "msm_g1")
         if cpu_leg:
@@ -765,9 +885,11 @@ def main():
             tot = sum_over_ranks_bigint(sub_expect, BLS_R, dist_on, device)
             got_s, _ = hs["r"]
             assert wire_to_affine(BLS12_381_G1, got_s) == BlsG1.BASE.multiplyUnsafe(tot).toAffine(), "strong MSM mismatch"
-            extra["msm_g1_strong"] = {"metric": "bls12_381_g1_msm_points_per_sec", "value": ns * world * K / wall_s,
-                                      "unit": "points/s", "ms_per_msm": wall_s / K * 1e3, "total_points": ns * world,
-                                      "points_per_gpu": ns, "scaling": "strong", "step_times": st_s.dist()}
+            by_points = {"metric": "bls12_381_g1_msm_points_per_sec", "value": ns * world * K / wall_s,
+                         "unit": "points/s", "ms_per_msm": wall_s / K * 1e3, "total_points": ns * world,
+                         "points_per_gpu": ns, "scaling": "strong", "mode": "points", "step_times": st_s.dist()}
+            extra["msm_g1_strong"] = strong_by_windows(BLS12_381_G1, BlsG1, n, 0x6D736D0000001003)
+            extra["msm_g1_strong"]["by_points"] = by_points
         if not result:
             result = dict(msm)
             result.update({"n_gpus": world, "steps": K, "warmup": W, "ms_per_step": msm["ms_per_msm"],
@@ -815,9 +937,11 @@ def main():
             tot = sum_over_ranks_bigint(sub_expect, BLS_R, dist_on, device)
             got_s, _ = hs2["r"]
             assert wire_to_affine(BLS12_381_G2, got_s) == BlsG2.BASE.multiplyUnsafe(tot).toAffine(), "strong G2 MSM mismatch"
-            extra["msm_g2_strong"] = {"metric": "bls12_381_g2_msm_points_per_sec", "value": ns * world * K / wall_s,
-                                      "unit": "points/s", "ms_per_msm": wall_s / K * 1e3, "total_points": ns * world,
-                                      "points_per_gpu": ns, "scaling": "strong", "step_times": st_s2.dist()}
+            by_points2 = {"metric": "bls12_381_g2_msm_points_per_sec", "value": ns * world * K / wall_s,
+                          "unit": "points/s", "ms_per_msm": wall_s / K * 1e3, "total_points": ns * world,
+                          "points_per_gpu": ns, "scaling": "strong", "mode": "points", "step_times": st_s2.dist()}
+            extra["msm_g2_strong"] = strong_by_windows(BLS12_381_G2, BlsG2, n2, 0x6D736D0000001004)
+            extra["msm_g2_strong"]["by_points"] = by_points2
         if not result:
             result = dict(msm2)
             result.update({"n_gpus": world, "steps": K, "warmup": W, "ms_per_step": msm2["ms_per_msm"],
@@ -980,13 +1104,21 @@ def main():
         result.update({"n_gpus": world, "steps": K, "warmup": W, "higher_is_better": True, "vs_baseline": None, "dtype": "u32",
                        "ms_per_step": e.get("ms_per_batch", e.get("ms_per_transform")), "data": "synthetic",
                        "scaling": "weak", "config": {"workload": key}})
+    # both halves of BASELINE's metric at the TOP level of the line (the driver's parsed record keeps the
+    # top-level keys): the G1 MSM with its own value / ms / roofline / cpu_baseline, and - runs with several GPUs - the
+    # strong-scaling MSM; `extra` keeps the full entries
+    for key in ("msm_g1", "msm_g1_strong", "msm_g2", "msm_g2_strong"):
+        if key in extra:
+            e = extra[key]
+            result[key] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_msm", "total_points", "points_per_gpu", "scaling", "mode",
+                                             "window_plan", "roofline", "cpu_baseline", "pipelined", "window_share") if k in e}
     if extra:
         result["extra"] = extra
     if rank == 0:
         result["host"] = host
         result["prewarm"] = (("%d untimed steps" % PREWARM_DIST_STEPS if dist_on else "%.0f ms of untimed steps" % (PREWARM_S * 1e3)) +
                              " before the W warm-up steps of every timed loop (boost-clock settling; the K timed steps are unchanged)")
-        result["pmc"] = "live rocprofv3 passes in this run" if live else "committed profile profiles/r03_pmc.json"
+        result["pmc"] = "live rocprofv3 passes in this run" if live else "committed profile (see roofline.traffic_source)"
         print(json.dumps(result))
         if args.out:
             with open(args.out, "w") as f:

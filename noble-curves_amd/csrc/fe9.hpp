@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "fp.hpp"
+#include "fe9_asm_gen.hpp"
 
 namespace ncg {
 
@@ -104,11 +105,66 @@ NCG_DI void fe9_tail(uint32_t (&r)[9], uint32_t (&t)[9], uint64_t c, uint32_t dt
   for (int i = 4; i < 9; i++) r[i] = t[i];
 }
 
+#ifndef NCG_FE9_ASM_BLOCKS
+#define NCG_FE9_ASM_BLOCKS 1
+#endif
+#define NCG_FE9_ARGS9(x) x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], x[8]
+
+// The multiply-adds of column pair k as ONE asm block (fe9_asm_gen.hpp, tools/gen_fe9_asm.py): adjacent inline-asm
+// STATEMENTS that share a register - every multiply-add names VCC - get a wait state from the compiler's hazard
+// recogniser (8 030 s_nop against 10 980 multiply-adds in the round-3 secp256k1 ladder); instructions inside one block do
+// not.  `fold`: the block starts with c += u * C1 of the previous column (so that this multiply-add is not a statement of
+// its own next to the block).
+template <int K, bool SQR>
+NCG_DI void fe9_blk(uint64_t& c, uint64_t& d, const uint32_t (&a)[9], const uint32_t (&b)[9], bool fold, uint32_t u, uint32_t C1) {
+#define NCG_FE9_CASE(k)                                                                               \
+  if constexpr (K == k) {                                                                             \
+    if constexpr (SQR) {                                                                              \
+      if (fold) fe9_blk_sqr_##k##_f(c, d, NCG_FE9_ARGS9(a), NCG_FE9_ARGS9(b), u, C1);                 \
+      else fe9_blk_sqr_##k(c, d, NCG_FE9_ARGS9(a), NCG_FE9_ARGS9(b));                                 \
+    } else {                                                                                          \
+      if (fold) fe9_blk_mul_##k##_f(c, d, NCG_FE9_ARGS9(a), NCG_FE9_ARGS9(b), u, C1);                 \
+      else fe9_blk_mul_##k(c, d, NCG_FE9_ARGS9(a), NCG_FE9_ARGS9(b));                                 \
+    }                                                                                                 \
+  }
+  NCG_FE9_CASE(0) NCG_FE9_CASE(1) NCG_FE9_CASE(2) NCG_FE9_CASE(3) NCG_FE9_CASE(4) NCG_FE9_CASE(5) NCG_FE9_CASE(6) NCG_FE9_CASE(7)
+#undef NCG_FE9_CASE
+}
+// columns 0..7 + their folds, shared by product and square: x = a, y = b (product) or x = a, y = 2a (square)
+template <class PR, bool SQR, int K = 0>
+NCG_DI void fe9_cols(uint64_t& c, uint64_t& d, uint32_t (&t)[9], const uint32_t (&x)[9], const uint32_t (&y)[9], uint32_t u_prev) {
+  constexpr uint32_t C0 = PR::C0, C1 = PR::C1;
+  if constexpr (K < 8) {
+    fe9_blk<K, SQR>(c, d, x, y, K > 0 && C1 != 0, u_prev, C1);
+    const uint32_t u = (uint32_t)d & FE9_MASK;
+    d >>= 29;
+    fe9_mac_k(c, u, C0);
+    t[K] = (uint32_t)c & FE9_MASK;
+    c >>= 29;
+    if constexpr (K == 7) {
+      if (C1) fe9_mac_k(c, u, C1);   // the last fold has no following block to ride in
+    }
+    fe9_cols<PR, SQR, K + 1>(c, d, t, x, y, u);
+  }
+}
+
 // r = a * b mod p (congruent), limbs of r below 2^29 + 2.  Requires limbs(a) < A*U, limbs(b) < B*U
 // with A*B <= 7 (so that 9 products fit 64 bits) - checked by the callers' types.
 template <class PR>
 NCG_DI void fe9_mul_limbs(uint32_t (&r)[9], const uint32_t (&a)[9], const uint32_t (&b)[9]) {
   constexpr uint32_t C0 = PR::C0, C1 = PR::C1;
+#if NCG_FE9_ASM_BLOCKS
+  {
+    uint64_t c, d;
+    fe9_blk_mul_head(c, d, NCG_FE9_ARGS9(a), NCG_FE9_ARGS9(b));
+    const uint32_t t8 = (uint32_t)d & FE9_MASK;
+    d >>= 29;
+    uint32_t t[9];
+    fe9_cols<PR, false>(c, d, t, a, b, 0u);
+    fe9_tail<PR>(r, t, c, (uint32_t)d, t8);
+    return;
+  }
+#endif
   uint64_t d = fe9_mul64(a[0], b[8]);  // high chain: columns 8, 9, ..., 16
 #pragma unroll
   for (int i = 1; i < 9; i++) fe9_mac(d, a[i], b[8 - i]);
@@ -142,6 +198,18 @@ NCG_DI void fe9_sqr_limbs(uint32_t (&r)[9], const uint32_t (&a)[9]) {
   uint32_t a2[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) a2[i] = a[i] << 1;
+#if NCG_FE9_ASM_BLOCKS
+  {
+    uint64_t c, d;
+    fe9_blk_sqr_head(c, d, NCG_FE9_ARGS9(a), NCG_FE9_ARGS9(a2));
+    const uint32_t t8 = (uint32_t)d & FE9_MASK;
+    d >>= 29;
+    uint32_t t[9];
+    fe9_cols<PR, true>(c, d, t, a, a2, 0u);
+    fe9_tail<PR>(r, t, c, (uint32_t)d, t8);
+    return;
+  }
+#endif
   // column k = sum_{i<j, i+j=k} 2 a_i a_j + [k even] a_{k/2}^2
   uint64_t d = fe9_mul64(a[4], a[4]);
 #pragma unroll
