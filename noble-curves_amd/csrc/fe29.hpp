@@ -441,6 +441,31 @@ NCG_MULFN Fe29Raw fe29x2p_mul_raw(Fe29Raw a, Fe29Raw b) {
   constexpr int N = 14;
   constexpr uint32_t MASK = (1u << 29) - 1u;
   const bool odd = pair_odd();
+#if NCG_FE29_COLS_PAIRED
+  {
+    uint32_t xs[2][N], ys[2][N];
+    int32_t cy = 0;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const uint32_t pa = pair_swap(a.v[i]);
+      any |= pa;
+      int32_t dd = (int32_t)ParamsBls29::PMUL[K][i] - (int32_t)pa + cy;
+      const uint32_t neg = i < N - 1 ? ((uint32_t)dd & MASK) : (uint32_t)dd;
+      cy = i < N - 1 ? (dd >> 29) : 0;
+      xs[0][i] = odd ? pa : a.v[i];
+      ys[0][i] = b.v[i];
+      xs[1][i] = odd ? a.v[i] : neg;
+      ys[1][i] = pair_swap(b.v[i]);
+    }
+    if (!odd && any == 0) {
+#pragma unroll
+      for (int i = 0; i < N; i++) xs[1][i] = 0;
+    }
+    mont_cols29<ParamsBls29, 2>(r.v, xs, ys);
+    return r;
+  }
+#endif
   uint64_t t[2 * N];
 #pragma unroll
   for (int k = 0; k < 2 * N; k++) t[k] = 0;
@@ -569,11 +594,30 @@ NCG_DI Fe29x2P<2> f_mulsub(const Fe29x2P<A>& a, const Fe29x2P<B>& b, const Fe29x
   constexpr int N = 14;
   constexpr uint32_t MASK = (1u << 29) - 1u;
   const bool odd = pair_odd();
+  const Fe29<(1 << KA)> na = f_neg(a.h);  // 2^KA p - own a
+  const Fe29<(1 << KC)> nc = f_neg(c.h);  // 2^KC p - own c
+#if NCG_FE29_COLS_PAIRED
+  {
+    uint32_t xs[4][N], ys[4][N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const uint32_t pa = pair_swap(a.h.v[i]), pna = pair_swap(na.v[i]), pnc = pair_swap(nc.v[i]), pc = pair_swap(c.h.v[i]);
+      xs[0][i] = odd ? pa : a.h.v[i];
+      ys[0][i] = b.h.v[i];
+      xs[1][i] = odd ? a.h.v[i] : pna;
+      ys[1][i] = pair_swap(b.h.v[i]);
+      xs[2][i] = odd ? pnc : nc.v[i];
+      ys[2][i] = d.h.v[i];
+      xs[3][i] = odd ? nc.v[i] : pc;
+      ys[3][i] = pair_swap(d.h.v[i]);
+    }
+    mont_cols29<ParamsBls29, 4>(o.v, xs, ys);
+    return Fe29x2P<2>(o);
+  }
+#endif
   uint64_t t[2 * N];
 #pragma unroll
   for (int k = 0; k < 2 * N; k++) t[k] = 0;
-  const Fe29<(1 << KA)> na = f_neg(a.h);  // 2^KA p - own a
-  const Fe29<(1 << KC)> nc = f_neg(c.h);  // 2^KC p - own c
   {  // (odd ? a_partner : a_own) * b_own
     uint32_t x[N];
 #pragma unroll
@@ -661,6 +705,20 @@ NCG_DI Fe29x2P<2> f_sqr(const Fe29x2P<A>& a) {
   const Fe29<2 * A> s = a0 + fe29_select(odd, a0, a1);
   const Fe29<A + KA> d = a0 - a1;
   const Fe29<A + KA> y = fe29_select(odd, Fe29<A + KA>(a1), d);
+#if NCG_FE29_COLS_PAIRED && defined(__HIP_DEVICE_COMPILE__)
+  {  // the lane's one product in the column-wise form too (same value as s * y)
+    static_assert(2L * A * (A + KA) <= (1L << 24), "operand bounds");
+    uint32_t xs[1][14], ys[1][14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+      xs[0][i] = s.v[i];
+      ys[0][i] = y.v[i];
+    }
+    Fe29<2> o;
+    mont_cols29<ParamsBls29, 1>(o.v, xs, ys);
+    return Fe29x2P<2>(o);
+  }
+#endif
   return Fe29x2P<2>(s * y);
 }
 template <int A>

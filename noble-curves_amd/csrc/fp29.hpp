@@ -78,12 +78,101 @@ inline void mont_muladd58_host(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N],
 }
 #endif
 
+// Column-wise (product-scanning) form of the same Montgomery product, for sums of NP products sharing ONE reduction:
+// column k is accumulated in NP + 1 independent 64-bit chains (one per product, one for the reduction terms q_i p_(k-i)
+// plus the carry) that are joined once per column - 2 (NP + 1) live accumulator registers instead of the 56 of the row-wise
+// form above, whose 28 column registers stay live through the whole product.  Same multiply-add count, the same column
+// bounds (every column sum is the sum the row-wise form holds in t[k]), bit-identical results.  It pays where it moves a
+// kernel across a register cliff - the lane-paired G2 MSM kernels (306 -> 232 registers: two waves per SIMD instead of
+// one; G2 2^18 MSM 3.71 -> 3.47 ms, verified sets 3.01 -> 2.70 ms, same box) - and costs 1-4 % elsewhere (the joins of the
+// chains; G1 accumulate 211 registers without spills is 1 % SLOWER than 256 + 6 spills), so only the paired products of
+// msm.o use it (NCG_FE29_COLS_PAIRED; profiles/r04_ab_cols.txt).
+#ifndef NCG_FE29_COLS
+#define NCG_FE29_COLS 0          // every bls12-381 base-field product of the translation unit
+#endif
+#ifndef NCG_FE29_COLS_PAIRED
+#define NCG_FE29_COLS_PAIRED NCG_FE29_COLS   // only the lane-paired Fp2 products (fe29.hpp)
+#endif
+template <class PR, int NP>
+NCG_DI void mont_cols29(uint32_t (&r)[PR::N], const uint32_t (&x)[NP][PR::N], const uint32_t (&y)[NP][PR::N]) {
+  constexpr int N = PR::N;
+  constexpr uint32_t MASK = (1u << 29) - 1u;
+  uint32_t q[N];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * N; k++) {
+    const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+    uint64_t s[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) s[p] = 0;
+    uint64_t sq = carry;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+#pragma unroll
+      for (int p = 0; p < NP; p++) s[p] += (uint64_t)x[p][i] * y[p][k - i];
+      if (k >= N || i < k) sq += (uint64_t)q[i] * (uint32_t)PR::P[k - i];
+    }
+    uint64_t T = sq;
+#pragma unroll
+    for (int p = 0; p < NP; p++) T += s[p];
+    if (k < N) {
+      q[k] = ((uint32_t)T * PR::INV) & MASK;
+      T += (uint64_t)q[k] * (uint32_t)PR::P[0];
+    } else {
+      r[k - N] = (uint32_t)T & MASK;
+    }
+    carry = T >> 29;
+  }
+}
+// the square in the same form: off-diagonal products once against the doubled operand
+template <class PR>
+NCG_DI void mont_cols29_sqr(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N]) {
+  constexpr int N = PR::N;
+  constexpr uint32_t MASK = (1u << 29) - 1u;
+  uint32_t a2[N], q[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) a2[i] = a[i] << 1;
+  uint64_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < 2 * N; k++) {
+    const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+    uint64_t s0 = 0, s1 = 0, sq = carry;
+#pragma unroll
+    for (int i = lo; i <= hi; i++) {
+      if (2 * i < k) {  // i < j = k - i: doubled; two chains by parity of i
+        if (i & 1) s1 += (uint64_t)a2[i] * a[k - i];
+        else s0 += (uint64_t)a2[i] * a[k - i];
+      } else if (2 * i == k) {
+        s1 += (uint64_t)a[i] * a[i];
+      }
+      if (k >= N || i < k) sq += (uint64_t)q[i] * (uint32_t)PR::P[k - i];
+    }
+    uint64_t T = sq + s0 + s1;
+    if (k < N) {
+      q[k] = ((uint32_t)T * PR::INV) & MASK;
+      T += (uint64_t)q[k] * (uint32_t)PR::P[0];
+    } else {
+      r[k - N] = (uint32_t)T & MASK;
+    }
+    carry = T >> 29;
+  }
+}
+
 // r = a*b*R^-1 mod p (R = 2^(29N)); inputs: limbs < 2^29, values < 2^12 p; output limbs < 2^29,
 // value < a*b/R + p.
 template <class PR>
 NCG_DI void mont_mul29(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], const uint32_t (&b)[PR::N]) {
 #ifndef __HIP_DEVICE_COMPILE__
   mont_mul58_host<PR>(r, a, b);
+  return;
+#elif NCG_FE29_COLS
+  uint32_t x[1][PR::N], y[1][PR::N];
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) {
+    x[0][i] = a[i];
+    y[0][i] = b[i];
+  }
+  mont_cols29<PR, 1>(r, x, y);
   return;
 #else
   constexpr int N = PR::N;
@@ -122,6 +211,17 @@ NCG_DI void mont_muladd29(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N], cons
                           const uint32_t (&c)[PR::N], const uint32_t (&d)[PR::N]) {
 #ifndef __HIP_DEVICE_COMPILE__
   mont_muladd58_host<PR>(r, a, b, c, d);
+  return;
+#elif NCG_FE29_COLS
+  uint32_t x[2][PR::N], y[2][PR::N];
+#pragma unroll
+  for (int i = 0; i < PR::N; i++) {
+    x[0][i] = a[i];
+    y[0][i] = b[i];
+    x[1][i] = c[i];
+    y[1][i] = d[i];
+  }
+  mont_cols29<PR, 2>(r, x, y);
   return;
 #else
   constexpr int N = PR::N;
@@ -163,6 +263,9 @@ template <class PR>
 NCG_DI void mont_sqr29(uint32_t (&r)[PR::N], const uint32_t (&a)[PR::N]) {
 #ifndef __HIP_DEVICE_COMPILE__
   mont_mul58_host<PR>(r, a, a);
+  return;
+#elif NCG_FE29_COLS
+  mont_cols29_sqr<PR>(r, a);
   return;
 #else
   constexpr int N = PR::N;

@@ -229,9 +229,10 @@ struct MsmSeg {
 // lane-paired G2 sits 24 registers above the 2-waves/SIMD line: ask for 2 (a little scratch
 // traffic in a loop of ~17k instructions per add is cheaper than half the occupancy)
 template <class C> struct AccumMinWaves { static constexpr int value = NCG_ACCUM_MINW; };
-// G2: one wave per SIMD (306 registers, no scratch).  At two waves the kernel kept 79 values in scratch memory: 3 % slower on
-// most boxes and 49 % slower on the boxes of the pool whose memory path is slow (profiles/r03_box_to_box.md)
-template <> struct AccumMinWaves<CurveG2P> { static constexpr int value = 1; };
+// G2: the row-wise Montgomery product needed 306 registers (one wave per SIMD; at two waves the kernel kept 79 values in
+// scratch memory: 3 % slower on most boxes and 49 % slower on the boxes of the pool whose memory path is slow,
+// profiles/r03_box_to_box.md).  With the column-wise product (fp29.hpp mont_cols29) it needs 232: two waves, no scratch.
+template <> struct AccumMinWaves<CurveG2P> { static constexpr int value = NCG_G2_ACCUM_WAVES; };
 template <> struct AccumMinWaves<CurveG1> { static constexpr int value = 2; };  // 256 VGPRs + 36 B scratch: 2 % faster than 1 wave
 template <class C>
 __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(const uint32_t* __restrict__ pts_mont,

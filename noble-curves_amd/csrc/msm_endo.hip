@@ -11,6 +11,7 @@
 #include "endo.hpp"
 #include "host_api.hpp"
 #include "msm.hpp"
+#include "msm_plan.hpp"
 
 namespace ncg {
 
@@ -109,7 +110,7 @@ int msm_make_plan_endo(int curve, int n_src, int c_override, MsmPlan* pl) {
   pl->n_src = n_src;
   pl->endo = E;
   pl->ls = curve == CURVE_BLS12_381_G2 ? 1 : 0;
-  pl->accum_waves = curve == CURVE_BLS12_381_G2 ? 1 : 2;
+  pl->accum_waves = curve == CURVE_BLS12_381_G2 ? NCG_G2_ACCUM_WAVES : 2;
   pl->c = c;
   pl->nb = 1 << (c - 1);
   pl->nwin = (bits + c - 1) / c;

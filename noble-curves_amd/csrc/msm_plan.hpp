@@ -6,6 +6,13 @@
 
 #include "msm.hpp"
 
+// waves/SIMD of the lane-paired G2 accumulate kernel (the whole library must agree: the window plan sizes the lane segment
+// for the kernel's resident-lane capacity).  2 since round 4: with the column-wise Montgomery product (fp29.hpp
+// mont_cols29, NCG_FE29_COLS in msm.o) the kernel needs 232 registers instead of 306.
+#ifndef NCG_G2_ACCUM_WAVES
+#define NCG_G2_ACCUM_WAVES 2
+#endif
+
 namespace ncg {
 
 inline void mp_set_bit(uint32_t* a, int bit) { a[bit >> 5] |= 1u << (bit & 31); }
@@ -79,7 +86,7 @@ inline int msm_make_plan_impl(int curve, int n, int c_override, MsmPlan* pl) {
   pl->n = n;
   pl->ls = curve == CURVE_BLS12_381_G2 ? 1 : 0;  // lane-paired kernels: 2 lanes per item
   // waves/SIMD the accumulate kernel runs at (registers): 4 for the 256-bit fields, 2 for bls12-381 G1, 1 for G2
-  pl->accum_waves = (curve == CURVE_SECP256K1 || curve == CURVE_ED25519) ? 4 : curve == CURVE_BLS12_381_G2 ? 1 : 2;
+  pl->accum_waves = (curve == CURVE_SECP256K1 || curve == CURVE_ED25519) ? 4 : curve == CURVE_BLS12_381_G2 ? NCG_G2_ACCUM_WAVES : 2;
   pl->c = c;
   pl->nb = 1 << (c - 1);
   pl->nwin = plan_windows(c, curve_order(curve), pl->hconst);
