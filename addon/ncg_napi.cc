@@ -730,6 +730,35 @@ static napi_value PointBytes(napi_env env, napi_callback_info info) {
   return r;
 }
 
+// hostRegister(Uint8Array) / hostUnregister(Uint8Array): pin a long-lived input / output buffer ONCE (ncg_host_register),
+// so that every later call on it moves by DMA at PCIe speed with no per-call page locking
+static napi_value HostRegister(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  uint8_t* p;
+  size_t len;
+  if (argc < 1 || !get_u8(env, argv[0], &p, &len)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: hostRegister(Uint8Array)");
+    return nullptr;
+  }
+  if (ncg_host_register(p, len) != 0) return throw_native(env);
+  return nullptr;
+}
+static napi_value HostUnregister(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  uint8_t* p;
+  size_t len;
+  if (argc < 1 || !get_u8(env, argv[0], &p, &len)) {
+    napi_throw_type_error(env, nullptr, "noble-gpu: hostUnregister(Uint8Array)");
+    return nullptr;
+  }
+  (void)ncg_host_unregister(p);
+  return nullptr;
+}
+
 static napi_value Version(napi_env env, napi_callback_info) {
   napi_value r;
   NAPI_OK(napi_create_string_utf8(env, ncg_version(), NAPI_AUTO_LENGTH, &r));
@@ -749,6 +778,7 @@ NAPI_MODULE_INIT() {
              {"packBigInts", PackBigInts}, {"unpackBigInts", UnpackBigInts}, {"uploadPoints", UploadPoints}, {"freePoints", FreePoints}, {"verifySubgroup", VerifySubgroup}, {"precomputePoints", PrecomputePoints}, {"inSubgroup", InSubgroup},
              {"msmResident", MsmResident}, {"mulVarResident", MulVarResident},
              {"ed25519VerifyMsgs", Ed25519VerifyMsgs}, {"ecdsaVerify", EcdsaVerify}, {"secpVerifyMsgs", SecpVerifyMsgs}, {"ecdsaRecover", EcdsaRecover},
+             {"hostRegister", HostRegister}, {"hostUnregister", HostUnregister},
              {"version", Version}};
   for (auto& f : fns) {
     napi_value v;

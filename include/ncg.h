@@ -72,6 +72,12 @@ const char* ncg_version(void);
 int ncg_point_bytes(int curve);
 int ncg_field_bytes(int curve);
 
+/* Pin a long-lived HOST buffer once (hipHostRegister): the host-pointer entry points then move it by DMA at PCIe speed
+ * with no per-call page locking - what a binding does for buffers it reuses (the N-API addon's input / output Buffers).
+ * Unpinned buffers stay correct: large ones are registered for the duration of each call. */
+int ncg_host_register(void* host_ptr, size_t bytes);
+int ncg_host_unregister(void* host_ptr);
+
 /* ---- batch variable-base scalar multiplication ---------------------------------------
  * out[i] = scalars[i] * points[i].  Replaces, batch-wise, Point.multiplyUnsafe(k)
  * (src/abstract/weierstrass.ts:915-928; GLV path :660-671 on secp256k1) and the value of

@@ -309,6 +309,19 @@ class Engine:
     def mul_var_batch_dev(self, curve, n, d_points, d_scalars, d_out, d_inf, stream=None):
         self._check(self.lib.ncg_mul_var_batch_dev(self.h, curve, n, d_points, d_scalars, d_out, d_inf, stream))
 
+    # ---- pinned host buffers ---------------------------------------------------------------------
+    def host_register(self, arr):
+        """Pin a long-lived numpy array once (ncg_host_register): host-pointer calls on it then run at PCIe speed."""
+        fn = self.lib.ncg_host_register
+        fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_size_t], ctypes.c_int
+        if fn(arr.ctypes.data, arr.nbytes) != 0:
+            raise NativeError((self.lib.ncg_last_error(None) or b"").decode() or "noble-gpu: host_register failed")
+
+    def host_unregister(self, arr):
+        fn = self.lib.ncg_host_unregister
+        fn.argtypes, fn.restype = [ctypes.c_void_p], ctypes.c_int
+        fn(arr.ctypes.data)
+
     # ---- multi-scalar multiplication -----------------------------------------------------------
     def msm(self, curve, points, scalars):
         """sum_i scalars[i]*points[i]; returns (affine wire bytes [PB], is_inf bool)."""

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include "knobs.hpp"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -175,6 +176,13 @@ void ncg_destroy(ncg_ctx* ctx) {
   (void)ncg_comm_destroy(ctx);
   if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
   if (ctx->sync_land) (void)hipHostFree(ctx->sync_land);
+  for (int i = 0; i < ncg_ctx::COPY_CHUNKS; i++) {
+    if (ctx->ev_in[i]) (void)hipEventDestroy(ctx->ev_in[i]);
+    if (ctx->ev_k[i]) (void)hipEventDestroy(ctx->ev_k[i]);
+  }
+  if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
+  if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
+  if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
   for (ncg_msm_lane& ln : ctx->lanes) {
     if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     if (ln.ws) (void)hipFree(ln.ws);
@@ -244,6 +252,48 @@ int ncg_mul_var_batch_dev(ncg_ctx* ctx, int curve, size_t n, const void* points_
   return NCG_OK;
 }
 
+// Long-lived host buffers (the Node addon's Buffers, a prover's witness arrays) can be pinned ONCE: the host-pointer entry
+// points then DMA straight from / to them.  Without it every call registers the large buffers it is handed and releases
+// them again (PinSet): correct, but the page locking is paid per call.
+int ncg_host_register(void* p, size_t bytes) {
+  if (!p || !bytes) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: host_register: NULL buffer");
+  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(nullptr, NCG_ERR_HIP, "noble-gpu: host_register: %s", hipGetErrorString(e));
+  }
+  return NCG_OK;
+}
+int ncg_host_unregister(void* p) {
+  if (!p) return NCG_OK;
+  hipError_t e = hipHostUnregister(p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(nullptr, NCG_ERR_HIP, "noble-gpu: host_unregister: %s", hipGetErrorString(e));
+  }
+  return NCG_OK;
+}
+
+// copy streams + chunk events of the host-pointer entry points (made on first use)
+static int ensure_copy_streams(ncg_ctx* ctx) {
+  if (ctx->copy_in) return NCG_OK;
+  hipError_t e = hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking);
+  for (int i = 0; i < ncg_ctx::COPY_CHUNKS && e == hipSuccess; i++) {
+    e = hipEventCreateWithFlags(&ctx->ev_in[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_k[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming);
+  if (e != hipSuccess) return set_err(ctx, NCG_ERR_HIP, "noble-gpu: cannot create copy streams: %s", hipGetErrorString(e));
+  return NCG_OK;
+}
+static void drain_copy_streams(ncg_ctx* ctx) {
+  if (ctx->copy_in) (void)hipStreamSynchronize(ctx->copy_in);
+  if (ctx->copy_out) (void)hipStreamSynchronize(ctx->copy_out);
+  if (ctx->msm_side.stream) (void)hipStreamSynchronize(ctx->msm_side.stream);
+  (void)hipStreamSynchronize(ctx->stream);
+}
+
 int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const void* scalars,
                       void* out_affine, uint8_t* out_is_inf) {
   if (!ctx) return set_err(nullptr, NCG_ERR_INVALID_ARG, "noble-gpu: ctx is NULL");
@@ -262,6 +312,39 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
   char* d_out = d_pts + pts_b;
   char* d_sc = d_out + pts_b;
   char* d_inf = d_sc + sc_b;
+  if (n >= ((size_t)1 << 17)) {
+    // Large batches in chunks: chunk i + 1 crosses PCIe while the kernels of chunk i run and the results of chunk i - 1
+    // go back (three streams, one event per chunk and direction).  The kernels are the batch's whole cost but for the
+    // first upload and the last download: 2^20 secp256k1 pairs 13.4 -> ~9.6 ms end to end.
+    rc = ensure_copy_streams(ctx);
+    if (rc) return rc;
+    pins.pin(points_affine, pts_b);
+    pins.pin(scalars, sc_b);
+    pins.pin(out_affine, pts_b);
+    if (out_is_inf) pins.pin(out_is_inf, n);
+    const int chunks = n >= ((size_t)1 << 19) ? ncg_ctx::COPY_CHUNKS : 4;
+    const size_t per = (((n + chunks - 1) / chunks) + 255) & ~(size_t)255;
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < chunks && e == hipSuccess && rc == NCG_OK; c++) {
+      const size_t lo = std::min(n, per * (size_t)c), cnt = std::min(n, lo + per) - lo;
+      if (cnt == 0) break;
+      e = hipMemcpyAsync(d_pts + lo * pb, (const char*)points_affine + lo * pb, cnt * pb, hipMemcpyHostToDevice, ctx->copy_in);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_sc + lo * 32, (const char*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, ctx->copy_in);
+      if (e == hipSuccess) e = hipEventRecord(ctx->ev_in[c], ctx->copy_in);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_in[c], 0);
+      if (e != hipSuccess) break;
+      rc = ncg_mul_var_batch_dev(ctx, curve, cnt, d_pts + lo * pb, d_sc + lo * 32, d_out + lo * pb, (uint8_t*)d_inf + lo, ctx->stream);
+      if (rc) break;
+      e = hipEventRecord(ctx->ev_k[c], ctx->stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_out, ctx->ev_k[c], 0);
+      if (e == hipSuccess) e = hipMemcpyAsync((char*)out_affine + lo * pb, d_out + lo * pb, cnt * pb, hipMemcpyDeviceToHost, ctx->copy_out);
+      if (e == hipSuccess && out_is_inf) e = hipMemcpyAsync(out_is_inf + lo, d_inf + lo, cnt, hipMemcpyDeviceToHost, ctx->copy_out);
+    }
+    drain_copy_streams(ctx);
+    if (rc) return rc;
+    if (e != hipSuccess) return set_err(ctx, NCG_ERR_HIP, "noble-gpu: mul_var_batch: %s", hipGetErrorString(e));
+    return NCG_OK;
+  }
   NCG_HIP(ctx, pins.h2d(d_pts, points_affine, pts_b));
   NCG_HIP(ctx, pins.h2d(d_sc, scalars, sc_b));
   rc = ncg_mul_var_batch_dev(ctx, curve, n, d_pts, d_sc, d_out, (uint8_t*)d_inf, ctx->stream);
@@ -462,12 +545,57 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
   if (n == 0) return ncg_msm_dev(ctx, curve, 0, nullptr, nullptr, out_affine, out_is_inf, nullptr);
   if (!points_affine || !scalars || !out_affine) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: NULL buffer");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
+  if (n > 0x7fffffffu) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: too many points");
   PinSet pins(ctx);
   size_t pts_b = n * pb, sc_b = n * 32;
-  int rc = ensure_scratch(ctx, pts_b + sc_b + 2048);
+  const size_t pts_al = (pts_b + 255) & ~(size_t)255, sc_al = (sc_b + 255) & ~(size_t)255;
+  const size_t stored_b = n * ncg::msm_stored_words_per_point(curve) * 4;
+  int rc = ensure_scratch(ctx, pts_al + sc_al + stored_b + 2048);
   if (rc) return rc;
   char* d_pts = (char*)ctx->scratch;
-  char* d_sc = d_pts + ((pts_b + 255) & ~(size_t)255);
+  char* d_sc = d_pts + pts_al;
+  if (n >= ((size_t)1 << 16)) {
+    // The scalars cross first (a quarter of the bytes): digits and the counting sort need nothing else and run while the
+    // points are still on the bus, chunk by chunk, each chunk converted to the accumulate kernel's storage format on the
+    // side stream as it lands.  Only the accumulate kernel waits for the last chunk.
+    rc = ensure_copy_streams(ctx);
+    if (rc) return rc;
+    char* d_stored = d_sc + sc_al;
+    ncg::MsmPlan pl;
+    rc = ncg_msm_plan_ws(ctx, curve, n, 0, &pl);
+    if (rc) return rc;
+    pl.pts_stored = 1;
+    pins.pin(points_affine, pts_b);
+    pins.pin(scalars, sc_b);
+    const size_t sw = ncg::msm_stored_words_per_point(curve) * 4;
+    const int chunks = ncg_ctx::COPY_CHUNKS;
+    const size_t per = (((n + chunks - 1) / chunks) + 255) & ~(size_t)255;
+    hipError_t e = hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream);
+    for (int c = 0; c < chunks && e == hipSuccess; c++) {
+      const size_t lo = std::min(n, per * (size_t)c), cnt = std::min(n, lo + per) - lo;
+      if (cnt == 0) break;
+      e = hipMemcpyAsync(d_pts + lo * pb, (const char*)points_affine + lo * pb, cnt * pb, hipMemcpyHostToDevice, ctx->copy_in);
+      if (e == hipSuccess) e = hipEventRecord(ctx->ev_in[c], ctx->copy_in);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ctx->msm_side.stream, ctx->ev_in[c], 0);
+      if (e == hipSuccess)
+        e = ncg::msm_points_to_stored(curve, (const uint32_t*)(d_pts + lo * pb), (int)cnt, (uint32_t*)(d_stored + lo * sw), ctx->msm_side.stream);
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_ready, ctx->msm_side.stream);
+    uint32_t bad = 0xFFFFFFFFu;
+    uint8_t inf_local = 0;
+    if (e == hipSuccess) {
+      ncg::MsmSide side;          // no fork / join of its own: the conversion is already in flight
+      side.pts_ready = ctx->ev_ready;
+      e = ncg::msm_run(curve, pl, (const uint32_t*)d_stored, (const uint32_t*)d_sc, ctx->msm_ws, (uint32_t*)out_affine, &inf_local,
+                       ctx->stream, &bad, &side);
+    }
+    drain_copy_streams(ctx);
+    if (e != hipSuccess) return set_err(ctx, NCG_ERR_HIP, "noble-gpu: msm: %s", hipGetErrorString(e));
+    if (bad != 0xFFFFFFFFu)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
+    if (out_is_inf) *out_is_inf = inf_local;
+    return NCG_OK;
+  }
   NCG_HIP(ctx, pins.h2d(d_pts, points_affine, pts_b));
   NCG_HIP(ctx, pins.h2d(d_sc, scalars, sc_b));
   return ncg_msm_dev(ctx, curve, n, d_pts, d_sc, out_affine, out_is_inf, ctx->stream);

@@ -62,6 +62,11 @@ struct ncg_ctx {
   int comm_rank = 0, comm_size = 1;
   void* comm_buf = nullptr;
   size_t comm_buf_bytes = 0;
+  // host-pointer entry points (ncg_msm, ncg_mul_var_batch): copy streams and per-chunk events, so that the chunks of a
+  // large host buffer cross PCIe while the kernels of earlier chunks (or the digit / sort kernels of the MSM) run
+  static constexpr int COPY_CHUNKS = 8;
+  hipStream_t copy_in = nullptr, copy_out = nullptr;
+  hipEvent_t ev_in[COPY_CHUNKS] = {}, ev_k[COPY_CHUNKS] = {}, ev_ready = nullptr;
   uint32_t* sync_land = nullptr;  // pinned landing area of the synchronous sharded entry points
   size_t sync_land_words = 0;
 };

@@ -59,6 +59,9 @@ struct MsmPlan;
 struct MsmSide {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  // set by the host-pointer entry point: the stored points are being produced elsewhere (chunked upload + conversion on
+  // other streams); the accumulate kernel waits for this event, the digit / sort kernels do not
+  hipEvent_t pts_ready = nullptr;
 };
 
 int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl);

@@ -833,6 +833,10 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       if (e != hipSuccess) return e;
       side_guard.armed = false;
     }
+    if (side && side->pts_ready) {  // host-pointer path: the points were still crossing PCIe while the sort ran
+      e = hipStreamWaitEvent(st, side->pts_ready, 0);
+      if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_msm_accum<D>, grid, dim3(256), 0, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta,
                        av, sg);
     uint32_t* long_runs = (uint32_t*)(base + L.long_runs);
