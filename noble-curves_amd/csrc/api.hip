@@ -555,40 +555,58 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
   char* d_pts = (char*)ctx->scratch;
   char* d_sc = d_pts + pts_al;
   if (n >= ((size_t)1 << 16)) {
-    // The scalars cross first (a quarter of the bytes): digits and the counting sort need nothing else and run while the
-    // points are still on the bus, chunk by chunk, each chunk converted to the accumulate kernel's storage format on the
-    // side stream as it lands.  Only the accumulate kernel waits for the last chunk.
+    // The scalars cross first (a quarter of the bytes): digits and the counting sort need nothing else.  The points follow
+    // in PARTS; each part is converted to the accumulate kernel's storage format on the side stream as it lands and then
+    // accumulated into the shared buckets (MsmPlan::part_flags) while the next part is still on the bus - only the last
+    // part's accumulate, the fold and the tail run after the last byte.  2^20 G1 points from pinned host memory: 9.3 ms
+    // (round 2, one copy then one MSM) -> 6.2 ms (sort under the transfer) -> see profiles/r04_host_path.json.
     rc = ensure_copy_streams(ctx);
     if (rc) return rc;
     char* d_stored = d_sc + sc_al;
-    ncg::MsmPlan pl;
-    rc = ncg_msm_plan_ws(ctx, curve, n, 0, &pl);
+    const int parts = n >= ((size_t)1 << 19) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;
+    const size_t per = (((n + parts - 1) / parts) + 255) & ~(size_t)255;
+    ncg::MsmPlan whole, layout;
+    if (ncg::msm_make_plan(curve, (int)n, 0, &whole) != 0 || ncg::msm_make_plan(curve, (int)std::min(n, per), whole.c, &layout) != 0)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+    layout.pts_stored = 1;
+    layout.n_layout = layout.n;
+    rc = msm_ensure_ws(ctx, curve, layout);
     if (rc) return rc;
-    pl.pts_stored = 1;
     pins.pin(points_affine, pts_b);
     pins.pin(scalars, sc_b);
     const size_t sw = ncg::msm_stored_words_per_point(curve) * 4;
-    const int chunks = ncg_ctx::COPY_CHUNKS;
-    const size_t per = (((n + chunks - 1) / chunks) + 255) & ~(size_t)255;
     hipError_t e = hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream);
-    for (int c = 0; c < chunks && e == hipSuccess; c++) {
-      const size_t lo = std::min(n, per * (size_t)c), cnt = std::min(n, lo + per) - lo;
-      if (cnt == 0) break;
-      e = hipMemcpyAsync(d_pts + lo * pb, (const char*)points_affine + lo * pb, cnt * pb, hipMemcpyHostToDevice, ctx->copy_in);
-      if (e == hipSuccess) e = hipEventRecord(ctx->ev_in[c], ctx->copy_in);
-      if (e == hipSuccess) e = hipStreamWaitEvent(ctx->msm_side.stream, ctx->ev_in[c], 0);
-      if (e == hipSuccess)
-        e = ncg::msm_points_to_stored(curve, (const uint32_t*)(d_pts + lo * pb), (int)cnt, (uint32_t*)(d_stored + lo * sw), ctx->msm_side.stream);
+    const uint32_t *d_fin = nullptr, *d_bad = nullptr;
+    ncg::MsmPlan last = layout;
+    for (int p = 0; p < parts && e == hipSuccess; p++) {
+      const size_t lo = std::min(n, per * (size_t)p), cnt = std::min(n, lo + per) - lo;
+      const bool is_last = p == parts - 1 || lo + cnt >= n;
+      if (cnt) {
+        e = hipMemcpyAsync(d_pts + lo * pb, (const char*)points_affine + lo * pb, cnt * pb, hipMemcpyHostToDevice, ctx->copy_in);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_in[p], ctx->copy_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->msm_side.stream, ctx->ev_in[p], 0);
+        if (e == hipSuccess)
+          e = ncg::msm_points_to_stored(curve, (const uint32_t*)(d_pts + lo * pb), (int)cnt, (uint32_t*)(d_stored + lo * sw), ctx->msm_side.stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_k[p], ctx->msm_side.stream);
+        if (e != hipSuccess) break;
+      }
+      ncg::MsmPlan pl;
+      if (ncg::msm_make_plan(curve, (int)std::max<size_t>(cnt, 1), whole.c, &pl) != 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+      msm_apply_ctx(ctx, pl);
+      pl.pts_stored = 1;
+      pl.n_layout = layout.n;
+      pl.index_base = (uint32_t)lo;
+      pl.part_flags = (p == 0 ? 1 : 0) | (is_last ? 2 : 0);
+      ncg::MsmSide side;            // no fork / join of its own: the conversion is already in flight on the side stream
+      side.pts_ready = cnt ? ctx->ev_k[p] : nullptr;
+      e = ncg::msm_device_phase(curve, pl, (const uint32_t*)(d_stored + lo * sw), (const uint32_t*)(d_sc + lo * 32), ctx->msm_ws, &d_fin,
+                                ctx->stream, &d_bad, &side);
+      last = pl;
+      if (is_last) break;
     }
-    if (e == hipSuccess) e = hipEventRecord(ctx->ev_ready, ctx->msm_side.stream);
     uint32_t bad = 0xFFFFFFFFu;
     uint8_t inf_local = 0;
-    if (e == hipSuccess) {
-      ncg::MsmSide side;          // no fork / join of its own: the conversion is already in flight
-      side.pts_ready = ctx->ev_ready;
-      e = ncg::msm_run(curve, pl, (const uint32_t*)d_stored, (const uint32_t*)d_sc, ctx->msm_ws, (uint32_t*)out_affine, &inf_local,
-                       ctx->stream, &bad, &side);
-    }
+    if (e == hipSuccess) e = ncg::msm_finish(curve, last, d_fin, (uint32_t*)out_affine, &inf_local, ctx->stream, d_bad, &bad);
     drain_copy_streams(ctx);
     if (e != hipSuccess) return set_err(ctx, NCG_ERR_HIP, "noble-gpu: msm: %s", hipGetErrorString(e));
     if (bad != 0xFFFFFFFFu)

@@ -84,7 +84,7 @@ hipError_t msm_device_phase(int curve, const MsmPlan& pl, const uint32_t* d_pts,
                             const uint32_t** d_fin, hipStream_t st, const uint32_t** d_bad = nullptr,
                             const MsmSide* side = nullptr);
 hipError_t msm_finish(int curve, const MsmPlan& pl, const uint32_t* d_fin, uint32_t* out_affine_host,
-                      uint8_t* out_inf_host, hipStream_t st);
+                      uint8_t* out_inf_host, hipStream_t st, const uint32_t* d_bad = nullptr, uint32_t* bad_host = nullptr);
 hipError_t msm_sum_partials(int curve, uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out,
                             hipStream_t st);  // d_gathered is scratch: reduced in place
 // asynchronous form: device phase + D2H of the grouped sums and the scalar-range flag into `land` (pinned host memory,

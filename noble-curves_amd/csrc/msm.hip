@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__
       uint32_t bw = 0;
 #pragma unroll
       for (int j = 0; j < 8; j++) (void)__builtin_subc(k[j], pl.order[j], bw, &bw);
-      if (bw == 0) atomicMin(bad_index, (uint32_t)i);  // scalar >= order
+      if (bw == 0) atomicMin(bad_index, pl.index_base + (uint32_t)i);  // scalar >= order
     }
     uint32_t cy = 0;
 #pragma unroll
@@ -269,7 +269,10 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
   const uint32_t* sw = sorted + (size_t)w * pl.n;
   uint32_t* hp = part_pts + (((size_t)w * sg.nseg + s) * 2) * XW;
   int head_b = -1, head_cont = 0, tail_b = -1;
-  Acc acc = G::identity();
+  // a later part of a multi-part MSM (MsmPlan::part_flags): the lane where a bucket STARTS continues from the sum the
+  // earlier parts left in that bucket; every other piece starts from the identity as before
+  const bool into = (pl.part_flags & 1) == 0;
+  Acc acc = (into && b_start >= lo) ? G::acc_load(buckets + ((size_t)w * pl.nb + b) * XW) : G::identity();
   for (uint32_t pos = lo; pos < hi; pos++) {
     if (pos == b_end) {  // bucket finished inside my range
       if (b_start >= lo) {
@@ -278,10 +281,10 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
         G::acc_store(hp, acc);
         head_b = b;
       }
-      acc = G::identity();
       do { b++; } while (bs[b + 1] <= pos);
       b_start = bs[b];
       b_end = bs[b + 1];
+      acc = into ? G::acc_load(buckets + ((size_t)w * pl.nb + b) * XW) : G::identity();
     }
     uint32_t e = sw[pos];
     const uint32_t* pp = pts_mont + (size_t)(e & 0x7fffffffu) * AFF;
@@ -678,8 +681,9 @@ static MsmSeg msm_seg(const MsmPlan& pl) {
     const long cap = 65536L * pl.accum_waves;
     double best = 1e300;
     sg.seg = 16;
+    const int n_seg = pl.n_layout > 0 ? pl.n_layout : pl.n;   // parts of one MSM share the segment of the layout plan
     for (int seg = 16; seg <= 160; seg++) {
-      const long nseg = (pl.n + seg - 1) / seg;
+      const long nseg = (n_seg + seg - 1) / seg;
       const long lanes = ((long)pl.nwin * nseg) << pl.ls;
       const long rounds = (lanes + cap - 1) / cap;
       const double cost = (double)rounds * seg + 3.0 * (double)lanes / (double)cap;
@@ -694,7 +698,7 @@ static MsmSeg msm_seg(const MsmPlan& pl) {
 }
 
 template <class C>
-static MsmLayout msm_layout(const MsmPlan& pl) {
+static MsmLayout msm_layout(const MsmPlan& pl_in) {
   MsmLayout L;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -702,6 +706,8 @@ static MsmLayout msm_layout(const MsmPlan& pl) {
     off = align256(off + bytes);
     return o;
   };
+  MsmPlan pl = pl_in;
+  if (pl.n_layout > pl.n) pl.n = pl.n_layout;  // parts of one MSM: every part addresses the layout of the largest
   L.pts_mont = take((pl.endo || pl.pts_stored || pl.shared) ? 0 : (size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);  // else: the caller's array
   L.digits = take((size_t)pl.nwin * pl.n * 2);
   L.counts = take((size_t)pl.nwin * pl.Q * pl.nb * 4);
@@ -754,6 +760,8 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   const int n = pl.n;
   hipError_t e;
 
+  const bool part_first = (pl.part_flags & 1) != 0, part_last = (pl.part_flags & 2) != 0;
+  if ((!part_first || !part_last) && (pl.shared || pl.endo)) return hipErrorInvalidValue;  // parts: generic plans only
   bool forked = false;
   // error paths between the fork and the join must not return while the side-stream kernel is still writing into the
   // workspace (the caller may free or re-size it): drain the side stream unless the join has been enqueued on `st`
@@ -765,8 +773,10 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     }
   } side_guard{side};
   uint32_t* bad = (uint32_t*)(base + L.bad);
-  e = hipMemsetAsync(bad, 0xFF, 4, st);
-  if (e != hipSuccess) return e;
+  if (part_first) {
+    e = hipMemsetAsync(bad, 0xFF, 4, st);
+    if (e != hipSuccess) return e;
+  }
   if (pl.endo) {  // d_pts is the expanded image set, already in storage format (msm_endo_expand)
     pts_mont = const_cast<uint32_t*>(d_pts);
     e = msm_endo_digits(pl, d_scalars, digits, bad, st);
@@ -825,8 +835,10 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     MsmSeg sg = msm_seg(av);
     uint32_t* part_pts = (uint32_t*)(base + L.part_pts);
     int* part_meta = (int*)(base + L.part_meta);
-    e = hipMemsetAsync(buckets, 0, (size_t)av.nwin * av.nb * XW * 4, st);  // empty buckets = infinity
-    if (e != hipSuccess) return e;
+    if (part_first) {
+      e = hipMemsetAsync(buckets, 0, (size_t)av.nwin * av.nb * XW * 4, st);  // empty buckets = infinity
+      if (e != hipSuccess) return e;
+    }
     dim3 grid((unsigned)((((size_t)sg.nseg << LS) + 255) / 256), av.nwin);
     if (forked) {
       e = hipStreamWaitEvent(st, side->join, 0);
@@ -888,6 +900,11 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       hipLaunchKernelGGL((k_msm_fixup_long<D, LCOOP>), dim3(MSM_LONG_BLOCKS), dim3(MSM_TAIL_THREADS), lds_b, st, part_pts, buckets, av, sg,
                          long_runs);
     }
+  }
+  if (!part_last) {  // more parts follow: the buckets stay as they are
+    *d_fin = nullptr;
+    if (d_bad) *d_bad = bad;
+    return hipGetLastError();
   }
   // fold: nb -> 1 per window in c-1 levels.  Wide levels: one item per addition (throughput); levels that no longer
   // fill the chip: four items per addition (latency, msm_coop.hpp); the last levels + the grouping: k_msm_tail.
@@ -1047,8 +1064,8 @@ hipError_t msm_device_phase(int curve, const MsmPlan& pl, const uint32_t* d_pts,
 #undef CALL
 }
 hipError_t msm_finish(int curve, const MsmPlan& pl, const uint32_t* d_fin, uint32_t* out_affine_host,
-                      uint8_t* out_inf_host, hipStream_t st) {
-#define CALL(C) msm_finish_t<C>(pl, d_fin, out_affine_host, out_inf_host, st)
+                      uint8_t* out_inf_host, hipStream_t st, const uint32_t* d_bad, uint32_t* bad_host) {
+#define CALL(C) msm_finish_t<C>(pl, d_fin, out_affine_host, out_inf_host, st, d_bad, bad_host)
   NCG_MSM_DISPATCH(curve, CALL)
 #undef CALL
 }

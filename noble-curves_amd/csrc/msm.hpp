@@ -65,6 +65,15 @@ struct MsmPlan {
   int seg_override = 0;
   int run_serial_override = -1;
   MsmTrace* trace = nullptr;  // host side: what the last launch actually used (ncg_msm_last_plan)
+  // The points of ONE MSM in several parts (the host-pointer entry point: part p is accumulated while part p + 1 is still
+  // crossing PCIe): every part runs digits / sort / accumulate / fix-up on ITS points - same c, nwin and bucket arrays -
+  // and a bucket's accumulator starts from what the earlier parts left in it instead of the identity; the fold and the
+  // tail run once, after the last part.  part_flags: bit 0 = first part (clears the buckets and the scalar verdict),
+  // bit 1 = last part (fold + tail).  n_layout: the workspace layout (and the lane segment) are those of an n_layout-point
+  // plan, so that all parts address the same bucket array; index_base: global index of the part's first point.
+  int part_flags = 3;
+  int n_layout = 0;
+  uint32_t index_base = 0;
 };
 
 // what the device phase actually ran with (host memory, filled by msm_device_phase when the plan names one)
