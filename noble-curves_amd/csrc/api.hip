@@ -570,6 +570,7 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
       return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
     layout.pts_stored = 1;
     layout.n_layout = layout.n;
+    layout.Q_layout = layout.Q;
     rc = msm_ensure_ws(ctx, curve, layout);
     if (rc) return rc;
     pins.pin(points_affine, pts_b);
@@ -595,6 +596,7 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
       msm_apply_ctx(ctx, pl);
       pl.pts_stored = 1;
       pl.n_layout = layout.n;
+      pl.Q_layout = layout.Q;
       pl.index_base = (uint32_t)lo;
       pl.part_flags = (p == 0 ? 1 : 0) | (is_last ? 2 : 0);
       ncg::MsmSide side;            // no fork / join of its own: the conversion is already in flight on the side stream

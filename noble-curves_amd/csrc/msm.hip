@@ -708,6 +708,7 @@ static MsmLayout msm_layout(const MsmPlan& pl_in) {
   };
   MsmPlan pl = pl_in;
   if (pl.n_layout > pl.n) pl.n = pl.n_layout;  // parts of one MSM: every part addresses the layout of the largest
+  if (pl.Q_layout > pl.Q) pl.Q = pl.Q_layout;
   L.pts_mont = take((pl.endo || pl.pts_stored || pl.shared) ? 0 : (size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);  // else: the caller's array
   L.digits = take((size_t)pl.nwin * pl.n * 2);
   L.counts = take((size_t)pl.nwin * pl.Q * pl.nb * 4);

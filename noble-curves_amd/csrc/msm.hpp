@@ -73,6 +73,7 @@ struct MsmPlan {
   // plan, so that all parts address the same bucket array; index_base: global index of the part's first point.
   int part_flags = 3;
   int n_layout = 0;
+  int Q_layout = 0;   // sort chunks of the layout plan (the per-chunk count arrays are sized by it)
   uint32_t index_base = 0;
 };
 
