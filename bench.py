@@ -634,6 +634,24 @@ def main():
                          "kernel_ms": kern_ms,
                          "valu": valu_block(pmc, "secp256k1", kern_ms * 1e-3, 3.4e5 * n, secp_mads_per_mult() * n)},
         }
+        if not dist_on:
+            # end to end through the host-pointer entry point (ncg_mul_var_batch): pinned-once host buffers, chunked H2D / kernels / D2H
+            e_p, e_s = pts.cpu().numpy(), sc.cpu().numpy()
+            e_o, e_i = np.zeros((n, 64), np.uint8), np.zeros((n,), np.uint8)
+            for arr in (e_p, e_s, e_o, e_i):
+                eng.host_register(arr)
+            try:
+                def estep():
+                    eng._check(eng.lib.ncg_mul_var_batch(eng.h, SECP256K1, n, e_p.ctypes.data, e_s.ctypes.data, e_o.ctypes.data, e_i.ctypes.data))
+                st_e = time_steps(estep, K, W, False)
+                assert np.array_equal(e_o, out.cpu().numpy()), "host-pointer batch multiply differs from the device-buffer one"
+                result["end_to_end"] = {"value": n * K / st_e[0], "unit": "scalar-mults/s", "ms_per_batch": st_e[0] / K * 1e3,
+                                        "bytes_in_out": int(e_p.nbytes + e_s.nbytes + e_o.nbytes + e_i.nbytes),
+                                        "note": "ncg_mul_var_batch on host buffers pinned once (96 MB in, 65 MB out per 2^20 pairs), chunks pipelined over "
+                                                "three streams; PCIe-inclusive, never the headline value; output compared bit-exactly"}
+            finally:
+                for arr in (e_p, e_s, e_o, e_i):
+                    eng.host_unregister(arr)
         if cpu_leg:
             pts_h, sc_h, out_h = pts.cpu().numpy(), sc.cpu().numpy(), out.cpu().numpy()
 
@@ -717,6 +735,26 @@ def main():
                               "valu": valu_block(pmc, key, wall / K, ref_mac_pt * nn,
                                                  (g1_msm_mads_per_point(nwin, nn, 1 << (c - 1), True) * (3 if curve == BLS12_381_G2 else 1)) * nn)}}
         if not dist_on:
+            # end to end through the HOST-pointer entry point (the boundary the N-API addon binds: ncg_msm): inputs in pinned host
+            # memory (ncg_host_register once), scalars first, the points in parts accumulated while the next part crosses PCIe
+            pts_h, sc_h = pts.cpu().numpy(), sc.cpu().numpy()
+            eng.host_register(pts_h)
+            eng.host_register(sc_h)
+            try:
+                eh = {}
+
+                def estep():
+                    eh["r"] = eng.msm(curve, pts_h, sc_h)
+
+                st_e = time_steps(estep, K, W, False)
+                assert np.array_equal(eh["r"][0], got), "host-pointer MSM differs from the device-buffer MSM"
+                entry["end_to_end"] = {"value": nn * K / st_e[0], "unit": "points/s", "ms_per_msm": st_e[0] / K * 1e3,
+                                       "bytes_in": int(pts_h.nbytes + sc_h.nbytes), "step_times": {"wall_ms": st_e.dist()["wall_ms"]},
+                                       "note": "ncg_msm on host buffers pinned once: H2D of every byte + MSM + result, per call (PCIe-inclusive; "
+                                               "never the headline value); result compared bit-exactly with the device-buffer MSM"}
+            finally:
+                eng.host_unregister(pts_h)
+                eng.host_unregister(sc_h)
             # several MSMs in flight (ncg_msm_async_submit / _collect): the dependent tail of one MSM (narrow fold levels,
             # per-window tail, D2H, host Horner) overlaps the sort / accumulate kernels of the next
             def chk(r):
@@ -735,17 +773,18 @@ def main():
             # (average over all G parts).  The G slots are combined and checked, so the timed path is the shipped one.
             # Not included: the all-gather of G x 29 KB (58 KB on G2) over xGMI.
             shares = {}
+            wres = eng.upload_points(curve, pts.cpu().numpy())          # the mode's premise: the set is resident on every GPU
             for G in (2, 4, 8):
-                slots = [eng.msm_shard_windows_local_dev(curve, nn, r, G, dev_ptr(pts), dev_ptr(sc), stream) for r in range(G)]
+                slots = [eng.msm_shard_windows_local_dev(curve, nn, r, G, 0, dev_ptr(sc), stream, wres) for r in range(G)]
                 stack = np.stack(slots)
                 cg, _ = eng.msm_shard_combine(curve, nn, stack, stream)
                 assert np.array_equal(cg, got), "window-sharded MSM (%d parts) differs from the single-GPU MSM" % G
-                st_l = time_steps(lambda: eng.msm_shard_windows_local_dev(curve, nn, 0, G, dev_ptr(pts), dev_ptr(sc), stream), K, W, False)
+                st_l = time_steps(lambda: eng.msm_shard_windows_local_dev(curve, nn, 0, G, 0, dev_ptr(sc), stream, wres), K, W, False)
                 st_c = time_steps(lambda: eng.msm_shard_combine(curve, nn, stack, stream), K, W, False)
                 coll = {}
 
                 def sub(lane, i, G=G):
-                    eng.msm_async_submit(lane, curve, nn, dev_ptr(pts), dev_ptr(sc), stream, None, eng.async_part(i % G, G))
+                    eng.msm_async_submit(lane, curve, nn, 0, dev_ptr(sc), stream, wres, eng.async_part(i % G, G))
                     coll[lane] = i % G
 
                 def col(lane):
@@ -759,7 +798,8 @@ def main():
                 shares["G%d" % G] = {"latency_ms": lat, "local_part0_ms": st_l[0] / K * 1e3, "combine_finish_ms": st_c[0] / K * 1e3,
                                      "pipelined_part_ms": pw / jobs * 1e3, "speedup_latency": (wall / K * 1e3) / lat,
                                      "speedup_pipelined": (wall / K * 1e3) / (pw / jobs * 1e3)}
-            entry["window_share"] = dict(shares, note="per-rank share of ONE %d-point MSM cut by windows over G ranks, emulated on one GPU; speedup_* = "
+            wres.free()
+            entry["window_share"] = dict(shares, note="per-rank share of ONE %d-point MSM cut by windows over G ranks (resident set, stored form), emulated on one GPU; speedup_* = "
                                                       "this run's single-GPU ms_per_msm / share; the xGMI all-gather (~30 us) is not included" % nn)
             # the same MSM on a resident set verified to lie in the prime-order subgroup (ncg_points_verify_subgroup,
             # once per set): the scalars are split along the curve endomorphism (csrc/endo.hpp) - same group
@@ -1111,7 +1151,7 @@ def main():
         if key in extra:
             e = extra[key]
             result[key] = {k: e[k] for k in ("metric", "value", "unit", "ms_per_msm", "total_points", "points_per_gpu", "scaling", "mode",
-                                             "window_plan", "roofline", "cpu_baseline", "pipelined", "window_share") if k in e}
+                                             "window_plan", "roofline", "cpu_baseline", "pipelined", "window_share", "end_to_end") if k in e}
     if extra:
         result["extra"] = extra
     if rank == 0:
