@@ -458,10 +458,15 @@ def cpu_info():
         node = subprocess.run(["node", "--version"], capture_output=True, text=True, timeout=10).stdout.strip() or None
     except (OSError, subprocess.SubprocessError):
         pass
+    from oracle import refjs
+    ok = refjs.available()
     return {"cpu_model": model, "logical_cores": os.cpu_count(), "node_version": node,
-            "reference_runnable": False,
-            "reference_note": "the TypeScript reference needs Node >= 20.19 with type stripping and @noble/hashes (SURVEY 8c); "
-                              "the CPU figures are the oracle's C restatement of the same algorithm (kind: port)"}
+            "reference_runnable": ok,
+            "reference_note": ("the reference's own TypeScript sources run on this host: type-stripped by oracle/ref_js/downlevel.py into oracle/_ref/js "
+                               "(types, generics, casts removed; every line of arithmetic untouched), @noble/hashes replaced by node:crypto, a few "
+                               "library polyfills for Node 12 (kind: reference; the C port's figures are kept under cpu_baseline.port)") if ok else
+                              ("the TypeScript reference needs Node >= 20.19 with type stripping and @noble/hashes (SURVEY 8c) and oracle/_ref/js is not built; "
+                               "the CPU figures are the oracle's C restatement of the same algorithm (kind: port)")}
 
 
 def cpu_baseline_rates(work, total_items, chunk, seconds, check=None):
@@ -579,6 +584,20 @@ def main():
     extra = {}
     host = cpu_info() if rank == 0 else {}
 
+    from oracle import refjs
+    ref_ok = rank == 0 and refjs.available()
+
+    def with_reference(port_entry, ref_info, unit, sample):
+        """cpu_baseline = the REFERENCE's own TypeScript code on this host's Node (oracle/_ref/js: /root/reference/src type-stripped
+        by oracle/ref_js/downlevel.py; one thread - the reference is single-threaded JS) when that build is present, with the C
+        port's figures (1 thread and all threads) kept beside it; otherwise the port alone."""
+        if not ref_info:
+            return port_entry
+        e = {"value": ref_info["per_s"], "unit": unit, "cores": 1, "kind": "reference", "sample": sample,
+             "runtime": "node %s (BigInt), @noble/hashes replaced by node:crypto" % ref_info.get("node"),
+             "cpu_model": host.get("cpu_model"), "logical_cores": host.get("logical_cores"), "port": port_entry}
+        return e
+
     def baseline_entry(r1, d1, rall, dall, threads, unit, sample):
         e = {"value": r1, "unit": unit, "cores": 1, "kind": "port", "sample": sample % d1,
              "cpu_model": host.get("cpu_model"), "logical_cores": host.get("logical_cores")}
@@ -691,11 +710,26 @@ def main():
                 "sample": "1 point, 1000 random scalars (xorshift64 seed 0x6e6f626c6501) + the literal 2^180-15820 of benchmark/point.ts:20; "
                           "oracle/c restatement (RCB formulas, 64-bit Montgomery limbs), results equal and equal to the GPU batch multiply",
                 "cpu_model": host.get("cpu_model"),
-                "note": "BASELINE configs[0] is the reference's CPU plumbing case; the TypeScript itself cannot run here (host.reference_note)"}
+                "note": "BASELINE configs[0] is the reference's CPU plumbing case; `reference` (when present) = the reference's own code on this host, the figures above = the C port"}
             r1, d1, rall, dall, thr = cpu_baseline_rates(work, n, 500, args.cpu_seconds, check)
-            result["cpu_baseline"] = baseline_entry(r1, d1, rall, dall, thr, "scalar-mults/s",
-                                                    "first %d pairs of the same batch through oracle/c (RCB + GLV wNAF-4), outputs "
-                                                    "compared bit-exactly with the GPU's; all_threads: the next pairs, one chunk stream per thread")
+            port_e = baseline_entry(r1, d1, rall, dall, thr, "scalar-mults/s",
+                                    "first %d pairs of the same batch through oracle/c (RCB + GLV wNAF-4), outputs "
+                                    "compared bit-exactly with the GPU's; all_threads: the next pairs, one chunk stream per thread")
+            ref_info = None
+            if ref_ok:
+                M = 4096
+                o_r, ref_info = refjs.multiply(SECP256K1, pts_h[:M], sc_h[:M], unsafe=True)
+                assert np.array_equal(o_r, out_h[:M]), "the reference's Point.multiplyUnsafe differs from the GPU batch multiply"
+                pbj = refjs.point_bench(1.5)
+                assert pbj["equal"]
+                extra["configs0_point_multiply"]["reference"] = {
+                    "kind": "reference", "cores": 1, "unit": "ops/s", "Point_mul": pbj["Point_mul"], "Point_mulUns": pbj["Point_mulUns"],
+                    "Point_mul_random_scalars": pbj["Point_mul_random"], "Point_mulUns_random_scalars": pbj["Point_mulUns_random"],
+                    "note": "benchmark/point.ts:20-32 run by the reference's own code on this host (node %s): Point.multiply / multiplyUnsafe of one "
+                            "public-key point by 2^180 - 15820 (BASE precomputed with W = 6 as the benchmark does), and by 1 000 random scalars" % pbj["node"]}
+            result["cpu_baseline"] = with_reference(port_e, ref_info, "scalar-mults/s",
+                                                    "first 4096 pairs of the same batch through the reference's Point.multiplyUnsafe (weierstrass.ts:915-928), "
+                                                    "outputs compared bit-exactly with the GPU's")
 
     # ------------------------------------------------------------------ bls12-381 G1 / G2 MSM
     def msm_workload(curve, Pt, cname, nn, seed, alg_b, ref_mac_pt, key):
@@ -904,10 +938,19 @@ def main():
                 with ThreadPoolExecutor(max_workers=thr) as ex:
                     list(ex.map(lambda t: cport.pippenger("bls12_381_g1", pts_h[t * mm:(t + 1) * mm], sc_h[t * mm:(t + 1) * mm]), range(thr)))
                 rall = thr * mm / (time.perf_counter() - t0)
-            msm["cpu_baseline"] = baseline_entry(m / dt, m, rall, thr * (min(m, n // thr)) if rall else 0, thr, "points/s",
-                                                 "first %d points of the same MSM through oracle/c pippenger (curve.ts:863-905 "
-                                                 "restated), result compared bit-exactly with the GPU MSM on the same subset; "
-                                                 "all_threads: one independent MSM of n/threads points per thread (points/s summed)")
+            port_e = baseline_entry(m / dt, m, rall, thr * (min(m, n // thr)) if rall else 0, thr, "points/s",
+                                    "first %d points of the same MSM through oracle/c pippenger (curve.ts:863-905 "
+                                    "restated), result compared bit-exactly with the GPU MSM on the same subset; "
+                                    "all_threads: one independent MSM of n/threads points per thread (points/s summed)")
+            ref_info = None
+            if ref_ok:
+                mr = min(n, 1 << 12)
+                o_r, ref_info = refjs.pippenger(BLS12_381_G1, pts_h[:mr], sc_h[:mr])
+                g_r, _ = eng.msm_dev(BLS12_381_G1, mr, dev_ptr(sub["pts"]), dev_ptr(sub["sc"]), stream)
+                assert np.array_equal(o_r, g_r), "the reference's pippenger differs from the GPU MSM"
+            msm["cpu_baseline"] = with_reference(port_e, ref_info, "points/s",
+                                                 "first 4096 points of the same MSM through the reference's pippenger (abstract/curve.ts:863-905), one call; "
+                                                 "result compared bit-exactly with the GPU MSM on the same subset")
         extra["msm_g1"] = msm
         if dist_on:
             # strong scaling (configs[3] as written): ONE 2^log2n-point MSM whose points are split
@@ -958,10 +1001,19 @@ def main():
                 with ThreadPoolExecutor(max_workers=thr2) as ex:
                     list(ex.map(lambda t: cport.pippenger("bls12_381_g2", pts2_h[t * mm2:(t + 1) * mm2], sc2_h[t * mm2:(t + 1) * mm2]), range(thr2)))
                 rall2 = thr2 * mm2 / (time.perf_counter() - t0)
-            msm2["cpu_baseline"] = baseline_entry(m2 / dt2, m2, rall2, thr2 * mm2 if rall2 else 0, thr2, "points/s",
-                                                  "first %d points of the same MSM through oracle/c pippenger over Fp2 (curve.ts:863-905, "
-                                                  "tower.ts:393-475 restated), result compared bit-exactly with the GPU MSM on the same subset; "
-                                                  "all_threads: one independent MSM of n/threads points per thread (points/s summed)")
+            port_e2 = baseline_entry(m2 / dt2, m2, rall2, thr2 * mm2 if rall2 else 0, thr2, "points/s",
+                                     "first %d points of the same MSM through oracle/c pippenger over Fp2 (curve.ts:863-905, "
+                                     "tower.ts:393-475 restated), result compared bit-exactly with the GPU MSM on the same subset; "
+                                     "all_threads: one independent MSM of n/threads points per thread (points/s summed)")
+            ref_info2 = None
+            if ref_ok:
+                mr2 = min(n2, 1 << 10)
+                o_r2, ref_info2 = refjs.pippenger(BLS12_381_G2, pts2_h[:mr2], sc2_h[:mr2])
+                g_r2, _ = eng.msm_dev(BLS12_381_G2, mr2, dev_ptr(sub2["pts"]), dev_ptr(sub2["sc"]), stream)
+                assert np.array_equal(o_r2, g_r2), "the reference's G2 pippenger differs from the GPU MSM"
+            msm2["cpu_baseline"] = with_reference(port_e2, ref_info2, "points/s",
+                                                  "first 1024 points of the same MSM through the reference's pippenger over Fp2, one call; result compared "
+                                                  "bit-exactly with the GPU MSM on the same subset")
         extra["msm_g2"] = msm2
         if dist_on:
             ns = n2 // world
@@ -1049,6 +1101,15 @@ def main():
             ed_cpu = baseline_entry(r1, d1, rall, dall, thr, "verifies/s",
                                     "first %d signatures of the same batch through oracle/c (edwards.ts:942-989 restated) plus "
                                     "hashlib SHA-512 per item, verdicts compared with the GPU's")
+            if ref_ok:
+                mr = 2048
+                pick = list(range(mr - 196)) + list(range(tail, tail + 196)) if nz == 196 and tail + 196 <= nv else list(range(mr))
+                v_r, ed_ref = refjs.ed25519_verify([sig_np[i].tobytes() for i in pick], [msg_list[i] for i in pick],
+                                                   [pk_np[i].tobytes() for i in pick], zip215=True)
+                assert np.array_equal(v_r, got[pick]), "the reference's ed25519.verify differs from the GPU verdicts"
+                ed_cpu = with_reference(ed_cpu, ed_ref, "verifies/s",
+                                        "2048 signatures of the same batch (incl. the 196 zip215.json cases) through the reference's ed25519.verify "
+                                        "(edwards.ts:942-989, SHA-512 by node:crypto), verdicts compared with the GPU's")
         kern_s = ev_ms_k / K * 1e-3
         traffic, tsrc = pmc.traffic("ed25519") if nv == 1 << 18 else (None, None)
         extra["ed25519_verify"] = {"metric": "ed25519_verifies_per_sec", "value": world * nv * K / wall,

@@ -1,0 +1,80 @@
+"""Python side of oracle/ref_js: build the type-stripped copy of the reference (when /root/reference is present) and run the
+REFERENCE's own TypeScript code on this machine's Node for known answers and CPU timings.  TEST INFRASTRUCTURE: only tests/,
+__graft_entry__ and bench.py's cpu_baseline leg use it.  oracle/_ref/js is git-ignored (no reference source is committed);
+it travels to the GPU box with the snapshot, where /root/reference does not exist."""
+import json
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_JS = os.path.join(HERE, "_ref", "js")
+SRC = os.path.join(HERE, "ref_js")
+CURVE_NAME = {0: "secp256k1", 1: "ed25519", 2: "bls12_381_g1", 3: "bls12_381_g2"}
+
+
+def node():
+    return shutil.which("node") or shutil.which("nodejs")
+
+
+def build(reference="/root/reference/src"):
+    """oracle/_ref/js from the reference's sources where they lie (no-op when they are absent and a build exists)."""
+    if not os.path.isdir(reference):
+        return available()
+    subprocess.check_call(["python3", os.path.join(SRC, "downlevel.py"), "--src", reference, "--out", REF_JS])
+    for f in ("hashes_shim.mjs", "polyfill.mjs", "run_ref.mjs"):
+        shutil.copy(os.path.join(SRC, f), os.path.join(REF_JS, f))
+    return available()
+
+
+def available():
+    return node() is not None and os.path.exists(os.path.join(REF_JS, "run_ref.mjs")) and os.path.exists(os.path.join(REF_JS, "secp256k1.mjs"))
+
+
+def _run(cmd, data, out_bytes, *args, timeout=600):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(data)
+        r = subprocess.run([node(), os.path.join(REF_JS, "run_ref.mjs"), cmd, fin, fout] + [str(a) for a in args],
+                           capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0:
+            raise RuntimeError("reference run failed: " + (r.stderr or r.stdout)[-600:])
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        out = np.fromfile(fout, dtype=np.uint8) if out_bytes else None
+    return out, info
+
+
+def multiply(curve, points_wire, scalars_wire, unsafe=True):
+    """rows of Point.multiplyUnsafe / Point.multiply through the reference; wire arrays as in include/ncg.h"""
+    p = np.ascontiguousarray(points_wire, dtype=np.uint8)
+    s = np.ascontiguousarray(scalars_wire, dtype=np.uint8).reshape(-1, 32)
+    p = p.reshape(s.shape[0], -1)
+    out, info = _run("mul_unsafe" if unsafe else "mul", np.concatenate([p, s], axis=1).tobytes(), True, CURVE_NAME[curve])
+    return out.reshape(p.shape), info
+
+
+def pippenger(curve, points_wire, scalars_wire):
+    p = np.ascontiguousarray(points_wire, dtype=np.uint8)
+    s = np.ascontiguousarray(scalars_wire, dtype=np.uint8).reshape(-1, 32)
+    out, info = _run("pippenger", p.tobytes() + s.tobytes(), True, CURVE_NAME[curve], timeout=1800)
+    return out, info
+
+
+def ed25519_verify(sigs, msgs, pks, zip215=True):
+    rec = bytearray()
+    for sg, m, pk in zip(sigs, msgs, pks):
+        assert len(m) <= 64
+        rec += bytes(sg) + bytes(pk) + len(m).to_bytes(4, "little") + bytes(m).ljust(64, b"\0")
+    out, info = _run("ed25519_verify", bytes(rec), True, "zip215" if zip215 else "strict")
+    return out.astype(bool), info
+
+
+def point_bench(seconds=2.0):
+    r = subprocess.run([node(), os.path.join(REF_JS, "run_ref.mjs"), "point_bench", str(seconds)], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("reference run failed: " + (r.stderr or r.stdout)[-600:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
