@@ -1296,6 +1296,7 @@ int ncg_ntt_dev(ncg_ctx* ctx, int field, int log2n, size_t batch, const void* om
   if (batch == 0) return NCG_OK;
   if (batch > 65535) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: batch too large");
   if (!omega || !in_dev || !out_dev) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: NULL buffer");
+  if (misaligned16(in_dev) || misaligned16(out_dev)) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: ntt: device buffers must be 16-byte aligned");
   NCG_HIP(ctx, hipSetDevice(ctx->device));
   int rc = ensure_ntt_table(ctx, log2n, (const uint32_t*)omega);
   if (rc) return rc;

@@ -148,6 +148,12 @@ def test_msm_refuses_misaligned_device_buffers():
         with pytest.raises(Exception, match="16-byte aligned"):
             eng.msm_split_windows_dev(BLS12_381_G1, 40, 2, buf.data_ptr(), p)
     assert gpu_msm(BLS12_381_G1, pts, sc) == exp.toAffine()      # the context keeps working
+    from noble_curves_amd import fft as gfft
+    om = gfft.rootsOfUnity(gfft.bls12_381_Fr, 7).omega(5)
+    with pytest.raises(Exception, match="16-byte aligned"):
+        eng.ntt_dev(5, 1, om, buf.data_ptr() + 8, buf.data_ptr() + 4096, None)
+    with pytest.raises(Exception, match="16-byte aligned"):
+        eng.ntt_dev(5, 1, om, buf.data_ptr(), buf.data_ptr() + 4100, None)
 
 
 def sum_points(Pt, pts):
