@@ -653,7 +653,7 @@ def main():
                          "kernel_ms": kern_ms,
                          "valu": valu_block(pmc, "secp256k1", kern_ms * 1e-3, 3.4e5 * n, secp_mads_per_mult() * n)},
         }
-        if not dist_on:
+        if not dist_on and not args.quick_verify:   # (the PMC / kernel-stats child runs keep to the headline launches)
             # end to end through the host-pointer entry point (ncg_mul_var_batch): pinned-once host buffers, chunked H2D / kernels / D2H
             e_p, e_s = pts.cpu().numpy(), sc.cpu().numpy()
             e_o, e_i = np.zeros((n, 64), np.uint8), np.zeros((n,), np.uint8)
@@ -768,7 +768,7 @@ def main():
                               "kernel": "k_msm_accum (dominant; achieved is for the whole MSM incl. the host finish, traffic for that kernel)",
                               "valu": valu_block(pmc, key, wall / K, ref_mac_pt * nn,
                                                  (g1_msm_mads_per_point(nwin, nn, 1 << (c - 1), True) * (3 if curve == BLS12_381_G2 else 1)) * nn)}}
-        if not dist_on:
+        if not dist_on and not args.quick_verify:   # (the PMC / kernel-stats child runs keep to the headline launches)
             # end to end through the HOST-pointer entry point (the boundary the N-API addon binds: ncg_msm): inputs in pinned host
             # memory (ncg_host_register once), scalars first, the points in parts accumulated while the next part crosses PCIe
             pts_h, sc_h = pts.cpu().numpy(), sc.cpu().numpy()
@@ -835,6 +835,7 @@ def main():
             wres.free()
             entry["window_share"] = dict(shares, note="per-rank share of ONE %d-point MSM cut by windows over G ranks (resident set, stored form), emulated on one GPU; speedup_* = "
                                                       "this run's single-GPU ms_per_msm / share; the xGMI all-gather (~30 us) is not included" % nn)
+        if not dist_on:
             # the same MSM on a resident set verified to lie in the prime-order subgroup (ncg_points_verify_subgroup,
             # once per set): the scalars are split along the curve endomorphism (csrc/endo.hpp) - same group
             # element, half (G1) / a quarter (G2) of the windows.  pippenger itself accepts arbitrary curve
