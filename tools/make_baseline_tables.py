@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Rewrites section 5 of BASELINE.md from the committed round profiles (profiles/r03_*, r02 beside them), so the tables are
+"""Rewrites section 5 of BASELINE.md from the committed round profiles (profiles/r04_*, r03 beside them), so the tables are
 transcriptions of measured files, not hand-typed numbers.  python tools/make_baseline_tables.py"""
 import json
 import os
@@ -14,38 +14,42 @@ def load(name):
 
 
 def main():
-    b = load("r03_bench_line.json")
-    b1 = load("r02_bench_line.json")
-    ex, ex1 = load("r03_bench_extra.json"), load("r02_bench_extra.json")
+    b = load("r04_bench_line.json")
+    b1 = load("r03_bench_line.json")
+    ex, ex1 = load("r04_bench_extra.json"), load("r03_bench_extra.json")
     e = b["extra"]
     host = b.get("host", {})
     out = []
-    out.append("## 5. Results table (round 3, one MI355X, the driver's command `python3 bench.py --gpus 1 --steps 20 --warmup 5`: `profiles/r03_bench_line.json`, `profiles/r03_bench_kernel_stats.csv`, `profiles/r03_pmc.json`)\n")
+    out.append("## 5. Results table (round 4, one MI355X, the driver's command `python3 bench.py --gpus 1 --steps 20 --warmup 5`: `profiles/r04_bench_line.json`, `profiles/r04_bench_kernel_stats.csv`, `profiles/r04_pmc.json`; the same build on a faster box of the pool: `profiles/r04_bench_line_fast_box.json`)\n")
     out.append("Throughput with inputs resident in HBM, one run of the driver's command on a fresh box (per-step event / wall distributions "
-               "are in the line: `step_times`; the same command on other boxes: `profiles/r03_driver_cmd_run*.json`; the driver's own "
-               "round-2 box read 12-80 %% slower than any box seen here, DESIGN.md section 7).  Every result is verified "
+               "are in the line: `step_times`; the pool's boxes differ by up to 5 %% on these kernels, DESIGN.md section 7: the second line "
+               "named above reads secp256k1 8.66 ms, ed25519 2.78 ms on the same build).  Every result is verified "
                "bit-exactly before it is printed (sample vs the CPU oracle's C restatement, full-size checksum / progression identity, "
                "ed25519 verdicts by construction + the reference's 196 zip215.json cases).  `hbm_frac` = algorithmic bytes ÷ 8 TB/s (the "
                "contract's figure; the path is VALU-bound, §2 caveat); `mad_frac` = executed `v_mad_u64_u32` (counted from the kernel's "
                "operation sequence) ÷ the measured multiplier ceiling 3.08×10¹³/s; `valu_issue` = SQ_INSTS_VALU × 64 ÷ kernel time ÷ "
                "3.93×10¹³ lane-ops/s (rocprofv3 PMC, live in the bench run); `traffic` = HBM bytes per launch of the dominant kernel "
-               "(FETCH_SIZE/WRITE_SIZE with the per-pattern calibration of `tools/pmc_calib`).  CPU baseline = `oracle/c` restatement of "
-               "the reference algorithm on the GPU box's host (%s, %s logical cores; Node %s cannot run the TypeScript reference).\n"
+               "(FETCH_SIZE/WRITE_SIZE with the per-pattern calibration of `tools/pmc_calib`, in `profiles/r04_pmc.json`).  CPU baseline = the "
+               "REFERENCE's own TypeScript code on the GPU box's host (%s, %s logical cores; Node %s running the type-stripped sources of "
+               "`oracle/_ref/js`, one thread), each result compared bit-exactly with the GPU's; the C port of round 1-3 beside it.\n"
                % (host.get("cpu_model"), host.get("logical_cores"), host.get("node_version")))
-    out.append("| config | N | time (r02 → r03) | throughput | hbm_frac | mad_frac | valu_issue | traffic / algorithmic | CPU port 1 thread / all threads | bit-exact |")
-    out.append("|---|---|---|---|---|---|---|---|---|---|")
+    out.append("| config | N | time (r03 → r04) | throughput | hbm_frac | mad_frac | valu_issue | traffic / algorithmic | CPU: reference (1 thread) | CPU: C port 1 thread / all threads | bit-exact |")
+    out.append("|---|---|---|---|---|---|---|---|---|---|---|")
 
     def row(name, n, t1, t2, unit, entry, alg_bytes):
         rf = entry["roofline"]
         v = rf["valu"]
         cb = entry.get("cpu_baseline", {})
+        ref = cb if cb.get("kind") == "reference" else {}
+        cb = cb.get("port", cb)
         at = cb.get("all_threads", {})
         tr = rf.get("traffic")
-        out.append("| %s | %s | %s → **%.2f ms** | **%.3g %s** | %.2f %% | %s | %s | %s | %s / %s | yes |" % (
+        out.append("| %s | %s | %s → **%.2f ms** | **%.3g %s** | %.2f %% | %s | %s | %s | %s | %s / %s | yes |" % (
             name, n, ("%.2f ms" % t1) if t1 else "—", t2, entry["value"], unit, 100 * rf["frac"],
             ("%.0f %%" % (100 * v["mad_frac"])) if "mad_frac" in v else "—",
             ("%.0f %%" % (100 * v["valu_issue_frac"])) if "valu_issue_frac" in v else "—",
             ("%.2f GB / %.0f MB = %.0f×" % (tr / 1e9, alg_bytes / 1e6, tr / alg_bytes)) if tr else "—",
+            ("**%.3g /s**" % ref["value"]) if ref else "—",
             ("%.3g /s" % cb["value"]) if cb else "—", ("%.3g /s (%d thr)" % (at["value"], at["cores"])) if at else "—"))
 
     e1 = b1["extra"]
@@ -60,8 +64,27 @@ def main():
     out.append("\ned25519 kernel-only (pre-hashed challenges): %.2f ms → **%.2f ms** (%.3g verifies/s); the device hash adds "
                "%.2f ms per 2¹⁸ signatures.  Multi-GPU (2/4/8): measured by the driver's scaling run - `bench.py --gpus N` reports weak "
                "scaling per line, `extra.msm_g1_strong` / `msm_g2_strong` = one 2²⁰ / 2¹⁸-point MSM split over the N GPUs through "
-               "`ncg_msm_sharded_dev` (RCCL all-gather of one fixed-size slot per rank); `python bench.py --gpus N` launches its own ranks; strong-scaling budget: DESIGN.md section 6.\n"
+               "`ncg_msm_sharded_windows_dev` (every rank holds the set and runs a range of the windows; RCCL all-gather of one fixed-size slot per rank), synchronously and with three in flight; `python bench.py --gpus N` launches its own ranks; strong-scaling budget measured on one GPU: below and DESIGN.md section 6.\n"
                % (e1["ed25519_verify"]["ms_per_batch"], ko["ms_per_batch"], ko["value"], e["ed25519_verify"]["ms_per_batch"] - ko["ms_per_batch"]))
+    # round 4: MSMs in flight, per-rank window shares, end to end
+    for key, nm in (("msm_g1", "G1 2²⁰"), ("msm_g2", "G2 2¹⁸")):
+        m = e[key]
+        if "pipelined" in m:
+            pp = m["pipelined"]
+            out.append("%s MSM with several in flight (`ncg_msm_async_submit` / `_collect`, DESIGN §5): **%.2f ms** per MSM at depth 2, %.2f at depth 3 "
+                       "(one at a time: %.2f ms); through the host-pointer entry point on buffers pinned once (`end_to_end`, PCIe-inclusive): **%.2f ms**.\n"
+                       % (nm, pp["depth2"]["ms_per_msm"], pp["depth3"]["ms_per_msm"], m["ms_per_msm"], m["end_to_end"]["ms_per_msm"]))
+        if "window_share" in m:
+            ws = m["window_share"]
+            out.append("| %s: one rank's share, window-sharded over G ranks (emulated on one GPU, resident set; DESIGN §6) | G = 2 | G = 4 | G = 8 |" % nm)
+            out.append("|---|---|---|---|")
+            out.append("| latency of one MSM: local phase of part 0 + combine / finish on the G slots | " + " | ".join(
+                "%.2f ms (%.1f×)" % (ws["G%d" % g]["latency_ms"], ws["G%d" % g]["speedup_latency"]) for g in (2, 4, 8)) + " |")
+            out.append("| sustained, parts of successive MSMs in flight on three lanes | " + " | ".join(
+                "%.2f ms (%.1f×)" % (ws["G%d" % g]["pipelined_part_ms"], ws["G%d" % g]["speedup_pipelined"]) for g in (2, 4, 8)) + " |\n")
+    if "end_to_end" in b:
+        out.append("secp256k1 2²⁰ batch multiply through the host-pointer entry point (pinned once, chunks pipelined over three streams): **%.2f ms** "
+                   "(96 MB in, 65 MB out).\n" % b["end_to_end"]["ms_per_batch"])
     r1, r2 = e["msm_g1"].get("resident_subgroup_set"), e["msm_g2"].get("resident_subgroup_set")
     p1, p2 = (r1 or {}).get("precomputed"), (r2 or {}).get("precomputed")
     if r1 and r2:
@@ -74,39 +97,48 @@ def main():
     if p1 and p2:
         out.append("The same verified sets with `ncg_points_precompute` (interleavedMSMUnsafe's per-point tables in device form: window-"
                    "shifted copies, built once in %.0f / %.0f ms; one shared bucket set, no combine across windows): G1 2²⁰ **%.2f ms**, "
-                   "G2 2¹⁸ **%.2f ms**; per size and path: `profiles/r03_msm_timing.json`.\n"
+                   "G2 2¹⁸ **%.2f ms**; per size and path: `profiles/r04_msm_timing.json`.\n"
                    % (p1["precompute_once_ms"], p2["precompute_once_ms"], p1["ms_per_msm"], p2["ms_per_msm"]))
     c0 = e.get("configs0_point_multiply")
     if c0:
-        out.append("BASELINE configs[0] (`benchmark/point.ts:20-32`, CPU plumbing; port, 1 core of the box's %s): `Point.multiply` "
+        rj = c0.get("reference")
+        out.append("BASELINE configs[0] (`benchmark/point.ts:20-32`, CPU plumbing; 1 core of the box's %s): %sC port: `Point.multiply` "
                    "%.0f ops/s (%.0f µs), `Point.multiplyUnsafe` %.0f ops/s (%.0f µs).\n"
-                   % (c0.get("cpu_model"), c0["Point_multiply"]["value"], c0["Point_multiply"]["us_per_op"],
+                   % (c0.get("cpu_model"),
+                      ("the REFERENCE's own code (Node 12, BASE precomputed with W = 6 as the benchmark does): `Point.multiply` **%.0f ops/s**, "
+                       "`Point.multiplyUnsafe` **%.0f ops/s** (1 000 random scalars: %.0f / %.0f ops/s); " % (
+                           rj["Point_mul"], rj["Point_mulUns"], rj["Point_mul_random_scalars"], rj["Point_mulUns_random_scalars"])) if rj else "",
+                      c0["Point_multiply"]["value"], c0["Point_multiply"]["us_per_op"],
                       c0["Point_multiplyUnsafe"]["value"], c0["Point_multiplyUnsafe"]["us_per_op"]))
     out.append("Targets: ≥10⁷ secp256k1 scalar-mults/s per MI355X — met (%.1f×); \"≥40 %% HBM roofline\" for the 2²⁰ G1 MSM is not physically "
                "meaningful (§2 caveat): its dominant kernel runs at %.0f %% of the measured multiplier ceiling in EXECUTED multiplies.\n"
                % (b["value"] / 1e7, 100 * e["msm_g1"]["roofline"]["valu"]["mad_frac"]))
-    out.append("### Other entry points (one MI355X, `tools/bench_extra.py`, `profiles/r03_bench_extra.json`; r02 beside it)\n")
-    out.append("| entry point | N | r02 | r03 | throughput |")
+    out.append("### Other entry points (one MI355X, `tools/bench_extra.py`, `profiles/r04_bench_extra.json`; r03 beside it)\n")
+    out.append("| entry point | N | r03 | r04 | throughput |")
     out.append("|---|---|---|---|---|")
     for k, v in ex.items():
         o = ex1.get(k)
         out.append("| %s | 2^%d | %s | %.2f ms | %.3g %s/s |" % (k, v["n"].bit_length() - 1, ("%.2f ms" % o["ms"]) if o else "—", v["ms"], v["per_s"], v["unit"]))
-    out.append("\n### End to end from JavaScript (`addon/bench_js.js`, Node 12 on the GPU box, secp256k1, `profiles/r03_js_bench.jsonl`)\n")
+    out.append("\n### End to end from JavaScript (`addon/bench_js.js`, Node 12 on the GPU box, secp256k1, `profiles/r04_js_bench.jsonl`)\n")
     out.append("BigInt marshalling + N-API + H2D/D2H + kernels.  `resident` = the point set was uploaded once (`uploadPoints`), only the scalars "
                "cross per call - as `BigInt[]` read natively as 64-bit words, or as packed bytes (SURVEY 8a gotcha 8).  Every BigInt that crosses "
                "N-API costs ~100 ns (`napi_get_element` + `napi_get_value_bigint_words`; handle scopes and JS-side conversions measured no "
                "better), so the reference-shaped call with 2¹⁶ Point objects stays at ≈16 ms; `pippenger` / `multiplyUnsafeBatch` therefore also "
                "take packed columns (`packPoints`, `packScalars`, `BigUint64Array`) in place of `Point[]` / `BigInt[]`.\n")
-    out.append("| N | `pippenger` from JS (Point[] / BigInt[]) | packed columns (`packPoints` once + BigUint64Array scalars) | resident, BigInt[] scalars | resident, packed scalars | native call alone | `multiplyUnsafeBatch` from JS | native |")
-    out.append("|---|---|---|---|---|---|---|---|")
-    for line in open(P("r03_js_bench.jsonl")):
+    out.append("Round 4: `native.hostRegister(buffer)` pins a long-lived input buffer once - the `pinned` columns (no per-call page locking; the MSM "
+               "itself runs in parts under the transfer, DESIGN §5).\n")
+    out.append("| N | `pippenger` from JS (Point[] / BigInt[]) | packed columns (`packPoints` once + BigUint64Array scalars) | packed columns, pinned | resident, BigInt[] scalars | resident, packed scalars | native call alone | native, pinned | `multiplyUnsafeBatch` from JS | native | native, pinned |")
+    out.append("|---|---|---|---|---|---|---|---|---|---|---|")
+    for line in open(P("r04_js_bench.jsonl")):
         line = line.strip()
         if not line.startswith("{"):
             continue
         j = json.loads(line)
-        out.append("| 2^%d | %.1f ms | %.2f ms | %.2f ms | %.2f ms | %.2f ms | %.1f ms | %.2f ms |" % (
-            j["n"].bit_length() - 1, j["pippenger_js_ms"], j.get("pippenger_packed_columns_ms", float("nan")), j["pippenger_resident_bigint_ms"], j["pippenger_resident_bytes_ms"],
-            j["pippenger_native_ms"], j["multiplyUnsafeBatch_js_ms"], j["multiplyUnsafeBatch_native_ms"]))
+        out.append("| 2^%d | %.1f ms | %.2f ms | **%.2f ms** | %.2f ms | %.2f ms | %.2f ms | **%.2f ms** | %.1f ms | %.2f ms | %.2f ms |" % (
+            j["n"].bit_length() - 1, j["pippenger_js_ms"], j.get("pippenger_packed_columns_ms", float("nan")), j.get("pippenger_packed_columns_pinned_ms", float("nan")),
+            j["pippenger_resident_bigint_ms"], j["pippenger_resident_bytes_ms"],
+            j["pippenger_native_ms"], j.get("pippenger_native_pinned_ms", float("nan")), j["multiplyUnsafeBatch_js_ms"], j["multiplyUnsafeBatch_native_ms"],
+            j.get("multiplyUnsafeBatch_native_pinned_ms", float("nan"))))
     text = "\n".join(out) + "\n"
     path = os.path.join(ROOT, "BASELINE.md")
     s = open(path).read()
