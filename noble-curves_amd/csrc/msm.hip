@@ -184,16 +184,22 @@ __global__ void __launch_bounds__(256) k_msm_shared_starts(uint32_t* __restrict_
 }
 
 // sorted[w*n + pos] = point index | sign<<31, grouped by bucket within the window
+// Bucket range [b_lo, b_hi) per launch (round 4): the scattered 4-byte stores are what the kernel costs (220 us of a 2^20-point
+// G1 MSM against 45 us with the same LDS atomics and stores that stay in L2 - measured, tools/exp_scatter.py), because a
+// window's 4 MB list, written at random positions by blocks on every XCD, never sits in an L2.  Launched once per bucket
+// range with the window-major block ids of msm_sort_block (a window's blocks share an XCD), the region a pass writes is
+// 4 MB / passes per window - L2-resident - and leaves the cache as whole lines.
 __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict__ digits,
                                                       const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ bucket_start,
-                                                      uint32_t* __restrict__ sorted, MsmPlan pl) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t offs[];
+                                                      uint32_t* __restrict__ sorted, MsmPlan pl, int b_lo, int b_hi) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t offs_raw[];
   int q, w;
   if (!msm_sort_block(pl, q, w)) return;
   const uint32_t* src = counts + ((size_t)w * pl.Q + q) * pl.nb;
   const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
-  for (int b = threadIdx.x; b < pl.nb; b += blockDim.x) offs[b] = src[b] + bs[b];
+  uint32_t* offs = offs_raw - b_lo;   // indexed by bucket
+  for (int b = b_lo + threadIdx.x; b < b_hi; b += blockDim.x) offs[b] = src[b] + bs[b];
   __syncthreads();
   const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
   const int16_t* dg = digits + (size_t)w * pl.n;
@@ -203,8 +209,9 @@ __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict_
   const uint32_t level = pl.shared ? (uint32_t)(w + pl.w0) * (uint32_t)pl.n : 0u;  // the window's shifted copy (global window index)
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     int d = dg[i];
-    if (d != 0) {
-      uint32_t pos = atomicAdd(&offs[(d < 0 ? -d : d) - 1], 1u);
+    const int bk = (d < 0 ? -d : d) - 1;
+    if (d != 0 && bk >= b_lo && bk < b_hi) {
+      uint32_t pos = atomicAdd(&offs[bk], 1u);
       dst[pos] = (level + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
     }
   }
@@ -828,7 +835,15 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   } else {
     hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), (size_t)(pl.nb + pl.nb / 32 + 1) * 4, st, bstart, pl);
   }
-  hipLaunchKernelGGL(k_msm_scatter, sort_grid, dim3(1024), lds, st, digits, counts, bstart, sorted, pl);
+  {
+    const int passes = std::max(1, std::min(pl.scatter_passes, pl.nb / 256));
+    const int per = (pl.nb + passes - 1) / passes;
+    for (int p = 0; p < passes; p++) {
+      const int b_lo = p * per, b_hi = std::min(pl.nb, b_lo + per);
+      if (b_lo >= b_hi) break;
+      hipLaunchKernelGGL(k_msm_scatter, sort_grid, dim3(1024), (size_t)(b_hi - b_lo) * 4, st, digits, counts, bstart, sorted, pl, b_lo, b_hi);
+    }
+  }
   // from here on: the accumulate view (shared-bucket mode: ONE window of nwin * n entries whose starts are shared_start)
   const MsmPlan av = msm_acc_view(pl);
   const uint32_t* acc_start = pl.shared ? shared_start : bstart;

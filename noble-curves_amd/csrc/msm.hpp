@@ -51,6 +51,7 @@ struct MsmPlan {
   int endo = 0;
   int n_src = 0;
   int xcd_map = 0;  // sort kernels: window-major block ids so that a window's blocks share an XCD (one L2)
+  int scatter_passes = 1;  // k_msm_scatter launches, one bucket range each (with xcd_map: the range a pass writes stays in L2)
   int pts_stored = 0;  // the caller's points are already in the accumulate kernel's storage format (resident sets)
   // shared-bucket mode (precomputed sets, msm_precomp.hip): the point array holds one window-shifted copy of the
   // set per window, level w = 2^(c w) P at [w * n, (w + 1) * n), so every window adds into ONE bucket set: sorted
@@ -93,6 +94,10 @@ inline void msm_plan_take_windows(MsmPlan& pl, int w0, int cnt, int q_blocks = 5
   if (Q > cap) Q = cap;
   pl.Q = Q;
   pl.chunk = (pl.n + Q - 1) / Q;
+  if (cnt < 8) {  // the XCD-local sort needs a window per XCD (msm_plan.hpp msm_plan_sort_locality)
+    pl.xcd_map = 0;
+    pl.scatter_passes = 1;
+  }
 }
 
 // the plan the kernels AFTER the sort see: the plan itself, or - shared-bucket mode - one window holding every entry

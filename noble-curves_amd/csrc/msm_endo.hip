@@ -126,6 +126,7 @@ int msm_make_plan_endo(int curve, int n_src, int c_override, MsmPlan* pl) {
   Q = std::min(Q, std::max(1, n / 4096));
   pl->Q = Q;
   pl->chunk = (n + Q - 1) / Q;
+  msm_plan_sort_locality(*pl);
   return 0;
 }
 
