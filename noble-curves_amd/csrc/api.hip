@@ -176,6 +176,9 @@ void ncg_destroy(ncg_ctx* ctx) {
   (void)ncg_comm_destroy(ctx);
   if (ctx->comm_buf) (void)hipFree(ctx->comm_buf);
   if (ctx->sync_land) (void)hipHostFree(ctx->sync_land);
+  if (ctx->comm_fork) (void)hipEventDestroy(ctx->comm_fork);
+  if (ctx->comm_join) (void)hipEventDestroy(ctx->comm_join);
+  if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
   for (int i = 0; i < ncg_ctx::COPY_CHUNKS; i++) {
     if (ctx->ev_in[i]) (void)hipEventDestroy(ctx->ev_in[i]);
     if (ctx->ev_k[i]) (void)hipEventDestroy(ctx->ev_k[i]);

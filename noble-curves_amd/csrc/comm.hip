@@ -103,6 +103,7 @@ struct JobRes {
   size_t* comm_buf_bytes;
   uint32_t** land;       // pinned host: the gathered slots, then the summed payload
   size_t* land_words;
+  bool funnel = false;   // asynchronous lanes: the collective goes through the context's one communication stream
 };
 // what finish needs to know about an enqueued job
 struct JobState {
@@ -277,7 +278,7 @@ JobRes ctx_res(ncg_ctx* ctx, hipStream_t st) {
   return JobRes{st, &ctx->msm_side, &ctx->msm_ws, &ctx->msm_ws_bytes, &ctx->comm_buf, &ctx->comm_buf_bytes, &ctx->sync_land, &ctx->sync_land_words};
 }
 JobRes lane_res(ncg_msm_lane& ln) {
-  return JobRes{ln.stream, &ln.side, &ln.ws, &ln.ws_bytes, &ln.comm_buf, &ln.comm_buf_bytes, &ln.land, &ln.land_words};
+  return JobRes{ln.stream, &ln.side, &ln.ws, &ln.ws_bytes, &ln.comm_buf, &ln.comm_buf_bytes, &ln.land, &ln.land_words, true};
 }
 
 int identity_out(int curve, void* out_affine, uint8_t* out_is_inf) {
@@ -302,8 +303,26 @@ int job_enqueue(ncg_ctx* ctx, const JobRes& R, const ShardJob& J, bool collectiv
     const Rccl* r = rccl();
     if (!r) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: librccl.so not found");
     char* base = (char*)*R.comm_buf;
-    // in place: rank r's slot already sits at offset r * stride of the receive buffer
-    NCG_NCCL(ctx, r, r->AllGather(base + S->stride * (size_t)ctx->comm_rank, base, S->stride, ncclUint8, (ncclComm_t)ctx->comm, R.st));
+    // in place: rank r's slot already sits at offset r * stride of the receive buffer.  Jobs on the asynchronous lanes funnel
+    // their collective through ONE stream per context (fork / join events around it): every collective of the communicator
+    // is then enqueued on the same stream, in submit order, on every rank - no two all-gathers of one communicator are ever in
+    // flight on different streams.
+    hipStream_t cs = R.st;
+    if (R.funnel) {
+      if (!ctx->comm_stream) {
+        NCG_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        NCG_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_fork, hipEventDisableTiming));
+        NCG_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_join, hipEventDisableTiming));
+      }
+      cs = ctx->comm_stream;
+      NCG_HIP(ctx, hipEventRecord(ctx->comm_fork, R.st));
+      NCG_HIP(ctx, hipStreamWaitEvent(cs, ctx->comm_fork, 0));
+    }
+    NCG_NCCL(ctx, r, r->AllGather(base + S->stride * (size_t)ctx->comm_rank, base, S->stride, ncclUint8, (ncclComm_t)ctx->comm, cs));
+    if (R.funnel) {
+      NCG_HIP(ctx, hipEventRecord(ctx->comm_join, cs));
+      NCG_HIP(ctx, hipStreamWaitEvent(R.st, ctx->comm_join, 0));
+    }
   }
   return job_enqueue_combine(ctx, R, S, G);
 }
