@@ -462,10 +462,10 @@ def cpu_info():
     ok = refjs.available()
     return {"cpu_model": model, "logical_cores": os.cpu_count(), "node_version": node,
             "reference_runnable": ok,
-            "reference_note": ("the reference's own TypeScript sources run on this host: type-stripped by oracle/ref_js/downlevel.py into oracle/_ref/js "
+            "reference_note": ("the reference's own TypeScript sources run on this host: type-stripped by oracle/ref_js/downlevel.py into oracle/_ref/refjs.bundle "
                                "(types, generics, casts removed; every line of arithmetic untouched), @noble/hashes replaced by node:crypto, a few "
                                "library polyfills for Node 12 (kind: reference; the C port's figures are kept under cpu_baseline.port)") if ok else
-                              ("the TypeScript reference needs Node >= 20.19 with type stripping and @noble/hashes (SURVEY 8c) and oracle/_ref/js is not built; "
+                              ("the TypeScript reference needs Node >= 20.19 with type stripping and @noble/hashes (SURVEY 8c) and oracle/_ref/refjs.bundle is not built; "
                                "the CPU figures are the oracle's C restatement of the same algorithm (kind: port)")}
 
 
@@ -588,7 +588,7 @@ def main():
     ref_ok = rank == 0 and refjs.available()
 
     def with_reference(port_entry, ref_info, unit, sample):
-        """cpu_baseline = the REFERENCE's own TypeScript code on this host's Node (oracle/_ref/js: /root/reference/src type-stripped
+        """cpu_baseline = the REFERENCE's own TypeScript code on this host's Node (oracle/_ref/refjs.bundle: /root/reference/src type-stripped
         by oracle/ref_js/downlevel.py; one thread - the reference is single-threaded JS) when that build is present, with the C
         port's figures (1 thread and all threads) kept beside it; otherwise the port alone."""
         if not ref_info:

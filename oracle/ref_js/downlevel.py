@@ -3,9 +3,10 @@
 
 TEST INFRASTRUCTURE (oracle/): the product never imports anything produced here.  The reference (paulmillr/noble-curves,
 /root/reference/src) is TypeScript that Node >= 20.19 executes directly; this image has Node 12.22 and no TypeScript
-compiler.  This script reads the reference's files WHERE THEY LIE and writes type-stripped copies into oracle/_ref/js/
-(git-ignored, never committed: reference sources do not enter the repository; the directory travels to the GPU box with the
-snapshot like any other build output).  With them, `oracle/ref_js/run_ref.js` times the reference's OWN `Point.multiply`,
+compiler.  This script reads the reference's files WHERE THEY LIE and writes type-stripped copies into a directory that
+oracle/refjs.py packs into oracle/_ref/refjs.bundle (a gzip tar: git-ignored, never committed - reference sources do not enter
+the repository or linger in the working tree; the bundle travels to the GPU box with the snapshot like any other build
+output and is unpacked into a temporary directory while a test or the bench runs).  With them, `oracle/ref_js/run_ref.js` times the reference's OWN `Point.multiply`,
 `multiplyUnsafe` and `pippenger` on the box's host cores (bench.py `cpu_baseline.kind = "reference"`) and produces
 known answers that pin the Python oracle a second time (tests/test_reference_js.py).
 
@@ -19,7 +20,7 @@ What it does - a tokenizer and one structural pass, no type checking, nothing se
   * `a?.b` / `a ?? b` (a handful of places) -> conditional expressions
 Everything else - every line of arithmetic - is the reference's text, byte for byte.
 
-    python oracle/ref_js/downlevel.py [--src /root/reference/src] [--out oracle/_ref/js] [files...]
+    python oracle/ref_js/downlevel.py [--src /root/reference/src] --out <dir> [files...]      (normally through oracle/refjs.py build())
 """
 import argparse
 import os

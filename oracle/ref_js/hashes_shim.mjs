@@ -1,5 +1,5 @@
 // Stand-in for the `@noble/hashes` entry points the reference's curve code imports (utils.js, sha2.js, hmac.js), on top of
-// node:crypto - TEST INFRASTRUCTURE for oracle/_ref/js (oracle/ref_js/downlevel.py copies it there).  Only what the hot
+// node:crypto - TEST INFRASTRUCTURE for oracle/_ref/refjs.bundle (oracle/ref_js/downlevel.py copies it there).  Only what the hot
 // path's files touch: byte helpers and argument checks with the upstream argument meaning, SHA-256/384/512 and HMAC as
 // callable hash objects (`h(msg)`, `h.create().update().digest()`, `.outputLen`, `.blockLen`).
 import crypto from 'crypto';

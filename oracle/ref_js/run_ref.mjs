@@ -1,4 +1,4 @@
-// Runs the REFERENCE's own code (paulmillr/noble-curves, type-stripped into oracle/_ref/js by downlevel.py) on this
+// Runs the REFERENCE's own code (paulmillr/noble-curves, type-stripped into oracle/_ref/refjs.bundle by downlevel.py) on this
 // machine's Node: timings for bench.py's cpu_baseline (`kind: "reference"`) and known answers that pin the Python oracle
 // (tests/test_reference_js.py).  TEST INFRASTRUCTURE - the product never runs this.
 //

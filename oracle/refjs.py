@@ -1,7 +1,7 @@
 """Python side of oracle/ref_js: build the type-stripped copy of the reference (when /root/reference is present) and run the
 REFERENCE's own TypeScript code on this machine's Node for known answers and CPU timings.  TEST INFRASTRUCTURE: only tests/,
-__graft_entry__ and bench.py's cpu_baseline leg use it.  oracle/_ref/js is git-ignored (no reference source is committed);
-it travels to the GPU box with the snapshot, where /root/reference does not exist."""
+__graft_entry__ and bench.py's cpu_baseline leg use it.  The build artefact oracle/_ref/refjs.bundle is git-ignored (no reference
+source is committed); it travels to the GPU box with the snapshot, where /root/reference does not exist."""
 import json
 import os
 import shutil
@@ -11,9 +11,10 @@ import tempfile
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REF_JS = os.path.join(HERE, "_ref", "js")
+BUNDLE = os.path.join(HERE, "_ref", "refjs.bundle")     # the build artefact: gzip tar of the type-stripped modules (git-ignored)
 SRC = os.path.join(HERE, "ref_js")
 CURVE_NAME = {0: "secp256k1", 1: "ed25519", 2: "bls12_381_g1", 3: "bls12_381_g2"}
+_unpacked = None
 
 
 def node():
@@ -21,17 +22,44 @@ def node():
 
 
 def build(reference="/root/reference/src"):
-    """oracle/_ref/js from the reference's sources where they lie (no-op when they are absent and a build exists)."""
+    """oracle/_ref/refjs.bundle from the reference's sources where they lie (no-op when they are absent and a bundle exists).
+    The type-stripped modules exist only inside the bundle and, while a test or the bench runs, in a temporary directory:
+    no look-alike of a reference source file is left in the working tree."""
+    global _unpacked
     if not os.path.isdir(reference):
         return available()
-    subprocess.check_call(["python3", os.path.join(SRC, "downlevel.py"), "--src", reference, "--out", REF_JS])
-    for f in ("hashes_shim.mjs", "polyfill.mjs", "run_ref.mjs"):
-        shutil.copy(os.path.join(SRC, f), os.path.join(REF_JS, f))
+    import tarfile
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call(["python3", os.path.join(SRC, "downlevel.py"), "--src", reference, "--out", d], stdout=subprocess.DEVNULL)
+        for f in ("hashes_shim.mjs", "polyfill.mjs", "run_ref.mjs"):
+            shutil.copy(os.path.join(SRC, f), os.path.join(d, f))
+        os.makedirs(os.path.dirname(BUNDLE), exist_ok=True)
+        with tarfile.open(BUNDLE + ".tmp", "w:gz") as tar:
+            tar.add(d, arcname="js")
+        os.replace(BUNDLE + ".tmp", BUNDLE)
+    old = os.path.join(HERE, "_ref", "js")
+    if os.path.isdir(old):
+        shutil.rmtree(old, ignore_errors=True)
+    _unpacked = None
     return available()
 
 
 def available():
-    return node() is not None and os.path.exists(os.path.join(REF_JS, "run_ref.mjs")) and os.path.exists(os.path.join(REF_JS, "secp256k1.mjs"))
+    return node() is not None and os.path.exists(BUNDLE)
+
+
+def ref_dir():
+    """the bundle unpacked into a per-process temporary directory (removed at exit)"""
+    global _unpacked
+    if _unpacked is None:
+        import atexit
+        import tarfile
+        d = tempfile.mkdtemp(prefix="ncg_refjs_")
+        with tarfile.open(BUNDLE, "r:gz") as tar:
+            tar.extractall(d)
+        atexit.register(shutil.rmtree, d, True)
+        _unpacked = os.path.join(d, "js")
+    return _unpacked
 
 
 def _run(cmd, data, out_bytes, *args, timeout=600):
@@ -39,7 +67,7 @@ def _run(cmd, data, out_bytes, *args, timeout=600):
         fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
         with open(fin, "wb") as f:
             f.write(data)
-        r = subprocess.run([node(), os.path.join(REF_JS, "run_ref.mjs"), cmd, fin, fout] + [str(a) for a in args],
+        r = subprocess.run([node(), os.path.join(ref_dir(), "run_ref.mjs"), cmd, fin, fout] + [str(a) for a in args],
                            capture_output=True, text=True, timeout=timeout)
         if r.returncode != 0:
             raise RuntimeError("reference run failed: " + (r.stderr or r.stdout)[-600:])
@@ -74,7 +102,7 @@ def ed25519_verify(sigs, msgs, pks, zip215=True):
 
 
 def point_bench(seconds=2.0):
-    r = subprocess.run([node(), os.path.join(REF_JS, "run_ref.mjs"), "point_bench", str(seconds)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([node(), os.path.join(ref_dir(), "run_ref.mjs"), "point_bench", str(seconds)], capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         raise RuntimeError("reference run failed: " + (r.stderr or r.stdout)[-600:])
     return json.loads(r.stdout.strip().splitlines()[-1])

@@ -1,5 +1,5 @@
 """The Python oracle against the REFERENCE ITSELF, executed here: the reference's TypeScript sources, type-stripped by
-oracle/ref_js/downlevel.py into oracle/_ref/js (git-ignored; built by __graft_entry__.build() when /root/reference is
+oracle/ref_js/downlevel.py into oracle/_ref/refjs.bundle (git-ignored; built by __graft_entry__.build() when /root/reference is
 present, shipped to the GPU box with the snapshot), run on this machine's Node 12 with node:crypto standing in for
 @noble/hashes.  This pins the oracle a second time - beside the reference's golden vectors (test_oracle_golden.py) - on inputs
 chosen here: random and edge scalars through Point.multiplyUnsafe / Point.multiply (weierstrass.ts:900-928), the scalar
@@ -15,7 +15,7 @@ from oracle import refjs
 from oracle.curves import makeRng
 from oracle.edwards import eddsa_verify
 
-pytestmark = pytest.mark.skipif(not refjs.available(), reason="oracle/_ref/js not built (needs /root/reference once, and node)")
+pytestmark = pytest.mark.skipif(not refjs.available(), reason="oracle/_ref/refjs.bundle not built (needs /root/reference once, and node)")
 
 
 def _affine_rows(curve, out):

@@ -31,7 +31,7 @@ def main():
                "3.93×10¹³ lane-ops/s (rocprofv3 PMC, live in the bench run); `traffic` = HBM bytes per launch of the dominant kernel "
                "(FETCH_SIZE/WRITE_SIZE with the per-pattern calibration of `tools/pmc_calib`, in `profiles/r04_pmc.json`).  CPU baseline = the "
                "REFERENCE's own TypeScript code on the GPU box's host (%s, %s logical cores; Node %s running the type-stripped sources of "
-               "`oracle/_ref/js`, one thread), each result compared bit-exactly with the GPU's; the C port of round 1-3 beside it.\n"
+               "`oracle/_ref/refjs.bundle`, one thread), each result compared bit-exactly with the GPU's; the C port of round 1-3 beside it.\n"
                % (host.get("cpu_model"), host.get("logical_cores"), host.get("node_version")))
     out.append("| config | N | time (r03 → r04) | throughput | hbm_frac | mad_frac | valu_issue | traffic / algorithmic | CPU: reference (1 thread) | CPU: C port 1 thread / all threads | bit-exact |")
     out.append("|---|---|---|---|---|---|---|---|---|---|---|")
