@@ -106,12 +106,17 @@ def main():
     fg = cal.get("calib_gather64", {}).get("fetch_bytes_per_counter_byte")
     fs = cal.get("calib_stream_read16", {}).get("fetch_bytes_per_counter_byte")
     wg = cal.get("calib_write64", {}).get("write_bytes_per_counter_byte")
+    # the same per-pattern factors bench.py applies (FETCH_FACTOR / KERNELS there): kernels that stream 16 bytes per lane read
+    # FETCH_SIZE in units that count each byte half (factor 2.0), gather-dominated kernels (item-major 64-byte records through an
+    # index) one to one (0.99) - tools/pmc_calib.hip
+    STREAMING = ("k_ntt_pass", "k_points_to_mont", "k_msm_digits", "k_msm_hist", "k_msm_bucket_totals", "k_msm_scan", "k_encode", "k_ntt_fill_table")
     for k, e in out["kernels"].items():
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-            f = fg or fs or 2.0
+            stream = any(t in k for t in STREAMING)
+            f = (fs or 2.0) if stream else (fg or fs or 2.0)
             w = wg or 1.0
             e["hbm_bytes_per_launch"] = int(e["FETCH_SIZE"] * 1024 * f + e["WRITE_SIZE"] * 1024 * w)
-            e["hbm_bytes_factors"] = {"fetch": f, "write": w}
+            e["hbm_bytes_factors"] = {"fetch": f, "write": w, "pattern": "stream" if stream else "gather"}
     json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
     print("%d kernels -> %s" % (len(out["kernels"]), args.out))
 
