@@ -824,8 +824,8 @@ def main():
                 def col(lane):
                     return coll[lane], eng.msm_async_collect_slot(lane, curve)
                 seen = {}
-                pw, _ = time_pipelined(sub, col, 3, G * max(2, (K + G - 1) // G), W, False, lambda r: seen.__setitem__(r[0], r[1]))
-                jobs = G * max(2, (K + G - 1) // G)
+                jobs = G * max(5, (2 * K + G - 1) // G)          # whole MSMs' worth of parts: 40 at the driver's K = 20
+                pw, _ = time_pipelined(sub, col, 3, jobs, W, False, lambda r: seen.__setitem__(r[0], r[1]))
                 cg2, _ = eng.msm_shard_combine(curve, nn, np.stack([seen[r] for r in range(G)]), stream)
                 assert np.array_equal(cg2, got), "window-sharded MSM (%d parts, pipelined) differs from the single-GPU MSM" % G
                 lat = (st_l[0] + st_c[0]) / K * 1e3
