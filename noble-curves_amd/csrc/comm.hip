@@ -299,7 +299,7 @@ int job_enqueue(ncg_ctx* ctx, const JobRes& R, const ShardJob& J, bool collectiv
   }
   int rc = job_local_phase(ctx, R, job, collective ? job.part : 0, G, S);
   if (rc) return rc;
-  if (G > 1) {
+  if (collective && ctx->comm) {  // a one-rank communicator runs the (in-place, trivial) all-gather too: same call path as G > 1
     const Rccl* r = rccl();
     if (!r) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: librccl.so not found");
     char* base = (char*)*R.comm_buf;
