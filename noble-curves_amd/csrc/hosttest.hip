@@ -403,19 +403,27 @@ int ht_msm_shard_combine(int curve, int n_max, int nparts, const uint8_t* slots,
 #undef CALL
 }
 // host finish of the MSM alone: variant 0 = the device templates compiled for the host, 1 = the default
-// (bls12-381: 64-bit-limb Jacobian form of bls_host64.hpp)
+// (bls12-381: 64-bit-limb Jacobian form of bls_host64.hpp; its field product on MULX / ADX where the CPU has them),
+// 2 = the default with the portable field product forced
+static int ht_msm_finish_default(int curve, int c, int nwin, const uint32_t* fin, uint32_t* out, uint8_t* out_inf) {
+#define CALL(C) (msm_host_finish_any<C>(fin, c, nwin, out, out_inf), 0)
+  HT_CURVE_DISPATCH(curve, CALL)
+#undef CALL
+}
 int ht_msm_finish(int curve, int c, int nwin, const uint32_t* fin, uint32_t* out, uint8_t* out_inf, int variant) {
   if (variant == 0) {
 #define CALL(C) (msm_host_finish<C>(fin, c, nwin, out, out_inf), 0)
     HT_CURVE_DISPATCH(curve, CALL)
 #undef CALL
   }
-#define CALL(C) (msm_host_finish_any<C>(fin, c, nwin, out, out_inf), 0)
-  HT_CURVE_DISPATCH(curve, CALL)
-#undef CALL
+  h64::adx_override() = variant == 2 ? 0 : -1;
+  const int rc = ht_msm_finish_default(curve, c, nwin, fin, out, out_inf);
+  h64::adx_override() = -1;
+  return rc;
 }
-// bls_host64.hpp on raw operands: op 0: Montgomery product of two canonical residues given as 6 x 64-bit words (result
-// 6 words); op 1: from_fe29 of 14 stored limbs (result 6 words, Montgomery form R = 2^384)
+int ht_h64_have_adx(void) { return h64::have_adx() ? 1 : 0; }
+// bls_host64.hpp on raw operands: op 0 / 2: Montgomery product of two canonical residues given as 6 x 64-bit words (result
+// 6 words; 0 = as dispatched, 2 = the portable form); op 1: from_fe29 of 14 stored limbs (result 6 words, Montgomery form R = 2^384)
 int ht_h64_op(int op, const uint64_t* a, const uint64_t* b, const uint32_t* limbs, uint64_t* r) {
   h64::Fp x, y, z;
   if (op == 0) {
@@ -424,6 +432,12 @@ int ht_h64_op(int op, const uint64_t* a, const uint64_t* b, const uint32_t* limb
       y.v[i] = b[i];
     }
     z = h64::mul(x, y);
+  } else if (op == 2) {  // the portable product, whatever the CPU
+    for (int i = 0; i < 6; i++) {
+      x.v[i] = a[i];
+      y.v[i] = b[i];
+    }
+    z = h64::mul_c(x, y);
   } else if (op == 1) {
     z = h64::from_fe29(limbs);
   } else {

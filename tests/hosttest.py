@@ -159,13 +159,18 @@ def fr29_op(op, a_limbs, b_limbs=None):
     return [int(x) for x in R], ovf
 
 
-def h64_mul(a, b):
-    """bls_host64.hpp Montgomery product (R = 2^384) of two residues below p -> integer"""
+def h64_mul(a, b, portable=False):
+    """bls_host64.hpp Montgomery product (R = 2^384) of two residues below p -> integer.  portable=False: the form the
+    library dispatches to on this CPU (MULX / ADX when present); True: the portable form."""
     A = np.array([(a >> (64 * i)) & (2 ** 64 - 1) for i in range(6)], dtype=np.uint64)
     B = np.array([(b >> (64 * i)) & (2 ** 64 - 1) for i in range(6)], dtype=np.uint64)
     R = np.zeros(6, dtype=np.uint64)
-    assert lib().ht_h64_op(0, A.ctypes.data, B.ctypes.data, None, R.ctypes.data) == 0
+    assert lib().ht_h64_op(2 if portable else 0, A.ctypes.data, B.ctypes.data, None, R.ctypes.data) == 0
     return sum(int(x) << (64 * i) for i, x in enumerate(R))
+
+
+def h64_have_adx():
+    return bool(lib().ht_h64_have_adx())
 
 
 def h64_from_fe29(limbs):

@@ -81,7 +81,7 @@ def test_host_finish_matches_oracle(curve, c, nwin):
         exp = expected(Pt, Vs, c, nwin, ng)
         for lazy in (False, True):
             fin = [wd for j in range(ng) for w in range(nwin) for wd in acc_words(curve, Vs[j][w], rng, lazy)]
-            for variant in (0, 1):
+            for variant in (0, 1, 2):   # 2: the 64-bit form with the portable field product forced (1 = MULX / ADX where present)
                 out, inf = hosttest.msm_finish(curve, c, nwin, np.array(fin, dtype=np.uint32), POINT_BYTES[curve], variant)
                 assert inf == exp.is0(), (variant, lazy)
                 want = bytes(POINT_BYTES[curve]) if exp.is0() else affine_to_wire(curve, exp.toAffine())
@@ -103,12 +103,15 @@ def test_host64_product_and_limb_import_at_the_edges():
     rng = makeRng(0x64F1)
     p = BLS_P
     rinv = pow(1 << 384, -1, p)
+    print("bls_host64 product on MULX / ADX:", hosttest.h64_have_adx())
     edge = [0, 1, 2, p - 1, p - 2, (1 << 380) - 1, (1 << 381) - 1 - ((1 << 381) - 1) // p * 0]
     edge = [e % p for e in edge] + [((1 << 64) - 1) << (64 * i) for i in range(5)]
-    vals = edge + [rng.rndBelow(p) for _ in range(40)]
+    vals = edge + [rng.rndBelow(p) for _ in range(120)]
     for a in vals:
         for b in (vals[:8] + vals[-6:]):
-            assert hosttest.h64_mul(a % p, b % p) == (a % p) * (b % p) * rinv % p
+            want = (a % p) * (b % p) * rinv % p
+            assert hosttest.h64_mul(a % p, b % p) == want
+            assert hosttest.h64_mul(a % p, b % p, portable=True) == want
     for trial in range(200):
         x = rng.rndBelow(p) if trial > 2 else [0, 1, p - 1][trial]
         k = rng.rndBelow(64) if trial % 3 else 63
