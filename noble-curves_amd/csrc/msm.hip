@@ -241,6 +241,65 @@ template <class C> struct AccumMinWaves { static constexpr int value = NCG_ACCUM
 // profiles/r03_box_to_box.md).  With the column-wise product (fp29.hpp mont_cols29) it needs 232: two waves, no scratch.
 template <> struct AccumMinWaves<CurveG2P> { static constexpr int value = NCG_G2_ACCUM_WAVES; };
 template <> struct AccumMinWaves<CurveG1> { static constexpr int value = 2; };  // 256 VGPRs + 36 B scratch: 2 % faster than 1 wave
+// Point prefetch through LDS-DMA (gfx950 global_load_lds_dwordx4: global -> LDS with no register in between).  One mixed
+// addition is ~9-10 k instructions (~20 us per lane at two waves per SIMD) and begins with a dependent pair of loads - the
+// sorted entry, then the 112 / 224-byte point it names, a random gather - that only one other wave can cover.  With the
+// prefetch the point of entry pos + 1 travels into the wave's LDS slab while the addition of entry pos runs, and the entry
+// of pos + 2 into a register; the addition starts from 7 ds_read_b128.  Holding the next point in registers instead would
+// cost 28 VGPRs that neither kernel has (256 / 232 in use).  Layout of a wave's slab: chunk j (16 bytes per lane) of every
+// lane at [j][lane] - the only layout the instruction writes (LDS address = uniform base + lane * 16).  G1: a lane's seven
+// chunks are its point (x, y).  Lane-paired G2: the even lane fetches x (c0, c1), the odd lane y (c0, c1), 112 bytes each,
+// and each lane then reads its own component of both coordinates from its own and its partner's chunks.
+#ifndef NCG_ACCUM_PREFETCH
+#define NCG_ACCUM_PREFETCH 0
+#endif
+template <class C> struct AccumPrefetch { static constexpr bool value = false; };
+template <> struct AccumPrefetch<CurveG1> { static constexpr bool value = NCG_ACCUM_PREFETCH != 0; };
+template <> struct AccumPrefetch<CurveG2P> { static constexpr bool value = NCG_ACCUM_PREFETCH != 0; };
+constexpr int ACCUM_PF_CHUNKS = 7;                          // 7 x 16 bytes per lane
+constexpr int ACCUM_PF_WAVE_WORDS = ACCUM_PF_CHUNKS * 64 * 4;  // one wave's slab, in words
+
+// this lane's 112 bytes starting at `src` (16-byte aligned) -> chunk slots of the wave's slab
+NCG_DI void accum_pf_issue(const uint32_t* src, uint32_t* slab) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+  for (int j = 0; j < ACCUM_PF_CHUNKS; j++)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * j),
+                                     (__attribute__((address_space(3))) void*)(slab + j * 256), 16, 0, 0);
+#endif
+}
+// word k (0..27) of the 112 bytes that lane `ln` of this wave fetched
+NCG_DI uint32_t accum_pf_word(const uint32_t* slab, int ln, int k) { return slab[(k >> 2) * 256 + ln * 4 + (k & 3)]; }
+
+template <class C> struct AccumPf;
+template <> struct AccumPf<CurveG1> {
+  using G = MsmGroup<CurveG1>;
+  static NCG_DI const uint32_t* src(const uint32_t* point) { return point; }
+  static NCG_DI typename G::Aff read(const uint32_t* slab, int ln) {
+    typename G::Aff q;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+      q.x.v[i] = accum_pf_word(slab, ln, i);
+      q.y.v[i] = accum_pf_word(slab, ln, 14 + i);
+    }
+    return q;
+  }
+};
+template <> struct AccumPf<CurveG2P> {
+  using G = MsmGroup<CurveG2P>;
+  static NCG_DI const uint32_t* src(const uint32_t* point) { return point + (pair_odd() ? 28 : 0); }
+  static NCG_DI typename G::Aff read(const uint32_t* slab, int ln) {
+    const int odd = ln & 1, even_ln = ln & ~1, odd_ln = ln | 1;
+    typename G::Aff q;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+      q.x.h.v[i] = odd ? accum_pf_word(slab, even_ln, 14 + i) : accum_pf_word(slab, even_ln, i);
+      q.y.h.v[i] = odd ? accum_pf_word(slab, odd_ln, 14 + i) : accum_pf_word(slab, odd_ln, i);
+    }
+    return q;
+  }
+};
+
 template <class C>
 __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(const uint32_t* __restrict__ pts_mont,
                                                    const uint32_t* __restrict__ sorted,
@@ -280,6 +339,40 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
   // earlier parts left in that bucket; every other piece starts from the identity as before
   const bool into = (pl.part_flags & 1) == 0;
   Acc acc = (into && b_start >= lo) ? G::acc_load(buckets + ((size_t)w * pl.nb + b) * XW) : G::identity();
+  if constexpr (AccumPrefetch<C>::value) {
+#ifdef __HIP_DEVICE_COMPILE__
+    __shared__ __attribute__((aligned(16))) uint32_t pf_lds[4 * ACCUM_PF_WAVE_WORDS];
+    uint32_t* slab = pf_lds + (threadIdx.x >> 6) * ACCUM_PF_WAVE_WORDS;
+    const int ln = threadIdx.x & 63;
+    uint32_t e_cur = sw[lo];
+    accum_pf_issue(AccumPf<C>::src(pts_mont + (size_t)(e_cur & 0x7fffffffu) * AFF), slab);
+    uint32_t e_next = lo + 1 < hi ? sw[lo + 1] : e_cur;
+    for (uint32_t pos = lo; pos < hi; pos++) {
+      // the point of entry pos has landed (the wave's own vmcnt is what orders its ds_read behind the DMA)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const typename G::Aff q = AccumPf<C>::read(slab, ln);
+      const bool neg = (e_cur >> 31) != 0;
+      // the slab is free again once the reads have returned: send for the next point, and for the entry after it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (pos + 1 < hi) accum_pf_issue(AccumPf<C>::src(pts_mont + (size_t)(e_next & 0x7fffffffu) * AFF), slab);
+      e_cur = e_next;
+      if (pos + 2 < hi) e_next = sw[pos + 2];
+      if (pos == b_end) {  // bucket finished inside my range
+        if (b_start >= lo) {
+          G::acc_store(buckets + ((size_t)w * pl.nb + b) * XW, acc);
+        } else {
+          G::acc_store(hp, acc);
+          head_b = b;
+        }
+        do { b++; } while (bs[b + 1] <= pos);
+        b_start = bs[b];
+        b_end = bs[b + 1];
+        acc = into ? G::acc_load(buckets + ((size_t)w * pl.nb + b) * XW) : G::identity();
+      }
+      acc = G::madd(acc, q, neg);
+    }
+#endif
+  } else
   for (uint32_t pos = lo; pos < hi; pos++) {
     if (pos == b_end) {  // bucket finished inside my range
       if (b_start >= lo) {
