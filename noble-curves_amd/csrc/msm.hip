@@ -117,7 +117,20 @@ __global__ void __launch_bounds__(256) k_msm_bucket_totals(uint32_t* __restrict_
   if (b >= pl.nb) return;
   uint32_t* cw = counts + (size_t)w * pl.Q * pl.nb + b;
   uint32_t tot = 0;
-  for (int q = 0; q < pl.Q; q++) {
+  // eight loads in flight per lane: the column walk is a chain of memory latencies otherwise (Q = 128..512 round trips -
+  // 64 us of a window-sharded part that runs two windows, one wave per SIMD)
+  int q = 0;
+  for (; q + 8 <= pl.Q; q += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = cw[(size_t)(q + j) * pl.nb];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      cw[(size_t)(q + j) * pl.nb] = tot;
+      tot += v[j];
+    }
+  }
+  for (; q < pl.Q; q++) {
     uint32_t v = cw[(size_t)q * pl.nb];
     cw[(size_t)q * pl.nb] = tot;
     tot += v;
