@@ -383,11 +383,17 @@ class Engine:
         """Collective: joins this context to the communicator named by `unique_id`."""
         uid = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
         self._check(self.lib.ncg_comm_init(self.h, nranks, rank, uid))
+        self._has_comm = True
 
     def comm_size(self):
         return self.lib.ncg_comm_size(self.h)
 
+    def has_comm(self):
+        """True between comm_init and comm_destroy (comm_size() reads 1 both without a communicator and with one of a single rank)."""
+        return bool(getattr(self, "_has_comm", False))
+
     def comm_destroy(self):
+        self._has_comm = False
         self._check(self.lib.ncg_comm_destroy(self.h))
 
     def msm_sharded_dev(self, curve, n_local, d_points, d_scalars, stream=None, n_max=0):

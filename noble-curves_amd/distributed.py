@@ -39,18 +39,20 @@ def _dist():
 _native_comm_failed = False
 
 
-def init_comm(engine, device=None):
+def init_comm(engine, device=None, single_ok=False):
     """Collective: give `engine` an RCCL communicator spanning the torch.distributed world (backend nccl).
-    Returns True if the native multi-GPU path is active, False for single-rank / gloo dry runs.  If the
+    Returns True if the native multi-GPU path is active, False for single-rank / gloo dry runs (single_ok=True builds
+    the communicator for a world of one rank too: the same id broadcast, ncclCommInitRank and all-gather calls, which is
+    how the 1-GPU box exercises this path beside torch's own RCCL communicator - tests/test_gpu_multi.py).  If the
     communicator cannot be made on ANY rank (RCCL library not loadable, ncclCommInitRank error) every rank
     learns it through one all-reduce, the reason goes to stderr once, and the callers use the
     torch.distributed exchange instead - still device buffers over RCCL, only outside the C ABI."""
     global _native_comm_failed
     import torch
     dist = _dist()
-    if dist is None or dist.get_world_size() == 1 or dist.get_backend() != "nccl" or _native_comm_failed:
+    if dist is None or (dist.get_world_size() == 1 and not single_ok) or dist.get_backend() != "nccl" or _native_comm_failed:
         return False
-    if engine.comm_size() == dist.get_world_size():
+    if engine.has_comm() and engine.comm_size() == dist.get_world_size():
         return True
     rank, world = dist.get_rank(), dist.get_world_size()
     uid = torch.zeros(128, dtype=torch.uint8, device=device)
@@ -73,8 +75,7 @@ def init_comm(engine, device=None):
     if int(bad.item()) != 0:
         import sys
         _native_comm_failed = True
-        if engine.comm_size() > 1:
-            engine.comm_destroy()
+        engine.comm_destroy()   # (no-op without one) this rank's communicator may exist while another rank's does not
         print("[noble-gpu] rank %d: native RCCL communicator unavailable (%s); exchanging through torch.distributed"
               % (rank, err if err else "another rank failed"), file=sys.stderr, flush=True)
         return False

@@ -294,3 +294,69 @@ def test_two_ranks_share_the_gpu_over_gloo_with_the_native_engine():
         p.join(60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res) and not any(r[2] for r in res)
+
+
+def _nccl_single_worker(port, q):
+    """One-rank torch.distributed group on the nccl (= RCCL) backend with the engine's own communicator beside it."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from noble_curves_amd import get_engine as ge
+        from noble_curves_amd._native import Engine as _E
+        ASYNC_WINDOWS = _E.ASYNC_WINDOWS
+        from noble_curves_amd.distributed import init_comm
+        eng = ge(0)
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)                           # torch's own communicator is up first
+        assert init_comm(eng, dev, single_ok=True)   # id broadcast over torch's group, ncclCommInitRank inside libncg
+        assert eng.has_comm() and eng.comm_size() == 1
+        assert init_comm(eng, dev, single_ok=True)   # second call: nothing to do
+        n = 300
+        pw, sw, exp = _case(BLS12_381_G1, n, 0xACC1)
+        dp, ds = torch.from_numpy(pw).to(dev), torch.from_numpy(sw).to(dev)
+        want = exp.toAffine()
+        out, inf = eng.msm_sharded_dev(BLS12_381_G1, n, dp.data_ptr(), ds.data_ptr())          # all-gather of 1 slot
+        ok = wire_to_affine(BLS12_381_G1, out) == want and not inf
+        out, inf = eng.msm_sharded_windows_dev(BLS12_381_G1, n, dp.data_ptr(), ds.data_ptr())  # window mode
+        ok = ok and wire_to_affine(BLS12_381_G1, out) == want
+        for lane in (0, 1, 2):                       # collectives of the asynchronous lanes funnel through one stream
+            eng.msm_async_submit(lane, BLS12_381_G1, n, dp.data_ptr(), ds.data_ptr(), flags=ASYNC_WINDOWS)
+        for lane in (0, 1, 2):
+            out, inf = eng.msm_async_collect(lane, BLS12_381_G1)
+            ok = ok and wire_to_affine(BLS12_381_G1, out) == want
+        dist.all_reduce(t)                           # and torch's communicator still works afterwards
+        torch.cuda.synchronize()
+        ok = ok and float(t[0]) == 1.0
+        eng.comm_destroy()
+        assert not eng.has_comm()
+        dist.destroy_process_group()
+        q.put(("ok" if ok else "wrong result", ""))
+    except Exception as e:  # noqa: BLE001 - reported to the parent
+        import traceback
+        q.put(("error", "%s\n%s" % (e, traceback.format_exc())))
+
+
+@pytest.mark.timeout(300)
+def test_native_communicator_beside_torch_nccl_group():
+    """The path `bench.py --gpus N` takes on a multi-GPU node, as far as one GPU can run it: torch.distributed on the
+    nccl backend, distributed.init_comm (unique id from rank 0 broadcast over torch's group, ncclCommInitRank inside
+    libncg.so, the RCCL library shared with torch), then the point-sharded, window-sharded and in-flight collectives."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_worker, args=(port, q))
+    p.start()
+    status, detail = q.get(timeout=240)
+    p.join(60)
+    assert status == "ok", detail
+    assert p.exitcode == 0
