@@ -44,9 +44,9 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 16 lanes/clk/SIMD at the nominal 2.4 GHz = 3.93e13 lane-ops/s
 MAD_PEAK = 3.08e13                         # v_mad_u64_u32 ceiling measured on MI355X (profiles/r01_ubench_instr_rates.json,
                                            # profiles/r02_valu_rates.jsonl: ~2x the issue time of a plain 32-bit VALU op)
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 # FETCH_SIZE / WRITE_SIZE -> bytes, calibrated per access pattern with tools/pmc_calib on known byte counts
-# (profiles/r03_pmc.json "calibration"): item-major 64 B gathers count at face value, 16 B/lane coalesced
+# (profiles/r04_pmc.json "calibration"): item-major 64 B gathers count at face value, 16 B/lane coalesced
 # streams at half (MI355X_MICROARCH.md, HBM), writes at face value.
 FETCH_FACTOR = {"gather": 1.0, "stream": 2.0}
 KERNELS = {   # workload -> (kernel-name prefix in rocprofv3 output, FETCH access pattern)
@@ -128,7 +128,7 @@ def pmc_live(workload, log2n, budget_s=420.0):
 
 class Pmc:
     """HBM traffic and executed-VALU figures per kernel: live counters if this run collected them, else the
-    committed profile (profiles/r03_pmc.json, same command, earlier box)."""
+    committed profile (profiles/r04_pmc.json, same command, earlier box)."""
 
     def __init__(self, live):
         self.live = live
@@ -140,7 +140,7 @@ class Pmc:
             if v:
                 return v, "live"
         v = _pmc_lookup(self.committed, prefix)
-        return (v, "profiles/r03_pmc.json") if v else (None, None)
+        return (v, "profiles/r04_pmc.json") if v else (None, None)
 
     def traffic(self, workload, launches_per_unit=1):
         prefix, pattern = KERNELS[workload]
@@ -534,6 +534,9 @@ def main():
     ap.add_argument("--quick-verify", action="store_true", help="(PMC child runs) skip the slow host-side cross-checks")
     ap.add_argument("--out", default=None, help="also write the JSON line to this file")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--dist-dry-run", action="store_true",
+                    help="run the multi-rank code path (nccl process group, the engine's RCCL communicator, sharded / in-flight MSM legs) with a world of ONE "
+                         "rank: what a 1-GPU box can execute of `--gpus N`; the line is labelled dist_dry_run")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -541,7 +544,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist_on = world > 1
+    dist_on = world > 1 or args.dist_dry_run
+    if args.dist_dry_run and world == 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29531")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     if dist_on and args.backend == "nccl" and torch.cuda.device_count() < world and not os.environ.get("NCG_BENCH_FORCE_NCCL"):
         # fewer GPUs than ranks (a 1-GPU box): RCCL refuses two ranks on one device, so the ranks share GPUs and
@@ -579,7 +586,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_live_pmc and not args.quick_verify:
         live = pmc_live(args.workload, args.log2n)
     pmc = Pmc(live)
-    native_multi = init_comm(eng, device) if dist_on else False
+    native_multi = init_comm(eng, device, single_ok=args.dist_dry_run) if dist_on else False
     result = {}
     extra = {}
     host = cpu_info() if rank == 0 else {}
@@ -1221,6 +1228,8 @@ def main():
         result["prewarm"] = (("%d untimed steps" % PREWARM_DIST_STEPS if dist_on else "%.0f ms of untimed steps" % (PREWARM_S * 1e3)) +
                              " before the W warm-up steps of every timed loop (boost-clock settling; the K timed steps are unchanged)")
         result["pmc"] = "live rocprofv3 passes in this run" if live else "committed profile (see roofline.traffic_source)"
+        if args.dist_dry_run:
+            result["dist_dry_run"] = "multi-rank code path executed with a world of one rank (nccl group + the engine's RCCL communicator); not a scaling figure"
         print(json.dumps(result))
         if args.out:
             with open(args.out, "w") as f:
