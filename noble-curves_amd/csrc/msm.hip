@@ -1,6 +1,11 @@
 // MSM kernels and the single-GPU driver (see msm.hpp for the pipeline).
 #include "msm.hpp"
 #include "knobs.hpp"
+// This file is compiled TWICE (Makefile): as msm.o with every curve except bls12-381 G1, and - through msm_g1.hip, which
+// defines NCG_MSM_TU_G1 and includes it - as msm_g1.o with the G1 instantiations alone, because the two want different
+// instruction schedulers: LLVM's max-ILP strategy runs the G1 kernels 1.6 % faster (2^20 MSM 3.55 -> 3.48 ms) and the
+// lane-paired G2 kernels 0.9 % slower (3.39 -> 3.42 ms), measured on MI355X, and the strategy is a per-file option.  The
+// curve-independent kernels (digits, counting sort) are `static`: each unit has its own copy of those few hundred bytes.
 
 #include <algorithm>
 #include <chrono>
@@ -36,7 +41,7 @@ template <> struct TailMinWaves<CurveG1> { static constexpr int value = 2; };
 // A scalar >= the group order is outside the reference's contract (validateMSMScalars, curve.ts:398-404:
 // 'invalid scalar at index i') and outside the window plan: it is reported through *bad_index (smallest
 // offending index) and the call fails.
-__global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
+static __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __restrict__ scalars, int16_t* __restrict__ digits,
                                                     MsmPlan pl, uint32_t* __restrict__ bad_index) {
   __shared__ uint32_t sh[256 * 11];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,7 +96,7 @@ __device__ __forceinline__ bool msm_sort_block(const MsmPlan& pl, int& q, int& w
 
 // ------------------------------------------------------------------ 3. counting sort
 // counts[(w*Q + q)*nb + b]: number of entries of chunk q in bucket b (bucket value b+1)
-__global__ void __launch_bounds__(1024) k_msm_hist(const int16_t* __restrict__ digits, uint32_t* __restrict__ counts,
+static __global__ void __launch_bounds__(1024) k_msm_hist(const int16_t* __restrict__ digits, uint32_t* __restrict__ counts,
                                                    MsmPlan pl) {
   extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
   int q, w;
@@ -111,7 +116,7 @@ __global__ void __launch_bounds__(1024) k_msm_hist(const int16_t* __restrict__ d
 
 // Per (window, bucket): exclusive prefix of the chunk counts (in place) and the bucket size.
 // Adjacent lanes handle adjacent buckets, so every access is coalesced.
-__global__ void __launch_bounds__(256) k_msm_bucket_totals(uint32_t* __restrict__ counts,
+static __global__ void __launch_bounds__(256) k_msm_bucket_totals(uint32_t* __restrict__ counts,
                                                            uint32_t* __restrict__ bucket_start, MsmPlan pl) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
   if (b >= pl.nb) return;
@@ -141,7 +146,7 @@ __global__ void __launch_bounds__(256) k_msm_bucket_totals(uint32_t* __restrict_
 // One block per window: exclusive scan of the bucket sizes -> bucket_start[w][0..nb].  The sizes are staged in
 // LDS with coalesced loads (row stride padded by one word per 32 so that the per-thread runs do not share a bank),
 // every thread scans its run of nb / 1024 values there, a Hillis-Steele scan joins the per-thread totals.
-__global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ bucket_start, MsmPlan pl) {
+static __global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ bucket_start, MsmPlan pl) {
   extern __shared__ __attribute__((aligned(16))) uint32_t sizes[];   // nb + nb / 32 words
   __shared__ uint32_t part[1024];
   const int w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(1024) k_msm_scan(uint32_t* __restrict__ bucket
 // exclusive scan over b = the list position of the bucket (k_msm_scan on the one-window array shared_start), then
 // every window's share of the bucket gets its start: bucket_start[w][b] = S_b + sum_{w' < w} size[w'][b]
 // (k_msm_shared_starts).  shared_start[0 .. nb] = S_b are the accumulate view's starts.
-__global__ void __launch_bounds__(256) k_msm_shared_totals(const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ shared_start,
+static __global__ void __launch_bounds__(256) k_msm_shared_totals(const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ shared_start,
                                                            MsmPlan pl) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= pl.nb) return;
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(256) k_msm_shared_totals(const uint32_t* __res
   for (int w = 0; w < pl.nwin; w++) tot += bucket_start[(size_t)w * (pl.nb + 1) + b];
   shared_start[b] = tot;
 }
-__global__ void __launch_bounds__(256) k_msm_shared_starts(uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ shared_start,
+static __global__ void __launch_bounds__(256) k_msm_shared_starts(uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ shared_start,
                                                            MsmPlan pl) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= pl.nb) return;
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(256) k_msm_shared_starts(uint32_t* __restrict_
 // window's 4 MB list, written at random positions by blocks on every XCD, never sits in an L2.  Launched once per bucket
 // range with the window-major block ids of msm_sort_block (a window's blocks share an XCD), the region a pass writes is
 // 4 MB / passes per window - L2-resident - and leaves the cache as whole lines.
-__global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict__ digits,
+static __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __restrict__ digits,
                                                       const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ bucket_start,
                                                       uint32_t* __restrict__ sorted, MsmPlan pl, int b_lo, int b_hi) {
@@ -270,7 +275,7 @@ template <class C> struct AccumPrefetch { static constexpr bool value = false; }
 template <> struct AccumPrefetch<CurveG1> { static constexpr bool value = NCG_ACCUM_PREFETCH != 0; };
 template <> struct AccumPrefetch<CurveG2P> { static constexpr bool value = NCG_ACCUM_PREFETCH != 0; };
 constexpr int ACCUM_PF_CHUNKS = 7;                          // 7 x 16 bytes per lane
-constexpr int ACCUM_PF_WAVE_WORDS = ACCUM_PF_CHUNKS * 64 * 4;  // one wave's slab, in words
+[[maybe_unused]] constexpr int ACCUM_PF_WAVE_WORDS = ACCUM_PF_CHUNKS * 64 * 4;  // one wave's slab, in words
 
 // this lane's 112 bytes starting at `src` (16-byte aligned) -> chunk slots of the wave's slab
 NCG_DI void accum_pf_issue(const uint32_t* src, uint32_t* slab) {
@@ -772,7 +777,9 @@ __global__ void __launch_bounds__(256) k_msm_sum_partials(uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------ planning (msm_plan.hpp)
+#ifndef NCG_MSM_TU_G1
 int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) { return msm_make_plan_impl(curve, n, c_override, pl); }
+#endif
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -1170,6 +1177,44 @@ static hipError_t msm_sum_partials_t(uint32_t* d_gathered, int nparts, size_t np
   return hipGetLastError();
 }
 
+template <class C>
+static hipError_t msm_points_to_stored_t(const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st) {
+  using D = typename DeviceCurve<C>::type;
+  constexpr int LS = LaneShift<D>::value;
+  hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts_wire, d_out, n);
+  return hipGetLastError();
+}
+// ---- bls12-381 G1 lives in msm_g1.o (see the head of this file): the three templates that launch curve kernels forward there
+hipError_t msm_g1_device(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws, const uint32_t** d_fin,
+                         hipStream_t st, const uint32_t** d_bad, const MsmSide* side);
+hipError_t msm_g1_sum_partials(uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out, hipStream_t st);
+hipError_t msm_g1_points_to_stored(const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st);
+#ifdef NCG_MSM_TU_G1
+hipError_t msm_g1_device(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws, const uint32_t** d_fin,
+                         hipStream_t st, const uint32_t** d_bad, const MsmSide* side) {
+  return msm_device_t<CurveG1>(pl, d_pts, d_scalars, ws, d_fin, st, d_bad, side);
+}
+hipError_t msm_g1_sum_partials(uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out, hipStream_t st) {
+  return msm_sum_partials_t<CurveG1>(d_gathered, nparts, npoints, d_out, st);
+}
+hipError_t msm_g1_points_to_stored(const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st) {
+  return msm_points_to_stored_t<CurveG1>(d_pts_wire, n, d_out, st);
+}
+#else
+template <>
+hipError_t msm_device_t<CurveG1>(const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws, const uint32_t** d_fin,
+                                 hipStream_t st, const uint32_t** d_bad, const MsmSide* side) {
+  return msm_g1_device(pl, d_pts, d_scalars, ws, d_fin, st, d_bad, side);
+}
+template <>
+hipError_t msm_sum_partials_t<CurveG1>(uint32_t* d_gathered, int nparts, size_t npoints, uint32_t* d_out, hipStream_t st) {
+  return msm_g1_sum_partials(d_gathered, nparts, npoints, d_out, st);
+}
+template <>
+hipError_t msm_points_to_stored_t<CurveG1>(const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st) {
+  return msm_g1_points_to_stored(d_pts_wire, n, d_out, st);
+}
+
 #define NCG_MSM_DISPATCH(curve, CALL)                       \
   switch (curve) {                                          \
     case CURVE_SECP256K1: return CALL(CurveSecp);           \
@@ -1251,13 +1296,6 @@ size_t msm_stored_words_per_point(int curve) {
     default: return 0;
   }
 }
-template <class C>
-static hipError_t msm_points_to_stored_t(const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st) {
-  using D = typename DeviceCurve<C>::type;
-  constexpr int LS = LaneShift<D>::value;
-  hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts_wire, d_out, n);
-  return hipGetLastError();
-}
 hipError_t msm_points_to_stored(int curve, const uint32_t* d_pts_wire, int n, uint32_t* d_out, hipStream_t st) {
 #define CALL(C) msm_points_to_stored_t<C>(d_pts_wire, n, d_out, st)
   NCG_MSM_DISPATCH(curve, CALL)
@@ -1278,5 +1316,7 @@ hipError_t msm_run(int curve, const MsmPlan& pl, const uint32_t* d_pts, const ui
     default: return hipErrorInvalidValue;
   }
 }
+
+#endif  // NCG_MSM_TU_G1
 
 }  // namespace ncg
