@@ -506,9 +506,13 @@ class Stripper:
                         continue
                 i += 1
                 continue
-            if tx == ")" or tx == "]":
-                # type arguments after a call result are not used by the reference
-                pass
+            if tx == ")" and self.tt(i + 1) == "<" and not self.T[i + 1].ws:
+                # type arguments on a call RESULT:  getLoop(...)<P>(values)  (fft.ts:558) - only the plain form `<Ident, ...>(`
+                a = self.try_type_args(i + 1)
+                if a > 0 and all(self.is_id(k) or self.tt(k) in (",", ".") for k in range(i + 2, a - 1)):
+                    self.delete(i + 1, a)
+                    i = a
+                    continue
             if tx == "!" and i > 0 and not t.ws and self.expr_end(i - 1) and self.tt(i + 1) != "=":
                 self.delete(i, i + 1)
                 i += 1

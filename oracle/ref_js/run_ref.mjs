@@ -9,10 +9,14 @@
 //   mul         <curve> same                                             Point.multiply (weierstrass.ts:900-907); k = 0 rows are skipped (it throws)
 //   pippenger   <curve> in: n x point, then n x scalar   out: 1 point    pippenger (abstract/curve.ts:863-905)
 //   ed25519_verify in: n x (sig 64 || pk 32 || msglen u32 || msg padded to 64)  out: n bytes   ed25519.verify (edwards.ts:942-989), zip215 flag in args
+//   h2c <g1|g2> <dstHex> [encode]  in: n x (msglen u32 || msg padded to 64)   out: n x point   hashToCurve / encodeToCurve (hash-to-curve.ts:487-500)
+//   fft <direct|inverse> <brpIn 0/1> <brpOut 0/1>   in: N x 32 B LE residues of Fr    out: N x 32 B   FFT(rootsOfUnity(Fr), Fr) (fft.ts:518-577)
+//   codec <curve>  in: n x point   out: n x (compressed bytes: 33 / 32 / 48 / 96)      Point.toBytes(true) -> Point.fromBytes -> must equal the input
 //   point_bench <seconds>   benchmark/point.ts:20-32 on secp256k1: Point_mul / Point_mulUns of one point by 2^180 - 15820, and by random scalars
 import './polyfill.mjs';
 import fs from 'fs';
 import { pippenger } from './abstract/curve.mjs';
+import { FFT, rootsOfUnity } from './abstract/fft.mjs';
 import { bls12_381 } from './bls12-381.mjs';
 import { ed25519 } from './ed25519.mjs';
 import { secp256k1 } from './secp256k1.mjs';
@@ -122,6 +126,60 @@ if (cmd === 'mul_unsafe' || cmd === 'mul') {
   fs.writeFileSync(outFile, out);
   res.n = n;
   res.per_s = n / (res.ms / 1e3);
+} else if (cmd === 'h2c') {
+  const H = args[0] === 'g2' ? bls12_381.G2 : bls12_381.G1;
+  const C = CURVES[args[0] === 'g2' ? 'bls12_381_g2' : 'bls12_381_g1'];
+  const DST = new Uint8Array(Buffer.from(args[1], 'hex'));
+  const encode = args[2] === 'encode';
+  const buf = fs.readFileSync(inFile);
+  const rec = 4 + 64, n = buf.length / rec;
+  const out = new Uint8Array(n * pb(C));
+  const t0 = now();
+  for (let i = 0; i < n; i++) {
+    const len = buf.readUInt32LE(i * rec);
+    const msg = new Uint8Array(buf.slice(i * rec + 4, i * rec + 4 + len));
+    const P = encode ? H.encodeToCurve(msg, { DST }) : H.hashToCurve(msg, { DST });
+    writePoint(C, P, out, i * pb(C));
+  }
+  res.ms = now() - t0;
+  fs.writeFileSync(outFile, out);
+  res.n = n;
+  res.per_s = n / (res.ms / 1e3);
+} else if (cmd === 'fft') {
+  const Fr = bls12_381.fields.Fr;
+  const f = FFT(rootsOfUnity(Fr), Fr);
+  const buf = fs.readFileSync(inFile);
+  const N = buf.length / 32;
+  const vals = [];
+  for (let i = 0; i < N; i++) vals.push(le2n(buf, i * 32, 32));
+  const brpIn = args[1] === '1', brpOut = args[2] === '1';
+  const t0 = now();
+  const r = args[0] === 'inverse' ? f.inverse(vals, brpIn, brpOut) : f.direct(vals, brpIn, brpOut);
+  res.ms = now() - t0;
+  const out = new Uint8Array(N * 32);
+  for (let i = 0; i < N; i++) n2le(r[i], out, i * 32, 32);
+  fs.writeFileSync(outFile, out);
+  res.n = N;
+  res.per_s = N / (res.ms / 1e3);
+} else if (cmd === 'codec') {
+  const C = CURVES[args[0]];
+  const buf = fs.readFileSync(inFile);
+  const n = buf.length / pb(C);
+  let out = null, L = 0;
+  for (let i = 0; i < n; i++) {
+    const P = readPoint(C, buf, i * pb(C));
+    const enc = C.edwards ? P.toBytes() : P.toBytes(true);
+    if (!out) {
+      L = enc.length;
+      out = new Uint8Array(n * L);
+    }
+    if (enc.length !== L) throw new Error('codec: encoding length changed');
+    if (!C.P.fromBytes(enc).equals(P)) throw new Error('codec: fromBytes(toBytes(P)) != P at ' + i);
+    out.set(enc, i * L);
+  }
+  fs.writeFileSync(outFile, out || new Uint8Array(0));
+  res.n = n;
+  res.enc_len = L;
 } else if (cmd === 'point_bench') {
   // benchmark/point.ts:20-32: one public-key point, Point.multiply / multiplyUnsafe by the literal 2^180 - 15820; plus the
   // 1 000-random-scalar form BASELINE configs[0] names

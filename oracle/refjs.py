@@ -101,6 +101,32 @@ def ed25519_verify(sigs, msgs, pks, zip215=True):
     return out.astype(bool), info
 
 
+def hash_to_curve(curve, msgs, dst, encode=False):
+    """bls12_381.G1 / G2 hashToCurve (encode: encodeToCurve) of each message through the reference; returns wire points [n, PB]."""
+    rec = bytearray()
+    for m in msgs:
+        assert len(m) <= 64
+        rec += len(m).to_bytes(4, "little") + bytes(m).ljust(64, b"\0")
+    g = "g2" if CURVE_NAME[curve].endswith("g2") else "g1"
+    out, info = _run("h2c", bytes(rec), True, g, bytes(dst).hex(), *(["encode"] if encode else []))
+    return out.reshape(len(msgs), -1), info
+
+
+def fft(values, inverse=False, brp_in=False, brp_out=False):
+    """FFT(rootsOfUnity(Fr), Fr).direct / .inverse of a list of residues of the bls12-381 scalar field (fft.ts:518-577)."""
+    data = b"".join(int(v).to_bytes(32, "little") for v in values)
+    out, info = _run("fft", data, True, "inverse" if inverse else "direct", int(brp_in), int(brp_out))
+    b = out.tobytes()
+    return [int.from_bytes(b[i * 32:(i + 1) * 32], "little") for i in range(len(values))], info
+
+
+def codec(curve, points_wire):
+    """Point.toBytes(compressed) of each wire point (and Point.fromBytes of the result, which must give the point back)."""
+    p = np.ascontiguousarray(points_wire, dtype=np.uint8)
+    out, info = _run("codec", p.tobytes(), True, CURVE_NAME[curve])
+    return out.reshape(p.shape[0], -1), info
+
+
 def point_bench(seconds=2.0):
     r = subprocess.run([node(), os.path.join(ref_dir(), "run_ref.mjs"), "point_bench", str(seconds)], capture_output=True, text=True, timeout=600)
     if r.returncode != 0:

@@ -79,3 +79,63 @@ def test_oracle_ed25519_verify_equals_the_reference_run_here():
         assert list(got) == want, "zip215=%s" % zip215
         if zip215:
             assert all(got)       # every case of the file is valid under ZIP-215 (test/ed25519.test.ts:397-410)
+
+
+@pytest.mark.parametrize("curve", [BLS12_381_G1, BLS12_381_G2])
+def test_oracle_hash_to_curve_equals_the_reference_run_here(curve):
+    """bls12_381.G1 / G2 .hashToCurve and .encodeToCurve (hash-to-curve.ts:487-500: expand_message_xmd, hash_to_field, SSWU + isogeny,
+    clear cofactor) on messages and domain-separation tags chosen here."""
+    from oracle import h2c as OH
+    H = OH.G1_hasher if curve == BLS12_381_G1 else OH.G2_hasher
+    msgs = [b"", b"abc", b"abcdef0123456789", b"\x00" * 32, bytes(range(64)), b"q128_" + b"q" * 59]
+    for dst in (H.DST, b"QUUX-V01-CS02-with-BLS12381G%d_XMD:SHA-256_SSWU_RO_" % (1 if curve == BLS12_381_G1 else 2), b"x"):
+        for encode in (False, True):
+            got, _ = refjs.hash_to_curve(curve, msgs, dst, encode=encode)
+            for i, m in enumerate(msgs):
+                want = (H.encodeToCurve(m, dst) if encode else H.hashToCurve(m, dst)).toAffine()
+                assert wire_to_affine(curve, got[i]) == want, (dst, encode, i)
+
+
+def test_oracle_fft_equals_the_reference_run_here():
+    """FFT(rootsOfUnity(Fr), Fr) of the bls12-381 scalar field (fft.ts:518-577): direct and inverse, every combination of
+    bit-reversed input / output, sizes 1 .. 256."""
+    from oracle.curves import BLS_R
+    from oracle.fft import FFT, RootsOfUnity
+    from oracle.field import Field
+    Fr = Field(BLS_R)
+    f = FFT(RootsOfUnity(Fr), Fr)
+    rng = makeRng(0xFF7)
+    for bits in (0, 1, 3, 8):
+        vals = [rng.rndBelow(BLS_R) for _ in range(1 << bits)]
+        if bits:
+            vals[0], vals[-1] = 0, BLS_R - 1
+        for inverse in (False, True):
+            for brp_in in (False, True):
+                for brp_out in (False, True):
+                    got, _ = refjs.fft(vals, inverse, brp_in, brp_out)
+                    want = (f.inverse if inverse else f.direct)(vals, brp_in, brp_out)
+                    assert got == want, (bits, inverse, brp_in, brp_out)
+
+
+@pytest.mark.parametrize("curve", [SECP256K1, ED25519, BLS12_381_G1, BLS12_381_G2])
+def test_oracle_point_encodings_equal_the_reference_run_here(curve):
+    """Point.toBytes (compressed SEC1 / RFC 8032 / zkcrypto flags, weierstrass.ts:551-566, edwards.ts:620-628, bls12-381.ts G1 / G2
+    encoders) of random points, the base point and points whose y decides the sign / sort bit both ways; the reference also decodes
+    each encoding back (Point.fromBytes) inside the run."""
+    from oracle import weierstrass as OW
+    Pt = ORACLE_CURVE[curve]
+    order = Pt.Fn.ORDER
+    rng = makeRng(0xC0DEC + curve)
+    pts = [Pt.BASE, Pt.BASE.negate()] + [Pt.BASE.multiplyUnsafe(rng.rndBelow(order - 1) + 1) for _ in range(12)]
+    pts += [p.negate() for p in pts[2:6]]
+    got, info = refjs.codec(curve, points_to_wire(curve, pts))
+    for i, p in enumerate(pts):
+        if curve == SECP256K1:
+            want = OW.sec1_encode(p, True)
+        elif curve == ED25519:
+            want = p.toBytes()
+        elif curve == BLS12_381_G1:
+            want = OW.bls_g1_encode_compressed(p)
+        else:
+            want = OW.bls_g2_encode_compressed(p)
+        assert bytes(got[i]) == bytes(want), i
