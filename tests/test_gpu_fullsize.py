@@ -46,7 +46,15 @@ def test_secp256k1_2p20_checksum_and_sample():
     tot, _ = eng.msm_dev(SECP256K1, n, out.data_ptr(), ones.data_ptr(), stream)
     assert wire_to_affine(SECP256K1, tot) == Secp256k1.BASE.multiplyUnsafe(expect).toAffine()
     assert int(inf.sum().item()) == 1 and int(inf[0].item()) == 1
-    idx = np.unique(np.concatenate([np.arange(64), np.arange(n - 64, n), np.random.RandomState(1).randint(0, n, 256)]))
+    # every item pinned: a RANDOM linear combination sum_i r_i * out_i == (sum_i r_i k_i p_i) G with 64-bit r_i - a plain sum could
+    # hide two compensating wrong items, this cannot (one wrong item changes it unless r_i = 0 mod its order)
+    rr = np.random.RandomState(0xC0FFEE).randint(1, 1 << 62, size=n, dtype=np.int64)
+    rw = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    rw[:, :8] = torch.from_numpy(rr.view(np.uint8).reshape(n, 8)).to(dev)
+    tot_r, _ = eng.msm_dev(SECP256K1, n, out.data_ptr(), rw.data_ptr(), stream)
+    expect_r = sum(int(r) * k * p for r, k, p in zip(rr, ks, pks)) % SECP256K1_N
+    assert wire_to_affine(SECP256K1, tot_r) == Secp256k1.BASE.multiplyUnsafe(expect_r).toAffine()
+    idx = np.unique(np.concatenate([np.arange(64), np.arange(n - 64, n), np.random.RandomState(1).randint(0, n, 4096)]))
     o_c, i_c = cport.multiply_unsafe("secp256k1", pts[idx].cpu().numpy(), sc[idx].cpu().numpy())
     assert np.array_equal(o_c, out[idx].cpu().numpy()) and np.array_equal(i_c, inf[idx].cpu().numpy())
     # fixed-base path at full size: sum_i k_i*G == (sum k_i) G
