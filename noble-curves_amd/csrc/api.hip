@@ -182,6 +182,7 @@ void ncg_destroy(ncg_ctx* ctx) {
   for (int i = 0; i < ncg_ctx::COPY_CHUNKS; i++) {
     if (ctx->ev_in[i]) (void)hipEventDestroy(ctx->ev_in[i]);
     if (ctx->ev_k[i]) (void)hipEventDestroy(ctx->ev_k[i]);
+    if (ctx->ev_sc[i]) (void)hipEventDestroy(ctx->ev_sc[i]);
   }
   if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
   if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
@@ -285,6 +286,7 @@ static int ensure_copy_streams(ncg_ctx* ctx) {
   for (int i = 0; i < ncg_ctx::COPY_CHUNKS && e == hipSuccess; i++) {
     e = hipEventCreateWithFlags(&ctx->ev_in[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_k[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_sc[i], hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming);
   if (e != hipSuccess) return set_err(ctx, NCG_ERR_HIP, "noble-gpu: cannot create copy streams: %s", hipGetErrorString(e));
@@ -558,15 +560,21 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
   char* d_pts = (char*)ctx->scratch;
   char* d_sc = d_pts + pts_al;
   if (n >= ((size_t)1 << 16)) {
-    // The scalars cross first (a quarter of the bytes): digits and the counting sort need nothing else.  The points follow
-    // in PARTS; each part is converted to the accumulate kernel's storage format on the side stream as it lands and then
-    // accumulated into the shared buckets (MsmPlan::part_flags) while the next part is still on the bus - only the last
-    // part's accumulate, the fold and the tail run after the last byte.  2^20 G1 points from pinned host memory: 9.3 ms
-    // (round 2, one copy then one MSM) -> 6.2 ms (sort under the transfer) -> see profiles/r04_host_path.json.
+    // Points AND scalars cross in PARTS, each part's scalars (a quarter of its bytes) ahead of its points: a part's digits and
+    // counting sort need only its own scalars, its points are converted to the accumulate kernel's storage format on the side
+    // stream as they land, and it is accumulated into the shared buckets (MsmPlan::part_flags) while the next part is still on
+    // the bus - only the last part's accumulate, the fold and the tail run after the last byte.  2^20 G1 points from pinned host
+    // memory: 9.3 ms (round 2, one copy then one MSM) -> 6.2 ms (sort under the transfer) -> 5.4 ms (parts; all scalars first)
+    // -> see profiles/r04_host_path.json (the first part is ready after 32 MB instead of 56).
     rc = ensure_copy_streams(ctx);
     if (rc) return rc;
     char* d_stored = d_sc + sc_al;
-    const int parts = n >= ((size_t)1 << 19) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;
+    // measured on one box (tools/host_parts_sweep.py): G1 2^20 6.0 / 5.0 / 4.5 / 4.9 ms with 1 / 2 / 4 / 8 parts, G2 2^18 5.7 / 4.3 / 4.4 / 6.2
+    int parts = n >= ((size_t)1 << 19) ? 4 : n >= ((size_t)1 << 17) ? 2 : 1;
+    {
+      const int k = ncg::knob("NCG_MSM_HOST_PARTS", 0);   // A/B builds only
+      if (k >= 1 && k <= ncg_ctx::COPY_CHUNKS) parts = k;
+    }
     const size_t per = (((n + parts - 1) / parts) + 255) & ~(size_t)255;
     ncg::MsmPlan whole, layout;
     if (ncg::msm_make_plan(curve, (int)n, 0, &whole) != 0 || ncg::msm_make_plan(curve, (int)std::min(n, per), whole.c, &layout) != 0)
@@ -579,14 +587,17 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
     pins.pin(points_affine, pts_b);
     pins.pin(scalars, sc_b);
     const size_t sw = ncg::msm_stored_words_per_point(curve) * 4;
-    hipError_t e = hipMemcpyAsync(d_sc, scalars, sc_b, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipSuccess;
     const uint32_t *d_fin = nullptr, *d_bad = nullptr;
     ncg::MsmPlan last = layout;
     for (int p = 0; p < parts && e == hipSuccess; p++) {
       const size_t lo = std::min(n, per * (size_t)p), cnt = std::min(n, lo + per) - lo;
       const bool is_last = p == parts - 1 || lo + cnt >= n;
       if (cnt) {
-        e = hipMemcpyAsync(d_pts + lo * pb, (const char*)points_affine + lo * pb, cnt * pb, hipMemcpyHostToDevice, ctx->copy_in);
+        e = hipMemcpyAsync(d_sc + lo * 32, (const char*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, ctx->copy_in);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_sc[p], ctx->copy_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_sc[p], 0);   // this part's digits wait for its scalars only
+        if (e == hipSuccess) e = hipMemcpyAsync(d_pts + lo * pb, (const char*)points_affine + lo * pb, cnt * pb, hipMemcpyHostToDevice, ctx->copy_in);
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_in[p], ctx->copy_in);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->msm_side.stream, ctx->ev_in[p], 0);
         if (e == hipSuccess)

@@ -66,7 +66,7 @@ struct ncg_ctx {
   // large host buffer cross PCIe while the kernels of earlier chunks (or the digit / sort kernels of the MSM) run
   static constexpr int COPY_CHUNKS = 8;
   hipStream_t copy_in = nullptr, copy_out = nullptr;
-  hipEvent_t ev_in[COPY_CHUNKS] = {}, ev_k[COPY_CHUNKS] = {}, ev_ready = nullptr;
+  hipEvent_t ev_in[COPY_CHUNKS] = {}, ev_k[COPY_CHUNKS] = {}, ev_sc[COPY_CHUNKS] = {}, ev_ready = nullptr;
   hipStream_t comm_stream = nullptr;  // the one stream every collective of the asynchronous lanes is enqueued on
   hipEvent_t comm_fork = nullptr, comm_join = nullptr;
   uint32_t* sync_land = nullptr;  // pinned landing area of the synchronous sharded entry points

@@ -445,12 +445,14 @@ hipError_t map_to_curve_batch(int curve, const uint32_t* u, int count, uint32_t*
                          jac_tmp, out, inf, n);
     } else {
       hipLaunchKernelGGL(k_map_to_g2<false>, dim3((n + 63) / 64), dim3(64), 0, st, u, count, out, inf, n);
-#endif
+    }
+#else
     } else {
       // no workspace: the C ABI always passes one (api.hip ensure_mul_ws).  The fused single-kernel form (730 KB of code,
       // 1 867 spilled registers: VERDICT r03 weak #4) is no longer part of the shipped library.
       return hipErrorInvalidValue;
     }
+#endif
   } else {
     return hipErrorInvalidValue;
   }

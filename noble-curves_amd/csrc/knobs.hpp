@@ -12,6 +12,7 @@
 //     NCG_MSM_SEG, NCG_MSM_QBLOCKS, NCG_MSM_XCD     accumulate segment length, sort chunk count, XCD-aware sort grid
 //     NCG_MSM_RUN_SERIAL, NCG_MSM_COOP_LEVEL        fix-up serial threshold, cooperative level kernel on / off
 //     NCG_MSM_HOST64                                host finish in 64-bit limbs on / off
+//     NCG_MSM_HOST_PARTS                            parts of the host-pointer MSM (1..8)
 //     NCG_SECP_W, NCG_G1_W, NCG_G2_W, NCG_AFF_K, NCG_ED_VARIANT, NCG_DEC_G2_FUSED, NCG_H2C_G2_FUSED   kernel variants
 #pragma once
 #include <cstdlib>
