@@ -59,7 +59,11 @@ struct PinSet {
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
   }
   ~PinSet() {
-    if (n) (void)hipStreamSynchronize(ctx->stream);
+    if (n) {  // nothing may still be reading or writing the buffers when they are unpinned - on ANY path out of the caller
+      (void)hipStreamSynchronize(ctx->stream);
+      if (ctx->copy_in) (void)hipStreamSynchronize(ctx->copy_in);
+      if (ctx->copy_out) (void)hipStreamSynchronize(ctx->copy_out);
+    }
     for (int i = 0; i < n; i++) (void)hipHostUnregister(regs[i]);
   }
 };
@@ -606,7 +610,10 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
         if (e != hipSuccess) break;
       }
       ncg::MsmPlan pl;
-      if (ncg::msm_make_plan(curve, (int)std::max<size_t>(cnt, 1), whole.c, &pl) != 0) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+      if (ncg::msm_make_plan(curve, (int)std::max<size_t>(cnt, 1), whole.c, &pl) != 0) {
+        drain_copy_streams(ctx);   // copies of this and earlier parts are in flight
+        return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
+      }
       msm_apply_ctx(ctx, pl);
       pl.pts_stored = 1;
       pl.n_layout = layout.n;
