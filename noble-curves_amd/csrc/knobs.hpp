@@ -13,6 +13,7 @@
 //     NCG_MSM_RUN_SERIAL, NCG_MSM_COOP_LEVEL        fix-up serial threshold, cooperative level kernel on / off
 //     NCG_MSM_HOST64                                host finish in 64-bit limbs on / off
 //     NCG_MSM_HOST_PARTS                            parts of the host-pointer MSM (1..8)
+//     NCG_MULVAR_HOST_EVEN                          1 = four equal chunks in the host-pointer batch multiply instead of 1 : 3 : 3 : 1
 //     NCG_SECP_W, NCG_G1_W, NCG_G2_W, NCG_AFF_K, NCG_ED_VARIANT, NCG_DEC_G2_FUSED, NCG_H2C_G2_FUSED   kernel variants
 #pragma once
 #include <cstdlib>
