@@ -46,6 +46,13 @@ gpu.native.hostRegister(sb);
 if (packedPts instanceof Uint8Array && packedPts.buffer !== pb.buffer) gpu.native.hostRegister(packedPts);
 const [tMsmPinned] = best(() => gpu.native.msm(0, pb, sb), 5);
 const [tMulPinned] = best(() => gpu.native.mulVarBatch(0, pb, sb), 3);
+// ... and with the OUTPUT array kept by the caller and pinned once too (mulVarBatch's optional 4th argument)
+const outKeep = new Uint8Array(n * 65);
+gpu.native.hostRegister(outKeep);
+const [tMulPinnedOut, rKeep] = best(() => gpu.native.mulVarBatch(0, pb, sb, outKeep), 3);
+const rFresh = gpu.native.mulVarBatch(0, pb, sb);
+for (let i = 0; i < rFresh.length; i += 4099) if (rFresh[i] !== rKeep[i]) throw new Error('mulVarBatch(out) differs');
+gpu.native.hostUnregister(outKeep);
 const [tPackedPinned] = best(() => gpu.pippenger(Point, packedPts, sc64), 5);
 gpu.native.hostUnregister(pb);
 gpu.native.hostUnregister(sb);
@@ -55,5 +62,5 @@ gpu.pippengerResident(set, ss);
 const [tResBig] = ms(() => gpu.pippengerResident(set, ss));
 const [tResBytes] = ms(() => gpu.pippengerResident(set, sb));
 set.free();
-console.log(JSON.stringify({ n, pippenger_native_pinned_ms: tMsmPinned, multiplyUnsafeBatch_native_pinned_ms: tMulPinned, pippenger_packed_columns_pinned_ms: tPackedPinned, pippenger_resident_bigint_ms: tResBig, pippenger_resident_bytes_ms: tResBytes, pippenger_js_ms: tMsm, pippenger_packed_columns_ms: tPacked, pippenger_native_ms: tMsmN, multiplyUnsafeBatch_js_ms: tMul,
+console.log(JSON.stringify({ n, pippenger_native_pinned_ms: tMsmPinned, multiplyUnsafeBatch_native_pinned_ms: tMulPinned, multiplyUnsafeBatch_native_pinned_out_ms: tMulPinnedOut, pippenger_packed_columns_pinned_ms: tPackedPinned, pippenger_resident_bigint_ms: tResBig, pippenger_resident_bytes_ms: tResBytes, pippenger_js_ms: tMsm, pippenger_packed_columns_ms: tPacked, pippenger_native_ms: tMsmN, multiplyUnsafeBatch_js_ms: tMul,
   multiplyUnsafeBatch_native_ms: tMulN }));

@@ -4,7 +4,7 @@
 //
 //   init(deviceId = 0)                               -> undefined (throws Error('noble-gpu: ...'))
 //   msm(curveId, points: Uint8Array, scalars: Uint8Array)            -> Uint8Array PB + 1 (flag)
-//   mulVarBatch(curveId, points, scalars)            -> Uint8Array n * (PB + 1)  (points then flags)
+//   mulVarBatch(curveId, points, scalars[, out])     -> Uint8Array n * (PB + 1)  (points then flags; `out`: reuse the caller's array)
 //   mulBaseBatch(curveId, scalars)                   -> Uint8Array n * (PB + 1)
 //   ed25519VerifyBatch(sigs, pks, ks, zip215: bool)  -> Uint8Array n (0 / 1)
 //   decodePoints(curveId, encoded, zip215: bool)     -> Uint8Array n * (PB + 2)  (points, ok flags, inf flags)
@@ -147,9 +147,12 @@ static napi_value Msm(napi_env env, napi_callback_info info) {
   return res;
 }
 
+// mulVarBatch(curveId, points, scalars[, out]): with `out` (a Uint8Array of n * (PB + 1) bytes the caller keeps - and may pin once
+// with hostRegister) the results land there and `out` is returned; without it a fresh array is made per call, which at 2^20 items is
+// 68 MB of first-touch page faults and a per-call page lock before the first result byte can be written.
 static napi_value MulVarBatch(napi_env env, napi_callback_info info) {
-  size_t argc = 3;
-  napi_value argv[3];
+  size_t argc = 4;
+  napi_value argv[4];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   if (!need_ctx(env)) return nullptr;
   int32_t curve;
@@ -157,7 +160,7 @@ static napi_value MulVarBatch(napi_env env, napi_callback_info info) {
   size_t pl, sl;
   if (argc < 3 || napi_get_value_int32(env, argv[0], &curve) != napi_ok || !get_u8(env, argv[1], &pts, &pl) ||
       !get_u8(env, argv[2], &sc, &sl)) {
-    napi_throw_type_error(env, nullptr, "noble-gpu: mulVarBatch(curveId, Uint8Array, Uint8Array)");
+    napi_throw_type_error(env, nullptr, "noble-gpu: mulVarBatch(curveId, Uint8Array, Uint8Array[, Uint8Array out])");
     return nullptr;
   }
   int pb = ncg_point_bytes(curve);
@@ -166,8 +169,20 @@ static napi_value MulVarBatch(napi_env env, napi_callback_info info) {
     napi_throw_error(env, nullptr, "arrays of points and scalars must have equal length");
     return nullptr;
   }
-  napi_value res = make_u8(env, n * (pb + 1), &out);
-  if (!res) return nullptr;
+  napi_value res;
+  napi_valuetype vt = napi_undefined;
+  if (argc >= 4) napi_typeof(env, argv[3], &vt);
+  if (argc >= 4 && vt != napi_undefined && vt != napi_null) {
+    size_t ol;
+    if (!get_u8(env, argv[3], &out, &ol) || ol != n * (size_t)(pb + 1)) {
+      napi_throw_error(env, nullptr, "noble-gpu: mulVarBatch: out must be a Uint8Array of n * (point bytes + 1) bytes");
+      return nullptr;
+    }
+    res = argv[3];
+  } else {
+    res = make_u8(env, n * (pb + 1), &out);
+    if (!res) return nullptr;
+  }
   if (n && ncg_mul_var_batch(g_ctx, curve, n, pts, sc, out, out + n * pb) != 0) return throw_native(env);
   return res;
 }
