@@ -210,16 +210,24 @@ class Engine:
         self._check(self.lib.ncg_sync(self.h))
 
     # ---- batch variable-base multiply -------------------------------------------------------
-    def mul_var_batch(self, curve, points, scalars):
-        """points: uint8 [n, POINT_BYTES]; scalars: uint8 [n, 32] -> (out [n, PB], is_inf [n])."""
+    def mul_var_batch(self, curve, points, scalars, out=None, inf=None):
+        """points: uint8 [n, POINT_BYTES]; scalars: uint8 [n, 32] -> (out [n, PB], is_inf [n]).  `out` / `inf`: result arrays the
+        caller keeps (and may pin once with host_register) - a fresh 64 MB array per call costs first-touch page faults and a page
+        lock before the first result byte lands (2^20 secp256k1 pairs: 43-52 ms per call against 10 with kept, pinned arrays)."""
         pb = POINT_BYTES[curve]
         points = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, pb)
         scalars = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
         n = points.shape[0]
         if scalars.shape[0] != n:
             raise ValueError("arrays of points and scalars must have equal length")
-        out = np.empty((n, pb), dtype=np.uint8)
-        inf = np.empty((n,), dtype=np.uint8)
+        if out is None:
+            out = np.empty((n, pb), dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.shape != (n, pb) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous uint8 array of shape (n, point bytes)")
+        if inf is None:
+            inf = np.empty((n,), dtype=np.uint8)
+        elif inf.dtype != np.uint8 or inf.shape != (n,) or not inf.flags["C_CONTIGUOUS"]:
+            raise ValueError("inf must be a C-contiguous uint8 array of shape (n,)")
         if n:
             self._check(self.lib.ncg_mul_var_batch(self.h, curve, n, points.ctypes.data, scalars.ctypes.data,
                                                    out.ctypes.data, inf.ctypes.data))

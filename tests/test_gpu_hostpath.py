@@ -11,7 +11,7 @@ import torch
 import bench
 from helpers import ORACLE_CURVE, wire_to_affine
 from noble_curves_amd import get_engine
-from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, ED25519, SECP256K1
+from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, ED25519, POINT_BYTES, SECP256K1
 
 pytestmark = pytest.mark.gpu
 
@@ -77,3 +77,13 @@ def test_host_pointer_batch_multiply_in_chunks_equals_device_batch(curve, n):
     torch.cuda.synchronize()
     o, i = eng.mul_var_batch(curve, pts.cpu().numpy(), sc.cpu().numpy())
     assert np.array_equal(o, out.cpu().numpy()) and np.array_equal(i, inf.cpu().numpy())
+    # the same call into result arrays the caller keeps and pins once (the chunk pattern 1 : 3 : 3 : 1 at n >= 2^19)
+    ko, ki = np.zeros((n, POINT_BYTES[curve]), np.uint8), np.zeros((n,), np.uint8)
+    eng.host_register(ko)
+    try:
+        o2, i2 = eng.mul_var_batch(curve, pts.cpu().numpy(), sc.cpu().numpy(), out=ko, inf=ki)
+    finally:
+        eng.host_unregister(ko)
+    assert o2 is ko and i2 is ki and np.array_equal(ko, o) and np.array_equal(ki, i)
+    with pytest.raises(ValueError, match="out must be"):
+        eng.mul_var_batch(curve, pts.cpu().numpy(), sc.cpu().numpy(), out=ko[:-1])
