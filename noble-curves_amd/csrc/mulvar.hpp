@@ -65,6 +65,44 @@ NCG_DI Jac<Fe9<PR, B>> jac_madd_zr(const Jac<Fe9<PR, B>>& p, const Affine<Fe9<PR
   return {X3, Y3, p.Z * H};
 }
 
+// The same step in co-Z form (Meloni's ZADDU): D and T share their Z, the sum T' = D + T comes out with Z' = Z (D.x - T.x) and D is
+// RE-EXPRESSED at that Z' for free (W1, A1 are by-products), so the next step is co-Z again: 4M + 2S per table entry against
+// 8M + 3S for the mixed addition above (no Z^2, Z^3 products: the operands are already at one Z; the running Z is not
+// tracked - the rescale pass of the table build multiplies the ratios up anyway).  Values are those of jac_madd_zr: with
+// dx = D.x - T.x (= its H) and dy = D.y - T.y (= its R): X3 = dy^2 - (D.x + T.x) dx^2, Y3 = dy (D.x dx^2 - X3) - D.y dx^3.
+// Incomplete in the same case (dx = 0 <=> D = +-T), reported through `degenerate`.
+template <class F>
+NCG_DI void coz_addu(Affine<F>& D, Affine<F>& T, F& zr, bool& degenerate) {
+  auto dx = D.x - T.x;
+  degenerate = degenerate || f_eqz(dx);
+  auto C = f_sqr(dx);
+  auto W1 = D.x * C;
+  auto W2 = T.x * C;
+  auto dy = D.y - T.y;
+  auto A1 = D.y * (W1 - W2);
+  auto X3 = f_sqr(dy) - W1 - W2;
+  auto Y3 = dy * (W1 - X3) - A1;
+  zr = dx * F::one();  // stored: bring the bound back under the storage bound
+  D = {W1, A1};
+  T = {X3, Y3};
+}
+template <class PR, int B>
+NCG_DI void coz_addu(Affine<Fe9<PR, B>>& D, Affine<Fe9<PR, B>>& T, Fe9<PR, B>& zr, bool& degenerate) {
+  auto dxw = D.x - T.x;
+  degenerate = degenerate || f_eqz(dxw);
+  auto dx = fe9_norm(dxw);
+  auto dy = fe9_norm(D.y - T.y);
+  auto C = f_sqr(dx);
+  auto W1 = D.x * C;
+  auto W2 = T.x * C;
+  auto A1 = D.y * (W1 - W2);
+  auto X3 = fe9_norm(f_sqr(dy) - W1 - W2);
+  auto Y3 = dy * (W1 - X3) - A1;
+  zr = dx;
+  D = {W1, A1};
+  T = {X3, Y3};
+}
+
 // Complete (every exceptional case handled by jac_madd / jac_dbl) MSB-first double-and-add over the
 // whole 256-bit scalar: the value of the reference's multiplyUnsafe for ANY curve point
 // (src/abstract/weierstrass.ts:915-928 on the complete formulas :793-880).  Only lanes whose
@@ -127,8 +165,8 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     Jac<F> D = jac_dbl(Jac<F>{P.x, P.y, F::one()});
     auto dz2 = f_sqr(D.Z);
     auto dz3 = dz2 * D.Z;
-    Affine<F> Dp{D.X, D.Y};
-    Jac<F> T{P.x * dz2, P.y * dz3, F::one()};
+    Affine<F> Dc{D.X, D.Y};                 // 2P and P on the isomorphic curve, both at Z = 1: co-Z from the start
+    Affine<F> T{P.x * dz2, P.y * dz3};
     F zr[ZR_IN_TAB ? 1 : TS];
     auto zr_put = [&](int j, const F& v) {
       if constexpr (ZR_IN_TAB) FieldIO<F>::store_strided(tab + (TS * 2 * TW + j * TW) * stride, stride, v);
@@ -138,17 +176,17 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
       if constexpr (ZR_IN_TAB) return FieldIO<F>::load_strided(tab + (TS * 2 * TW + j * TW) * stride, stride);
       else return zr[j];
     };
-    FieldIO<F>::store_strided(tab, stride, T.X);
-    FieldIO<F>::store_strided(tab + TW * stride, stride, T.Y);
+    FieldIO<F>::store_strided(tab, stride, T.x);
+    FieldIO<F>::store_strided(tab + TW * stride, stride, T.y);
     // with the Z-ratios in memory nothing here indexes a register array: keep the loops rolled (the
     // unrolled build is 15 mixed additions of straight-line code in front of the ladder)
 #pragma unroll(ZR_IN_TAB ? 1 : TS)
     for (int j = 1; j < TS; j++) {
       F zj;
-      T = jac_madd_zr(T, Dp, zj, degenerate);
+      coz_addu(Dc, T, zj, degenerate);
       zr_put(j, zj);
-      FieldIO<F>::store_strided(tab + (j * 2 * TW) * stride, stride, T.X);
-      FieldIO<F>::store_strided(tab + (j * 2 * TW + TW) * stride, stride, T.Y);
+      FieldIO<F>::store_strided(tab + (j * 2 * TW) * stride, stride, T.x);
+      FieldIO<F>::store_strided(tab + (j * 2 * TW + TW) * stride, stride, T.y);
     }
     // bring every entry to the last entry's Z
     F s = F::one();
@@ -163,7 +201,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
       FieldIO<F>::store_strided(tab + (j * 2 * TW) * stride, stride, x * s2);
       FieldIO<F>::store_strided(tab + (j * 2 * TW + TW) * stride, stride, y * s3);
     }
-    Zg = D.Z * T.Z;
+    Zg = D.Z * s;   // s = the product of all the ratios = the Z the last entry was built at
   }
 
   // ---- scalar recoding ---------------------------------------------------------------------
