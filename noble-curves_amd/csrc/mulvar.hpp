@@ -24,53 +24,16 @@
 
 namespace ncg {
 
-// madd that also returns the Z ratio (Z3 = Z1 * zr); used only while building the table.  The
-// formula is incomplete: it is wrong when p = +-q (H = 0), which happens while building
-// [1,3,..]P exactly when P has small order (j*P = +-2P for some odd j < 2^W) - possible for any
-// input the reference accepts on bls12-381 G1/G2 (cofactor > 1; Point.fromAffine does not
-// subgroup-check, src/abstract/weierstrass.ts:710-718).  `degenerate` records that case; the
-// caller then recomputes the lane with the complete ladder mul_var_slow below.
-template <class F>
-NCG_DI Jac<F> jac_madd_zr(const Jac<F>& p, const Affine<F>& q, F& zr, bool& degenerate) {
-  auto Z1Z1 = f_sqr(p.Z);
-  auto U2 = q.x * Z1Z1;
-  auto S2 = q.y * p.Z * Z1Z1;
-  auto H = U2 - p.X;
-  auto R = S2 - p.Y;
-  degenerate = degenerate || f_eqz(H);
-  auto HH = f_sqr(H);
-  auto HHH = H * HH;
-  auto V = p.X * HH;
-  auto X3 = f_sqr(R) - HHH - f_dbl(V);
-  auto Y3 = R * (V - X3) - p.Y * HHH;
-  zr = H * F::one();  // stored: bring the bound back under the storage bound
-  return {X3, Y3, p.Z * H};
-}
-template <class PR, int B>
-NCG_DI Jac<Fe9<PR, B>> jac_madd_zr(const Jac<Fe9<PR, B>>& p, const Affine<Fe9<PR, B>>& q, Fe9<PR, B>& zr,
-                                   bool& degenerate) {
-  auto Z1Z1 = f_sqr(p.Z);
-  auto U2 = q.x * Z1Z1;
-  auto S2 = q.y * (p.Z * Z1Z1);
-  auto Hw = U2 - p.X;
-  degenerate = degenerate || f_eqz(Hw);
-  auto H = fe9_norm(Hw);
-  auto R = fe9_norm(S2 - p.Y);
-  auto HH = f_sqr(H);
-  auto HHH = H * HH;
-  auto V = p.X * HH;
-  auto X3 = fe9_norm(f_sqr(R) - HHH - f_dbl(V));
-  auto Y3 = R * (V - X3) - p.Y * HHH;
-  zr = H;
-  return {X3, Y3, p.Z * H};
-}
-
-// The same step in co-Z form (Meloni's ZADDU): D and T share their Z, the sum T' = D + T comes out with Z' = Z (D.x - T.x) and D is
-// RE-EXPRESSED at that Z' for free (W1, A1 are by-products), so the next step is co-Z again: 4M + 2S per table entry against
-// 8M + 3S for the mixed addition above (no Z^2, Z^3 products: the operands are already at one Z; the running Z is not
-// tracked - the rescale pass of the table build multiplies the ratios up anyway).  Values are those of jac_madd_zr: with
-// dx = D.x - T.x (= its H) and dy = D.y - T.y (= its R): X3 = dy^2 - (D.x + T.x) dx^2, Y3 = dy (D.x dx^2 - X3) - D.y dx^3.
-// Incomplete in the same case (dx = 0 <=> D = +-T), reported through `degenerate`.
+// One step of the table build T' = T + D (D = 2P) in co-Z form (Meloni's ZADDU): D and T share their Z, the sum comes out with
+// Z' = Z (D.x - T.x) and D is RE-EXPRESSED at that Z' for free (W1, A1 are by-products), so the next step is co-Z again:
+// 4M + 2S per table entry (a mixed Jacobian addition that also returns its Z ratio, the first form of this build, costs 8M + 3S:
+// Z^2 and Z^3 products that co-Z operands do not need).  `zr` = D.x - T.x is the ratio Z' / Z; the running Z itself is not tracked
+// here - the rescale pass of the table build multiplies the ratios up anyway.  With dx = D.x - T.x and dy = D.y - T.y:
+// X3 = dy^2 - (D.x + T.x) dx^2, Y3 = dy (D.x dx^2 - X3) - D.y dx^3.
+// The formula is incomplete: it is wrong when D = +-T (dx = 0), which happens while building [1,3,..]P exactly when P has small
+// order (j*P = +-2P for some odd j < 2^W) - possible for any input the reference accepts on bls12-381 G1/G2 (cofactor > 1;
+// Point.fromAffine does not subgroup-check, src/abstract/weierstrass.ts:710-718).  `degenerate` records that case; the caller
+// then recomputes the lane with the complete ladder mul_var_slow below.
 template <class F>
 NCG_DI void coz_addu(Affine<F>& D, Affine<F>& T, F& zr, bool& degenerate) {
   auto dx = D.x - T.x;

@@ -64,19 +64,21 @@ NCG_DI void mul_var_lane_g2psi(const uint32_t* __restrict__ pt_wire, const uint3
     Jac<F> D = jac_dbl(Jac<F>{P.x, P.y, F::one()});
     auto dz2 = f_sqr(D.Z);
     auto dz3 = dz2 * D.Z;
-    Affine<F> Dp{D.X, D.Y};
-    Jac<F> T{P.x * dz2, P.y * dz3, F::one()};
-    FieldIO<F>::store_strided(tab, 1, T.X);
-    FieldIO<F>::store_strided(tab + TW, 1, T.Y);
+    Affine<F> Dc{D.X, D.Y};   // co-Z steps (mulvar.hpp coz_addu); the running Z is kept here: the rescale below starts from cz
+    Affine<F> T{P.x * dz2, P.y * dz3};
+    F Tz = F::one();
+    FieldIO<F>::store_strided(tab, 1, T.x);
+    FieldIO<F>::store_strided(tab + TW, 1, T.y);
 #pragma unroll 1
     for (int j = 1; j < TS; j++) {
       F zj;
-      T = jac_madd_zr(T, Dp, zj, degenerate);
+      coz_addu(Dc, T, zj, degenerate);
+      Tz = Tz * zj;
       FieldIO<F>::store_strided(tab + Cfg::ZR_OFF + j * TW, 1, zj);
-      FieldIO<F>::store_strided(tab + j * 2 * TW, 1, T.X);
-      FieldIO<F>::store_strided(tab + j * 2 * TW + TW, 1, T.Y);
+      FieldIO<F>::store_strided(tab + j * 2 * TW, 1, T.x);
+      FieldIO<F>::store_strided(tab + j * 2 * TW + TW, 1, T.y);
     }
-    const F Zg = D.Z * T.Z;
+    const F Zg = D.Z * Tz;
     const F cz = p2_conj(Zg);
     Zr = Zg * cz;
     const Fe29x2P<1> psx = p2_const(ParamsBls29::PSI_X_C0, ParamsBls29::PSI_X_C1);
