@@ -42,12 +42,17 @@ int ncg_set_err(ncg_ctx* ctx, int code, const char* fmt, ...) {
 // released when the object goes out of scope, after the stream has been drained.
 struct PinSet {
   ncg_ctx* ctx;
-  void* regs[8];
+  struct Range { uintptr_t lo, hi; };
+  Range regs[24];
   int n = 0;
   explicit PinSet(ncg_ctx* c) : ctx(c) {}
+  // Page-locks [p, p + bytes) for the duration of the call (whole pages).  A copy must lie inside ONE registration, and two
+  // registrations must not share a page: callers that pin an array piecewise cut it at page boundaries (PagedParts below).
+  // Buffers the caller registered itself (ncg_host_register) fail here and are left alone.
   void pin(const void* p, size_t bytes) {
-    if (bytes < ((size_t)4 << 20) || n >= 8) return;
-    if (hipHostRegister((void*)p, bytes, hipHostRegisterDefault) == hipSuccess) regs[n++] = (void*)p;
+    if (bytes < ((size_t)1 << 20) || n >= 24) return;
+    const uintptr_t lo = (uintptr_t)p & ~(uintptr_t)4095, hi = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
+    if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) regs[n++] = Range{lo, hi};
     else (void)hipGetLastError();  // already pinned by the caller, or not registrable: plain copy
   }
   hipError_t h2d(void* dst, const void* src, size_t bytes) {
@@ -64,7 +69,30 @@ struct PinSet {
       if (ctx->copy_in) (void)hipStreamSynchronize(ctx->copy_in);
       if (ctx->copy_out) (void)hipStreamSynchronize(ctx->copy_out);
     }
-    for (int i = 0; i < n; i++) (void)hipHostUnregister(regs[i]);
+    for (int i = 0; i < n; i++) (void)hipHostUnregister((void*)regs[i].lo);
+  }
+};
+
+// One host array crossing the bus piecewise: consecutive byte ranges whose INNER boundaries are page boundaries of the host
+// address space, so that each piece can be page-locked on its own just before its copy is enqueued (the host locks piece p + 1
+// while piece p is on the bus; locking 128 MB up front costs ~3 ms before the first byte moves) and no two registrations share a
+// page.  Uploads round a piece's end UP (a few bytes of the next piece travel early); downloads round it DOWN (the last partial
+// page of a piece is fetched with the next one, when all of it has been computed).
+struct PagedParts {
+  const char* base;
+  size_t total, done = 0;
+  PagedParts(const void* b, size_t t) : base((const char*)b), total(t) {}
+  // piece that makes bytes [0, need_end) available (upload) / that may fetch everything below need_end (download)
+  bool next(size_t need_end, bool last, bool round_up, size_t* lo, size_t* hi) {
+    const uintptr_t a = (uintptr_t)base + need_end;
+    size_t e = last ? total : (size_t)(((round_up ? a + 4095 : a) & ~(uintptr_t)4095) - (uintptr_t)base);
+    if (!last && (a & ~(uintptr_t)4095) < (uintptr_t)base) e = 0;   // (download, first page before the array)
+    e = std::min(e, total);
+    if (e <= done) return false;
+    *lo = done;
+    *hi = e;
+    done = e;
+    return true;
   }
 };
 
@@ -327,10 +355,7 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
     // first upload and the last download: 2^20 secp256k1 pairs 13.4 -> ~9.6 ms end to end.
     rc = ensure_copy_streams(ctx);
     if (rc) return rc;
-    pins.pin(points_affine, pts_b);
-    pins.pin(scalars, sc_b);
-    pins.pin(out_affine, pts_b);
-    if (out_is_inf) pins.pin(out_is_inf, n);
+    // (page locking per chunk, just ahead of its copies - see ncg_msm)
     // Chunk sizes 1 : 3 : 3 : 1 (in eighths of the batch) for large batches: a launch of the ladder pays ~0.3 ms of ramp whatever
     // its size (tools/secp_rounds.py: 9.8 ns per item for one round of 196 608 items, 8.6 for two, 8.3 for the whole batch), so the
     // middle chunks are big, and only the first upload and the last download are exposed, so the outer ones are small.
@@ -341,11 +366,20 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
     const size_t unit = (((n + 7) / 8) + 255) & ~(size_t)255;
     hipError_t e = hipSuccess;
     size_t lo = 0;
+    PagedParts in_pts(points_affine, pts_b), in_sc(scalars, sc_b), out_pts(out_affine, pts_b), out_inf(out_is_inf, n);
     for (int c = 0; c < chunks && e == hipSuccess && rc == NCG_OK; c++) {
       const size_t cnt = std::min(n - lo, unit * (size_t)eighths[c]);
       if (cnt == 0) break;
-      e = hipMemcpyAsync(d_pts + lo * pb, (const char*)points_affine + lo * pb, cnt * pb, hipMemcpyHostToDevice, ctx->copy_in);
-      if (e == hipSuccess) e = hipMemcpyAsync(d_sc + lo * 32, (const char*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, ctx->copy_in);
+      const bool last = lo + cnt >= n;
+      size_t a, b;
+      if (in_pts.next((lo + cnt) * pb, last, true, &a, &b)) {
+        pins.pin((const char*)points_affine + a, b - a);
+        e = hipMemcpyAsync(d_pts + a, (const char*)points_affine + a, b - a, hipMemcpyHostToDevice, ctx->copy_in);
+      }
+      if (e == hipSuccess && in_sc.next((lo + cnt) * 32, last, true, &a, &b)) {
+        pins.pin((const char*)scalars + a, b - a);
+        e = hipMemcpyAsync(d_sc + a, (const char*)scalars + a, b - a, hipMemcpyHostToDevice, ctx->copy_in);
+      }
       if (e == hipSuccess) e = hipEventRecord(ctx->ev_in[c], ctx->copy_in);
       if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_in[c], 0);
       if (e != hipSuccess) break;
@@ -353,8 +387,14 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
       if (rc) break;
       e = hipEventRecord(ctx->ev_k[c], ctx->stream);
       if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_out, ctx->ev_k[c], 0);
-      if (e == hipSuccess) e = hipMemcpyAsync((char*)out_affine + lo * pb, d_out + lo * pb, cnt * pb, hipMemcpyDeviceToHost, ctx->copy_out);
-      if (e == hipSuccess && out_is_inf) e = hipMemcpyAsync(out_is_inf + lo, d_inf + lo, cnt, hipMemcpyDeviceToHost, ctx->copy_out);
+      if (e == hipSuccess && out_pts.next((lo + cnt) * pb, last, false, &a, &b)) {
+        pins.pin((char*)out_affine + a, b - a);   // (locked while the chunk's kernels run)
+        e = hipMemcpyAsync((char*)out_affine + a, d_out + a, b - a, hipMemcpyDeviceToHost, ctx->copy_out);
+      }
+      if (e == hipSuccess && out_is_inf && out_inf.next(lo + cnt, last, false, &a, &b)) {
+        pins.pin(out_is_inf + a, b - a);
+        e = hipMemcpyAsync(out_is_inf + a, d_inf + a, b - a, hipMemcpyDeviceToHost, ctx->copy_out);
+      }
       lo += cnt;
     }
     drain_copy_streams(ctx);
@@ -596,20 +636,29 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
     layout.Q_layout = layout.Q;
     rc = msm_ensure_ws(ctx, curve, layout);
     if (rc) return rc;
-    pins.pin(points_affine, pts_b);
-    pins.pin(scalars, sc_b);
+    // page locking per PART, right before the part's copies are enqueued: the copies are asynchronous, so the host locks the
+    // pages of part p + 1 while part p is on the bus (locking all 128 MB of a 2^20-point G1 MSM up front costs ~3 ms before the
+    // first byte moves).  Buffers the caller pinned with ncg_host_register are left alone (the registration attempt fails fast).
     const size_t sw = ncg::msm_stored_words_per_point(curve) * 4;
     hipError_t e = hipSuccess;
+    PagedParts in_pts(points_affine, pts_b), in_sc(scalars, sc_b);
     const uint32_t *d_fin = nullptr, *d_bad = nullptr;
     ncg::MsmPlan last = layout;
     for (int p = 0; p < parts && e == hipSuccess; p++) {
       const size_t lo = std::min(n, per * (size_t)p), cnt = std::min(n, lo + per) - lo;
       const bool is_last = p == parts - 1 || lo + cnt >= n;
       if (cnt) {
-        e = hipMemcpyAsync(d_sc + lo * 32, (const char*)scalars + lo * 32, cnt * 32, hipMemcpyHostToDevice, ctx->copy_in);
+        size_t a, b;
+        if (in_sc.next((lo + cnt) * 32, is_last, true, &a, &b)) {
+          pins.pin((const char*)scalars + a, b - a);
+          e = hipMemcpyAsync(d_sc + a, (const char*)scalars + a, b - a, hipMemcpyHostToDevice, ctx->copy_in);
+        }
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_sc[p], ctx->copy_in);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_sc[p], 0);   // this part's digits wait for its scalars only
-        if (e == hipSuccess) e = hipMemcpyAsync(d_pts + lo * pb, (const char*)points_affine + lo * pb, cnt * pb, hipMemcpyHostToDevice, ctx->copy_in);
+        if (e == hipSuccess && in_pts.next((lo + cnt) * pb, is_last, true, &a, &b)) {
+          pins.pin((const char*)points_affine + a, b - a);
+          e = hipMemcpyAsync(d_pts + a, (const char*)points_affine + a, b - a, hipMemcpyHostToDevice, ctx->copy_in);
+        }
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_in[p], ctx->copy_in);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->msm_side.stream, ctx->ev_in[p], 0);
         if (e == hipSuccess)
