@@ -46,14 +46,25 @@ struct PinSet {
   Range regs[24];
   int n = 0;
   explicit PinSet(ncg_ctx* c) : ctx(c) {}
-  // Page-locks [p, p + bytes) for the duration of the call (whole pages).  A copy must lie inside ONE registration, and two
-  // registrations must not share a page: callers that pin an array piecewise cut it at page boundaries (PagedParts below).
+  // Page-locks [p, p + bytes) for the duration of the call.  A copy must lie inside ONE registration, and two registrations
+  // must not share a page: callers that pin an array piecewise cut it at page boundaries (PagedParts below).
   // Buffers the caller registered itself (ncg_host_register) fail here and are left alone.
+  // (The EXACT range is registered, not its pages: the runtime treats a pointer as pinned by the registered range, and a range
+  // widened to its pages would claim the head of whatever the caller allocated next to the buffer - a copy into that neighbour
+  // would then start inside a registration and run out of it: hipErrorInvalidValue.)
   void pin(const void* p, size_t bytes) {
     if (bytes < ((size_t)1 << 20) || n >= 24) return;
-    const uintptr_t lo = (uintptr_t)p & ~(uintptr_t)4095, hi = ((uintptr_t)p + bytes + 4095) & ~(uintptr_t)4095;
-    if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) regs[n++] = Range{lo, hi};
-    else (void)hipGetLastError();  // already pinned by the caller, or not registrable: plain copy
+    {  // already pinned (ncg_host_register, hipHostMalloc): a second registration of a PIECE of it would succeed and cost the
+       // page locking again - ask first
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, p) == hipSuccess) {
+        if (at.type == hipMemoryTypeHost) return;
+      } else {
+        (void)hipGetLastError();  // plain pageable memory is "invalid value" to this query on some runtimes
+      }
+    }
+    if (hipHostRegister((void*)p, bytes, hipHostRegisterDefault) == hipSuccess) regs[n++] = Range{(uintptr_t)p, (uintptr_t)p + bytes};
+    else (void)hipGetLastError();  // not registrable: plain copy
   }
   hipError_t h2d(void* dst, const void* src, size_t bytes) {
     pin(src, bytes);
