@@ -1,0 +1,77 @@
+"""The line bench.py prints must be something the driver can keep: one compact JSON object, well under the 8 KB
+stdout tail it parses (BENCH_r04 came back `parsed: null` from a 36.7 KB line).  Built here from committed full
+result objects of real runs (single GPU; the multi-rank dry run with the strong-scaling blocks)."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_compact  # noqa: E402
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _full(name):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", ["r04_bench_line_last_tree.json", "r04_bench_line.json", "r03_bench_line.json"])
+def test_compact_line_fits_and_keeps_the_contract(name):
+    full = _full(name)
+    line = bench_compact.dumps(bench_compact.compact_line(full, "gpurun_out/bench_full.json"))
+    assert "\n" not in line
+    assert len(line) < bench_compact.LIMIT < 8192
+    c = json.loads(line)
+    for k in CONTRACT:
+        assert k in c, k
+    assert c["metric"] == full["metric"] and c["n_gpus"] == full["n_gpus"] and c["steps"] == full["steps"]
+    assert abs(c["value"] - full["value"]) <= 1e-6 * full["value"]
+    assert abs(c["ms_per_step"] - full["ms_per_step"]) <= 1e-6 * full["ms_per_step"]
+    assert c["config"]["workload"]
+    rf = c["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    assert "mad_frac" in rf["valu"]
+    cb = c["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    # both halves of BASELINE's metric, flat
+    for key in ("msm_g1", "msm_g2"):
+        b = c[key]
+        for k in ("value", "unit", "ms_per_msm", "roofline", "cpu_baseline"):
+            assert k in b, (key, k)
+        src = (full.get("extra") or {}).get(key) or full[key]
+        assert abs(b["ms_per_msm"] - src["ms_per_msm"]) <= 1e-5 * src["ms_per_msm"]
+    assert "ms_per_batch" in c["ed25519"] and "ms_per_transform" in c["ntt"]
+
+
+def test_compact_line_of_a_multi_rank_run_keeps_the_strong_blocks():
+    full = _full("r04_bench_dist_dry_run.json")
+    c = bench_compact.compact_line(full)
+    assert len(bench_compact.dumps(c)) < bench_compact.LIMIT
+    for key in ("msm_g1_strong", "msm_g2_strong"):
+        assert c[key]["scaling"] == "strong" and c[key]["mode"] and c[key]["ms_per_msm"] > 0
+
+
+def test_compact_line_never_exceeds_the_limit_even_with_bloated_input():
+    full = _full("r04_bench_line_last_tree.json")
+    full["config"]["workload"] = "x" * 5000
+    full["data"] = "y" * 5000
+    for e in full["extra"].values():
+        if isinstance(e, dict):
+            e["note"] = "z" * 20000
+    assert len(bench_compact.dumps(bench_compact.compact_line(full))) < bench_compact.LIMIT
+
+
+def test_single_workload_lines_keep_what_the_ab_scripts_read():
+    full = _full("r04_bench_line_last_tree.json")
+    e = dict(full["extra"]["msm_g1"])
+    e.update({"n_gpus": 1, "steps": 10, "warmup": 3, "ms_per_step": None, "config": {"workload": "msm_g1"}})
+    c = bench_compact.compact_line(e)
+    assert c["ms_per_msm"] > 0 and c["resident_subgroup_set"]["ms_per_msm"] > 0
