@@ -35,15 +35,24 @@ function leNumber(buf, off, len) {
 }
 function coordsOf(aff, isFp2) { return isFp2 ? [aff.x.c0, aff.x.c1, aff.y.c0, aff.y.c1] : [aff.x, aff.y]; }
 
-function validateMSMPoints(points, c) {         // curve.ts:390-395
-  if (!Array.isArray(points)) throw new Error('array expected');
+// Field.isValid / isValidNot0 of the scalar field (modular.ts:925-936): a non-bigint is a TypeError, not `false`
+function isValidScalar(Fn, s) {
+  if (typeof s !== 'bigint') throw new TypeError('invalid field element: expected bigint, got ' + typeof s);
+  return s >= 0n && s < Fn.ORDER;
+}
+function isValidScalarNot0(Fn, s) { return s !== 0n && isValidScalar(Fn, s); }
+function validateMSMPoints(points, c) {         // curve.ts:390-395 (aarray: utils.ts:134-143)
+  if (!Array.isArray(points)) throw new TypeError('"points" expected array, got type=' + typeof points);
   points.forEach((p, i) => { if (!(p instanceof c)) throw new Error('invalid point at index ' + i); });
 }
 function validateMSMScalars(scalars, field) {   // curve.ts:398-404
   if (!Array.isArray(scalars)) throw new Error('array of scalars expected');
-  scalars.forEach((s, i) => {
-    if (typeof s !== 'bigint' || s < 0n || s >= field.ORDER) throw new Error('invalid scalar at index ' + i);
-  });
+  scalars.forEach((s, i) => { if (!isValidScalar(field, s)) throw new Error('invalid scalar at index ' + i); });
+}
+// Point.multiply / multiplyUnsafe argument errors: weierstrass.ts:904, :920; edwards.ts:561, :573
+function scalarRangeError(id, not0) {
+  if (id === CURVE.ED25519) return new RangeError('invalid scalar: expected ' + (not0 ? '1' : '0') + ' <= sc < curve.n');
+  return new RangeError('invalid scalar: out of range');
 }
 // coordinates / scalars cross as packed little-endian bytes; the BigInt -> bytes step runs natively
 // (napi_get_value_bigint_words), ~5x faster than the hex-string route it replaces
@@ -314,9 +323,7 @@ function multiplyUnsafeBatch(c, points, scalars) {
   const id = curveId(c);
   validateMSMPoints(points, c);
   if (points.length !== scalars.length) throw new Error('arrays of points and scalars must have equal length');
-  scalars.forEach((s) => {                     // weierstrass.ts:920
-    if (typeof s !== 'bigint' || s < 0n || s >= c.Fn.ORDER) throw new RangeError('invalid scalar: out of range');
-  });
+  scalars.forEach((s) => { if (!isValidScalar(c.Fn, s)) throw scalarRangeError(id, false); });   // weierstrass.ts:920, edwards.ts:573
   if (points.length === 0) return [];
   init();
   const n = points.length, pb = native.pointBytes(id);
@@ -325,9 +332,7 @@ function multiplyUnsafeBatch(c, points, scalars) {
 }
 function multiplyBaseBatch(c, scalars) {
   const id = curveId(c);
-  scalars.forEach((s) => {                     // weierstrass.ts:904
-    if (typeof s !== 'bigint' || s < 1n || s >= c.Fn.ORDER) throw new RangeError('invalid scalar: out of range');
-  });
+  scalars.forEach((s) => { if (!isValidScalarNot0(c.Fn, s)) throw scalarRangeError(id, true); });   // weierstrass.ts:904, edwards.ts:561
   if (id === CURVE.ED25519) return multiplyUnsafeBatch(c, scalars.map(() => c.BASE), scalars);
   if (scalars.length === 0) return [];
   init();

@@ -1,8 +1,10 @@
 'use strict';
-// Smoke test of the addon + shim.  The reference itself cannot be loaded on this Node (v12: no
-// TypeScript), so a minimal Point class with the reference's CurvePointCons surface stands in;
-// expected values come from the reference's fixtures (tests/golden, extracted from
-// test/vectors/secp256k1/privates-2.txt) - k*G for k in the file.
+// Smoke test of the addon + shim with NO reference on the path: a minimal Point class with the reference's
+// CurvePointCons surface stands in (any class with that surface can be registered); expected values come from the
+// reference's fixtures (tests/golden, extracted from test/vectors/secp256k1/privates-2.txt) - k*G for k in the file.
+// The shim driven by the reference's OWN classes (secp256k1.Point, bls12_381.G1/G2.Point, ed25519.Point from the
+// type-stripped bundle) and compared with the reference's own pippenger / multiply on the same objects is
+// addon/ref_dropin_test.mjs.
 const assert = require('assert');
 const fs = require('fs');
 const path = require('path');
