@@ -5,7 +5,7 @@ const gpu = require('./noble_gpu.js');
 const N = 0xfffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141n;
 const P = 0xfffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2fn;
 class Point {
-  constructor(x, y, inf) { this.x = x; this.y = y; this.inf = !!inf; }
+  constructor(x, y, inf) { this.x = x; this.y = y; this.inf = !!inf; Object.freeze(this); }   // frozen like the reference's instances (weierstrass.ts:703)
   static fromAffine(a) { return (a.x === 0n && a.y === 0n) ? Point.ZERO : new Point(a.x, a.y); }
   toAffine() { return this.inf ? { x: 0n, y: 0n } : { x: this.x, y: this.y }; }
 }
@@ -22,6 +22,11 @@ for (let i = 0; i < n; i++) { ks.push(((rnd() << 64n) | rnd()) % (N - 1n) + 1n);
 const pts = gpu.multiplyBaseBatch(Point, ks);
 const ms = (f) => { const t0 = process.hrtime.bigint(); const r = f(); return [Number(process.hrtime.bigint() - t0) / 1e6, r]; };
 gpu.pippenger(Point, pts.slice(0, 64), ss.slice(0, 64));
+// reference-shaped call, Point[] + BigInt[]: the FIRST call on an array marshals it (toAffine + packing) and leaves a device copy
+// behind; later calls on the same array of the same frozen objects skip all of that (noble_gpu.js cachedSet)
+gpu.setPointCache({ enabled: false });
+const [tMsmNoCache] = ms(() => gpu.pippenger(Point, pts, ss));
+gpu.setPointCache({ enabled: true });
 const [tMsm] = ms(() => gpu.pippenger(Point, pts, ss));
 const [tMul] = ms(() => gpu.multiplyUnsafeBatch(Point, pts, ss));
 const best = (f, reps) => { let b = Infinity, r; for (let i = 0; i < reps; i++) { const [t, v] = ms(f); if (t < b) b = t; r = v; } return [b, r]; };
@@ -37,6 +42,13 @@ const [tMulN] = ms(() => gpu.native.mulVarBatch(0, pb, sb));
 // packed columns (packPoints once, scalars as BigUint64Array): the reference-shaped call without per-value N-API work
 const packedPts = gpu.packPoints(Point, pts);
 const sc64 = new BigUint64Array(sb.buffer);
+const rFirst = gpu.pippenger(Point, pts, ss);
+const [tCachedBig, rCb] = best(() => gpu.pippenger(Point, pts, ss), 3);          // cached Point[] + BigInt[] scalars
+const [tCachedTyped, rCt] = best(() => gpu.pippenger(Point, pts, sc64), 5);      // cached Point[] + BigUint64Array scalars
+const [tCachedBytes] = best(() => gpu.pippenger(Point, pts, sb), 5);             // ... + packed bytes
+if (rCb.x !== rFirst.x || rCb.y !== rFirst.y || rCt.x !== rFirst.x || rCt.y !== rFirst.y) throw new Error('cached pippenger differs');
+const cacheStats = gpu.setPointCache();
+gpu.clearPointCache();
 const [tPacked, rPacked] = ms(() => gpu.pippenger(Point, packedPts, sc64));
 const rRef = gpu.pippenger(Point, pts, ss);
 if (rPacked.x !== rRef.x || rPacked.y !== rRef.y) throw new Error('packed pippenger differs');
@@ -62,5 +74,5 @@ gpu.pippengerResident(set, ss);
 const [tResBig] = ms(() => gpu.pippengerResident(set, ss));
 const [tResBytes] = ms(() => gpu.pippengerResident(set, sb));
 set.free();
-console.log(JSON.stringify({ n, pippenger_native_pinned_ms: tMsmPinned, multiplyUnsafeBatch_native_pinned_ms: tMulPinned, multiplyUnsafeBatch_native_pinned_out_ms: tMulPinnedOut, pippenger_packed_columns_pinned_ms: tPackedPinned, pippenger_resident_bigint_ms: tResBig, pippenger_resident_bytes_ms: tResBytes, pippenger_js_ms: tMsm, pippenger_packed_columns_ms: tPacked, pippenger_native_ms: tMsmN, multiplyUnsafeBatch_js_ms: tMul,
+console.log(JSON.stringify({ n, pippenger_js_first_call_ms: tMsm, pippenger_js_no_cache_ms: tMsmNoCache, pippenger_js_cached_points_bigint_scalars_ms: tCachedBig, pippenger_js_cached_points_typed_scalars_ms: tCachedTyped, pippenger_js_cached_points_byte_scalars_ms: tCachedBytes, cache_hits: cacheStats.hits, cache_misses: cacheStats.misses, pippenger_native_pinned_ms: tMsmPinned, multiplyUnsafeBatch_native_pinned_ms: tMulPinned, multiplyUnsafeBatch_native_pinned_out_ms: tMulPinnedOut, pippenger_packed_columns_pinned_ms: tPackedPinned, pippenger_resident_bigint_ms: tResBig, pippenger_resident_bytes_ms: tResBytes, pippenger_js_ms: tMsm, pippenger_packed_columns_ms: tPacked, pippenger_native_ms: tMsmN, multiplyUnsafeBatch_js_ms: tMul,
   multiplyUnsafeBatch_native_ms: tMulN }));

@@ -18,6 +18,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../include/ncg.h"
@@ -747,6 +748,9 @@ static napi_value PointBytes(napi_env env, napi_callback_info info) {
 
 // hostRegister(Uint8Array) / hostUnregister(Uint8Array): pin a long-lived input / output buffer ONCE (ncg_host_register),
 // so that every later call on it moves by DMA at PCIe speed with no per-call page locking
+// A registered array must outlive its registration: a strong reference is held from hostRegister until hostUnregister, so the
+// backing store cannot be collected (and its address range handed to another allocation) while HIP still has it pinned.
+static std::map<uintptr_t, napi_ref> g_registered;
 static napi_value HostRegister(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -757,7 +761,15 @@ static napi_value HostRegister(napi_env env, napi_callback_info info) {
     napi_throw_type_error(env, nullptr, "noble-gpu: hostRegister(Uint8Array)");
     return nullptr;
   }
+  if (g_registered.count((uintptr_t)p)) return nullptr;   // already registered through this addon
   if (ncg_host_register(p, len) != 0) return throw_native(env);
+  napi_ref ref = nullptr;
+  if (napi_create_reference(env, argv[0], 1, &ref) != napi_ok) {
+    (void)ncg_host_unregister(p);
+    napi_throw_error(env, nullptr, "noble-gpu: hostRegister: cannot hold a reference to the array");
+    return nullptr;
+  }
+  g_registered[(uintptr_t)p] = ref;
   return nullptr;
 }
 static napi_value HostUnregister(napi_env env, napi_callback_info info) {
@@ -771,6 +783,11 @@ static napi_value HostUnregister(napi_env env, napi_callback_info info) {
     return nullptr;
   }
   (void)ncg_host_unregister(p);
+  auto it = g_registered.find((uintptr_t)p);
+  if (it != g_registered.end()) {
+    (void)napi_delete_reference(env, it->second);
+    g_registered.erase(it);
+  }
   return nullptr;
 }
 

@@ -41,7 +41,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 16 lanes/clk/SIMD at the nominal 2.4 GHz = 3.93e13 lane-ops/s
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
+CYC_MAD, CYC_PLAIN = 5.59, 2.89            # measured cycles per wave-instruction and SIMD at 8 waves/SIMD (profiles/r03_valu_rates.jsonl):
+                                           # v_mad_u64_u32 / v_add_u32; 64 lanes / 5.59 cycles x 1024 SIMDs x 2.4 GHz = the MAD_PEAK below
 MAD_PEAK = 3.08e13                         # v_mad_u64_u32 ceiling measured on MI355X (profiles/r01_ubench_instr_rates.json,
                                            # profiles/r02_valu_rates.jsonl: ~2x the issue time of a plain 32-bit VALU op)
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
@@ -160,7 +162,7 @@ class Pmc:
 
 BOUND_NOTE = ("bound by VALU issue (integer multiply-add chains), not by HBM or MFMA - SURVEY 8d; `achieved` / `peak` / `frac` "
               "are the contract's HBM figures (algorithmic bytes / kernel time vs 8 TB/s), the fractions that describe the "
-              "kernel are roofline.valu.mad_frac and valu_issue_frac")
+              "kernel are roofline.valu.mad_frac and issue_frac")
 
 
 def valu_block(pmc, workload, kern_s, ref_mac, exec_mads, launches=1):
@@ -172,12 +174,17 @@ def valu_block(pmc, workload, kern_s, ref_mac, exec_mads, launches=1):
                                 "x items; peak = measured v_mad_u64_u32 ceiling"}
     insts, src = pmc.valu_insts(workload)
     if insts:
-        lane_ops = insts * 64.0 * launches / kern_s
-        blk.update({"executed_valu_lane_ops_per_s": lane_ops, "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                    "valu_issue_frac": lane_ops / VALU_PEAK_LANE_OPS, "sq_insts_valu_per_launch": insts,
+        # issue time the executed instruction mix needs at the MEASURED per-instruction issue costs (tools/valu_rates.hip,
+        # profiles/r03_valu_rates.jsonl, 8 waves per SIMD): a v_mad_u64_u32 holds a SIMD for 5.59 cycles per wave-instruction, a
+        # plain 32-bit VALU op for 2.89 - against the kernel's time on the chip's 1024 SIMDs at the nominal 2.4 GHz
+        wave_insts = insts * launches
+        wave_mads = exec_mads / 64.0
+        issue_s = (wave_mads * CYC_MAD + max(0.0, wave_insts - wave_mads) * CYC_PLAIN) / (N_SIMD * CLOCK_HZ)
+        blk.update({"issue_frac": issue_s / kern_s, "sq_insts_valu_per_launch": insts, "mad_share_of_valu_insts": wave_mads / wave_insts,
                     "valu_source": src,
-                    "valu_issue_note": "SQ_INSTS_VALU x 64 lanes / kernel time vs 16 lanes/clk/SIMD at 2.4 GHz; plain 32-bit "
-                                       "ops issue faster than that (frac can pass 1), multiplies slower"})
+                    "issue_note": "(v_mad_u64_u32 x 5.59 + other VALU x 2.89 cycles per wave-instruction, both measured) / (1024 SIMDs x "
+                                  "2.4 GHz) / kernel time: the share of the kernel's time its SIMDs spend issuing at the measured rates; "
+                                  "SQ_INSTS_VALU from the counter pass, multiplies counted statically"})
     return blk
 
 

@@ -56,11 +56,18 @@ struct PinSet {
     if (bytes < ((size_t)1 << 20) || n >= 24) return;
     {  // already pinned (ncg_host_register, hipHostMalloc): a second registration of a PIECE of it would succeed and cost the
        // page locking again - ask first
+      // (both ends: a buffer registered only as a PREFIX of this piece is not "already pinned" - it is left to the plain copy,
+      // which reports the partial registration instead of a DMA running past it)
       hipPointerAttribute_t at;
       if (hipPointerGetAttributes(&at, p) == hipSuccess) {
         if (at.type == hipMemoryTypeHost) return;
       } else {
         (void)hipGetLastError();  // plain pageable memory is "invalid value" to this query on some runtimes
+      }
+      if (hipPointerGetAttributes(&at, (const char*)p + bytes - 1) == hipSuccess) {
+        if (at.type == hipMemoryTypeHost) return;   // the tail belongs to someone's registration: registering the range would overlap it
+      } else {
+        (void)hipGetLastError();
       }
     }
     if (hipHostRegister((void*)p, bytes, hipHostRegisterDefault) == hipSuccess) regs[n++] = Range{(uintptr_t)p, (uintptr_t)p + bytes};
@@ -137,6 +144,10 @@ int ncg_msm_ensure_buf(ncg_ctx* ctx, int curve, ncg::MsmPlan& pl, void** ws, siz
   msm_apply_ctx(ctx, pl);
   size_t need = ncg::msm_workspace_bytes(curve, pl);
   if (*ws_bytes < need) {
+    // ncg_msm_last_plan reads the long-run counter of the last MSM out of ITS workspace: forget the pointer when that
+    // workspace is the one being replaced (the trace then reports 0 runs instead of reading freed memory)
+    const char* lr = (const char*)ctx->msm_trace.d_long_runs;
+    if (*ws && lr && lr >= (const char*)*ws && lr < (const char*)*ws + *ws_bytes) ctx->msm_trace.d_long_runs = nullptr;
     if (*ws) (void)hipFree(*ws);
     *ws = nullptr;
     *ws_bytes = 0;
@@ -335,11 +346,15 @@ static int ensure_copy_streams(ncg_ctx* ctx) {
   if (e != hipSuccess) return set_err(ctx, NCG_ERR_HIP, "noble-gpu: cannot create copy streams: %s", hipGetErrorString(e));
   return NCG_OK;
 }
-static void drain_copy_streams(ncg_ctx* ctx) {
-  if (ctx->copy_in) (void)hipStreamSynchronize(ctx->copy_in);
-  if (ctx->copy_out) (void)hipStreamSynchronize(ctx->copy_out);
-  if (ctx->msm_side.stream) (void)hipStreamSynchronize(ctx->msm_side.stream);
-  (void)hipStreamSynchronize(ctx->stream);
+// Waits for every stream a host-pointer call may have used; returns the FIRST failure (an asynchronous copy or kernel error
+// surfaces here, not at enqueue time), after having waited on all of them.
+static hipError_t drain_copy_streams(ncg_ctx* ctx) {
+  hipError_t first = hipSuccess, e;
+  if (ctx->copy_in && (e = hipStreamSynchronize(ctx->copy_in)) != hipSuccess && first == hipSuccess) first = e;
+  if (ctx->copy_out && (e = hipStreamSynchronize(ctx->copy_out)) != hipSuccess && first == hipSuccess) first = e;
+  if (ctx->msm_side.stream && (e = hipStreamSynchronize(ctx->msm_side.stream)) != hipSuccess && first == hipSuccess) first = e;
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && first == hipSuccess) first = e;
+  return first;
 }
 
 int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const void* scalars,
@@ -408,8 +423,9 @@ int ncg_mul_var_batch(ncg_ctx* ctx, int curve, size_t n, const void* points_affi
       }
       lo += cnt;
     }
-    drain_copy_streams(ctx);
+    const hipError_t ed = drain_copy_streams(ctx);
     if (rc) return rc;
+    if (e == hipSuccess) e = ed;
     if (e != hipSuccess) return set_err(ctx, NCG_ERR_HIP, "noble-gpu: mul_var_batch: %s", hipGetErrorString(e));
     return NCG_OK;
   }
@@ -679,7 +695,7 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
       }
       ncg::MsmPlan pl;
       if (ncg::msm_make_plan(curve, (int)std::max<size_t>(cnt, 1), whole.c, &pl) != 0) {
-        drain_copy_streams(ctx);   // copies of this and earlier parts are in flight
+        (void)drain_copy_streams(ctx);   // copies of this and earlier parts are in flight
         return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: cannot plan windows");
       }
       msm_apply_ctx(ctx, pl);
@@ -698,7 +714,8 @@ int ncg_msm(ncg_ctx* ctx, int curve, size_t n, const void* points_affine, const 
     uint32_t bad = 0xFFFFFFFFu;
     uint8_t inf_local = 0;
     if (e == hipSuccess) e = ncg::msm_finish(curve, last, d_fin, (uint32_t*)out_affine, &inf_local, ctx->stream, d_bad, &bad);
-    drain_copy_streams(ctx);
+    const hipError_t ed = drain_copy_streams(ctx);
+    if (e == hipSuccess) e = ed;
     if (e != hipSuccess) return set_err(ctx, NCG_ERR_HIP, "noble-gpu: msm: %s", hipGetErrorString(e));
     if (bad != 0xFFFFFFFFu)
       return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad);
@@ -724,6 +741,9 @@ static int points_build_stored(ncg_ctx* ctx, ncg_points* h, hipStream_t st) {
     return NCG_OK;
   }
   e = ncg::msm_points_to_stored(h->curve, (const uint32_t*)h->d_pts, (int)h->n, (uint32_t*)d, st);
+  // the cache is published only once the conversion has FINISHED: another lane's stream (ncg_msm_async_submit) or a later call on
+  // ctx->stream reads d_stored with no ordering against `st` otherwise (one synchronisation per set, as points_build_endo does)
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
     (void)hipFree(d);
     return set_err(ctx, NCG_ERR_HIP, "noble-gpu: points_to_stored: %s", hipGetErrorString(e));

@@ -112,6 +112,9 @@ struct JobState {
   int c = 0, nwin = 0;   // the WHOLE plan
   size_t stride = 0, sum_words = 0;
   bool identity = false;  // nothing to do: the result is the identity (curve.ts:878)
+  size_t slice = 0;       // SHARD_POINTS from ONE caller (ncg_msm_split_dev, ncg_msm_multi): points per part, so that a bad scalar
+                          // is reported with its index in the caller's arrays ('invalid scalar at index i', curve.ts:402); 0 = the
+                          // caller is one rank of several and only knows shard-relative indices
 };
 struct ShardJob {
   int curve = 0;
@@ -257,6 +260,8 @@ int job_finish_host(ncg_ctx* ctx, const JobRes& R, const JobState& S, void* out_
   uint32_t bad_idx = 0;
   const int bad_rank = ncg::msm_shard_first_bad(hs.data(), nparts, &bad_idx);
   if (bad_rank >= 0) {
+    if (S.mode == ncg::SHARD_POINTS && nparts > 1 && S.slice)
+      return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %zu (not below the group order)", S.slice * (size_t)bad_rank + bad_idx);
     if (S.mode == ncg::SHARD_POINTS && nparts > 1)
       return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm_sharded: invalid scalar at index %u of shard %d (not below the group order)", bad_idx, bad_rank);
     return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: invalid scalar at index %u (not below the group order)", bad_idx);
@@ -598,6 +603,7 @@ static int split_run(ncg_ctx* ctx, ShardJob J, int parts, size_t n, int pb, void
   int rc = job_enqueue_combine(ctx, R, &S, parts);
   if (rc) return rc;
   NCG_HIP(ctx, hipStreamSynchronize(st));
+  if (J.mode == ncg::SHARD_POINTS) S.slice = per;
   return job_finish_host(ctx, R, S, out_affine, out_is_inf);
 }
 
@@ -870,6 +876,7 @@ int ncg_msm_multi(ncg_multi* m, int curve, size_t n, const void* points_affine, 
   }
   (void)hipSetDevice(m->ctx[0]->device);
   if (rc) return fail(rc);
+  states[0].slice = per;
   rc = job_finish_host(m->ctx[0], R0, states[0], out_affine, out_is_inf);
   if (rc) return fail(rc);
   return NCG_OK;

@@ -50,11 +50,13 @@ def test_host_pointer_msm_in_parts_equals_device_msm(curve, n):
         finally:
             eng.host_unregister(pts_h)
             eng.host_unregister(sc_h)
-    if curve == BLS12_381_G1:                                  # the progression identity pins the value itself
-        sci = [int.from_bytes(cases[0][i].tobytes(), "little") for i in range(n)]
-        sci[n // 2 + 3] = 0
+    # the progression identity pins the VALUE itself on every curve (not only product == product): P_i = k_i G, so the MSM is
+    # (sum k_i s_i mod order) G, computed by the oracle (test/slow-curves.test.ts:185-252 builds its expected value this way)
+    for sc_h in cases:
+        sci = [int.from_bytes(sc_h[i].tobytes(), "little") for i in range(n)]
+        sci[n // 2 + 3] = 0                                    # the ZERO member contributes nothing
         exp = Pt.BASE.multiplyUnsafe(sum(k * s for k, s in zip(ks, sci)) % order).toAffine()
-        assert wire_to_affine(curve, eng.msm(curve, pts_h, cases[0])[0]) == exp
+        assert wire_to_affine(curve, eng.msm(curve, pts_h, sc_h)[0]) == exp
     bad = cases[0].copy()
     idx = n - 5                                                # in the last part
     bad[idx] = np.frombuffer(int(order).to_bytes(32, "little"), dtype=np.uint8)
@@ -69,7 +71,7 @@ def test_host_pointer_batch_multiply_in_chunks_equals_device_batch(curve, n):
     eng = get_engine()
     dev = torch.device("cuda", 0)
     Pt = ORACLE_CURVE[curve]
-    pts, _ = bench.gen_points(eng, curve, Pt, n, 0x77AA + curve, 0x9, dev, None)
+    pts, ks = bench.gen_points(eng, curve, Pt, n, 0x77AA + curve, 0x9, dev, None)
     sc = bench.gen_scalars(n, 250, 5, dev, edge_order=Pt.Fn.ORDER)
     out = torch.empty_like(pts)
     inf = torch.empty((n,), dtype=torch.uint8, device=dev)
@@ -77,6 +79,12 @@ def test_host_pointer_batch_multiply_in_chunks_equals_device_batch(curve, n):
     torch.cuda.synchronize()
     o, i = eng.mul_var_batch(curve, pts.cpu().numpy(), sc.cpu().numpy())
     assert np.array_equal(o, out.cpu().numpy()) and np.array_equal(i, inf.cpu().numpy())
+    # ... and the values themselves against the oracle on a sample that touches every chunk: s_i P_i = (s_i k_i mod order) G
+    sc_h = sc.cpu().numpy()
+    for j in list(range(0, n, n // 13)) + [n - 1]:
+        sj = int.from_bytes(sc_h[j].tobytes(), "little")
+        want = Pt.BASE.multiplyUnsafe(sj * ks[j] % Pt.Fn.ORDER)
+        assert wire_to_affine(curve, o[j]) == want.toAffine() and bool(i[j]) == want.is0(), j
     # the same call into result arrays the caller keeps and pins once (the chunk pattern 1 : 3 : 3 : 1 at n >= 2^19)
     ko, ki = np.zeros((n, POINT_BYTES[curve]), np.uint8), np.zeros((n,), np.uint8)
     eng.host_register(ko)
