@@ -912,6 +912,15 @@ def main():
         res = eng.upload_points(curve, pts.cpu().numpy())     # resident on every GPU (stored form built once)
         hs = {}
 
+        # the N = 1 figure OF THIS RUN: the same MSM on the same resident set by one GPU alone (every rank runs it on its own GPU at
+        # the same time - no collective; the slowest rank's time is kept), so that speedup_vs_n1 compares like with like
+        def step_1():
+            hs["one"] = res.msm_dev(dev_ptr(sc), stream)
+
+        st_1 = time_steps(step_1, K, W, dist_on)
+        wall_1 = max_over_ranks(st_1[0], dist_on, device)
+        assert wire_to_affine(curve, hs["one"][0]) == exp, "resident-set MSM mismatch"
+
         def step_w():
             hs["r"] = msm_sharded_windows(eng, curve, nn, 0, dev_ptr(sc), stream, device, res)
 
@@ -923,6 +932,11 @@ def main():
                "window_plan": eng.msm_plan_info(curve, nn),
                "transport": "ncg_msm_sharded_windows_dev (RCCL all-gather inside the C ABI)" if native_multi else "host-staged slots over torch.distributed (%s)" % args.backend,
                "note": "every rank holds all %d points (resident set) and scalars; rank r runs windows [w0, w0 + cnt); slots concatenated" % nn}
+        out["ms_per_msm_n1"] = wall_1 / K * 1e3
+        out["speedup_vs_n1"] = wall_1 / wall_w
+        out["n1_note"] = "ms_per_msm_n1 = the same MSM on the same resident set by ONE GPU (ncg_msm_resident_dev), measured in this run on every rank at once, slowest rank"
+        if native_multi:
+            out["rccl_ranks"] = eng.comm_count()[0]           # ncclCommCount of the communicator the all-gather ran on
         if native_multi:
             def chk(r):
                 assert wire_to_affine(curve, r[0]) == exp, "pipelined window-sharded MSM mismatch"
@@ -930,6 +944,7 @@ def main():
                                        lambda lane: eng.msm_async_collect(lane, curve), 3, K, W, dist_on, chk)
             pwall = max_over_ranks(pwall, dist_on, device)
             out["pipelined"] = {"value": nn * K / pwall, "unit": "points/s", "ms_per_msm": pwall / K * 1e3, "depth": 3, "completion_intervals_ms": iv,
+                                "speedup_vs_n1": wall_1 / pwall,
                                 "note": "3 window-sharded MSMs in flight per rank (ncg_msm_async_submit with NCG_MSM_ASYNC_WINDOWS); every result checked"}
         res.free()
         return out

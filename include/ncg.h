@@ -288,6 +288,8 @@ int ncg_comm_init(ncg_ctx* ctx, int nranks, int rank, const uint8_t* id128);
 int ncg_comm_destroy(ncg_ctx* ctx); /* also done by ncg_destroy */
 int ncg_comm_size(ncg_ctx* ctx);
 int ncg_comm_rank(ncg_ctx* ctx);
+/* the communicator's OWN answer (ncclCommCount / ncclCommUserRank); *out_ranks = 0 when the context has none */
+int ncg_comm_count(ncg_ctx* ctx, int* out_ranks, int* out_rank);
 int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max,
                         const void* points_affine_dev, const void* scalars_dev, void* out_affine,
                         uint8_t* out_is_inf, void* stream);

@@ -140,6 +140,7 @@ _OPTIONAL_PROTOS = {
     "ncg_comm_destroy": [_vp],
     "ncg_comm_size": [_vp],
     "ncg_comm_rank": [_vp],
+    "ncg_comm_count": [_vp, _vp, _vp],
     "ncg_msm_sharded_dev": [_vp, _i32, _sz, _sz, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_msm_split_dev": [_vp, _i32, _sz, _i32, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint8), _vp],
     "ncg_msm_shard_local_dev": [_vp, _i32, _sz, _sz, _vp, _vp, _vp, _vp],
@@ -395,6 +396,12 @@ class Engine:
 
     def comm_size(self):
         return self.lib.ncg_comm_size(self.h)
+
+    def comm_count(self):
+        """(ranks, my rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank); (0, -1) without one."""
+        n, me = ctypes.c_int(0), ctypes.c_int(-1)
+        self._check(self.lib.ncg_comm_count(self.h, ctypes.byref(n), ctypes.byref(me)))
+        return int(n.value), int(me.value)
 
     def has_comm(self):
         """True between comm_init and comm_destroy (comm_size() reads 1 both without a communicator and with one of a single rank)."""

@@ -38,6 +38,8 @@ struct Rccl {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;        // optional (diagnostics: ncg_comm_count)
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -58,6 +60,8 @@ const Rccl* rccl() {
     NCG_SYM(CommInitRank, ncclCommInitRank);
     NCG_SYM(CommInitAll, ncclCommInitAll);
     NCG_SYM(CommDestroy, ncclCommDestroy);
+    NCG_SYM(CommCount, ncclCommCount);
+    NCG_SYM(CommUserRank, ncclCommUserRank);
     NCG_SYM(AllGather, ncclAllGather);
     NCG_SYM(GroupStart, ncclGroupStart);
     NCG_SYM(GroupEnd, ncclGroupEnd);
@@ -177,7 +181,8 @@ int job_local_phase(ncg_ctx* ctx, const JobRes& R, const ShardJob& J, int slot_i
     ncg::msm_shard_window_range(whole.nwin, J.part, J.nparts, &w0, &cnt);
     // one or two windows per rank: 64 sort chunks per window instead of 256 (k_msm_bucket_totals walks the chunks serially:
     // 64 -> 21 us of a 0.9 ms share; measured 0.905 -> 0.856 ms for G = 8, no difference from 4 windows per rank up)
-    ncg::msm_plan_take_windows(local, w0, cnt, cnt <= 2 ? 128 : 512);
+    static const int share_q = ncg::knob("NCG_MSM_SHARE_QBLOCKS", 128);   // A/B builds
+    ncg::msm_plan_take_windows(local, w0, cnt, cnt <= 2 ? share_q : 512);
   }
   const size_t xw = ncg::msm_acc_words(curve);
   const size_t ng = (size_t)ncg::msm_ngroups(whole.c);
@@ -404,6 +409,22 @@ int ncg_comm_destroy(ncg_ctx* ctx) {
 
 int ncg_comm_size(ncg_ctx* ctx) { return ctx ? ctx->comm_size : 0; }
 int ncg_comm_rank(ncg_ctx* ctx) { return ctx ? ctx->comm_rank : -1; }
+// What the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank), not the context's bookkeeping: the number of
+// ranks the collectives of this context really span.  0 ranks = no communicator.  bench.py prints it as `rccl_ranks`.
+int ncg_comm_count(ncg_ctx* ctx, int* out_ranks, int* out_rank) {
+  if (!ctx || !out_ranks) return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: comm_count: NULL argument");
+  *out_ranks = 0;
+  if (out_rank) *out_rank = -1;
+  if (!ctx->comm) return NCG_OK;
+  const Rccl* r = rccl();
+  if (!r || !r->CommCount || !r->CommUserRank) return set_err(ctx, NCG_ERR_UNSUPPORTED, "noble-gpu: comm_count: librccl.so has no ncclCommCount");
+  int n = 0, me = -1;
+  NCG_NCCL(ctx, r, r->CommCount((ncclComm_t)ctx->comm, &n));
+  NCG_NCCL(ctx, r, r->CommUserRank((ncclComm_t)ctx->comm, &me));
+  *out_ranks = n;
+  if (out_rank) *out_rank = me;
+  return NCG_OK;
+}
 
 int ncg_msm_sharded_dev(ncg_ctx* ctx, int curve, size_t n_local, size_t n_max, const void* points_affine_dev,
                         const void* scalars_dev, void* out_affine, uint8_t* out_is_inf, void* stream) {

@@ -11,6 +11,7 @@
 //   A/B builds only (-DNCG_AB_BUILD, tools/ab_*.sh, tools/msm_debug.py): ignored by the shipped library
 //     NCG_MSM_SEG, NCG_MSM_QBLOCKS, NCG_MSM_XCD     accumulate segment length, sort chunk count, XCD-aware sort grid
 //     NCG_MSM_RUN_SERIAL, NCG_MSM_COOP_LEVEL        fix-up serial threshold, cooperative level kernel on / off
+//     NCG_MSM_MERGE_UNITS, NCG_MSM_TOTALS_SPLIT     cooperative fix-up units for per-window plans (1 / 0), column walk of the count arrays split over lanes
 //     NCG_MSM_HOST64                                host finish in 64-bit limbs on / off
 //     NCG_MSM_HOST_PARTS                            parts of the host-pointer MSM (1..8)
 //     NCG_MULVAR_HOST_EVEN                          1 = four equal chunks in the host-pointer batch multiply instead of 1 : 3 : 3 : 1

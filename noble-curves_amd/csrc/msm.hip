@@ -143,6 +143,60 @@ static __global__ void __launch_bounds__(256) k_msm_bucket_totals(uint32_t* __re
   bucket_start[(size_t)w * (pl.nb + 1) + b] = tot;  // size for now; k_msm_scan turns it into a start
 }
 
+// The same for plans with MANY chunks per window (the ranks of a window-sharded MSM: 2 windows x 256 chunks): a workgroup
+// takes 32 adjacent buckets (one 128-byte line per row) and cuts the column walk into 8 slices of Q / 8 rows, one per wave
+// quarter; slice totals meet in LDS, then every slice rewrites its rows with its base.  The walk is a chain of memory
+// latencies - Q / 8 rounds with eight loads in flight in the one-lane form, 64 us of a 0.88 ms share; here 2 x Q / 64 rounds.
+static __global__ void __launch_bounds__(256) k_msm_bucket_totals_split(uint32_t* __restrict__ counts,
+                                                                 uint32_t* __restrict__ bucket_start, MsmPlan pl) {
+  __shared__ uint32_t part[8][32];
+  const int bx = threadIdx.x & 31, qs = threadIdx.x >> 5, w = blockIdx.y;
+  const int b = blockIdx.x * 32 + bx;
+  const bool live = b < pl.nb;
+  const int per = (pl.Q + 7) >> 3;
+  const int q0 = min(pl.Q, qs * per), q1 = min(pl.Q, q0 + per);
+  uint32_t* cw = counts + (size_t)w * pl.Q * pl.nb + (live ? b : 0);
+  uint32_t tot = 0;
+  if (live) {
+    int q = q0;
+    for (; q + 8 <= q1; q += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = cw[(size_t)(q + j) * pl.nb];
+#pragma unroll
+      for (int j = 0; j < 8; j++) tot += v[j];
+    }
+    for (; q < q1; q++) tot += cw[(size_t)q * pl.nb];
+  }
+  part[qs][bx] = tot;
+  __syncthreads();
+  uint32_t base = 0, all = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t p = part[j][bx];
+    if (j < qs) base += p;
+    all += p;
+  }
+  if (!live) return;
+  int q = q0;
+  for (; q + 8 <= q1; q += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = cw[(size_t)(q + j) * pl.nb];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      cw[(size_t)(q + j) * pl.nb] = base;
+      base += v[j];
+    }
+  }
+  for (; q < q1; q++) {
+    const uint32_t v = cw[(size_t)q * pl.nb];
+    cw[(size_t)q * pl.nb] = base;
+    base += v;
+  }
+  if (qs == 0) bucket_start[(size_t)w * (pl.nb + 1) + b] = all;  // size for now; k_msm_scan turns it into a start
+}
+
 // One block per window: exclusive scan of the bucket sizes -> bucket_start[w][0..nb].  The sizes are staged in
 // LDS with coalesced loads (row stride padded by one word per 32 so that the per-thread runs do not share a bank),
 // every thread scans its run of nb / 1024 values there, a Hillis-Steele scan joins the per-thread totals.
@@ -233,6 +287,194 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __re
       dst[pos] = (level + (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
     }
   }
+}
+
+// ------------------------------------------------------------------ 3b. the counting sort in TWO levels (round 5)
+// What the one-level scatter costs is its stores: every entry is a 4-byte write at a random position of its window's 4 MB
+// list (16 M different 64-byte sectors per 2^20-point MSM), ~0.2 ms where the same kernel with stores that stay in a cache
+// takes 45 us (tools/exp_scatter.py).  Two levels make every store local:
+//   k_sort2_count / _scan   per (chunk, window): entries per COARSE RANGE of buckets (64 ranges of nb / 64 buckets) and their
+//                           prefix: region r of a window's list holds the buckets of range r (128 KB of counts per MSM where
+//                           the one-level sort writes, prefixes and re-reads 64 MB of per-chunk bucket counts).
+//   k_sort2_scatter         per (chunk, window): every entry goes to ITS REGION of a temporary list, packed with the low
+//                           bits of its bucket: a block writes 64 sequential streams - whole lines leave the cache.
+//   k_sort2_fine            per (range, window): counts the nb / 64 buckets of its region in LDS, writes their starts
+//                           (bucket_start: no separate totals / scan kernels), and places the entries - scattered stores again,
+//                           but inside ONE 64 KB span written by ONE workgroup.
+// Same result as hist / bucket_totals / scan / scatter: bucket_start[w][0..nb] and the per-window list grouped by bucket
+// (the order inside a bucket differs, as it already does between runs: LDS atomics).  Entries pack index, sign and the low
+// bucket bits into 32 bits, so the form is used when they fit (n <= 2^22 at c = 16) and for per-window lists only; other
+// plans keep the one-level kernels.
+constexpr int SORT2_RANGES = 64;
+
+// Slot from the LDS counter of `key` for every lane with `valid`; called by whole waves.  Lanes of a wave that hold the same
+// key would serialise on one LDS address (identical scalars, benchmark/bls12-381.ts:64-79: every lane, every time); when the
+// first key is shared by a quarter of the wave the claims are aggregated per distinct key instead (one atomic per key).
+__device__ __forceinline__ uint32_t sort2_claim(uint32_t* ctr, uint32_t key, bool valid) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const uint64_t act = __ballot(valid);
+  uint32_t pos = 0;
+  if (act == 0) return 0;
+  const int lane = (int)(threadIdx.x & 63);
+  const uint32_t k0 = (uint32_t)__shfl((int)key, __ffsll((long long)act) - 1);
+  if (__popcll(__ballot(valid && key == k0)) >= 16) {
+    uint64_t todo = act;
+    while (todo) {
+      const int f = __ffsll((long long)todo) - 1;
+      const uint32_t kf = (uint32_t)__shfl((int)key, f);
+      const uint64_t grp = __ballot(valid && key == kf) & todo;
+      uint32_t base = 0;
+      if (lane == f) base = atomicAdd(&ctr[kf], (uint32_t)__popcll(grp));
+      base = (uint32_t)__shfl((int)base, f);
+      if ((grp >> lane) & 1) pos = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+      todo &= ~grp;
+    }
+  } else if (valid) {
+    pos = atomicAdd(&ctr[key], 1u);
+  }
+  return pos;
+#else
+  return 0;
+#endif
+}
+
+// ccount[(w*Q + q)*64 + r]: entries of chunk q whose bucket lies in range r
+static __global__ void __launch_bounds__(1024) k_sort2_count(const int16_t* __restrict__ digits, uint32_t* __restrict__ ccount,
+                                                      MsmPlan pl, int sh) {
+  __shared__ uint32_t cnt[16][SORT2_RANGES];   // one copy per wave: the 64 counters are hot
+  int q, w;
+  if (!msm_sort_block(pl, q, w)) return;
+  for (int t = threadIdx.x; t < 16 * SORT2_RANGES; t += blockDim.x) (&cnt[0][0])[t] = 0;
+  __syncthreads();
+  uint32_t* mine = cnt[threadIdx.x >> 6];
+  const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
+  const int16_t* dg = digits + (size_t)w * pl.n;
+  for (int i0 = lo; i0 < hi; i0 += blockDim.x) {   // whole waves run every round (sort2_claim)
+    const int i = i0 + threadIdx.x;
+    const int d = i < hi ? dg[i] : 0;
+    (void)sort2_claim(mine, (uint32_t)(((d < 0 ? -d : d) - 1) >> sh) & (SORT2_RANGES - 1), d != 0);
+  }
+  __syncthreads();
+  if (threadIdx.x < SORT2_RANGES) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += cnt[k][threadIdx.x];
+    ccount[((size_t)w * pl.Q + q) * SORT2_RANGES + threadIdx.x] = t;
+  }
+}
+
+// per window: ccount -> exclusive prefix over the chunks inside each range; region_start[w][0..64] = where range r begins
+static __global__ void __launch_bounds__(SORT2_RANGES) k_sort2_scan(uint32_t* __restrict__ ccount, uint32_t* __restrict__ region_start,
+                                                             MsmPlan pl) {
+  __shared__ uint32_t tot[SORT2_RANGES];
+  const int w = blockIdx.x, r = threadIdx.x;
+  uint32_t* c = ccount + (size_t)w * pl.Q * SORT2_RANGES + r;
+  uint32_t run = 0;
+  int q = 0;
+  for (; q + 8 <= pl.Q; q += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = c[(size_t)(q + j) * SORT2_RANGES];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      c[(size_t)(q + j) * SORT2_RANGES] = run;
+      run += v[j];
+    }
+  }
+  for (; q < pl.Q; q++) {
+    const uint32_t v = c[(size_t)q * SORT2_RANGES];
+    c[(size_t)q * SORT2_RANGES] = run;
+    run += v;
+  }
+  tot[r] = run;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int k = 0; k < r; k++) before += tot[k];
+  uint32_t* rs = region_start + (size_t)w * (SORT2_RANGES + 1);
+  rs[r] = before;
+  if (r == SORT2_RANGES - 1) rs[SORT2_RANGES] = before + run;
+}
+
+// tmp[w][region of the entry's range] = index | sign << idxbits | (bucket & (2^sh - 1)) << (idxbits + 1)
+static __global__ void __launch_bounds__(1024) k_sort2_scatter(const int16_t* __restrict__ digits, const uint32_t* __restrict__ ccount,
+                                                        const uint32_t* __restrict__ region_start, uint32_t* __restrict__ tmp,
+                                                        MsmPlan pl, int sh, int idxbits) {
+  __shared__ uint32_t cur[SORT2_RANGES];
+  int q, w;
+  if (!msm_sort_block(pl, q, w)) return;
+  if (threadIdx.x < SORT2_RANGES)
+    cur[threadIdx.x] = region_start[(size_t)w * (SORT2_RANGES + 1) + threadIdx.x] + ccount[((size_t)w * pl.Q + q) * SORT2_RANGES + threadIdx.x];
+  __syncthreads();
+  const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
+  const int16_t* dg = digits + (size_t)w * pl.n;
+  uint32_t* dst = tmp + (size_t)w * pl.n;
+  const uint32_t lowmask = (1u << sh) - 1u;
+  for (int i0 = lo; i0 < hi; i0 += blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    const int d = i < hi ? dg[i] : 0;
+    const uint32_t bk = (uint32_t)((d < 0 ? -d : d) - 1);
+    const uint32_t pos = sort2_claim(cur, (bk >> sh) & (SORT2_RANGES - 1), d != 0);
+    if (d != 0) dst[pos] = (uint32_t)i | ((d < 0 ? 1u : 0u) << idxbits) | ((bk & lowmask) << (idxbits + 1));
+  }
+}
+
+// one workgroup per (range, window): bucket starts of the range, then the entries of its region into bucket order
+static __global__ void __launch_bounds__(512) k_sort2_fine(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
+                                                    uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ sorted, MsmPlan pl,
+                                                    int sh, int idxbits) {
+  __shared__ uint32_t cnt[512];
+  __shared__ uint32_t scan[512];
+  const int r = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+  const int BL = 1 << sh;   // buckets per range (<= 512: nb <= 2^15)
+  const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r], b = region_start[(size_t)w * (SORT2_RANGES + 1) + r + 1];
+  cnt[t] = 0;
+  __syncthreads();
+  const uint32_t* src = tmp + (size_t)w * pl.n;
+  for (uint32_t i0 = a; i0 < b; i0 += blockDim.x) {
+    const uint32_t i = i0 + t;
+    const uint32_t e = i < b ? src[i] : 0u;
+    (void)sort2_claim(cnt, e >> (idxbits + 1), i < b);
+  }
+  __syncthreads();
+  // inclusive Hillis-Steele scan of the <= 512 bucket sizes
+  uint32_t v = t < BL ? cnt[t] : 0u;
+  scan[t] = v;
+  __syncthreads();
+  for (int off = 1; off < 512; off <<= 1) {
+    const uint32_t add = t >= off ? scan[t - off] : 0u;
+    __syncthreads();
+    scan[t] += add;
+    __syncthreads();
+  }
+  const uint32_t start = a + scan[t] - v;   // exclusive
+  uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  if (t < BL) bs[(size_t)r * BL + t] = start;
+  if (r == SORT2_RANGES - 1 && t == 0) bs[pl.nb] = b;
+  __syncthreads();
+  cnt[t] = start;   // now the cursors
+  __syncthreads();
+  uint32_t* dst = sorted + (size_t)w * pl.n;
+  const uint32_t idxmask = (1u << idxbits) - 1u;
+  for (uint32_t i0 = a; i0 < b; i0 += blockDim.x) {
+    const uint32_t i = i0 + t;
+    const uint32_t e = i < b ? src[i] : 0u;
+    const uint32_t pos = sort2_claim(cnt, e >> (idxbits + 1), i < b);
+    if (i < b) dst[pos] = (e & idxmask) | (((e >> idxbits) & 1u) << 31);
+  }
+}
+
+// does the two-level form apply to this plan?  (*sh = log2 of the buckets per range, *idxbits = bits of an entry index)
+static bool msm_sort2_ok(const MsmPlan& pl, int n_max, int* sh, int* idxbits) {
+  static const int on = knob("NCG_MSM_SORT2", 1);   // A/B builds: 0 = the one-level kernels
+  if (!on || pl.shared || pl.nb < 1024 || pl.nb > (1 << 15)) return false;
+  int lg = 0;
+  while ((1 << lg) < pl.nb) lg++;
+  int ib = 1;
+  while (ib < 31 && (1u << ib) < (unsigned)std::max(n_max, 2)) ib++;
+  if (ib + 1 + (lg - 6) > 32) return false;
+  *sh = lg - 6;
+  *idxbits = ib;
+  return true;
 }
 
 // ------------------------------------------------------------------ 4. bucket accumulation
@@ -784,7 +1026,7 @@ int msm_make_plan(int curve, int n, int c_override, MsmPlan* pl) { return msm_ma
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct MsmLayout {
-  size_t pts_mont, digits, counts, bucket_start, sorted, shared_start, buckets, part_pts, part_meta, long_runs, bad, red0, red1, tail0, tail1, fin, total;
+  size_t pts_mont, digits, counts, bucket_start, sorted, sort_tmp, shared_start, buckets, part_pts, part_meta, long_runs, bad, red0, red1, tail0, tail1, fin, total;
 };
 
 static MsmSeg msm_seg(const MsmPlan& pl) {
@@ -834,6 +1076,10 @@ static MsmLayout msm_layout(const MsmPlan& pl_in) {
   L.counts = take((size_t)pl.nwin * pl.Q * pl.nb * 4);
   L.bucket_start = take((size_t)pl.nwin * (pl.nb + 1) * 4);
   L.sorted = take((size_t)pl.nwin * pl.n * 4);
+  {
+    int sh = 0, ib = 0;
+    L.sort_tmp = take(msm_sort2_ok(pl, pl.n, &sh, &ib) ? (size_t)pl.nwin * pl.n * 4 : 0);   // the regions of the two-level sort
+  }
   L.shared_start = take((size_t)(pl.nb + 1) * 4);
   const MsmPlan av = msm_acc_view(pl);   // one window of nwin * n entries in shared-bucket mode
   L.buckets = take((size_t)av.nwin * av.nb * MsmGroup<C>::ACC_WORDS * 4);
@@ -938,23 +1184,40 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     }
   }
   const dim3 sort_grid = pl.xcd_map ? dim3((unsigned)(pl.Q * ((pl.nwin + 7) & ~7))) : dim3(pl.Q, pl.nwin);
-  hipLaunchKernelGGL(k_msm_hist, sort_grid, dim3(1024), lds, st, digits, counts, pl);
-  hipLaunchKernelGGL(k_msm_bucket_totals, dim3((pl.nb + 255) / 256, pl.nwin), dim3(256), 0, st, counts, bstart, pl);
   uint32_t* shared_start = (uint32_t*)(base + L.shared_start);
-  if (pl.shared) {
-    hipLaunchKernelGGL(k_msm_shared_totals, dim3((pl.nb + 255) / 256), dim3(256), 0, st, bstart, shared_start, pl);
-    hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), (size_t)(pl.nb + pl.nb / 32 + 1) * 4, st, shared_start, pl);  // window 0 of a 1-window array
-    hipLaunchKernelGGL(k_msm_shared_starts, dim3((pl.nb + 255) / 256), dim3(256), 0, st, bstart, shared_start, pl);
+  int s2_sh = 0, s2_ib = 0;
+  if (msm_sort2_ok(pl, std::max(pl.n, pl.n_layout), &s2_sh, &s2_ib)) {   // two-level sort (3b): same bucket_start / sorted
+    uint32_t* ccount = counts;
+    uint32_t* region_start = counts + (size_t)pl.nwin * pl.Q * SORT2_RANGES;
+    uint32_t* tmp = (uint32_t*)(base + L.sort_tmp);
+    hipLaunchKernelGGL(k_sort2_count, sort_grid, dim3(1024), 0, st, digits, ccount, pl, s2_sh);
+    hipLaunchKernelGGL(k_sort2_scan, dim3(pl.nwin), dim3(SORT2_RANGES), 0, st, ccount, region_start, pl);
+    hipLaunchKernelGGL(k_sort2_scatter, sort_grid, dim3(1024), 0, st, digits, ccount, region_start, tmp, pl, s2_sh, s2_ib);
+    hipLaunchKernelGGL(k_sort2_fine, dim3(SORT2_RANGES, pl.nwin), dim3(512), 0, st, tmp, region_start, bstart, sorted, pl, s2_sh, s2_ib);
   } else {
-    hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), (size_t)(pl.nb + pl.nb / 32 + 1) * 4, st, bstart, pl);
-  }
-  {
-    const int passes = std::max(1, std::min(pl.scatter_passes, pl.nb / 256));
-    const int per = (pl.nb + passes - 1) / passes;
-    for (int p = 0; p < passes; p++) {
-      const int b_lo = p * per, b_hi = std::min(pl.nb, b_lo + per);
-      if (b_lo >= b_hi) break;
-      hipLaunchKernelGGL(k_msm_scatter, sort_grid, dim3(1024), (size_t)(b_hi - b_lo) * 4, st, digits, counts, bstart, sorted, pl, b_lo, b_hi);
+    hipLaunchKernelGGL(k_msm_hist, sort_grid, dim3(1024), lds, st, digits, counts, pl);
+    {
+      static const int split_knob = knob("NCG_MSM_TOTALS_SPLIT", -1);   // A/B builds: force on (1) / off (0)
+      if (split_knob >= 0 ? split_knob != 0 : pl.Q >= 64)
+        hipLaunchKernelGGL(k_msm_bucket_totals_split, dim3((pl.nb + 31) / 32, pl.nwin), dim3(256), 0, st, counts, bstart, pl);
+      else
+        hipLaunchKernelGGL(k_msm_bucket_totals, dim3((pl.nb + 255) / 256, pl.nwin), dim3(256), 0, st, counts, bstart, pl);
+    }
+    if (pl.shared) {
+      hipLaunchKernelGGL(k_msm_shared_totals, dim3((pl.nb + 255) / 256), dim3(256), 0, st, bstart, shared_start, pl);
+      hipLaunchKernelGGL(k_msm_scan, dim3(1), dim3(1024), (size_t)(pl.nb + pl.nb / 32 + 1) * 4, st, shared_start, pl);  // window 0 of a 1-window array
+      hipLaunchKernelGGL(k_msm_shared_starts, dim3((pl.nb + 255) / 256), dim3(256), 0, st, bstart, shared_start, pl);
+    } else {
+      hipLaunchKernelGGL(k_msm_scan, dim3(pl.nwin), dim3(1024), (size_t)(pl.nb + pl.nb / 32 + 1) * 4, st, bstart, pl);
+    }
+    {
+      const int passes = std::max(1, std::min(pl.scatter_passes, pl.nb / 256));
+      const int per = (pl.nb + passes - 1) / passes;
+      for (int p = 0; p < passes; p++) {
+        const int b_lo = p * per, b_hi = std::min(pl.nb, b_lo + per);
+        if (b_lo >= b_hi) break;
+        hipLaunchKernelGGL(k_msm_scatter, sort_grid, dim3(1024), (size_t)(b_hi - b_lo) * 4, st, digits, counts, bstart, sorted, pl, b_lo, b_hi);
+      }
     }
   }
   // from here on: the accumulate view (shared-bucket mode: ONE window of nwin * n entries whose starts are shared_start)
@@ -1004,12 +1267,19 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     // shared-bucket mode: every bucket holds nwin * n / nb entries, i.e. a handful of pieces - all of them, so their
     // owners add them serially (fully parallel over the buckets), as cooperative groups where the curve has them;
     // the work list is for the outliers only
-    if (pl.shared && CoopOK<D>::value) {
+    // ... and the same kernel for per-window plans whose buckets are cut into three or more pieces as a rule (lanes of `seg`
+    // entries against buckets of n / nb: the two-window ranks of a window-sharded MSM run seg = 16 against 32-entry buckets):
+    // the owner's serial chain of 3-4 single-lane additions (~30 us each on a lone wave) was the longest kernel of such a share
+    // after the accumulate itself (138 us of 0.88 ms); four lanes per addition shorten every link of it
+    static const int units_knob = knob("NCG_MSM_MERGE_UNITS", -1);   // A/B builds: force on (1) / off (0)
+    const bool merge_units = pl.shared || (units_knob >= 0 ? units_knob != 0 : run_serial_auto >= 3);
+    if (merge_units && CoopOK<D>::value) {
       constexpr bool MCOOP = CoopOK<D>::value;
       using K = TailOps<D, MCOOP>;
       const dim3 mgrid((unsigned)((((size_t)av.nb << K::UNIT_SHIFT) + 255) / 256), av.nwin);
       hipLaunchKernelGGL((k_msm_fixup_merge_units<D, MCOOP>), mgrid, dim3(256), (size_t)(256 >> K::UNIT_SHIFT) * K::LDS_WORDS * 4, st, part_pts,
-                         part_meta, acc_start, buckets, av, sg, long_runs, rs_forced ? run_serial : std::max(run_serial, MSM_RUN_SERIAL_SHARED));
+                         part_meta, acc_start, buckets, av, sg, long_runs,
+                         rs_forced ? run_serial : std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL));
     } else {
       hipLaunchKernelGGL(k_msm_fixup_merge<D>, grid, dim3(256), 0, st, part_pts, part_meta, acc_start, buckets, av, sg, long_runs,
                          rs_forced ? run_serial : std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL));

@@ -95,6 +95,7 @@ def test_rccl_communicator_single_rank():
         assert len(uid) == 128 and any(uid)
         eng.comm_init(1, 0, uid)
         assert eng.comm_size() == 1
+        assert eng.comm_count() == (1, 0)          # ncclCommCount / ncclCommUserRank of the communicator itself
         pw, sw, exp = _case(BLS12_381_G1, 90, 0xC0FFEE)
         dp, ds = _dev(pw), _dev(sw)
         got, inf = eng.msm_sharded_dev(BLS12_381_G1, 90, dp.data_ptr(), ds.data_ptr())
@@ -318,7 +319,7 @@ def _nccl_single_worker(port, q):
         t = torch.ones(4, device=dev)
         dist.all_reduce(t)                           # torch's own communicator is up first
         assert init_comm(eng, dev, single_ok=True)   # id broadcast over torch's group, ncclCommInitRank inside libncg
-        assert eng.has_comm() and eng.comm_size() == 1
+        assert eng.has_comm() and eng.comm_size() == 1 and eng.comm_count() == (1, 0)
         assert init_comm(eng, dev, single_ok=True)   # second call: nothing to do
         n = 300
         pw, sw, exp = _case(BLS12_381_G1, n, 0xACC1)

@@ -93,6 +93,11 @@ def msm_block(e):
             best = ("depth%s" % pl.get("depth", ""), pl)
         if best:
             out["in_flight"] = {"ms_per_msm": _r(best[1]["ms_per_msm"]), "lanes": best[0]}
+            if "speedup_vs_n1" in best[1]:
+                out["in_flight"]["speedup_vs_n1"] = _r(best[1]["speedup_vs_n1"], 4)
+    bp = e.get("by_points")
+    if isinstance(bp, dict) and "ms_per_msm" in bp:
+        out["by_points_ms"] = _r(bp["ms_per_msm"])
     ws = e.get("window_share")
     if isinstance(ws, dict):
         sh = {}
