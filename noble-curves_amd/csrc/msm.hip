@@ -293,31 +293,54 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __re
 // What the one-level scatter costs is its stores: every entry is a 4-byte write at a random position of its window's 4 MB
 // list (16 M different 64-byte sectors per 2^20-point MSM), ~0.2 ms where the same kernel with stores that stay in a cache
 // takes 45 us (tools/exp_scatter.py).  Two levels make every store local:
-//   k_sort2_count / _scan   per (chunk, window): entries per COARSE RANGE of buckets (64 ranges of nb / 64 buckets) and their
-//                           prefix: region r of a window's list holds the buckets of range r (128 KB of counts per MSM where
-//                           the one-level sort writes, prefixes and re-reads 64 MB of per-chunk bucket counts).
-//   k_sort2_scatter         per (chunk, window): every entry goes to ITS REGION of a temporary list, packed with the low
-//                           bits of its bucket: a block writes 64 sequential streams - whole lines leave the cache.
-//   k_sort2_fine            per (range, window): counts the nb / 64 buckets of its region in LDS, writes their starts
-//                           (bucket_start: no separate totals / scan kernels), and places the entries - scattered stores again,
-//                           but inside ONE 64 KB span written by ONE workgroup.
+//   k_sort2_count / _scan     per (chunk, window): entries per COARSE RANGE of buckets (64 ranges) and their prefix: region r
+//                             of a window's list holds the buckets of range r (128 KB of counts per MSM where the one-level
+//                             sort writes, prefixes and re-reads 64 MB of per-chunk bucket counts).
+//   k_sort2_scatter           per (chunk, window): every entry goes to ITS REGION of a temporary list, packed with the low
+//                             bits of its bucket: a block writes 64 sequential streams - whole lines leave the cache.
+//   k_sort2_fine_count / _scan / _place   a region is cut into SORT2_SLICES slices, one workgroup each (regions are NOT
+//                             equal: every zero scalar lands in the last bucket of every window, bench.py plants one in 17):
+//                             slice histograms of the range's buckets in LDS, their prefix (= bucket_start: no separate
+//                             totals / scan kernels), then the entries into bucket order - scattered stores again, but
+//                             inside one 64 KB span.
+// The TOP window of a plan can be short (255 bits = 19 x 13 + 8 for G2 at c = 13: digits 0..232) and its digits are never
+// negative: its 64 ranges cover the buckets it can reach only (msm_sort2_ok: top_sh), or four ranges would hold the whole window.
 // Same result as hist / bucket_totals / scan / scatter: bucket_start[w][0..nb] and the per-window list grouped by bucket
 // (the order inside a bucket differs, as it already does between runs: LDS atomics).  Entries pack index, sign and the low
 // bucket bits into 32 bits, so the form is used when they fit (n <= 2^22 at c = 16) and for per-window lists only; other
 // plans keep the one-level kernels.
 constexpr int SORT2_RANGES = 64;
+constexpr int SORT2_SLICES = 8;
+struct Sort2 {
+  int sh, idxbits;        // log2(buckets per range), bits of an entry index
+  int top_w, top_base, top_sh;   // local index of the plan's top window (-1: not in this plan / full), first bucket its ranges cover, its sh
+};
+__device__ __forceinline__ void sort2_window(const Sort2& s2, int w, uint32_t& base, int& sh) {
+  const bool top = w == s2.top_w;
+  base = top ? (uint32_t)s2.top_base : 0u;
+  sh = top ? s2.top_sh : s2.sh;
+}
 
-// Slot from the LDS counter of `key` for every lane with `valid`; called by whole waves.  Lanes of a wave that hold the same
-// key would serialise on one LDS address (identical scalars, benchmark/bls12-381.ts:64-79: every lane, every time); when the
-// first key is shared by a quarter of the wave the claims are aggregated per distinct key instead (one atomic per key).
+// Lanes of a wave that hold the same key serialise on one LDS address (identical scalars, benchmark/bls12-381.ts:64-79: every
+// lane, every time; the zero scalars of any input: the last bucket).  When the first key is shared by a quarter of the wave
+// the additions are aggregated per distinct key (one atomic per key and wave).  Called by whole waves.
+__device__ __forceinline__ bool sort2_heavy(uint32_t key, bool valid, uint64_t& act) {
+#ifdef __HIP_DEVICE_COMPILE__
+  act = __ballot(valid);
+  if (act == 0) return false;
+  const uint32_t k0 = (uint32_t)__shfl((int)key, __ffsll((long long)act) - 1);
+  return __popcll(__ballot(valid && key == k0)) >= 16;
+#else
+  return false;
+#endif
+}
+// position from the cursor of `key` for every valid lane
 __device__ __forceinline__ uint32_t sort2_claim(uint32_t* ctr, uint32_t key, bool valid) {
 #ifdef __HIP_DEVICE_COMPILE__
-  const uint64_t act = __ballot(valid);
+  uint64_t act;
   uint32_t pos = 0;
-  if (act == 0) return 0;
-  const int lane = (int)(threadIdx.x & 63);
-  const uint32_t k0 = (uint32_t)__shfl((int)key, __ffsll((long long)act) - 1);
-  if (__popcll(__ballot(valid && key == k0)) >= 16) {
+  if (sort2_heavy(key, valid, act)) {
+    const int lane = (int)(threadIdx.x & 63);
     uint64_t todo = act;
     while (todo) {
       const int f = __ffsll((long long)todo) - 1;
@@ -337,22 +360,52 @@ __device__ __forceinline__ uint32_t sort2_claim(uint32_t* ctr, uint32_t key, boo
   return 0;
 #endif
 }
+// the counting passes: no position comes back (the atomics are not waited for)
+__device__ __forceinline__ void sort2_tally(uint32_t* ctr, uint32_t key, bool valid) {
+#ifdef __HIP_DEVICE_COMPILE__
+  uint64_t act;
+  if (sort2_heavy(key, valid, act)) {
+    const int lane = (int)(threadIdx.x & 63);
+    uint64_t todo = act;
+    while (todo) {
+      const int f = __ffsll((long long)todo) - 1;
+      const uint32_t kf = (uint32_t)__shfl((int)key, f);
+      const uint64_t grp = __ballot(valid && key == kf) & todo;
+      if (lane == f) atomicAdd(&ctr[kf], (uint32_t)__popcll(grp));
+      todo &= ~grp;
+    }
+  } else if (valid) {
+    atomicAdd(&ctr[key], 1u);
+  }
+#endif
+}
 
 // ccount[(w*Q + q)*64 + r]: entries of chunk q whose bucket lies in range r
 static __global__ void __launch_bounds__(1024) k_sort2_count(const int16_t* __restrict__ digits, uint32_t* __restrict__ ccount,
-                                                      MsmPlan pl, int sh) {
+                                                      MsmPlan pl, Sort2 s2) {
   __shared__ uint32_t cnt[16][SORT2_RANGES];   // one copy per wave: the 64 counters are hot
   int q, w;
   if (!msm_sort_block(pl, q, w)) return;
   for (int t = threadIdx.x; t < 16 * SORT2_RANGES; t += blockDim.x) (&cnt[0][0])[t] = 0;
   __syncthreads();
   uint32_t* mine = cnt[threadIdx.x >> 6];
+  uint32_t base;
+  int sh;
+  sort2_window(s2, w, base, sh);
   const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
   const int16_t* dg = digits + (size_t)w * pl.n;
-  for (int i0 = lo; i0 < hi; i0 += blockDim.x) {   // whole waves run every round (sort2_claim)
-    const int i = i0 + threadIdx.x;
-    const int d = i < hi ? dg[i] : 0;
-    (void)sort2_claim(mine, (uint32_t)(((d < 0 ? -d : d) - 1) >> sh) & (SORT2_RANGES - 1), d != 0);
+  for (int i0 = lo; i0 < hi; i0 += 4 * (int)blockDim.x) {   // four loads in flight; whole waves run every round
+    int d[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x;
+      d[k] = i < hi ? dg[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t bk = (uint32_t)((d[k] < 0 ? -d[k] : d[k]) - 1);
+      if (d[k] != 0) atomicAdd(&mine[((bk - base) >> sh) & (SORT2_RANGES - 1)], 1u);   // (same-key lanes serialise in the LDS unit: 32 rounds per wave, harmless)
+    }
   }
   __syncthreads();
   if (threadIdx.x < SORT2_RANGES) {
@@ -395,76 +448,206 @@ static __global__ void __launch_bounds__(SORT2_RANGES) k_sort2_scan(uint32_t* __
   if (r == SORT2_RANGES - 1) rs[SORT2_RANGES] = before + run;
 }
 
-// tmp[w][region of the entry's range] = index | sign << idxbits | (bucket & (2^sh - 1)) << (idxbits + 1)
+// tmp[w][region of the entry's range] = index | sign << idxbits | (bucket offset inside the range) << (idxbits + 1)
 static __global__ void __launch_bounds__(1024) k_sort2_scatter(const int16_t* __restrict__ digits, const uint32_t* __restrict__ ccount,
                                                         const uint32_t* __restrict__ region_start, uint32_t* __restrict__ tmp,
-                                                        MsmPlan pl, int sh, int idxbits) {
+                                                        MsmPlan pl, Sort2 s2) {
   __shared__ uint32_t cur[SORT2_RANGES];
   int q, w;
   if (!msm_sort_block(pl, q, w)) return;
   if (threadIdx.x < SORT2_RANGES)
     cur[threadIdx.x] = region_start[(size_t)w * (SORT2_RANGES + 1) + threadIdx.x] + ccount[((size_t)w * pl.Q + q) * SORT2_RANGES + threadIdx.x];
   __syncthreads();
+  uint32_t base;
+  int sh;
+  sort2_window(s2, w, base, sh);
   const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
   const int16_t* dg = digits + (size_t)w * pl.n;
   uint32_t* dst = tmp + (size_t)w * pl.n;
   const uint32_t lowmask = (1u << sh) - 1u;
-  for (int i0 = lo; i0 < hi; i0 += blockDim.x) {
-    const int i = i0 + threadIdx.x;
-    const int d = i < hi ? dg[i] : 0;
-    const uint32_t bk = (uint32_t)((d < 0 ? -d : d) - 1);
-    const uint32_t pos = sort2_claim(cur, (bk >> sh) & (SORT2_RANGES - 1), d != 0);
-    if (d != 0) dst[pos] = (uint32_t)i | ((d < 0 ? 1u : 0u) << idxbits) | ((bk & lowmask) << (idxbits + 1));
+  for (int i0 = lo; i0 < hi; i0 += 4 * (int)blockDim.x) {
+    int d[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x;
+      d[k] = i < hi ? dg[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x;
+      const uint32_t off = (uint32_t)((d[k] < 0 ? -d[k] : d[k]) - 1) - base;
+      if (d[k] != 0) dst[atomicAdd(&cur[(off >> sh) & (SORT2_RANGES - 1)], 1u)] = (uint32_t)i | ((d[k] < 0 ? 1u : 0u) << s2.idxbits) | ((off & lowmask) << (s2.idxbits + 1));
+    }
   }
 }
 
-// one workgroup per (range, window): bucket starts of the range, then the entries of its region into bucket order
-static __global__ void __launch_bounds__(512) k_sort2_fine(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
-                                                    uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ sorted, MsmPlan pl,
-                                                    int sh, int idxbits) {
+// Regions of up to SORT2_STAGE entries (all of them unless the scalars are skewed) are sorted by ONE workgroup with the whole
+// region in registers and its output staged in LDS: one coalesced read, one coalesced write, no second pass over memory.
+// Larger regions (identical scalars; few distinct values) go through the three slice kernels below, which return at once
+// for every region the staged kernel took.
+constexpr int SORT2_PER_THREAD = 20;
+constexpr int SORT2_STAGE = 1024 * SORT2_PER_THREAD;   // entries: 80 KB of LDS
+// bucket starts of range r from the bucket sizes `v` (thread t = bucket t of the range; at most 512 buckets, blockDim >= 512);
+// returns this bucket's start.  Also writes what no range covers: the buckets past the top window's last range and the end marker.
+__device__ __forceinline__ uint32_t sort2_starts(uint32_t* scan, uint32_t v, uint32_t a, int r, int w, int BL, uint32_t base,
+                                                 const uint32_t* region_start, uint32_t* bucket_start, const MsmPlan& pl) {
+  const int t = threadIdx.x;
+  if (t < 512) scan[t] = v;
+  __syncthreads();
+  for (int off = 1; off < 512; off <<= 1) {   // inclusive Hillis-Steele scan of the <= 512 bucket sizes
+    const uint32_t add = (t < 512 && t >= off) ? scan[t - off] : 0u;
+    __syncthreads();
+    if (t < 512) scan[t] += add;
+    __syncthreads();
+  }
+  const uint32_t start = t < 512 ? a + scan[t] - v : 0u;
+  uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  const uint32_t first = base + (uint32_t)r * (uint32_t)BL;   // first bucket of this range
+  if (t < BL && first + t < (uint32_t)pl.nb) bs[first + t] = start;
+  if (r == 0)
+    for (uint32_t b = t; b < base; b += blockDim.x) bs[b] = 0;
+  if (r == SORT2_RANGES - 1) {
+    const uint32_t end = region_start[(size_t)w * (SORT2_RANGES + 1) + SORT2_RANGES];
+    for (uint32_t b = first + (uint32_t)BL + t; b <= (uint32_t)pl.nb; b += blockDim.x) bs[b] = end;
+  }
+  return start;
+}
+static __global__ void __launch_bounds__(1024) k_sort2_fine_staged(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
+                                                            uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ sorted, MsmPlan pl,
+                                                            Sort2 s2) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t stage[];   // SORT2_STAGE entries
   __shared__ uint32_t cnt[512];
   __shared__ uint32_t scan[512];
   const int r = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
-  const int BL = 1 << sh;   // buckets per range (<= 512: nb <= 2^15)
   const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r], b = region_start[(size_t)w * (SORT2_RANGES + 1) + r + 1];
+  if (b - a > (uint32_t)SORT2_STAGE) return;   // the slice kernels take it
+  uint32_t base;
+  int sh;
+  sort2_window(s2, w, base, sh);
+  if (t < 512) cnt[t] = 0;
+  __syncthreads();
+  const uint32_t* src = tmp + (size_t)w * pl.n;
+  uint32_t e[SORT2_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < SORT2_PER_THREAD; k++) {
+    const uint32_t i = a + (uint32_t)k * 1024u + (uint32_t)t;
+    e[k] = i < b ? src[i] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < SORT2_PER_THREAD; k++)
+    if (a + (uint32_t)k * 1024u + (uint32_t)t < b) atomicAdd(&cnt[e[k] >> (s2.idxbits + 1)], 1u);
+  __syncthreads();
+  const uint32_t v = t < 512 ? cnt[t] : 0u;
+  const uint32_t start = sort2_starts(scan, v, a, r, w, 1 << sh, base, region_start, bucket_start, pl);
+  __syncthreads();
+  if (t < 512) cnt[t] = start - a;   // cursors inside the stage
+  __syncthreads();
+  const uint32_t idxmask = (1u << s2.idxbits) - 1u;
+#pragma unroll
+  for (int k = 0; k < SORT2_PER_THREAD; k++)
+    if (a + (uint32_t)k * 1024u + (uint32_t)t < b)
+      stage[atomicAdd(&cnt[e[k] >> (s2.idxbits + 1)], 1u)] = (e[k] & idxmask) | (((e[k] >> s2.idxbits) & 1u) << 31);
+  __syncthreads();
+  uint32_t* dst = sorted + (size_t)w * pl.n + a;
+  for (uint32_t i = t; i < b - a; i += 1024) dst[i] = stage[i];
+}
+
+// slice s of region (r, w): [a + s * per, a + (s + 1) * per) with per = ceil(len / SLICES); false: the staged kernel took the region
+__device__ __forceinline__ bool sort2_slice(const uint32_t* region_start, int w, int r, int s, uint32_t& lo, uint32_t& hi) {
+  const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r], b = region_start[(size_t)w * (SORT2_RANGES + 1) + r + 1];
+  if (b - a <= (uint32_t)SORT2_STAGE) return false;
+  const uint32_t per = (b - a + SORT2_SLICES - 1) / SORT2_SLICES;
+  lo = min(b, a + (uint32_t)s * per);
+  hi = min(b, lo + per);
+  return true;
+}
+// fcount[((w*64 + r)*SLICES + s) << sh | t]: entries of slice s in bucket t of range r
+static __global__ void __launch_bounds__(512) k_sort2_fine_count(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
+                                                          uint32_t* __restrict__ fcount, MsmPlan pl, Sort2 s2) {
+  __shared__ uint32_t cnt[512];
+  const int r = blockIdx.x / SORT2_SLICES, s = blockIdx.x % SORT2_SLICES, w = blockIdx.y, t = threadIdx.x;
+  uint32_t lo, hi;
+  if (!sort2_slice(region_start, w, r, s, lo, hi)) return;
+  uint32_t base;
+  int sh;
+  sort2_window(s2, w, base, sh);
   cnt[t] = 0;
   __syncthreads();
   const uint32_t* src = tmp + (size_t)w * pl.n;
-  for (uint32_t i0 = a; i0 < b; i0 += blockDim.x) {
-    const uint32_t i = i0 + t;
-    const uint32_t e = i < b ? src[i] : 0u;
-    (void)sort2_claim(cnt, e >> (idxbits + 1), i < b);
+  for (uint32_t i0 = lo; i0 < hi; i0 += 4 * 512) {
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = i0 + k * 512 + t;
+      e[k] = i < hi ? src[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) sort2_tally(cnt, e[k] >> (s2.idxbits + 1), i0 + k * 512 + t < hi);
   }
   __syncthreads();
-  // inclusive Hillis-Steele scan of the <= 512 bucket sizes
-  uint32_t v = t < BL ? cnt[t] : 0u;
-  scan[t] = v;
-  __syncthreads();
-  for (int off = 1; off < 512; off <<= 1) {
-    const uint32_t add = t >= off ? scan[t - off] : 0u;
-    __syncthreads();
-    scan[t] += add;
-    __syncthreads();
+  if (t < (1 << sh)) fcount[((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES + s) << s2.sh) + t] = cnt[t];
+}
+// one workgroup per oversized (range, window): bucket sizes = sums over the slices -> bucket_start; fcount becomes each slice's cursor
+static __global__ void __launch_bounds__(512) k_sort2_fine_scan(const uint32_t* __restrict__ region_start, uint32_t* __restrict__ fcount,
+                                                         uint32_t* __restrict__ bucket_start, MsmPlan pl, Sort2 s2) {
+  __shared__ uint32_t scan[512];
+  const int r = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
+  uint32_t lo, hi;
+  if (!sort2_slice(region_start, w, r, 0, lo, hi)) return;
+  uint32_t base;
+  int sh;
+  sort2_window(s2, w, base, sh);
+  const int BL = 1 << sh;
+  const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r];
+  uint32_t* fc = fcount + ((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES) << s2.sh) + t;
+  uint32_t c[SORT2_SLICES], v = 0;
+#pragma unroll
+  for (int s = 0; s < SORT2_SLICES; s++) {
+    c[s] = t < BL ? fc[(size_t)s << s2.sh] : 0u;
+    v += c[s];
   }
-  const uint32_t start = a + scan[t] - v;   // exclusive
-  uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
-  if (t < BL) bs[(size_t)r * BL + t] = start;
-  if (r == SORT2_RANGES - 1 && t == 0) bs[pl.nb] = b;
+  uint32_t start = sort2_starts(scan, v, a, r, w, BL, base, region_start, bucket_start, pl);
+  if (t < BL) {
+#pragma unroll
+    for (int s = 0; s < SORT2_SLICES; s++) {
+      fc[(size_t)s << s2.sh] = start;
+      start += c[s];
+    }
+  }
+}
+static __global__ void __launch_bounds__(512) k_sort2_fine_place(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
+                                                          const uint32_t* __restrict__ fcount, uint32_t* __restrict__ sorted, MsmPlan pl,
+                                                          Sort2 s2) {
+  __shared__ uint32_t cur[512];
+  const int r = blockIdx.x / SORT2_SLICES, s = blockIdx.x % SORT2_SLICES, w = blockIdx.y, t = threadIdx.x;
+  uint32_t lo, hi;
+  if (!sort2_slice(region_start, w, r, s, lo, hi)) return;
+  uint32_t base;
+  int sh;
+  sort2_window(s2, w, base, sh);
+  cur[t] = t < (1 << sh) ? fcount[((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES + s) << s2.sh) + t] : 0u;
   __syncthreads();
-  cnt[t] = start;   // now the cursors
-  __syncthreads();
+  const uint32_t* src = tmp + (size_t)w * pl.n;
   uint32_t* dst = sorted + (size_t)w * pl.n;
-  const uint32_t idxmask = (1u << idxbits) - 1u;
-  for (uint32_t i0 = a; i0 < b; i0 += blockDim.x) {
-    const uint32_t i = i0 + t;
-    const uint32_t e = i < b ? src[i] : 0u;
-    const uint32_t pos = sort2_claim(cnt, e >> (idxbits + 1), i < b);
-    if (i < b) dst[pos] = (e & idxmask) | (((e >> idxbits) & 1u) << 31);
+  const uint32_t idxmask = (1u << s2.idxbits) - 1u;
+  for (uint32_t i0 = lo; i0 < hi; i0 += 4 * 512) {
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = i0 + k * 512 + t;
+      e[k] = i < hi ? src[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool valid = i0 + k * 512 + t < hi;
+      const uint32_t pos = sort2_claim(cur, e[k] >> (s2.idxbits + 1), valid);
+      if (valid) dst[pos] = (e[k] & idxmask) | (((e[k] >> s2.idxbits) & 1u) << 31);
+    }
   }
 }
 
-// does the two-level form apply to this plan?  (*sh = log2 of the buckets per range, *idxbits = bits of an entry index)
-static bool msm_sort2_ok(const MsmPlan& pl, int n_max, int* sh, int* idxbits) {
+// does the two-level form apply to this plan?  Fills the per-plan constants.
+static bool msm_sort2_ok(const MsmPlan& pl, int n_max, Sort2* s2) {
   static const int on = knob("NCG_MSM_SORT2", 1);   // A/B builds: 0 = the one-level kernels
   if (!on || pl.shared || pl.nb < 1024 || pl.nb > (1 << 15)) return false;
   int lg = 0;
@@ -472,9 +655,43 @@ static bool msm_sort2_ok(const MsmPlan& pl, int n_max, int* sh, int* idxbits) {
   int ib = 1;
   while (ib < 31 && (1u << ib) < (unsigned)std::max(n_max, 2)) ib++;
   if (ib + 1 + (lg - 6) > 32) return false;
-  *sh = lg - 6;
-  *idxbits = ib;
+  s2->sh = lg - 6;
+  s2->idxbits = ib;
+  s2->top_w = -1;
+  s2->top_base = 0;
+  s2->top_sh = lg - 6;
+  if (!pl.endo) {   // generic plans: the top window's field v = (k + H') >> c (nwin - 1) lies in [half, vmax] (H' carries the window's
+                    // own half), so its digits v - half are >= 0 and its buckets are [0, vmax - half) only
+    const int nwt = pl.nwin_total ? pl.nwin_total : pl.nwin;
+    const int wl = nwt - 1 - pl.w0;   // local index of the top window
+    if (wl >= 0 && wl < pl.nwin) {
+      uint32_t sum[11] = {0};
+      uint64_t cy = 0;
+      for (int i = 0; i < 10; i++) {
+        const uint64_t t = (uint64_t)(i < 8 ? pl.order[i] : 0u) + pl.hconst[i] + cy;
+        sum[i] = (uint32_t)t;
+        cy = t >> 32;
+      }
+      sum[10] = (uint32_t)cy;
+      const int bit = pl.c * (nwt - 1);
+      const uint64_t two = ((uint64_t)sum[(bit >> 5) + 1] << 32) | sum[bit >> 5];
+      const uint32_t vmax = (uint32_t)(two >> (bit & 31)) & ((1u << pl.c) - 1u);
+      const uint32_t half = 1u << (pl.c - 1);
+      const uint32_t span = vmax >= half ? vmax - half + 2u : half;   // buckets the window can reach (+ 1 of slack)
+      int tb = 0;
+      while ((1u << tb) < span) tb++;
+      if ((1u << tb) < half) {
+        s2->top_w = wl;
+        s2->top_base = 0;
+        s2->top_sh = std::max(0, tb - 6);
+      }
+    }
+  }
   return true;
+}
+// words of the scratch the two-level sort keeps where the one-level sort keeps its per-chunk bucket counts
+static size_t msm_sort2_words(const MsmPlan& pl) {
+  return (size_t)pl.nwin * ((size_t)pl.Q * SORT2_RANGES + SORT2_RANGES + 1 + 3) + (size_t)pl.nwin * pl.nb * SORT2_SLICES;
 }
 
 // ------------------------------------------------------------------ 4. bucket accumulation
@@ -1073,13 +1290,12 @@ static MsmLayout msm_layout(const MsmPlan& pl_in) {
   if (pl.Q_layout > pl.Q) pl.Q = pl.Q_layout;
   L.pts_mont = take((pl.endo || pl.pts_stored || pl.shared) ? 0 : (size_t)pl.n * MsmGroup<C>::AFF_WORDS * 4);  // else: the caller's array
   L.digits = take((size_t)pl.nwin * pl.n * 2);
-  L.counts = take((size_t)pl.nwin * pl.Q * pl.nb * 4);
+  Sort2 s2l;
+  const bool sort2 = msm_sort2_ok(pl, pl.n, &s2l);
+  L.counts = take(sort2 ? msm_sort2_words(pl) * 4 : (size_t)pl.nwin * pl.Q * pl.nb * 4);
   L.bucket_start = take((size_t)pl.nwin * (pl.nb + 1) * 4);
   L.sorted = take((size_t)pl.nwin * pl.n * 4);
-  {
-    int sh = 0, ib = 0;
-    L.sort_tmp = take(msm_sort2_ok(pl, pl.n, &sh, &ib) ? (size_t)pl.nwin * pl.n * 4 : 0);   // the regions of the two-level sort
-  }
+  L.sort_tmp = take(sort2 ? (size_t)pl.nwin * pl.n * 4 : 0);   // the regions of the two-level sort
   L.shared_start = take((size_t)(pl.nb + 1) * 4);
   const MsmPlan av = msm_acc_view(pl);   // one window of nwin * n entries in shared-bucket mode
   L.buckets = take((size_t)av.nwin * av.nb * MsmGroup<C>::ACC_WORDS * 4);
@@ -1185,15 +1401,30 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   }
   const dim3 sort_grid = pl.xcd_map ? dim3((unsigned)(pl.Q * ((pl.nwin + 7) & ~7))) : dim3(pl.Q, pl.nwin);
   uint32_t* shared_start = (uint32_t*)(base + L.shared_start);
-  int s2_sh = 0, s2_ib = 0;
-  if (msm_sort2_ok(pl, std::max(pl.n, pl.n_layout), &s2_sh, &s2_ib)) {   // two-level sort (3b): same bucket_start / sorted
+  Sort2 s2;
+  if (msm_sort2_ok(pl, std::max(pl.n, pl.n_layout), &s2)) {   // two-level sort (3b): same bucket_start / sorted
     uint32_t* ccount = counts;
-    uint32_t* region_start = counts + (size_t)pl.nwin * pl.Q * SORT2_RANGES;
+    uint32_t* region_start = ccount + (size_t)pl.nwin * pl.Q * SORT2_RANGES;
+    uint32_t* fcount = region_start + (((size_t)pl.nwin * (SORT2_RANGES + 1) + 3) & ~(size_t)3);
     uint32_t* tmp = (uint32_t*)(base + L.sort_tmp);
-    hipLaunchKernelGGL(k_sort2_count, sort_grid, dim3(1024), 0, st, digits, ccount, pl, s2_sh);
+    hipLaunchKernelGGL(k_sort2_count, sort_grid, dim3(1024), 0, st, digits, ccount, pl, s2);
     hipLaunchKernelGGL(k_sort2_scan, dim3(pl.nwin), dim3(SORT2_RANGES), 0, st, ccount, region_start, pl);
-    hipLaunchKernelGGL(k_sort2_scatter, sort_grid, dim3(1024), 0, st, digits, ccount, region_start, tmp, pl, s2_sh, s2_ib);
-    hipLaunchKernelGGL(k_sort2_fine, dim3(SORT2_RANGES, pl.nwin), dim3(512), 0, st, tmp, region_start, bstart, sorted, pl, s2_sh, s2_ib);
+    hipLaunchKernelGGL(k_sort2_scatter, sort_grid, dim3(1024), 0, st, digits, ccount, region_start, tmp, pl, s2);
+    {
+      static bool attr_done[16] = {};
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+        e = hipFuncSetAttribute((const void*)k_sort2_fine_staged, hipFuncAttributeMaxDynamicSharedMemorySize, SORT2_STAGE * 4);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 16) attr_done[dev] = true;
+      }
+    }
+    hipLaunchKernelGGL(k_sort2_fine_staged, dim3(SORT2_RANGES, pl.nwin), dim3(1024), (size_t)SORT2_STAGE * 4, st, tmp, region_start, bstart, sorted, pl, s2);
+    // regions too large for the staged kernel (skewed scalars): every workgroup of these three returns at once otherwise
+    hipLaunchKernelGGL(k_sort2_fine_count, dim3(SORT2_RANGES * SORT2_SLICES, pl.nwin), dim3(512), 0, st, tmp, region_start, fcount, pl, s2);
+    hipLaunchKernelGGL(k_sort2_fine_scan, dim3(SORT2_RANGES, pl.nwin), dim3(512), 0, st, region_start, fcount, bstart, pl, s2);
+    hipLaunchKernelGGL(k_sort2_fine_place, dim3(SORT2_RANGES * SORT2_SLICES, pl.nwin), dim3(512), 0, st, tmp, region_start, fcount, sorted, pl, s2);
   } else {
     hipLaunchKernelGGL(k_msm_hist, sort_grid, dim3(1024), lds, st, digits, counts, pl);
     {
