@@ -418,9 +418,10 @@ static __global__ void __launch_bounds__(1024) k_sort2_count(const int16_t* __re
 
 // per window: ccount -> exclusive prefix over the chunks inside each range; region_start[w][0..64] = where range r begins
 static __global__ void __launch_bounds__(SORT2_RANGES) k_sort2_scan(uint32_t* __restrict__ ccount, uint32_t* __restrict__ region_start,
-                                                             MsmPlan pl) {
+                                                             uint32_t* __restrict__ oversize, MsmPlan pl) {
   __shared__ uint32_t tot[SORT2_RANGES];
   const int w = blockIdx.x, r = threadIdx.x;
+  if (w == 0 && r == 0) oversize[0] = 0;   // the work list of k_sort2_fine_staged
   uint32_t* c = ccount + (size_t)w * pl.Q * SORT2_RANGES + r;
   uint32_t run = 0;
   int q = 0;
@@ -513,14 +514,17 @@ __device__ __forceinline__ uint32_t sort2_starts(uint32_t* scan, uint32_t v, uin
   return start;
 }
 static __global__ void __launch_bounds__(1024) k_sort2_fine_staged(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
-                                                            uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ sorted, MsmPlan pl,
-                                                            Sort2 s2) {
+                                                            uint32_t* __restrict__ oversize, uint32_t* __restrict__ bucket_start,
+                                                            uint32_t* __restrict__ sorted, MsmPlan pl, Sort2 s2) {
   extern __shared__ __attribute__((aligned(16))) uint32_t stage[];   // SORT2_STAGE entries
   __shared__ uint32_t cnt[512];
   __shared__ uint32_t scan[512];
   const int r = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
   const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r], b = region_start[(size_t)w * (SORT2_RANGES + 1) + r + 1];
-  if (b - a > (uint32_t)SORT2_STAGE) return;   // the slice kernels take it
+  if (b - a > (uint32_t)SORT2_STAGE) {   // the slice kernels take it
+    if (threadIdx.x == 0) oversize[1 + atomicAdd(&oversize[0], 1u)] = ((uint32_t)w << 8) | (uint32_t)r;
+    return;
+  }
   uint32_t base;
   int sh;
   sort2_window(s2, w, base, sh);
@@ -552,97 +556,117 @@ static __global__ void __launch_bounds__(1024) k_sort2_fine_staged(const uint32_
   for (uint32_t i = t; i < b - a; i += 1024) dst[i] = stage[i];
 }
 
-// slice s of region (r, w): [a + s * per, a + (s + 1) * per) with per = ceil(len / SLICES); false: the staged kernel took the region
-__device__ __forceinline__ bool sort2_slice(const uint32_t* region_start, int w, int r, int s, uint32_t& lo, uint32_t& hi) {
+// The oversized regions: k_sort2_fine_staged appends (window, range) to a work list (oversize[0] = count, cleared by
+// k_sort2_scan), and the three slice kernels run a SMALL fixed grid over list x slices - with an empty list (every input whose
+// scalars are not skewed) their workgroups read one word and leave.
+constexpr int SORT2_FALLBACK_BLOCKS = 128;
+// slice s of region (r, w): [a + s * per, a + (s + 1) * per) with per = ceil(len / SLICES)
+__device__ __forceinline__ void sort2_slice(const uint32_t* region_start, int w, int r, int s, uint32_t& lo, uint32_t& hi) {
   const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r], b = region_start[(size_t)w * (SORT2_RANGES + 1) + r + 1];
-  if (b - a <= (uint32_t)SORT2_STAGE) return false;
   const uint32_t per = (b - a + SORT2_SLICES - 1) / SORT2_SLICES;
   lo = min(b, a + (uint32_t)s * per);
   hi = min(b, lo + per);
-  return true;
 }
 // fcount[((w*64 + r)*SLICES + s) << sh | t]: entries of slice s in bucket t of range r
 static __global__ void __launch_bounds__(512) k_sort2_fine_count(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
-                                                          uint32_t* __restrict__ fcount, MsmPlan pl, Sort2 s2) {
+                                                          const uint32_t* __restrict__ oversize, uint32_t* __restrict__ fcount, MsmPlan pl,
+                                                          Sort2 s2) {
   __shared__ uint32_t cnt[512];
-  const int r = blockIdx.x / SORT2_SLICES, s = blockIdx.x % SORT2_SLICES, w = blockIdx.y, t = threadIdx.x;
-  uint32_t lo, hi;
-  if (!sort2_slice(region_start, w, r, s, lo, hi)) return;
-  uint32_t base;
-  int sh;
-  sort2_window(s2, w, base, sh);
-  cnt[t] = 0;
-  __syncthreads();
-  const uint32_t* src = tmp + (size_t)w * pl.n;
-  for (uint32_t i0 = lo; i0 < hi; i0 += 4 * 512) {
-    uint32_t e[4];
+  const int t = threadIdx.x;
+  const uint32_t items = oversize[0] * SORT2_SLICES;
+  for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const uint32_t wr = oversize[1 + item / SORT2_SLICES];
+    const int w = (int)(wr >> 8), r = (int)(wr & 255u), s = (int)(item % SORT2_SLICES);
+    uint32_t lo, hi;
+    sort2_slice(region_start, w, r, s, lo, hi);
+    uint32_t base;
+    int sh;
+    sort2_window(s2, w, base, sh);
+    cnt[t] = 0;
+    __syncthreads();
+    const uint32_t* src = tmp + (size_t)w * pl.n;
+    for (uint32_t i0 = lo; i0 < hi; i0 += 4 * 512) {
+      uint32_t e[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t i = i0 + k * 512 + t;
-      e[k] = i < hi ? src[i] : 0u;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t i = i0 + k * 512 + t;
+        e[k] = i < hi ? src[i] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) sort2_tally(cnt, e[k] >> (s2.idxbits + 1), i0 + k * 512 + t < hi);
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) sort2_tally(cnt, e[k] >> (s2.idxbits + 1), i0 + k * 512 + t < hi);
+    __syncthreads();
+    if (t < (1 << sh)) fcount[((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES + s) << s2.sh) + t] = cnt[t];
+    __syncthreads();
   }
-  __syncthreads();
-  if (t < (1 << sh)) fcount[((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES + s) << s2.sh) + t] = cnt[t];
 }
-// one workgroup per oversized (range, window): bucket sizes = sums over the slices -> bucket_start; fcount becomes each slice's cursor
-static __global__ void __launch_bounds__(512) k_sort2_fine_scan(const uint32_t* __restrict__ region_start, uint32_t* __restrict__ fcount,
-                                                         uint32_t* __restrict__ bucket_start, MsmPlan pl, Sort2 s2) {
+// per oversized (range, window): bucket sizes = sums over the slices -> bucket_start; fcount becomes each slice's cursor
+static __global__ void __launch_bounds__(512) k_sort2_fine_scan(const uint32_t* __restrict__ region_start, const uint32_t* __restrict__ oversize,
+                                                         uint32_t* __restrict__ fcount, uint32_t* __restrict__ bucket_start, MsmPlan pl,
+                                                         Sort2 s2) {
   __shared__ uint32_t scan[512];
-  const int r = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
-  uint32_t lo, hi;
-  if (!sort2_slice(region_start, w, r, 0, lo, hi)) return;
-  uint32_t base;
-  int sh;
-  sort2_window(s2, w, base, sh);
-  const int BL = 1 << sh;
-  const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r];
-  uint32_t* fc = fcount + ((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES) << s2.sh) + t;
-  uint32_t c[SORT2_SLICES], v = 0;
-#pragma unroll
-  for (int s = 0; s < SORT2_SLICES; s++) {
-    c[s] = t < BL ? fc[(size_t)s << s2.sh] : 0u;
-    v += c[s];
-  }
-  uint32_t start = sort2_starts(scan, v, a, r, w, BL, base, region_start, bucket_start, pl);
-  if (t < BL) {
+  const int t = threadIdx.x;
+  const uint32_t items = oversize[0];
+  for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const uint32_t wr = oversize[1 + item];
+    const int w = (int)(wr >> 8), r = (int)(wr & 255u);
+    uint32_t base;
+    int sh;
+    sort2_window(s2, w, base, sh);
+    const int BL = 1 << sh;
+    const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r];
+    uint32_t* fc = fcount + ((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES) << s2.sh) + t;
+    uint32_t c[SORT2_SLICES], v = 0;
 #pragma unroll
     for (int s = 0; s < SORT2_SLICES; s++) {
-      fc[(size_t)s << s2.sh] = start;
-      start += c[s];
+      c[s] = t < BL ? fc[(size_t)s << s2.sh] : 0u;
+      v += c[s];
     }
+    uint32_t start = sort2_starts(scan, v, a, r, w, BL, base, region_start, bucket_start, pl);
+    if (t < BL) {
+#pragma unroll
+      for (int s = 0; s < SORT2_SLICES; s++) {
+        fc[(size_t)s << s2.sh] = start;
+        start += c[s];
+      }
+    }
+    __syncthreads();
   }
 }
 static __global__ void __launch_bounds__(512) k_sort2_fine_place(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
-                                                          const uint32_t* __restrict__ fcount, uint32_t* __restrict__ sorted, MsmPlan pl,
-                                                          Sort2 s2) {
+                                                          const uint32_t* __restrict__ oversize, const uint32_t* __restrict__ fcount,
+                                                          uint32_t* __restrict__ sorted, MsmPlan pl, Sort2 s2) {
   __shared__ uint32_t cur[512];
-  const int r = blockIdx.x / SORT2_SLICES, s = blockIdx.x % SORT2_SLICES, w = blockIdx.y, t = threadIdx.x;
-  uint32_t lo, hi;
-  if (!sort2_slice(region_start, w, r, s, lo, hi)) return;
-  uint32_t base;
-  int sh;
-  sort2_window(s2, w, base, sh);
-  cur[t] = t < (1 << sh) ? fcount[((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES + s) << s2.sh) + t] : 0u;
-  __syncthreads();
-  const uint32_t* src = tmp + (size_t)w * pl.n;
-  uint32_t* dst = sorted + (size_t)w * pl.n;
-  const uint32_t idxmask = (1u << s2.idxbits) - 1u;
-  for (uint32_t i0 = lo; i0 < hi; i0 += 4 * 512) {
-    uint32_t e[4];
+  const int t = threadIdx.x;
+  const uint32_t items = oversize[0] * SORT2_SLICES;
+  for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const uint32_t wr = oversize[1 + item / SORT2_SLICES];
+    const int w = (int)(wr >> 8), r = (int)(wr & 255u), s = (int)(item % SORT2_SLICES);
+    uint32_t lo, hi;
+    sort2_slice(region_start, w, r, s, lo, hi);
+    uint32_t base;
+    int sh;
+    sort2_window(s2, w, base, sh);
+    cur[t] = t < (1 << sh) ? fcount[((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES + s) << s2.sh) + t] : 0u;
+    __syncthreads();
+    const uint32_t* src = tmp + (size_t)w * pl.n;
+    uint32_t* dst = sorted + (size_t)w * pl.n;
+    const uint32_t idxmask = (1u << s2.idxbits) - 1u;
+    for (uint32_t i0 = lo; i0 < hi; i0 += 4 * 512) {
+      uint32_t e[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const uint32_t i = i0 + k * 512 + t;
-      e[k] = i < hi ? src[i] : 0u;
-    }
+      for (int k = 0; k < 4; k++) {
+        const uint32_t i = i0 + k * 512 + t;
+        e[k] = i < hi ? src[i] : 0u;
+      }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const bool valid = i0 + k * 512 + t < hi;
-      const uint32_t pos = sort2_claim(cur, e[k] >> (s2.idxbits + 1), valid);
-      if (valid) dst[pos] = (e[k] & idxmask) | (((e[k] >> s2.idxbits) & 1u) << 31);
+      for (int k = 0; k < 4; k++) {
+        const bool valid = i0 + k * 512 + t < hi;
+        const uint32_t pos = sort2_claim(cur, e[k] >> (s2.idxbits + 1), valid);
+        if (valid) dst[pos] = (e[k] & idxmask) | (((e[k] >> s2.idxbits) & 1u) << 31);
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -691,7 +715,7 @@ static bool msm_sort2_ok(const MsmPlan& pl, int n_max, Sort2* s2) {
 }
 // words of the scratch the two-level sort keeps where the one-level sort keeps its per-chunk bucket counts
 static size_t msm_sort2_words(const MsmPlan& pl) {
-  return (size_t)pl.nwin * ((size_t)pl.Q * SORT2_RANGES + SORT2_RANGES + 1 + 3) + (size_t)pl.nwin * pl.nb * SORT2_SLICES;
+  return (size_t)pl.nwin * ((size_t)pl.Q * SORT2_RANGES + 2 * (SORT2_RANGES + 1) + 3) + 8 + (size_t)pl.nwin * pl.nb * SORT2_SLICES;
 }
 
 // ------------------------------------------------------------------ 4. bucket accumulation
@@ -1405,10 +1429,11 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   if (msm_sort2_ok(pl, std::max(pl.n, pl.n_layout), &s2)) {   // two-level sort (3b): same bucket_start / sorted
     uint32_t* ccount = counts;
     uint32_t* region_start = ccount + (size_t)pl.nwin * pl.Q * SORT2_RANGES;
-    uint32_t* fcount = region_start + (((size_t)pl.nwin * (SORT2_RANGES + 1) + 3) & ~(size_t)3);
+    uint32_t* oversize = region_start + (((size_t)pl.nwin * (SORT2_RANGES + 1) + 3) & ~(size_t)3);   // count, then <= nwin * 64 entries
+    uint32_t* fcount = oversize + (((size_t)pl.nwin * SORT2_RANGES + 1 + 3) & ~(size_t)3);
     uint32_t* tmp = (uint32_t*)(base + L.sort_tmp);
     hipLaunchKernelGGL(k_sort2_count, sort_grid, dim3(1024), 0, st, digits, ccount, pl, s2);
-    hipLaunchKernelGGL(k_sort2_scan, dim3(pl.nwin), dim3(SORT2_RANGES), 0, st, ccount, region_start, pl);
+    hipLaunchKernelGGL(k_sort2_scan, dim3(pl.nwin), dim3(SORT2_RANGES), 0, st, ccount, region_start, oversize, pl);
     hipLaunchKernelGGL(k_sort2_scatter, sort_grid, dim3(1024), 0, st, digits, ccount, region_start, tmp, pl, s2);
     {
       static bool attr_done[16] = {};
@@ -1420,11 +1445,12 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
         if (dev >= 0 && dev < 16) attr_done[dev] = true;
       }
     }
-    hipLaunchKernelGGL(k_sort2_fine_staged, dim3(SORT2_RANGES, pl.nwin), dim3(1024), (size_t)SORT2_STAGE * 4, st, tmp, region_start, bstart, sorted, pl, s2);
-    // regions too large for the staged kernel (skewed scalars): every workgroup of these three returns at once otherwise
-    hipLaunchKernelGGL(k_sort2_fine_count, dim3(SORT2_RANGES * SORT2_SLICES, pl.nwin), dim3(512), 0, st, tmp, region_start, fcount, pl, s2);
-    hipLaunchKernelGGL(k_sort2_fine_scan, dim3(SORT2_RANGES, pl.nwin), dim3(512), 0, st, region_start, fcount, bstart, pl, s2);
-    hipLaunchKernelGGL(k_sort2_fine_place, dim3(SORT2_RANGES * SORT2_SLICES, pl.nwin), dim3(512), 0, st, tmp, region_start, fcount, sorted, pl, s2);
+    hipLaunchKernelGGL(k_sort2_fine_staged, dim3(SORT2_RANGES, pl.nwin), dim3(1024), (size_t)SORT2_STAGE * 4, st, tmp, region_start, oversize, bstart,
+                       sorted, pl, s2);
+    // regions too large for the staged kernel (skewed scalars): a small grid over the work list, empty as a rule
+    hipLaunchKernelGGL(k_sort2_fine_count, dim3(SORT2_FALLBACK_BLOCKS), dim3(512), 0, st, tmp, region_start, oversize, fcount, pl, s2);
+    hipLaunchKernelGGL(k_sort2_fine_scan, dim3(SORT2_FALLBACK_BLOCKS), dim3(512), 0, st, region_start, oversize, fcount, bstart, pl, s2);
+    hipLaunchKernelGGL(k_sort2_fine_place, dim3(SORT2_FALLBACK_BLOCKS), dim3(512), 0, st, tmp, region_start, oversize, fcount, sorted, pl, s2);
   } else {
     hipLaunchKernelGGL(k_msm_hist, sort_grid, dim3(1024), lds, st, digits, counts, pl);
     {
