@@ -548,6 +548,13 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
+    # stdout carries exactly ONE line - the result - and it must be the LAST thing on it: libraries write there too (RCCL's
+    # version banner sits in the C stdio buffer until the process exits and lands AFTER the JSON line; gloo announces its peers).
+    # File descriptor 1 is pointed at stderr for everything else; the line goes out through a private duplicate of the real one.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1254,8 +1261,8 @@ def main():
         except OSError:
             full_path = None
         import bench_compact
-        sys.stdout.flush()
-        print(bench_compact.dumps(bench_compact.compact_line(result, full_path and os.path.relpath(full_path, ROOT))), flush=True)
+        json_out.write(bench_compact.dumps(bench_compact.compact_line(result, full_path and os.path.relpath(full_path, ROOT))) + "\n")
+        json_out.flush()
     if dist_on:
         import torch.distributed as dist
         dist.barrier()
