@@ -298,7 +298,7 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __re
 //                             sort writes, prefixes and re-reads 64 MB of per-chunk bucket counts).
 //   k_sort2_scatter           per (chunk, window): every entry goes to ITS REGION of a temporary list, packed with the low
 //                             bits of its bucket: a block writes 64 sequential streams - whole lines leave the cache.
-//   k_sort2_fine_count / _scan / _place   a region is cut into SORT2_SLICES slices, one workgroup each (regions are NOT
+//   k_sort2_fine_count / _place   a region is cut into SORT2_SLICES slices, one workgroup each (regions are NOT
 //                             equal: every zero scalar lands in the last bucket of every window, bench.py plants one in 17):
 //                             slice histograms of the range's buckets in LDS, their prefix (= bucket_start: no separate
 //                             totals / scan kernels), then the entries into bucket order - scattered stores again, but
@@ -311,6 +311,10 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __re
 // plans keep the one-level kernels.
 constexpr int SORT2_RANGES = 64;
 constexpr int SORT2_SLICES = 8;
+#ifndef NCG_SORT2_UNROLL
+#define NCG_SORT2_UNROLL 8
+#endif
+constexpr int SORT2_UNROLL = NCG_SORT2_UNROLL;   // entries a lane of the coarse kernels holds in flight
 struct Sort2 {
   int sh, idxbits;        // log2(buckets per range), bits of an entry index
   int top_w, top_base, top_sh;   // local index of the plan's top window (-1: not in this plan / full), first bucket its ranges cover, its sh
@@ -394,15 +398,15 @@ static __global__ void __launch_bounds__(1024) k_sort2_count(const int16_t* __re
   sort2_window(s2, w, base, sh);
   const int lo = q * pl.chunk, hi = min(pl.n, lo + pl.chunk);
   const int16_t* dg = digits + (size_t)w * pl.n;
-  for (int i0 = lo; i0 < hi; i0 += 4 * (int)blockDim.x) {   // four loads in flight; whole waves run every round
-    int d[4];
+  for (int i0 = lo; i0 < hi; i0 += SORT2_UNROLL * (int)blockDim.x) {   // SORT2_UNROLL loads in flight
+    int d[SORT2_UNROLL];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < SORT2_UNROLL; k++) {
       const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x;
       d[k] = i < hi ? dg[i] : 0;
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < SORT2_UNROLL; k++) {
       const uint32_t bk = (uint32_t)((d[k] < 0 ? -d[k] : d[k]) - 1);
       if (d[k] != 0) atomicAdd(&mine[((bk - base) >> sh) & (SORT2_RANGES - 1)], 1u);   // (same-key lanes serialise in the LDS unit: 32 rounds per wave, harmless)
     }
@@ -466,15 +470,15 @@ static __global__ void __launch_bounds__(1024) k_sort2_scatter(const int16_t* __
   const int16_t* dg = digits + (size_t)w * pl.n;
   uint32_t* dst = tmp + (size_t)w * pl.n;
   const uint32_t lowmask = (1u << sh) - 1u;
-  for (int i0 = lo; i0 < hi; i0 += 4 * (int)blockDim.x) {
-    int d[4];
+  for (int i0 = lo; i0 < hi; i0 += SORT2_UNROLL * (int)blockDim.x) {
+    int d[SORT2_UNROLL];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < SORT2_UNROLL; k++) {
       const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x;
       d[k] = i < hi ? dg[i] : 0;
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < SORT2_UNROLL; k++) {
       const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x;
       const uint32_t off = (uint32_t)((d[k] < 0 ? -d[k] : d[k]) - 1) - base;
       if (d[k] != 0) dst[atomicAdd(&cur[(off >> sh) & (SORT2_RANGES - 1)], 1u)] = (uint32_t)i | ((d[k] < 0 ? 1u : 0u) << s2.idxbits) | ((off & lowmask) << (s2.idxbits + 1));
@@ -484,14 +488,14 @@ static __global__ void __launch_bounds__(1024) k_sort2_scatter(const int16_t* __
 
 // Regions of up to SORT2_STAGE entries (all of them unless the scalars are skewed) are sorted by ONE workgroup with the whole
 // region in registers and its output staged in LDS: one coalesced read, one coalesced write, no second pass over memory.
-// Larger regions (identical scalars; few distinct values) go through the three slice kernels below, which return at once
+// Larger regions (identical scalars; few distinct values) go through the two slice kernels below, which return at once
 // for every region the staged kernel took.
 constexpr int SORT2_PER_THREAD = 20;
 constexpr int SORT2_STAGE = 1024 * SORT2_PER_THREAD;   // entries: 80 KB of LDS
 // bucket starts of range r from the bucket sizes `v` (thread t = bucket t of the range; at most 512 buckets, blockDim >= 512);
 // returns this bucket's start.  Also writes what no range covers: the buckets past the top window's last range and the end marker.
 __device__ __forceinline__ uint32_t sort2_starts(uint32_t* scan, uint32_t v, uint32_t a, int r, int w, int BL, uint32_t base,
-                                                 const uint32_t* region_start, uint32_t* bucket_start, const MsmPlan& pl) {
+                                                 const uint32_t* region_start, uint32_t* bucket_start, const MsmPlan& pl, bool write = true) {
   const int t = threadIdx.x;
   if (t < 512) scan[t] = v;
   __syncthreads();
@@ -502,6 +506,7 @@ __device__ __forceinline__ uint32_t sort2_starts(uint32_t* scan, uint32_t v, uin
     __syncthreads();
   }
   const uint32_t start = t < 512 ? a + scan[t] - v : 0u;
+  if (!write) return start;
   uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
   const uint32_t first = base + (uint32_t)r * (uint32_t)BL;   // first bucket of this range
   if (t < BL && first + t < (uint32_t)pl.nb) bs[first + t] = start;
@@ -557,7 +562,7 @@ static __global__ void __launch_bounds__(1024) k_sort2_fine_staged(const uint32_
 }
 
 // The oversized regions: k_sort2_fine_staged appends (window, range) to a work list (oversize[0] = count, cleared by
-// k_sort2_scan), and the three slice kernels run a SMALL fixed grid over list x slices - with an empty list (every input whose
+// k_sort2_scan), and the two slice kernels run a SMALL fixed grid over list x slices - with an empty list (every input whose
 // scalars are not skewed) their workgroups read one word and leave.
 constexpr int SORT2_FALLBACK_BLOCKS = 128;
 // slice s of region (r, w): [a + s * per, a + (s + 1) * per) with per = ceil(len / SLICES)
@@ -600,43 +605,12 @@ static __global__ void __launch_bounds__(512) k_sort2_fine_count(const uint32_t*
     __syncthreads();
   }
 }
-// per oversized (range, window): bucket sizes = sums over the slices -> bucket_start; fcount becomes each slice's cursor
-static __global__ void __launch_bounds__(512) k_sort2_fine_scan(const uint32_t* __restrict__ region_start, const uint32_t* __restrict__ oversize,
-                                                         uint32_t* __restrict__ fcount, uint32_t* __restrict__ bucket_start, MsmPlan pl,
-                                                         Sort2 s2) {
-  __shared__ uint32_t scan[512];
-  const int t = threadIdx.x;
-  const uint32_t items = oversize[0];
-  for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
-    const uint32_t wr = oversize[1 + item];
-    const int w = (int)(wr >> 8), r = (int)(wr & 255u);
-    uint32_t base;
-    int sh;
-    sort2_window(s2, w, base, sh);
-    const int BL = 1 << sh;
-    const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r];
-    uint32_t* fc = fcount + ((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES) << s2.sh) + t;
-    uint32_t c[SORT2_SLICES], v = 0;
-#pragma unroll
-    for (int s = 0; s < SORT2_SLICES; s++) {
-      c[s] = t < BL ? fc[(size_t)s << s2.sh] : 0u;
-      v += c[s];
-    }
-    uint32_t start = sort2_starts(scan, v, a, r, w, BL, base, region_start, bucket_start, pl);
-    if (t < BL) {
-#pragma unroll
-      for (int s = 0; s < SORT2_SLICES; s++) {
-        fc[(size_t)s << s2.sh] = start;
-        start += c[s];
-      }
-    }
-    __syncthreads();
-  }
-}
 static __global__ void __launch_bounds__(512) k_sort2_fine_place(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ region_start,
                                                           const uint32_t* __restrict__ oversize, const uint32_t* __restrict__ fcount,
-                                                          uint32_t* __restrict__ sorted, MsmPlan pl, Sort2 s2) {
+                                                          uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ sorted, MsmPlan pl,
+                                                          Sort2 s2) {
   __shared__ uint32_t cur[512];
+  __shared__ uint32_t scan[512];
   const int t = threadIdx.x;
   const uint32_t items = oversize[0] * SORT2_SLICES;
   for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
@@ -647,7 +621,20 @@ static __global__ void __launch_bounds__(512) k_sort2_fine_place(const uint32_t*
     uint32_t base;
     int sh;
     sort2_window(s2, w, base, sh);
-    cur[t] = t < (1 << sh) ? fcount[((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES + s) << s2.sh) + t] : 0u;
+    // bucket sizes = sums over the slices -> the range's bucket starts (written by slice 0); this slice's cursors = the start
+    // plus what the earlier slices hold of the bucket (every slice of a region redoes the 512-wide scan: cheaper than a launch)
+    const int BL = 1 << sh;
+    const uint32_t* fc = fcount + ((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES) << s2.sh) + t;
+    uint32_t v = 0, before = 0;
+#pragma unroll
+    for (int k = 0; k < SORT2_SLICES; k++) {
+      const uint32_t c = t < BL ? fc[(size_t)k << s2.sh] : 0u;
+      v += c;
+      if (k < s) before += c;
+    }
+    const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r];
+    const uint32_t start = sort2_starts(scan, v, a, r, w, BL, base, region_start, bucket_start, pl, s == 0);
+    cur[t] = start + before;
     __syncthreads();
     const uint32_t* src = tmp + (size_t)w * pl.n;
     uint32_t* dst = sorted + (size_t)w * pl.n;
@@ -1449,8 +1436,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
                        sorted, pl, s2);
     // regions too large for the staged kernel (skewed scalars): a small grid over the work list, empty as a rule
     hipLaunchKernelGGL(k_sort2_fine_count, dim3(SORT2_FALLBACK_BLOCKS), dim3(512), 0, st, tmp, region_start, oversize, fcount, pl, s2);
-    hipLaunchKernelGGL(k_sort2_fine_scan, dim3(SORT2_FALLBACK_BLOCKS), dim3(512), 0, st, region_start, oversize, fcount, bstart, pl, s2);
-    hipLaunchKernelGGL(k_sort2_fine_place, dim3(SORT2_FALLBACK_BLOCKS), dim3(512), 0, st, tmp, region_start, oversize, fcount, sorted, pl, s2);
+    hipLaunchKernelGGL(k_sort2_fine_place, dim3(SORT2_FALLBACK_BLOCKS), dim3(512), 0, st, tmp, region_start, oversize, fcount, bstart, sorted, pl, s2);
   } else {
     hipLaunchKernelGGL(k_msm_hist, sort_grid, dim3(1024), lds, st, digits, counts, pl);
     {
