@@ -309,13 +309,14 @@ static __global__ void __launch_bounds__(1024) k_msm_scatter(const int16_t* __re
 // (the order inside a bucket differs, as it already does between runs: LDS atomics).  Entries pack index, sign and the low
 // bucket bits into 32 bits, so the form is used when they fit (n <= 2^22 at c = 16) and for per-window lists only; other
 // plans keep the one-level kernels.
-constexpr int SORT2_RANGES = 64;
+constexpr int SORT2_MAX_RANGES = 256;   // ranges per window: 64, or 128 / 256 where 64 regions would not fit the staged kernel (Sort2::lgr)
 constexpr int SORT2_SLICES = 8;
 #ifndef NCG_SORT2_UNROLL
 #define NCG_SORT2_UNROLL 8
 #endif
 constexpr int SORT2_UNROLL = NCG_SORT2_UNROLL;   // entries a lane of the coarse kernels holds in flight
 struct Sort2 {
+  int lgr;                // log2(ranges per window): 6..8
   int sh, idxbits;        // log2(buckets per range), bits of an entry index
   int top_w, top_base, top_sh;   // local index of the plan's top window (-1: not in this plan / full), first bucket its ranges cover, its sh
 };
@@ -387,10 +388,11 @@ __device__ __forceinline__ void sort2_tally(uint32_t* ctr, uint32_t key, bool va
 // ccount[(w*Q + q)*64 + r]: entries of chunk q whose bucket lies in range r
 static __global__ void __launch_bounds__(1024) k_sort2_count(const int16_t* __restrict__ digits, uint32_t* __restrict__ ccount,
                                                       MsmPlan pl, Sort2 s2) {
-  __shared__ uint32_t cnt[16][SORT2_RANGES];   // one copy per wave: the 64 counters are hot
+  __shared__ uint32_t cnt[16][SORT2_MAX_RANGES];   // one copy per wave: the counters are hot
+  const int R = 1 << s2.lgr;
   int q, w;
   if (!msm_sort_block(pl, q, w)) return;
-  for (int t = threadIdx.x; t < 16 * SORT2_RANGES; t += blockDim.x) (&cnt[0][0])[t] = 0;
+  for (int t = threadIdx.x; t < 16 * SORT2_MAX_RANGES; t += blockDim.x) (&cnt[0][0])[t] = 0;
   __syncthreads();
   uint32_t* mine = cnt[threadIdx.x >> 6];
   uint32_t base;
@@ -408,60 +410,61 @@ static __global__ void __launch_bounds__(1024) k_sort2_count(const int16_t* __re
 #pragma unroll
     for (int k = 0; k < SORT2_UNROLL; k++) {
       const uint32_t bk = (uint32_t)((d[k] < 0 ? -d[k] : d[k]) - 1);
-      if (d[k] != 0) atomicAdd(&mine[((bk - base) >> sh) & (SORT2_RANGES - 1)], 1u);   // (same-key lanes serialise in the LDS unit: 32 rounds per wave, harmless)
+      if (d[k] != 0) atomicAdd(&mine[((bk - base) >> sh) & (R - 1)], 1u);   // (same-key lanes serialise in the LDS unit: 32 rounds per wave, harmless)
     }
   }
   __syncthreads();
-  if (threadIdx.x < SORT2_RANGES) {
+  if ((int)threadIdx.x < R) {
     uint32_t t = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) t += cnt[k][threadIdx.x];
-    ccount[((size_t)w * pl.Q + q) * SORT2_RANGES + threadIdx.x] = t;
+    ccount[((size_t)w * pl.Q + q) * R + threadIdx.x] = t;
   }
 }
 
 // per window: ccount -> exclusive prefix over the chunks inside each range; region_start[w][0..64] = where range r begins
-static __global__ void __launch_bounds__(SORT2_RANGES) k_sort2_scan(uint32_t* __restrict__ ccount, uint32_t* __restrict__ region_start,
-                                                             uint32_t* __restrict__ oversize, MsmPlan pl) {
-  __shared__ uint32_t tot[SORT2_RANGES];
-  const int w = blockIdx.x, r = threadIdx.x;
+static __global__ void __launch_bounds__(SORT2_MAX_RANGES) k_sort2_scan(uint32_t* __restrict__ ccount, uint32_t* __restrict__ region_start,
+                                                             uint32_t* __restrict__ oversize, MsmPlan pl, Sort2 s2) {
+  __shared__ uint32_t tot[SORT2_MAX_RANGES];
+  const int w = blockIdx.x, r = threadIdx.x, R = 1 << s2.lgr;   // launched with R lanes
   if (w == 0 && r == 0) oversize[0] = 0;   // the work list of k_sort2_fine_staged
-  uint32_t* c = ccount + (size_t)w * pl.Q * SORT2_RANGES + r;
+  uint32_t* c = ccount + (size_t)w * pl.Q * R + r;
   uint32_t run = 0;
   int q = 0;
   for (; q + 8 <= pl.Q; q += 8) {
     uint32_t v[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = c[(size_t)(q + j) * SORT2_RANGES];
+    for (int j = 0; j < 8; j++) v[j] = c[(size_t)(q + j) * R];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      c[(size_t)(q + j) * SORT2_RANGES] = run;
+      c[(size_t)(q + j) * R] = run;
       run += v[j];
     }
   }
   for (; q < pl.Q; q++) {
-    const uint32_t v = c[(size_t)q * SORT2_RANGES];
-    c[(size_t)q * SORT2_RANGES] = run;
+    const uint32_t v = c[(size_t)q * R];
+    c[(size_t)q * R] = run;
     run += v;
   }
   tot[r] = run;
   __syncthreads();
   uint32_t before = 0;
   for (int k = 0; k < r; k++) before += tot[k];
-  uint32_t* rs = region_start + (size_t)w * (SORT2_RANGES + 1);
+  uint32_t* rs = region_start + (size_t)w * (R + 1);
   rs[r] = before;
-  if (r == SORT2_RANGES - 1) rs[SORT2_RANGES] = before + run;
+  if (r == R - 1) rs[R] = before + run;
 }
 
 // tmp[w][region of the entry's range] = index | sign << idxbits | (bucket offset inside the range) << (idxbits + 1)
 static __global__ void __launch_bounds__(1024) k_sort2_scatter(const int16_t* __restrict__ digits, const uint32_t* __restrict__ ccount,
                                                         const uint32_t* __restrict__ region_start, uint32_t* __restrict__ tmp,
                                                         MsmPlan pl, Sort2 s2) {
-  __shared__ uint32_t cur[SORT2_RANGES];
+  __shared__ uint32_t cur[SORT2_MAX_RANGES];
   int q, w;
   if (!msm_sort_block(pl, q, w)) return;
-  if (threadIdx.x < SORT2_RANGES)
-    cur[threadIdx.x] = region_start[(size_t)w * (SORT2_RANGES + 1) + threadIdx.x] + ccount[((size_t)w * pl.Q + q) * SORT2_RANGES + threadIdx.x];
+  const int R = 1 << s2.lgr;
+  if ((int)threadIdx.x < R)
+    cur[threadIdx.x] = region_start[(size_t)w * (R + 1) + threadIdx.x] + ccount[((size_t)w * pl.Q + q) * R + threadIdx.x];
   __syncthreads();
   uint32_t base;
   int sh;
@@ -481,7 +484,7 @@ static __global__ void __launch_bounds__(1024) k_sort2_scatter(const int16_t* __
     for (int k = 0; k < SORT2_UNROLL; k++) {
       const int i = i0 + k * (int)blockDim.x + (int)threadIdx.x;
       const uint32_t off = (uint32_t)((d[k] < 0 ? -d[k] : d[k]) - 1) - base;
-      if (d[k] != 0) dst[atomicAdd(&cur[(off >> sh) & (SORT2_RANGES - 1)], 1u)] = (uint32_t)i | ((d[k] < 0 ? 1u : 0u) << s2.idxbits) | ((off & lowmask) << (s2.idxbits + 1));
+      if (d[k] != 0) dst[atomicAdd(&cur[(off >> sh) & (R - 1)], 1u)] = (uint32_t)i | ((d[k] < 0 ? 1u : 0u) << s2.idxbits) | ((off & lowmask) << (s2.idxbits + 1));
     }
   }
 }
@@ -494,7 +497,7 @@ constexpr int SORT2_PER_THREAD = 20;
 constexpr int SORT2_STAGE = 1024 * SORT2_PER_THREAD;   // entries: 80 KB of LDS
 // bucket starts of range r from the bucket sizes `v` (thread t = bucket t of the range; at most 512 buckets, blockDim >= 512);
 // returns this bucket's start.  Also writes what no range covers: the buckets past the top window's last range and the end marker.
-__device__ __forceinline__ uint32_t sort2_starts(uint32_t* scan, uint32_t v, uint32_t a, int r, int w, int BL, uint32_t base,
+__device__ __forceinline__ uint32_t sort2_starts(uint32_t* scan, uint32_t v, uint32_t a, int r, int w, int BL, uint32_t base, int R,
                                                  const uint32_t* region_start, uint32_t* bucket_start, const MsmPlan& pl, bool write = true) {
   const int t = threadIdx.x;
   if (t < 512) scan[t] = v;
@@ -512,8 +515,8 @@ __device__ __forceinline__ uint32_t sort2_starts(uint32_t* scan, uint32_t v, uin
   if (t < BL && first + t < (uint32_t)pl.nb) bs[first + t] = start;
   if (r == 0)
     for (uint32_t b = t; b < base; b += blockDim.x) bs[b] = 0;
-  if (r == SORT2_RANGES - 1) {
-    const uint32_t end = region_start[(size_t)w * (SORT2_RANGES + 1) + SORT2_RANGES];
+  if (r == R - 1) {
+    const uint32_t end = region_start[(size_t)w * (R + 1) + R];
     for (uint32_t b = first + (uint32_t)BL + t; b <= (uint32_t)pl.nb; b += blockDim.x) bs[b] = end;
   }
   return start;
@@ -524,8 +527,8 @@ static __global__ void __launch_bounds__(1024) k_sort2_fine_staged(const uint32_
   extern __shared__ __attribute__((aligned(16))) uint32_t stage[];   // SORT2_STAGE entries
   __shared__ uint32_t cnt[512];
   __shared__ uint32_t scan[512];
-  const int r = blockIdx.x, w = blockIdx.y, t = threadIdx.x;
-  const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r], b = region_start[(size_t)w * (SORT2_RANGES + 1) + r + 1];
+  const int r = blockIdx.x, w = blockIdx.y, t = threadIdx.x, R = 1 << s2.lgr;
+  const uint32_t a = region_start[(size_t)w * (R + 1) + r], b = region_start[(size_t)w * (R + 1) + r + 1];
   if (b - a > (uint32_t)SORT2_STAGE) {   // the slice kernels take it
     if (threadIdx.x == 0) oversize[1 + atomicAdd(&oversize[0], 1u)] = ((uint32_t)w << 8) | (uint32_t)r;
     return;
@@ -547,7 +550,7 @@ static __global__ void __launch_bounds__(1024) k_sort2_fine_staged(const uint32_
     if (a + (uint32_t)k * 1024u + (uint32_t)t < b) atomicAdd(&cnt[e[k] >> (s2.idxbits + 1)], 1u);
   __syncthreads();
   const uint32_t v = t < 512 ? cnt[t] : 0u;
-  const uint32_t start = sort2_starts(scan, v, a, r, w, 1 << sh, base, region_start, bucket_start, pl);
+  const uint32_t start = sort2_starts(scan, v, a, r, w, 1 << sh, base, R, region_start, bucket_start, pl);
   __syncthreads();
   if (t < 512) cnt[t] = start - a;   // cursors inside the stage
   __syncthreads();
@@ -566,8 +569,8 @@ static __global__ void __launch_bounds__(1024) k_sort2_fine_staged(const uint32_
 // scalars are not skewed) their workgroups read one word and leave.
 constexpr int SORT2_FALLBACK_BLOCKS = 128;
 // slice s of region (r, w): [a + s * per, a + (s + 1) * per) with per = ceil(len / SLICES)
-__device__ __forceinline__ void sort2_slice(const uint32_t* region_start, int w, int r, int s, uint32_t& lo, uint32_t& hi) {
-  const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r], b = region_start[(size_t)w * (SORT2_RANGES + 1) + r + 1];
+__device__ __forceinline__ void sort2_slice(const uint32_t* region_start, int R, int w, int r, int s, uint32_t& lo, uint32_t& hi) {
+  const uint32_t a = region_start[(size_t)w * (R + 1) + r], b = region_start[(size_t)w * (R + 1) + r + 1];
   const uint32_t per = (b - a + SORT2_SLICES - 1) / SORT2_SLICES;
   lo = min(b, a + (uint32_t)s * per);
   hi = min(b, lo + per);
@@ -583,7 +586,7 @@ static __global__ void __launch_bounds__(512) k_sort2_fine_count(const uint32_t*
     const uint32_t wr = oversize[1 + item / SORT2_SLICES];
     const int w = (int)(wr >> 8), r = (int)(wr & 255u), s = (int)(item % SORT2_SLICES);
     uint32_t lo, hi;
-    sort2_slice(region_start, w, r, s, lo, hi);
+    sort2_slice(region_start, 1 << s2.lgr, w, r, s, lo, hi);
     uint32_t base;
     int sh;
     sort2_window(s2, w, base, sh);
@@ -601,7 +604,7 @@ static __global__ void __launch_bounds__(512) k_sort2_fine_count(const uint32_t*
       for (int k = 0; k < 4; k++) sort2_tally(cnt, e[k] >> (s2.idxbits + 1), i0 + k * 512 + t < hi);
     }
     __syncthreads();
-    if (t < (1 << sh)) fcount[((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES + s) << s2.sh) + t] = cnt[t];
+    if (t < (1 << sh)) fcount[(((((size_t)w << s2.lgr) + r) * SORT2_SLICES + s) << s2.sh) + t] = cnt[t];
     __syncthreads();
   }
 }
@@ -617,14 +620,14 @@ static __global__ void __launch_bounds__(512) k_sort2_fine_place(const uint32_t*
     const uint32_t wr = oversize[1 + item / SORT2_SLICES];
     const int w = (int)(wr >> 8), r = (int)(wr & 255u), s = (int)(item % SORT2_SLICES);
     uint32_t lo, hi;
-    sort2_slice(region_start, w, r, s, lo, hi);
+    sort2_slice(region_start, 1 << s2.lgr, w, r, s, lo, hi);
     uint32_t base;
     int sh;
     sort2_window(s2, w, base, sh);
     // bucket sizes = sums over the slices -> the range's bucket starts (written by slice 0); this slice's cursors = the start
     // plus what the earlier slices hold of the bucket (every slice of a region redoes the 512-wide scan: cheaper than a launch)
     const int BL = 1 << sh;
-    const uint32_t* fc = fcount + ((((size_t)w * SORT2_RANGES + r) * SORT2_SLICES) << s2.sh) + t;
+    const uint32_t* fc = fcount + ((((((size_t)w << s2.lgr) + r) * SORT2_SLICES)) << s2.sh) + t;
     uint32_t v = 0, before = 0;
 #pragma unroll
     for (int k = 0; k < SORT2_SLICES; k++) {
@@ -632,8 +635,8 @@ static __global__ void __launch_bounds__(512) k_sort2_fine_place(const uint32_t*
       v += c;
       if (k < s) before += c;
     }
-    const uint32_t a = region_start[(size_t)w * (SORT2_RANGES + 1) + r];
-    const uint32_t start = sort2_starts(scan, v, a, r, w, BL, base, region_start, bucket_start, pl, s == 0);
+    const uint32_t a = region_start[(size_t)w * ((1 << s2.lgr) + 1) + r];
+    const uint32_t start = sort2_starts(scan, v, a, r, w, BL, base, 1 << s2.lgr, region_start, bucket_start, pl, s == 0);
     cur[t] = start + before;
     __syncthreads();
     const uint32_t* src = tmp + (size_t)w * pl.n;
@@ -665,12 +668,17 @@ static bool msm_sort2_ok(const MsmPlan& pl, int n_max, Sort2* s2) {
   while ((1 << lg) < pl.nb) lg++;
   int ib = 1;
   while (ib < 31 && (1u << ib) < (unsigned)std::max(n_max, 2)) ib++;
-  if (ib + 1 + (lg - 6) > 32) return false;
-  s2->sh = lg - 6;
+  // 64 ranges per window; 128 / 256 where a region would otherwise hold more than 16 384 entries on average (the staged kernel
+  // takes up to SORT2_STAGE = 20 480): the 2^21 entries of an endomorphism plan over 2^20 G1 points, plans of 2^21 / 2^22 points
+  int lgr = 6;
+  while (lgr < 8 && (n_max >> lgr) > 16384 && lg - lgr > 1) lgr++;
+  if (ib + 1 + (lg - lgr) > 32) return false;
+  s2->lgr = lgr;
+  s2->sh = lg - lgr;
   s2->idxbits = ib;
   s2->top_w = -1;
   s2->top_base = 0;
-  s2->top_sh = lg - 6;
+  s2->top_sh = lg - lgr;
   if (!pl.endo) {   // generic plans: the top window's field v = (k + H') >> c (nwin - 1) lies in [half, vmax] (H' carries the window's
                     // own half), so its digits v - half are >= 0 and its buckets are [0, vmax - half) only
     const int nwt = pl.nwin_total ? pl.nwin_total : pl.nwin;
@@ -694,7 +702,7 @@ static bool msm_sort2_ok(const MsmPlan& pl, int n_max, Sort2* s2) {
       if ((1u << tb) < half) {
         s2->top_w = wl;
         s2->top_base = 0;
-        s2->top_sh = std::max(0, tb - 6);
+        s2->top_sh = std::max(0, tb - lgr);
       }
     }
   }
@@ -702,7 +710,7 @@ static bool msm_sort2_ok(const MsmPlan& pl, int n_max, Sort2* s2) {
 }
 // words of the scratch the two-level sort keeps where the one-level sort keeps its per-chunk bucket counts
 static size_t msm_sort2_words(const MsmPlan& pl) {
-  return (size_t)pl.nwin * ((size_t)pl.Q * SORT2_RANGES + 2 * (SORT2_RANGES + 1) + 3) + 8 + (size_t)pl.nwin * pl.nb * SORT2_SLICES;
+  return (size_t)pl.nwin * ((size_t)pl.Q * SORT2_MAX_RANGES + 2 * (SORT2_MAX_RANGES + 1) + 3) + 8 + (size_t)pl.nwin * pl.nb * SORT2_SLICES;
 }
 
 // ------------------------------------------------------------------ 4. bucket accumulation
@@ -1415,12 +1423,13 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   Sort2 s2;
   if (msm_sort2_ok(pl, std::max(pl.n, pl.n_layout), &s2)) {   // two-level sort (3b): same bucket_start / sorted
     uint32_t* ccount = counts;
-    uint32_t* region_start = ccount + (size_t)pl.nwin * pl.Q * SORT2_RANGES;
-    uint32_t* oversize = region_start + (((size_t)pl.nwin * (SORT2_RANGES + 1) + 3) & ~(size_t)3);   // count, then <= nwin * 64 entries
-    uint32_t* fcount = oversize + (((size_t)pl.nwin * SORT2_RANGES + 1 + 3) & ~(size_t)3);
+    const int R = 1 << s2.lgr;
+    uint32_t* region_start = ccount + (size_t)pl.nwin * pl.Q * R;
+    uint32_t* oversize = region_start + (((size_t)pl.nwin * (R + 1) + 3) & ~(size_t)3);   // count, then <= nwin * R entries
+    uint32_t* fcount = oversize + (((size_t)pl.nwin * R + 1 + 3) & ~(size_t)3);
     uint32_t* tmp = (uint32_t*)(base + L.sort_tmp);
     hipLaunchKernelGGL(k_sort2_count, sort_grid, dim3(1024), 0, st, digits, ccount, pl, s2);
-    hipLaunchKernelGGL(k_sort2_scan, dim3(pl.nwin), dim3(SORT2_RANGES), 0, st, ccount, region_start, oversize, pl);
+    hipLaunchKernelGGL(k_sort2_scan, dim3(pl.nwin), dim3(R), 0, st, ccount, region_start, oversize, pl, s2);
     hipLaunchKernelGGL(k_sort2_scatter, sort_grid, dim3(1024), 0, st, digits, ccount, region_start, tmp, pl, s2);
     {
       static bool attr_done[16] = {};
@@ -1432,7 +1441,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
         if (dev >= 0 && dev < 16) attr_done[dev] = true;
       }
     }
-    hipLaunchKernelGGL(k_sort2_fine_staged, dim3(SORT2_RANGES, pl.nwin), dim3(1024), (size_t)SORT2_STAGE * 4, st, tmp, region_start, oversize, bstart,
+    hipLaunchKernelGGL(k_sort2_fine_staged, dim3(R, pl.nwin), dim3(1024), (size_t)SORT2_STAGE * 4, st, tmp, region_start, oversize, bstart,
                        sorted, pl, s2);
     // regions too large for the staged kernel (skewed scalars): a small grid over the work list, empty as a rule
     hipLaunchKernelGGL(k_sort2_fine_count, dim3(SORT2_FALLBACK_BLOCKS), dim3(512), 0, st, tmp, region_start, oversize, fcount, pl, s2);

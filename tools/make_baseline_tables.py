@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Rewrites section 5 of BASELINE.md from the committed round profiles (profiles/r04_*, r03 beside them), so the tables are
+"""Rewrites section 5 of BASELINE.md from the committed round profiles (profiles/r05_*, r04 beside them), so the tables are
 transcriptions of measured files, not hand-typed numbers.  python tools/make_baseline_tables.py"""
 import json
 import os
@@ -14,26 +14,26 @@ def load(name):
 
 
 def main():
-    b = load("r04_bench_line.json")
-    b1 = load("r03_bench_line.json")
-    ex, ex1 = load("r04_bench_extra.json"), load("r03_bench_extra.json")
+    b = load("r05_bench_full.json")          # the FULL result object of the driver's command (bench.py --out); stdout carries the compact line
+    b1 = load("r04_bench_line_last_tree.json")
+    ex, ex1 = load("r05_bench_extra.json"), load("r04_bench_extra.json")
     e = b["extra"]
     host = b.get("host", {})
     out = []
-    out.append("## 5. Results table (round 4, one MI355X, the driver's command `python3 bench.py --gpus 1 --steps 20 --warmup 5`: `profiles/r04_bench_line.json`, `profiles/r04_bench_kernel_stats.csv`, `profiles/r04_pmc.json`; the same build on a faster box of the pool: `profiles/r04_bench_line_fast_box.json`)\n")
+    out.append("## 5. Results table (round 5, one MI355X, the driver's command `python3 bench.py --gpus 1 --steps 20 --warmup 5` on a fresh box: `profiles/r05_bench_line.json` (the compact line the driver parses), `profiles/r05_bench_full.json` (the full object this table is made from), `profiles/r05_bench_kernel_stats.csv` + `profiles/r05_bench_line_stats_run.json` (rocprofv3 --stats around the same command, and that process's line), `profiles/r05_pmc.json`)\n")
     out.append("Throughput with inputs resident in HBM, one run of the driver's command on a fresh box (per-step event / wall distributions "
-               "are in the line: `step_times`; the pool's boxes differ by up to 5 %% on these kernels, DESIGN.md section 7: the second line "
-               "named above reads secp256k1 8.66 ms, ed25519 2.78 ms on the same build).  Every result is verified "
+               "are in the full object: `step_times`; the pool's boxes differ by up to 5 %% on these kernels, DESIGN.md section 7).  Every result is verified "
                "bit-exactly before it is printed (sample vs the CPU oracle's C restatement, full-size checksum / progression identity, "
                "ed25519 verdicts by construction + the reference's 196 zip215.json cases).  `hbm_frac` = algorithmic bytes ÷ 8 TB/s (the "
                "contract's figure; the path is VALU-bound, §2 caveat); `mad_frac` = executed `v_mad_u64_u32` (counted from the kernel's "
-               "operation sequence) ÷ the measured multiplier ceiling 3.08×10¹³/s; `valu_issue` = SQ_INSTS_VALU × 64 ÷ kernel time ÷ "
-               "3.93×10¹³ lane-ops/s (rocprofv3 PMC, live in the bench run); `traffic` = HBM bytes per launch of the dominant kernel "
-               "(FETCH_SIZE/WRITE_SIZE with the per-pattern calibration of `tools/pmc_calib`, in `profiles/r04_pmc.json`).  CPU baseline = the "
+               "operation sequence) ÷ the measured multiplier ceiling 3.08×10¹³/s; `issue` = the time the executed instruction mix needs at the "
+               "measured issue costs (multiply-adds × 5.59 + other VALU × 2.89 cycles per wave-instruction; SQ_INSTS_VALU live in the bench run) ÷ "
+               "kernel time; `traffic` = HBM bytes per launch of the dominant kernel "
+               "(FETCH_SIZE/WRITE_SIZE with the per-pattern calibration of `tools/pmc_calib`, in `profiles/r05_pmc.json`).  CPU baseline = the "
                "REFERENCE's own TypeScript code on the GPU box's host (%s, %s logical cores; Node %s running the type-stripped sources of "
                "`oracle/_ref/refjs.bundle`, one thread), each result compared bit-exactly with the GPU's; the C port of round 1-3 beside it.\n"
                % (host.get("cpu_model"), host.get("logical_cores"), host.get("node_version")))
-    out.append("| config | N | time (r03 → r04) | throughput | hbm_frac | mad_frac | valu_issue | traffic / algorithmic | CPU: reference (1 thread) | CPU: C port 1 thread / all threads | bit-exact |")
+    out.append("| config | N | time (r04 → r05) | throughput | hbm_frac | mad_frac | issue | traffic / algorithmic | CPU: reference (1 thread) | CPU: C port 1 thread / all threads | bit-exact |")
     out.append("|---|---|---|---|---|---|---|---|---|---|---|")
 
     def row(name, n, t1, t2, unit, entry, alg_bytes):
@@ -47,7 +47,7 @@ def main():
         out.append("| %s | %s | %s → **%.2f ms** | **%.3g %s** | %.2f %% | %s | %s | %s | %s | %s / %s | yes |" % (
             name, n, ("%.2f ms" % t1) if t1 else "—", t2, entry["value"], unit, 100 * rf["frac"],
             ("%.0f %%" % (100 * v["mad_frac"])) if "mad_frac" in v else "—",
-            ("%.0f %%" % (100 * v["valu_issue_frac"])) if "valu_issue_frac" in v else "—",
+            ("%.0f %%" % (100 * v["issue_frac"])) if "issue_frac" in v else "—",
             ("%.2f GB / %.0f MB = %.0f×" % (tr / 1e9, alg_bytes / 1e6, tr / alg_bytes)) if tr else "—",
             ("**%.3g /s**" % ref["value"]) if ref else "—",
             ("%.3g /s" % cb["value"]) if cb else "—", ("%.3g /s (%d thr)" % (at["value"], at["cores"])) if at else "—"))
@@ -97,7 +97,7 @@ def main():
     if p1 and p2:
         out.append("The same verified sets with `ncg_points_precompute` (interleavedMSMUnsafe's per-point tables in device form: window-"
                    "shifted copies, built once in %.0f / %.0f ms; one shared bucket set, no combine across windows): G1 2²⁰ **%.2f ms**, "
-                   "G2 2¹⁸ **%.2f ms**; per size and path: `profiles/r04_msm_timing.json`.\n"
+                   "G2 2¹⁸ **%.2f ms**; per size and path: `profiles/r05_msm_timing.json`.\n"
                    % (p1["precompute_once_ms"], p2["precompute_once_ms"], p1["ms_per_msm"], p2["ms_per_msm"]))
     c0 = e.get("configs0_point_multiply")
     if c0:
@@ -113,31 +113,29 @@ def main():
     out.append("Targets: ≥10⁷ secp256k1 scalar-mults/s per MI355X — met (%.1f×); \"≥40 %% HBM roofline\" for the 2²⁰ G1 MSM is not physically "
                "meaningful (§2 caveat): its dominant kernel runs at %.0f %% of the measured multiplier ceiling in EXECUTED multiplies.\n"
                % (b["value"] / 1e7, 100 * e["msm_g1"]["roofline"]["valu"]["mad_frac"]))
-    out.append("### Other entry points (one MI355X, `tools/bench_extra.py`, `profiles/r04_bench_extra.json`; r03 beside it)\n")
-    out.append("| entry point | N | r03 | r04 | throughput |")
+    out.append("### Other entry points (one MI355X, `tools/bench_extra.py`, `profiles/r05_bench_extra.json`; r04 beside it)\n")
+    out.append("| entry point | N | r04 | r05 | throughput |")
     out.append("|---|---|---|---|---|")
     for k, v in ex.items():
         o = ex1.get(k)
         out.append("| %s | 2^%d | %s | %.2f ms | %.3g %s/s |" % (k, v["n"].bit_length() - 1, ("%.2f ms" % o["ms"]) if o else "—", v["ms"], v["per_s"], v["unit"]))
-    out.append("\n### End to end from JavaScript (`addon/bench_js.js`, Node 12 on the GPU box, secp256k1, `profiles/r04_js_bench.jsonl`)\n")
-    out.append("BigInt marshalling + N-API + H2D/D2H + kernels.  `resident` = the point set was uploaded once (`uploadPoints`), only the scalars "
-               "cross per call - as `BigInt[]` read natively as 64-bit words, or as packed bytes (SURVEY 8a gotcha 8).  Every BigInt that crosses "
-               "N-API costs ~100 ns (`napi_get_element` + `napi_get_value_bigint_words`; handle scopes and JS-side conversions measured no "
-               "better), so the reference-shaped call with 2¹⁶ Point objects stays at ≈16 ms; `pippenger` / `multiplyUnsafeBatch` therefore also "
-               "take packed columns (`packPoints`, `packScalars`, `BigUint64Array`) in place of `Point[]` / `BigInt[]`.\n")
-    out.append("Round 4: `native.hostRegister(buffer)` pins a long-lived input buffer once - the `pinned` columns (no per-call page locking; the MSM "
-               "itself runs in parts under the transfer, DESIGN §5).\n")
-    out.append("| N | `pippenger` from JS (Point[] / BigInt[]) | packed columns (`packPoints` once + BigUint64Array scalars) | packed columns, pinned | resident, BigInt[] scalars | resident, packed scalars | native call alone | native, pinned | `multiplyUnsafeBatch` from JS | native | native, pinned |")
-    out.append("|---|---|---|---|---|---|---|---|---|---|---|")
-    for line in open(P("r04_js_bench.jsonl")):
+    out.append("\n### End to end from JavaScript (`addon/bench_js.js`, Node 12 on the GPU box, secp256k1, `profiles/r05_js_bench.jsonl`)\n")
+    out.append("BigInt marshalling + N-API + H2D/D2H + kernels.  Every BigInt that crosses N-API costs ~100 ns (`napi_get_element` + "
+               "`napi_get_value_bigint_words`), and a reference-shaped `pippenger(c, points, scalars)` call on `Point` objects spends its time in "
+               "`toAffine()` + packing.  Round 5: the shim keeps the device copy of an array of FROZEN points (the reference's instances are; "
+               "identity sweep per call, INTEGRATION.md), so only the first call on an array pays that; scalars as `BigUint64Array` / packed bytes "
+               "skip the per-BigInt cost.  `resident` = an explicit `uploadPoints` set; `pinned` = `native.hostRegister(buffer)` once.\n")
+    out.append("| N | `pippenger(c, Point[], bigint[])` first call | same array again, bigint[] scalars | same array again, **BigUint64Array scalars** | packed columns, pinned | resident set, packed scalars | native call alone, pinned | `multiplyUnsafeBatch` from JS | native, pinned |")
+    out.append("|---|---|---|---|---|---|---|---|---|")
+    for line in open(P("r05_js_bench.jsonl")):
         line = line.strip()
         if not line.startswith("{"):
             continue
         j = json.loads(line)
-        out.append("| 2^%d | %.1f ms | %.2f ms | **%.2f ms** | %.2f ms | %.2f ms | %.2f ms | **%.2f ms** | %.1f ms | %.2f ms | %.2f ms |" % (
-            j["n"].bit_length() - 1, j["pippenger_js_ms"], j.get("pippenger_packed_columns_ms", float("nan")), j.get("pippenger_packed_columns_pinned_ms", float("nan")),
-            j["pippenger_resident_bigint_ms"], j["pippenger_resident_bytes_ms"],
-            j["pippenger_native_ms"], j.get("pippenger_native_pinned_ms", float("nan")), j["multiplyUnsafeBatch_js_ms"], j["multiplyUnsafeBatch_native_ms"],
+        out.append("| 2^%d | %.1f ms | %.1f ms | **%.2f ms** | %.2f ms | %.2f ms | %.2f ms | %.1f ms | %.2f ms |" % (
+            j["n"].bit_length() - 1, j["pippenger_js_first_call_ms"], j["pippenger_js_cached_points_bigint_scalars_ms"],
+            j["pippenger_js_cached_points_typed_scalars_ms"], j.get("pippenger_packed_columns_pinned_ms", float("nan")),
+            j["pippenger_resident_bytes_ms"], j.get("pippenger_native_pinned_ms", float("nan")), j["multiplyUnsafeBatch_js_ms"],
             j.get("multiplyUnsafeBatch_native_pinned_ms", float("nan"))))
     text = "\n".join(out) + "\n"
     path = os.path.join(ROOT, "BASELINE.md")
