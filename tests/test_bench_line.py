@@ -20,7 +20,7 @@ def _full(name):
         return json.loads(f.read().strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("name", ["r04_bench_line_last_tree.json", "r04_bench_line.json", "r03_bench_line.json"])
+@pytest.mark.parametrize("name", ["r05_bench_full.json", "r04_bench_line_last_tree.json", "r04_bench_line.json", "r03_bench_line.json"])
 def test_compact_line_fits_and_keeps_the_contract(name):
     full = _full(name)
     line = bench_compact.dumps(bench_compact.compact_line(full, "gpurun_out/bench_full.json"))
@@ -51,12 +51,27 @@ def test_compact_line_fits_and_keeps_the_contract(name):
     assert "ms_per_batch" in c["ed25519"] and "ms_per_transform" in c["ntt"]
 
 
-def test_compact_line_of_a_multi_rank_run_keeps_the_strong_blocks():
-    full = _full("r04_bench_dist_dry_run.json")
+@pytest.mark.parametrize("name", ["r05_bench_dist_dry_run.json", "r05_gpus2_selflaunch_gloo.json", "r04_bench_dist_dry_run.json"])
+def test_compact_line_of_a_multi_rank_run_keeps_the_strong_blocks(name):
+    full = _full(name)
     c = bench_compact.compact_line(full)
     assert len(bench_compact.dumps(c)) < bench_compact.LIMIT
     for key in ("msm_g1_strong", "msm_g2_strong"):
         assert c[key]["scaling"] == "strong" and c[key]["mode"] and c[key]["ms_per_msm"] > 0
+        if name.startswith("r05"):      # round 5: the in-run one-GPU time of the same MSM and the speed-up against it
+            assert c[key]["ms_per_msm_n1"] > 0 and abs(c[key]["speedup_vs_n1"] - c[key]["ms_per_msm_n1"] / c[key]["ms_per_msm"]) < 1e-3
+    if name == "r05_bench_dist_dry_run.json":
+        assert c["msm_g1_strong"]["rccl_ranks"] == 1     # ncclCommCount of the one-rank communicator the dry run creates
+
+
+def test_committed_driver_line_is_what_the_compactor_makes_of_the_committed_full_object():
+    """profiles/r05_bench_line.json is the stdout of the driver's command, profiles/r05_bench_full.json its --out file"""
+    with open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) as f:
+        text = f.read()
+    assert text.count("\n") == 1 and len(text) < bench_compact.LIMIT
+    line = json.loads(text)
+    again = bench_compact.compact_line(_full("r05_bench_full.json"), line.get("full"))
+    assert again == line
 
 
 def test_compact_line_never_exceeds_the_limit_even_with_bloated_input():
