@@ -1102,7 +1102,7 @@ __global__ void __launch_bounds__(MSM_TAIL_THREADS) k_msm_fixup_long(const uint3
 // each adds 4-5 heads - a dependent chain that the cooperative additions shorten 2-3x.  Same contract as
 // k_msm_fixup_merge (runs longer than run_serial heads go to the work list).
 template <class C, bool COOP>
-__global__ void __launch_bounds__(256) k_msm_fixup_merge_units(const uint32_t* __restrict__ part_pts, const int* __restrict__ part_meta,
+__global__ void __launch_bounds__(256, 2) k_msm_fixup_merge_units(const uint32_t* __restrict__ part_pts, const int* __restrict__ part_meta,
                                                                const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ buckets,
                                                                MsmPlan pl, MsmSeg sg, uint32_t* __restrict__ long_runs, int run_serial) {
 #ifdef __HIP_DEVICE_COMPILE__
