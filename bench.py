@@ -1177,8 +1177,6 @@ def main():
                                                 "kernel": "k_ed25519_verify (+ k_ed25519_challenge in the hash-inclusive figure)",
                                                 "kernel_ms": ev_ms / K, "kernel_only_ms": ev_ms_k / K,
                                                 "valu": valu_block(pmc, "ed25519", kern_s, 4.9e5 * nv, ed25519_mads_per_verify() * nv)}}
-        extra["ed25519_verify"]["roofline"]["valu"].pop("executed_mad_per_s", None)
-        extra["ed25519_verify"]["roofline"]["valu"].pop("mad_frac", None)
         if ed_cpu:
             extra["ed25519_verify"]["cpu_baseline"] = ed_cpu
 
