@@ -1003,6 +1003,8 @@ int ncg_resident_plan(ncg_ctx* ctx, const ncg_points* pts, ncg::MsmPlan* pl, con
     if (prc != 0 || pl->nwin != pts->shift_nwin || (size_t)pl->n != pts->shift_m)
       return set_err(ctx, NCG_ERR_INVALID_ARG, "noble-gpu: msm: the precomputed levels do not match the window plan");
     pl->shared = 1;
+    pl->top_tb = 0;       // one bucket set for all windows: the weight of a bucket is its index, no spreading
+    pl->top_submask = 0;
     pl->pts_stored = 1;
     *d_pts = (const uint32_t*)pts->d_shift;
     return NCG_OK;

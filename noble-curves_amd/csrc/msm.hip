@@ -68,12 +68,16 @@ static __global__ void __launch_bounds__(256) k_msm_digits(const uint32_t* __res
     my[10] = 0;
     const uint32_t mask = (1u << pl.c) - 1u;
     const int half = 1 << (pl.c - 1);
+    const int nwt = pl.nwin_total ? pl.nwin_total : pl.nwin;
     for (int w = 0; w < pl.nwin; w++) {
       int bp = (w + pl.w0) * pl.c;
       int limb = bp >> 5, sft = bp & 31;
       uint64_t two = ((uint64_t)my[limb + 1] << 32) | my[limb];
       uint32_t v = (uint32_t)(two >> sft) & mask;
-      digits[(size_t)w * pl.n + i] = (int16_t)((int)v - half);
+      int dg = (int)v - half;
+      if (pl.top_tb && w + pl.w0 == nwt - 1 && dg > 0)   // short top window: sub-bucket by the point index (MsmPlan::top_tb)
+        dg = (int)((((uint32_t)i & pl.top_submask) << pl.top_tb) + (uint32_t)min(dg, 1 << pl.top_tb));
+      digits[(size_t)w * pl.n + i] = (int16_t)dg;
     }
   }
 }
@@ -679,7 +683,7 @@ static bool msm_sort2_ok(const MsmPlan& pl, int n_max, Sort2* s2) {
   s2->top_w = -1;
   s2->top_base = 0;
   s2->top_sh = lg - lgr;
-  if (!pl.endo) {   // generic plans: the top window's field v = (k + H') >> c (nwin - 1) lies in [half, vmax] (H' carries the window's
+  if (!pl.endo && !pl.top_tb) {   // generic plans whose top window is not spread (MsmPlan::top_tb): the top window's field v = (k + H') >> c (nwin - 1) lies in [half, vmax] (H' carries the window's
                     // own half), so its digits v - half are >= 0 and its buckets are [0, vmax - half) only
     const int nwt = pl.nwin_total ? pl.nwin_total : pl.nwin;
     const int wl = nwt - 1 - pl.w0;   // local index of the top window
@@ -796,6 +800,22 @@ template <> struct AccumPf<CurveG2P> {
   }
 };
 
+// next non-empty bucket after b (the one that holds sorted position `pos`).  Dense windows: the neighbour.  Sparse ones (a spread
+// top window that few scalars reach, small MSMs in wide windows) would walk thousands of empty buckets one dependent load at a
+// time - 0.4 ms for EIGHT entries in a 16 384-bucket window - so a second empty bucket sends the search to a bisection.
+__device__ __forceinline__ int msm_next_bucket(const uint32_t* __restrict__ bs, int b, uint32_t pos, int nb) {
+  b++;
+  if (bs[b + 1] > pos) return b;
+  b++;
+  if (bs[b + 1] > pos) return b;
+  int l = b, r = nb;  // bs[l] <= pos < bs[r]
+  while (r - l > 1) {
+    const int m = (l + r) >> 1;
+    if (bs[m] <= pos) l = m; else r = m;
+  }
+  return l;
+}
+
 template <class C>
 __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(const uint32_t* __restrict__ pts_mont,
                                                    const uint32_t* __restrict__ sorted,
@@ -860,7 +880,7 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
           G::acc_store(hp, acc);
           head_b = b;
         }
-        do { b++; } while (bs[b + 1] <= pos);
+        b = msm_next_bucket(bs, b, pos, pl.nb);
         b_start = bs[b];
         b_end = bs[b + 1];
         acc = into ? G::acc_load(buckets + ((size_t)w * pl.nb + b) * XW) : G::identity();
@@ -877,7 +897,7 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
         G::acc_store(hp, acc);
         head_b = b;
       }
-      do { b++; } while (bs[b + 1] <= pos);
+      b = msm_next_bucket(bs, b, pos, pl.nb);
       b_start = bs[b];
       b_end = bs[b + 1];
       acc = into ? G::acc_load(buckets + ((size_t)w * pl.nb + b) * XW) : G::identity();
@@ -1158,7 +1178,7 @@ constexpr int MSM_TAIL_REGION = 2 * MSM_TAIL_THREADS + 64;
 template <class C, bool COOP>
 __global__ void __launch_bounds__(MSM_TAIL_THREADS) k_msm_tail(const uint32_t* __restrict__ in, uint32_t* __restrict__ s0,
                                                                uint32_t* __restrict__ s1, uint32_t* __restrict__ fin,
-                                                               int narr, int nwin, int n_in, int g, int ngroups) {
+                                                               int narr, int nwin, int n_in, int g, int ngroups, int top_w, int top_tb) {
 #ifdef __HIP_DEVICE_COMPILE__
   using T = TailOps<C, COOP>;
   constexpr int XW = MsmGroup<C>::ACC_WORDS;
@@ -1201,9 +1221,17 @@ __global__ void __launch_bounds__(MSM_TAIL_THREADS) k_msm_tail(const uint32_t* _
   }
   // grouping: unit j combines the terms e_lo .. e_hi of this window into fin[j][w]; the chain runs in the unit's LDS accumulator
   uint32_t* acc = lds + T::SCRATCH_WORDS;
+  // a spread top window (MsmPlan::top_tb): only the pending sums of the levels below top_tb count - the weight of a bucket
+  // is (index mod 2^top_tb) + 1
+  const int levels = (w == top_w && top_tb > 0) ? min(top_tb, narr - 1) : narr - 1;
   for (int j = unit; j < ngroups; j += units) {
     const int e_lo = j * g;
-    const int e_hi = min((j + 1) * g, narr - 1) - 1;
+    const int e_hi = min((j + 1) * g, levels) - 1;
+    if (e_hi < e_lo) {   // nothing of this window in the group: the identity (all-zero accumulators decode as such)
+      uint32_t* dst = fin + ((size_t)j * nwin + w) * XW;
+      for (int i = (int)(threadIdx.x & ((1u << T::UNIT_SHIFT) - 1u)); i < XW; i += (1 << T::UNIT_SHIFT)) dst[i] = 0;
+      continue;
+    }
     auto at = [&](int a) { return cur + ((size_t)a * cur_a + cur_w) * XW; };
     T::copy(at(e_hi + 1), acc);
     T::sync();
@@ -1607,7 +1635,8 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     uint32_t* fin = (uint32_t*)(base + L.fin);
     using K = TailOps<D, CAN_COOP>;
     hipLaunchKernelGGL((k_msm_tail<D, CAN_COOP>), dim3(av.nwin), dim3(MSM_TAIL_THREADS), (size_t)tail_units * K::LDS_WORDS * 4, st, cur,
-                       t0, t1, fin, narr, av.nwin, n_in, MSM_GROUP, ng);
+                       t0, t1, fin, narr, av.nwin, n_in, MSM_GROUP, ng,
+                       pl.top_tb ? (pl.nwin_total ? pl.nwin_total : pl.nwin) - 1 - pl.w0 : -1, pl.top_tb);
     cur = fin;
   }
   *d_fin = cur;

@@ -61,6 +61,13 @@ struct MsmPlan {
   // nwin_total windows; the digit kernels cut bit position c (w0 + w), everything after them sees nwin local windows
   int w0 = 0;
   int nwin_total = 0;  // 0 = the plan is whole (nwin_total == nwin)
+  // SHORT TOP WINDOW (round 5): when the plan's last window holds few bits (255 = 19 x 13 + 8; secp256k1 at c = 16: 1-2 bits) its
+  // digits 1 .. 2^top_tb would put every entry of the window into a handful of buckets - runs of thousands of pieces for the fix-up.
+  // The digit kernel then spreads them: bucket = (index & top_submask) << top_tb | (digit - 1), i.e. 2^(c-1-top_tb) sub-buckets
+  // per digit value, and the tail drops the fold's pending sums of the levels >= top_tb for that window: the weight of bucket b
+  // becomes (b mod 2^top_tb) + 1 = the digit.  0 = off (full top window, endomorphism and shared-bucket plans).
+  int top_tb = 0;
+  uint32_t top_submask = 0;
   // per-context tuning overrides (ncg_msm_set_tuning; 0 / -1 = the measured defaults): entries per accumulate lane, and
   // how many following pieces the owner of a cut bucket adds itself before the run goes to the work list
   int seg_override = 0;
