@@ -116,13 +116,15 @@ inline int msm_make_plan_impl(int curve, int n, int c_override, MsmPlan* pl) {
     // decides how many bits the TOP window holds: 255-bit scalars in windows of 12 or 14 bits leave it 3 bits, i.e. a
     // handful of buckets holding every point of the window, which the fix-up then has to merge as very long runs
     // (measured: G1 2^17 c = 12 2.7 ms, c = 13 1.06 ms).  For bls12-381 the widths below are the measured best per
-    // size on MI355X (tools/msm_csweep.py, profiles/r03_msm_csweep.json): 8, 9, 10 (top window 1-5 bits short), 13, 15, 16.
+    // size on MI355X (tools/msm_csweep.py): round 3 (profiles/r03_msm_csweep.json) 8, 9, 10, 13, 15, 16; re-measured in round 5
+    // with the two-level sort and the spread top windows (profiles/r05_msm_csweep.json): a short top window no longer costs long
+    // fix-up runs, so c = 10 wins up to 2^15 (G1 2^15 0.73 -> 0.61 ms, G2 2^15 1.41 -> 1.24 ms) and c = 16 from 2^19.
     const int lg = ilog2((unsigned)std::max(n, 1));
     if (curve == CURVE_BLS12_381_G1) {
-      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 13, 13, 15, 15, 16};
+      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 7, 9, 10, 10, 10, 13, 13, 15, 16, 16};
       c = tab[std::min(lg, 20)];
     } else if (curve == CURVE_BLS12_381_G2) {
-      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 7, 7, 8, 9, 10, 13, 13, 13, 13, 15, 16};
+      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 7, 7, 9, 10, 10, 10, 13, 13, 13, 15, 16};
       c = tab[std::min(lg, 20)];
     } else {
       c = lg - 4;
