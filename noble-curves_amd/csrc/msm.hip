@@ -800,14 +800,13 @@ template <> struct AccumPf<CurveG2P> {
   }
 };
 
-// next non-empty bucket after b (the one that holds sorted position `pos`).  Dense windows: the neighbour.  Sparse ones (a spread
-// top window that few scalars reach, small MSMs in wide windows) would walk thousands of empty buckets one dependent load at a
-// time - 0.4 ms for EIGHT entries in a 16 384-bucket window - so a second empty bucket sends the search to a bisection.
-__device__ __forceinline__ int msm_next_bucket(const uint32_t* __restrict__ bs, int b, uint32_t pos, int nb) {
-  b++;
-  if (bs[b + 1] > pos) return b;
-  b++;
-  if (bs[b + 1] > pos) return b;
+// next non-empty bucket after b (the one that holds sorted position `pos`).  Dense windows: the neighbour, found by walking.
+// SPARSE windows (a spread top window that few scalars reach: MsmPlan::top_tb) would walk thousands of empty buckets one dependent
+// load at a time - 0.4 ms for EIGHT entries in a 16 384-bucket window - so there a second empty bucket sends the search to a
+// bisection.  The two forms are two instantiations of the kernel: the accumulate loop is register-bound (256 VGPRs + spills on
+// G1) and ANY extra instruction in it moves its code generation - the bisection in the loop, inline or out of line, cost the
+// 2^20-point G1 MSM 2-3 % (3.25 -> 3.37 ms, tools/ab_two_libs.sh), and that plan has no sparse window.
+__device__ __noinline__ int msm_bisect_bucket(const uint32_t* __restrict__ bs, int b, uint32_t pos, int nb) {
   int l = b, r = nb;  // bs[l] <= pos < bs[r]
   while (r - l > 1) {
     const int m = (l + r) >> 1;
@@ -815,8 +814,19 @@ __device__ __forceinline__ int msm_next_bucket(const uint32_t* __restrict__ bs, 
   }
   return l;
 }
+template <bool SPARSE>
+__device__ __forceinline__ int msm_next_bucket(const uint32_t* __restrict__ bs, int b, uint32_t pos, int nb) {
+  if constexpr (SPARSE) {
+    b++;
+    if (bs[b + 1] <= pos) b = msm_bisect_bucket(bs, b, pos, nb);
+    return b;
+  } else {
+    do { b++; } while (bs[b + 1] <= pos);
+    return b;
+  }
+}
 
-template <class C>
+template <class C, bool SPARSE>
 __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(const uint32_t* __restrict__ pts_mont,
                                                    const uint32_t* __restrict__ sorted,
                                                    const uint32_t* __restrict__ bucket_start,
@@ -880,7 +890,7 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
           G::acc_store(hp, acc);
           head_b = b;
         }
-        b = msm_next_bucket(bs, b, pos, pl.nb);
+        b = msm_next_bucket<SPARSE>(bs, b, pos, pl.nb);
         b_start = bs[b];
         b_end = bs[b + 1];
         acc = into ? G::acc_load(buckets + ((size_t)w * pl.nb + b) * XW) : G::identity();
@@ -897,7 +907,7 @@ __global__ void __launch_bounds__(256, AccumMinWaves<C>::value) k_msm_accum(cons
         G::acc_store(hp, acc);
         head_b = b;
       }
-      b = msm_next_bucket(bs, b, pos, pl.nb);
+      b = msm_next_bucket<SPARSE>(bs, b, pos, pl.nb);
       b_start = bs[b];
       b_end = bs[b + 1];
       acc = into ? G::acc_load(buckets + ((size_t)w * pl.nb + b) * XW) : G::identity();
@@ -1521,8 +1531,13 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       e = hipStreamWaitEvent(st, side->pts_ready, 0);
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_msm_accum<D>, grid, dim3(256), 0, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta,
-                       av, sg);
+    {
+      const int top_local = (pl.nwin_total ? pl.nwin_total : pl.nwin) - 1 - pl.w0;
+      if (pl.top_tb && top_local >= 0 && top_local < pl.nwin)   // this launch holds a spread top window: it may be sparse
+        hipLaunchKernelGGL((k_msm_accum<D, true>), grid, dim3(256), 0, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta, av, sg);
+      else
+        hipLaunchKernelGGL((k_msm_accum<D, false>), grid, dim3(256), 0, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta, av, sg);
+    }
     uint32_t* long_runs = (uint32_t*)(base + L.long_runs);
     e = hipMemsetAsync(long_runs, 0, 16, st);
     if (e != hipSuccess) return e;
