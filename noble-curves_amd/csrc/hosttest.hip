@@ -456,4 +456,20 @@ int ht_msm_plan(int curve, int n, int* out) {  // c, nwin, ngroups, acc words
   return 0;
 }
 
+// the short-top-window part of a plan (MsmPlan::top_tb): c (forced when c_override > 0), nwin, top_tb, top_submask, the
+// largest field the top window can hold (msm_plan_top_vmax) and H' (10 words) - tests/test_host_logic.py replays the digit
+// kernel's mapping on them with Python integers
+int ht_msm_plan_top(int curve, int n, int c_override, uint32_t* out16) {
+  MsmPlan pl;
+  if (msm_make_plan_impl(curve, n, c_override, &pl) != 0) return -1;
+  out16[0] = (uint32_t)pl.c;
+  out16[1] = (uint32_t)pl.nwin;
+  out16[2] = (uint32_t)pl.top_tb;
+  out16[3] = pl.top_submask;
+  out16[4] = msm_plan_top_vmax(pl);
+  out16[5] = (uint32_t)pl.nb;
+  for (int i = 0; i < 10; i++) out16[6 + i] = pl.hconst[i];
+  return 0;
+}
+
 }  // extern "C"

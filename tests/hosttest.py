@@ -42,6 +42,7 @@ def lib():
         _lib.ht_msm_shard_windows_local.argtypes = [i32, i32, i32, i32, vp, vp, vp]
         _lib.ht_msm_finish.argtypes = [i32, i32, i32, vp, vp, vp, i32]
         _lib.ht_msm_plan.argtypes = [i32, i32, vp]
+        _lib.ht_msm_plan_top.argtypes = [i32, i32, i32, vp]
         _lib.ht_h64_op.argtypes = [i32, vp, vp, vp, vp]
     return _lib
 
@@ -282,3 +283,12 @@ def msm_finish(curve, c, nwin, fin_words, point_bytes, variant):
     inf = np.zeros((1,), dtype=np.uint8)
     assert lib().ht_msm_finish(curve, c, nwin, fin.ctypes.data, out.ctypes.data, inf.ctypes.data, variant) == 0
     return out, bool(inf[0])
+
+
+def msm_plan_top(curve, n, c_override=0):
+    """{c, nwin, top_tb, top_submask, vmax, nb, hprime}: the short-top-window part of the window plan (MsmPlan::top_tb)."""
+    out = np.zeros(16, dtype=np.uint32)
+    assert lib().ht_msm_plan_top(curve, n, c_override, out.ctypes.data) == 0
+    hp = sum(int(out[6 + i]) << (32 * i) for i in range(10))
+    return {"c": int(out[0]), "nwin": int(out[1]), "top_tb": int(out[2]), "top_submask": int(out[3]), "vmax": int(out[4]), "nb": int(out[5]),
+            "hprime": hp}

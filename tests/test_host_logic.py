@@ -651,3 +651,44 @@ def test_ecdsa_scalar_side_lane_code():
                 assert u1 == (h % n) * inv % n and u2 == r * inv % n
     for r, s in ((0, 5), (5, 0), (n, 5), (5, n), ((1 << 256) - 1, 5)):
         assert not hosttest.ecdsa_prepare(r.to_bytes(32, "big") + s.to_bytes(32, "big"), bytes(32), False)[0]
+
+
+def test_short_top_window_spreading_keeps_every_digit_weight():
+    """MsmPlan::top_tb (round 5): a top window that holds few bits sends digit d >= 1 of point i to bucket
+    ((i & submask) << tb) | (d - 1), and the tail keeps only the fold's pending sums of the levels below tb, which weighs bucket b
+    by (b mod 2^tb) + 1.  Replayed with Python integers on the SHIPPED plan (csrc/msm_plan.hpp through the host twin): for random
+    and extreme scalars below the group order the weight of the bucket is the digit, the bucket exists, the spread digit fits the
+    int16 the kernel stores, and sum_w digit_w 2^(c w) - H' gives the scalar back (the reference's window sum, curve.ts:886-902)."""
+    import random
+    from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, ED25519, SECP256K1
+    from oracle.curves import BLS_R, ED25519_L, SECP256K1_N
+    rnd = random.Random(0x5EED)
+    cases = [(BLS12_381_G2, 1 << 18, 0, BLS_R, True), (BLS12_381_G1, 1 << 18, 0, BLS_R, True), (BLS12_381_G1, 1 << 20, 0, BLS_R, False),
+             (BLS12_381_G1, 1 << 16, 0, BLS_R, True), (SECP256K1, 1 << 20, 0, SECP256K1_N, True), (ED25519, 1 << 20, 0, ED25519_L, False),
+             (BLS12_381_G1, 1 << 15, 0, BLS_R, True), (BLS12_381_G2, 1 << 12, 14, BLS_R, True), (BLS12_381_G1, 4096, 12, BLS_R, True)]
+    for curve, n, c_over, order, expect_spread in cases:
+        p = hosttest.msm_plan_top(curve, n, c_over)
+        c, nwin, tb, sub, nb, hp = p["c"], p["nwin"], p["top_tb"], p["top_submask"], p["nb"], p["hprime"]
+        assert (tb > 0) == expect_spread, (curve, n, p)
+        half = 1 << (c - 1)
+        assert hp == sum(1 << (c * w + c - 1) for w in range(nwin)) and nb == half
+        ks = [0, 1, order - 1, order - 2, order >> 1, (1 << (order.bit_length() - 1)) - 1, 1 << (order.bit_length() - 1)]
+        ks += [rnd.randrange(order) for _ in range(300)]
+        top_max = 0
+        for i, k in enumerate(ks):
+            t = k + hp
+            assert t < 1 << (c * nwin)
+            digits = [((t >> (c * w)) & ((1 << c) - 1)) - half for w in range(nwin)]
+            assert sum(d << (c * w) for w, d in enumerate(digits)) == k          # signed windows: sum_w d_w 2^(c w) = k
+            d = digits[-1]
+            assert 0 <= d <= p["vmax"] - half + 1                                   # never negative in the top window
+            top_max = max(top_max, d)
+            if tb and d > 0:
+                idx = (i * 2654435761) & 0xFFFFF                                    # any point index
+                spread = ((idx & sub) << tb) + min(d, 1 << tb)                     # the digit kernel's mapping
+                assert 1 <= spread <= nb and spread < 1 << 15                      # a bucket of the window; fits int16
+                bucket = spread - 1
+                assert (bucket % (1 << tb)) + 1 == d                               # the weight the cut fold gives it
+                assert sub + 1 >= 8
+        if tb:
+            assert top_max <= 1 << tb
