@@ -1574,7 +1574,9 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       const dim3 mgrid((unsigned)((((size_t)av.nb << K::UNIT_SHIFT) + 255) / 256), av.nwin);
       hipLaunchKernelGGL((k_msm_fixup_merge_units<D, MCOOP>), mgrid, dim3(256), (size_t)(256 >> K::UNIT_SHIFT) * K::LDS_WORDS * 4, st, part_pts,
                          part_meta, acc_start, buckets, av, sg, long_runs,
-                         rs_forced ? run_serial : std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL));
+                         // up to 8 pieces per bucket stay with the bucket's own unit (a cooperative addition is ~8 us; the work list costs
+                         // a launch-wide 120 us as soon as many buckets overflow - the top window of 254-bit scalars holds 64-entry buckets)
+                         rs_forced ? run_serial : std::max(run_serial, MSM_RUN_SERIAL_SHARED));
     } else {
       hipLaunchKernelGGL(k_msm_fixup_merge<D>, grid, dim3(256), 0, st, part_pts, part_meta, acc_start, buckets, av, sg, long_runs,
                          rs_forced ? run_serial : std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL));
