@@ -56,12 +56,42 @@ function scalarRangeError(id, not0) {
 }
 // coordinates / scalars cross as packed little-endian bytes; the BigInt -> bytes step runs natively
 // (napi_get_value_bigint_words), ~5x faster than the hex-string route it replaces
+// Affine coordinates of every point with ONE field inversion (Montgomery's trick over Z, what the reference's own normalizeZ does,
+// curve.ts:311-326): a point with Z != 1 - any result of add / double / multiplyUnsafe - costs p.toAffine() a BigInt inversion
+// (~400 field products), 4 096 of them seconds.  Needs the reference's surface (p.Z, toAffine(invertedZ), Fp.mul / inv / eql / is0 /
+// ONE: weierstrass.ts:768-790, edwards.ts:603-607); any other registered class, and arrays whose points all have Z = 1, take
+// the plain path.
+function affineAll(c, points) {
+  const Fp = c.Fp, n = points.length;
+  const plain = () => { const out = new Array(n); for (let i = 0; i < n; i++) out[i] = points[i].toAffine(); return out; };
+  if (n < 2 || !Fp || typeof Fp.mul !== 'function' || typeof Fp.inv !== 'function' || typeof Fp.eql !== 'function' ||
+      typeof Fp.is0 !== 'function' || Fp.ONE === undefined || points[0].Z === undefined) return plain();
+  const pre = new Array(n);
+  let acc = Fp.ONE, any = false;
+  for (let i = 0; i < n; i++) {
+    const z = points[i].Z;
+    if (z === undefined || Fp.is0(z)) { pre[i] = undefined; continue; }   // ZERO: toAffine() answers by itself
+    if (!any && !Fp.eql(z, Fp.ONE)) any = true;
+    pre[i] = acc;
+    acc = Fp.mul(acc, z);
+  }
+  if (!any) return plain();
+  let inv = Fp.inv(acc);
+  const out = new Array(n);
+  for (let i = n - 1; i >= 0; i--) {
+    if (pre[i] === undefined) { out[i] = points[i].toAffine(); continue; }
+    out[i] = points[i].toAffine(Fp.mul(inv, pre[i]));
+    inv = Fp.mul(inv, points[i].Z);
+  }
+  return out;
+}
 function marshalPoints(c, id, points) {
   const pb = native.pointBytes(id), isFp2 = id === CURVE.BLS12_381_G2, fb = pb / (isFp2 ? 4 : 2);
   const flat = new Array(points.length * (isFp2 ? 4 : 2));
+  const aff = affineAll(c, points);
   let k = 0;
-  for (const p of points) {
-    const a = p.toAffine();
+  for (let i = 0; i < aff.length; i++) {
+    const a = aff[i];
     if (isFp2) { flat[k++] = a.x.c0; flat[k++] = a.x.c1; flat[k++] = a.y.c0; flat[k++] = a.y.c1; }
     else if (id === CURVE.ED25519) { flat[k++] = a.x % c.Fp.ORDER; flat[k++] = a.y % c.Fp.ORDER; }
     else { flat[k++] = a.x; flat[k++] = a.y; }
