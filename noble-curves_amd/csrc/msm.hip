@@ -34,7 +34,11 @@ __global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* __restri
 // fix-up / fold / grouping kernels: G1 sits 29-43 registers above the 2-waves/SIMD line and is 2-3 %
 // faster when asked to fit; the lane-paired G2 kernels are not (measured)
 template <class C> struct TailMinWaves { static constexpr int value = 1; };
-template <> struct TailMinWaves<CurveG1> { static constexpr int value = 2; };
+// (one wave per SIMD - 297 registers, no spills - measured again in round 5: the 2^20 G1 MSM 3.33 -> 3.48 ms; two it stays)
+#ifndef NCG_TAIL_MINW_G1
+#define NCG_TAIL_MINW_G1 2
+#endif
+template <> struct TailMinWaves<CurveG1> { static constexpr int value = NCG_TAIL_MINW_G1; };
 
 // ------------------------------------------------------------------ 2. signed digits
 // digits[w*n + i] = ((k_i + H') >> (c w)) & (2^c - 1)) - 2^(c-1)
