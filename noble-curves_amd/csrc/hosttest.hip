@@ -106,8 +106,9 @@ static int ht_shard_local_t(int curve, int n_local, int n_max, const uint32_t* p
   if (msm_make_plan_impl(curve, n_max, 0, &pl) != 0) return -1;
   const int ng = msm_ngroups(pl.c);
   int w0 = 0, cnt = pl.nwin;
-  if (mode == SHARD_WINDOWS) msm_shard_window_range(pl.nwin, part, nparts, &w0, &cnt);
-  const size_t fin_words = (size_t)ng * cnt * XW;
+  if (mode != SHARD_POINTS) msm_shard_window_range(pl.nwin, part, nparts, &w0, &cnt);
+  // SHARD_WINDOWS_SHARED (a precomputed set: every window adds into ONE bucket set, msm.hpp): the slot is one grouped-sum array
+  const size_t fin_words = (size_t)ng * (mode == SHARD_WINDOWS_SHARED ? 1 : cnt) * XW;
   memset(slot, 0, msm_shard_slot_bytes(curve));
   FinHeader h{(uint32_t)pl.c, (uint32_t)pl.nwin, (uint32_t)fin_words, (uint32_t)curve, (uint32_t)w0, (uint32_t)cnt, (uint32_t)mode, SHARD_NO_BAD};
   uint32_t* fin = (uint32_t*)(slot + sizeof h);
@@ -144,6 +145,16 @@ static int ht_shard_local_t(int curve, int n_local, int n_max, const uint32_t* p
     }
   }
   memcpy(slot, &h, sizeof h);
+  if (mode == SHARD_WINDOWS_SHARED) {  // what the shifted copies 2^(c w) P make of this rank's windows: V_0 = sum_w 2^(c w) W_w
+    typename G::Acc tot = G::identity();
+    for (int w = w0 + cnt - 1; w >= w0; w--) {
+      typename G::Acc t = win[w];
+      for (int b = 0; b < pl.c * w; b++) t = G::dbl(t);
+      tot = G::add(tot, t);
+    }
+    G::acc_store(fin, tot);  // V_j, j >= 1: all-zero words, as below
+    return 0;
+  }
   for (int w = 0; w < cnt; w++) G::acc_store(fin + (size_t)w * XW, win[w0 + w]);  // V_0 = W_w; V_j = identity for j >= 1
   return 0;
 }
@@ -170,7 +181,8 @@ static int ht_shard_combine_t(int curve, int n_max, int nparts, const uint8_t* s
     if (err && errlen > 0) snprintf(err, errlen, "noble-gpu: msm_sharded: invalid scalar at index %u of shard %d (not below the group order)", bad_idx, bad_rank);
     return 2;
   }
-  const size_t fin_words = (size_t)msm_ngroups(pl.c) * pl.nwin * XW;
+  const int fin_nwin = mode == SHARD_WINDOWS_SHARED ? 1 : pl.nwin;   // comm.hip job_finish_host: one window, no Horner across windows
+  const size_t fin_words = (size_t)msm_ngroups(pl.c) * fin_nwin * XW;
   std::vector<uint32_t> sum(fin_words);
   if (mode == SHARD_WINDOWS) {
     msm_shard_assemble_windows(slots, stride, hs.data(), nparts, curve, pl, sum.data());
@@ -182,7 +194,7 @@ static int ht_shard_combine_t(int curve, int n_max, int nparts, const uint8_t* s
       G::acc_store(sum.data() + t * XW, acc);
     }
   }
-  msm_host_finish_any<C>(sum.data(), pl.c, pl.nwin, out, out_inf);
+  msm_host_finish_any<C>(sum.data(), pl.c, fin_nwin, out, out_inf);
   return 0;
 }
 #define HT_CURVE_DISPATCH(curve, CALL)                \
@@ -387,8 +399,8 @@ int ht_ed_halve(const uint32_t* k, const uint32_t* s, uint32_t* out) {
 }
 
 size_t ht_msm_shard_slot_bytes(int curve) { return msm_shard_slot_bytes(curve); }
-int ht_msm_shard_windows_local(int curve, int n, int part, int nparts, const uint32_t* pts_wire, const uint32_t* scalars, uint8_t* slot) {
-#define CALL(C) ht_shard_local_t<C>(curve, n, n, pts_wire, scalars, slot, SHARD_WINDOWS, part, nparts)
+int ht_msm_shard_windows_local(int curve, int n, int part, int nparts, const uint32_t* pts_wire, const uint32_t* scalars, uint8_t* slot, int shared) {
+#define CALL(C) ht_shard_local_t<C>(curve, n, n, pts_wire, scalars, slot, shared ? SHARD_WINDOWS_SHARED : SHARD_WINDOWS, part, nparts)
   HT_CURVE_DISPATCH(curve, CALL)
 #undef CALL
 }

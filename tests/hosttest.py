@@ -39,7 +39,7 @@ def lib():
         _lib.ht_msm_shard_slot_bytes.restype = ctypes.c_size_t
         _lib.ht_msm_shard_local.argtypes = [i32, i32, i32, vp, vp, vp]
         _lib.ht_msm_shard_combine.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32]
-        _lib.ht_msm_shard_windows_local.argtypes = [i32, i32, i32, i32, vp, vp, vp]
+        _lib.ht_msm_shard_windows_local.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32]
         _lib.ht_msm_finish.argtypes = [i32, i32, i32, vp, vp, vp, i32]
         _lib.ht_msm_plan.argtypes = [i32, i32, vp]
         _lib.ht_msm_plan_top.argtypes = [i32, i32, i32, vp]
@@ -259,10 +259,11 @@ def msm_shard_local(curve, n_local, n_max, pts_ptr, scalars_ptr):
     return slot
 
 
-def msm_shard_windows_local(curve, n, part, nparts, pts_ptr, scalars_ptr):
-    """window-sharded mode: this part's range of the windows over ALL n points (host addresses)."""
+def msm_shard_windows_local(curve, n, part, nparts, pts_ptr, scalars_ptr, shared=False):
+    """window-sharded mode: this part's range of the windows over ALL n points (host addresses).  shared: the slot a
+    PRECOMPUTED set produces (SHARD_WINDOWS_SHARED: one grouped-sum array per rank, the ranks' slots are added)."""
     slot = np.zeros((msm_shard_slot_bytes(curve),), dtype=np.uint8)
-    assert lib().ht_msm_shard_windows_local(curve, n, part, nparts, pts_ptr, scalars_ptr, slot.ctypes.data) == 0
+    assert lib().ht_msm_shard_windows_local(curve, n, part, nparts, pts_ptr, scalars_ptr, slot.ctypes.data, 1 if shared else 0) == 0
     return slot
 
 
