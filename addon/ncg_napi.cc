@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "../include/ncg.h"
@@ -750,7 +751,11 @@ static napi_value PointBytes(napi_env env, napi_callback_info info) {
 // so that every later call on it moves by DMA at PCIe speed with no per-call page locking
 // A registered array must outlive its registration: a strong reference is held from hostRegister until hostUnregister, so the
 // backing store cannot be collected (and its address range handed to another allocation) while HIP still has it pinned.
-static std::map<uintptr_t, napi_ref> g_registered;
+// The map is process-wide (ncg_host_register is) while a napi_ref belongs to ONE env: worker_threads each load the addon, so the
+// map is guarded by a mutex and an entry remembers the env that made it; only that env may delete its reference.
+struct Registered { napi_env env; napi_ref ref; size_t len; };
+static std::map<uintptr_t, Registered> g_registered;
+static std::mutex g_registered_mu;
 static napi_value HostRegister(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -761,7 +766,14 @@ static napi_value HostRegister(napi_env env, napi_callback_info info) {
     napi_throw_type_error(env, nullptr, "noble-gpu: hostRegister(Uint8Array)");
     return nullptr;
   }
-  if (g_registered.count((uintptr_t)p)) return nullptr;   // already registered through this addon
+  std::lock_guard<std::mutex> lock(g_registered_mu);
+  auto have = g_registered.find((uintptr_t)p);
+  if (have != g_registered.end()) {
+    if (have->second.len >= len) return nullptr;   // already registered through this addon, at least this long
+    // the same base with a LARGER length: silently succeeding would leave the tail unpinned
+    napi_throw_error(env, nullptr, "noble-gpu: hostRegister: this buffer is already registered with a smaller length - hostUnregister it first");
+    return nullptr;
+  }
   if (ncg_host_register(p, len) != 0) return throw_native(env);
   napi_ref ref = nullptr;
   if (napi_create_reference(env, argv[0], 1, &ref) != napi_ok) {
@@ -769,7 +781,7 @@ static napi_value HostRegister(napi_env env, napi_callback_info info) {
     napi_throw_error(env, nullptr, "noble-gpu: hostRegister: cannot hold a reference to the array");
     return nullptr;
   }
-  g_registered[(uintptr_t)p] = ref;
+  g_registered[(uintptr_t)p] = Registered{env, ref, len};
   return nullptr;
 }
 static napi_value HostUnregister(napi_env env, napi_callback_info info) {
@@ -782,10 +794,15 @@ static napi_value HostUnregister(napi_env env, napi_callback_info info) {
     napi_throw_type_error(env, nullptr, "noble-gpu: hostUnregister(Uint8Array)");
     return nullptr;
   }
-  (void)ncg_host_unregister(p);
+  std::lock_guard<std::mutex> lock(g_registered_mu);
   auto it = g_registered.find((uintptr_t)p);
+  if (it != g_registered.end() && it->second.env != env) {
+    napi_throw_error(env, nullptr, "noble-gpu: hostUnregister: this buffer was registered from another thread's environment");
+    return nullptr;
+  }
+  (void)ncg_host_unregister(p);
   if (it != g_registered.end()) {
-    (void)napi_delete_reference(env, it->second);
+    (void)napi_delete_reference(env, it->second.ref);
     g_registered.erase(it);
   }
   return nullptr;

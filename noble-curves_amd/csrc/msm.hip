@@ -692,19 +692,13 @@ static bool msm_sort2_ok(const MsmPlan& pl, int n_max, Sort2* s2) {
     const int nwt = pl.nwin_total ? pl.nwin_total : pl.nwin;
     const int wl = nwt - 1 - pl.w0;   // local index of the top window
     if (wl >= 0 && wl < pl.nwin) {
-      uint32_t sum[11] = {0};
-      uint64_t cy = 0;
-      for (int i = 0; i < 10; i++) {
-        const uint64_t t = (uint64_t)(i < 8 ? pl.order[i] : 0u) + pl.hconst[i] + cy;
-        sum[i] = (uint32_t)t;
-        cy = t >> 32;
-      }
-      sum[10] = (uint32_t)cy;
-      const int bit = pl.c * (nwt - 1);
-      const uint64_t two = ((uint64_t)sum[(bit >> 5) + 1] << 32) | sum[bit >> 5];
-      const uint32_t vmax = (uint32_t)(two >> (bit & 31)) & ((1u << pl.c) - 1u);
+      // the ONE computation of the top field's bound (msm_plan.hpp; ADVICE r05: the sort, the spread and the tail must agree on it).
+      // A scalar >= the group order can exceed it: its top digit then wraps through `& (R - 1)` into another region of this window -
+      // memory-safe (every region index stays below R), and harmless only because such a call returns the bad-scalar error and
+      // its sum is discarded by every caller (k_msm_digits records the index; msm_finish_t / job_finish_host check it first)
+      const uint32_t vmax = msm_plan_top_vmax(pl);
       const uint32_t half = 1u << (pl.c - 1);
-      const uint32_t span = vmax >= half ? vmax - half + 2u : half;   // buckets the window can reach (+ 1 of slack)
+      const uint32_t span = vmax >= half ? vmax - half + 2u : half;   // buckets the window can reach: largest digit vmax - half, + 1, + 1 of slack (msm_plan_top_spread: maxd + 1)
       int tb = 0;
       while ((1u << tb) < span) tb++;
       if ((1u << tb) < half) {
@@ -1556,11 +1550,16 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     const int run_serial_auto = std::max(knob("NCG_MSM_RUN_SERIAL", MSM_RUN_SERIAL), std::min(8, heads_typ));
     const bool rs_forced = pl.run_serial_override >= 0;  // ncg_msm_set_tuning: exactly this many (tests force the work list)
     const int run_serial = rs_forced ? pl.run_serial_override : run_serial_auto;
+    // the threshold the fix-up kernel actually runs with, decided ONCE (the trace reported another value than the launch
+    // used for per-window plans on the cooperative-units kernel)
+    static const int units_knob = knob("NCG_MSM_MERGE_UNITS", -1);   // A/B builds: force on (1) / off (0)
+    const bool merge_units = (pl.shared || (units_knob >= 0 ? units_knob != 0 : run_serial_auto >= 3)) && CoopOK<D>::value;
+    const int run_serial_eff = rs_forced ? run_serial : std::max(run_serial, (merge_units || pl.shared) ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL);
     if (pl.trace) {
       MsmTrace& tr = *pl.trace;
       tr.c = pl.c; tr.nwin = pl.nwin; tr.nb = pl.nb; tr.seg = sg.seg; tr.nseg = sg.nseg; tr.w0 = pl.w0;
       tr.nwin_total = pl.nwin_total ? pl.nwin_total : pl.nwin;
-      tr.run_serial = rs_forced ? run_serial : std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL);
+      tr.run_serial = run_serial_eff;
       tr.d_long_runs = (const uint32_t*)(base + L.long_runs);
     }
     // shared-bucket mode: every bucket holds nwin * n / nb entries, i.e. a handful of pieces - all of them, so their
@@ -1570,9 +1569,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     // entries against buckets of n / nb: the two-window ranks of a window-sharded MSM run seg = 16 against 32-entry buckets):
     // the owner's serial chain of 3-4 single-lane additions (~30 us each on a lone wave) was the longest kernel of such a share
     // after the accumulate itself (138 us of 0.88 ms); four lanes per addition shorten every link of it
-    static const int units_knob = knob("NCG_MSM_MERGE_UNITS", -1);   // A/B builds: force on (1) / off (0)
-    const bool merge_units = pl.shared || (units_knob >= 0 ? units_knob != 0 : run_serial_auto >= 3);
-    if (merge_units && CoopOK<D>::value) {
+    if (merge_units) {
       constexpr bool MCOOP = CoopOK<D>::value;
       using K = TailOps<D, MCOOP>;
       const dim3 mgrid((unsigned)((((size_t)av.nb << K::UNIT_SHIFT) + 255) / 256), av.nwin);
@@ -1580,10 +1577,9 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
                          part_meta, acc_start, buckets, av, sg, long_runs,
                          // up to 8 pieces per bucket stay with the bucket's own unit (a cooperative addition is ~8 us; the work list costs
                          // a launch-wide 120 us as soon as many buckets overflow - the top window of 254-bit scalars holds 64-entry buckets)
-                         rs_forced ? run_serial : std::max(run_serial, MSM_RUN_SERIAL_SHARED));
+                         run_serial_eff);
     } else {
-      hipLaunchKernelGGL(k_msm_fixup_merge<D>, grid, dim3(256), 0, st, part_pts, part_meta, acc_start, buckets, av, sg, long_runs,
-                         rs_forced ? run_serial : std::max(run_serial, pl.shared ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL));
+      hipLaunchKernelGGL(k_msm_fixup_merge<D>, grid, dim3(256), 0, st, part_pts, part_meta, acc_start, buckets, av, sg, long_runs, run_serial_eff);
     }
     {
       constexpr bool LCOOP = CoopOK<D>::value;

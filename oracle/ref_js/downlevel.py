@@ -848,6 +848,11 @@ class Stripper:
 
 
 SHIM_PREFIX = "./"
+# packages the reference's TEST and BENCHMARK files import that are not installed here -> the stand-ins of oracle/ref_js/harness/
+# (a test runner, a property-test generator, a benchmark loop, the gz reader of an absent vectors submodule): harness, no arithmetic
+HARNESS = {"@paulmillr/jsbt/test.js": "harness/jsbt_test.mjs", "@paulmillr/jsbt/benchmark.js": "harness/jsbt_bench.mjs",
+           "@paulmillr/jsbt/benchmark-compare.js": "harness/jsbt_compare.mjs", "fast-check": "harness/fast_check.mjs",
+           "./vectors/acvp-vectors/utils.js": "harness/acvp_utils.mjs"}
 
 
 def map_path(lit):
@@ -855,9 +860,47 @@ def map_path(lit):
     p = lit[1:-1]
     if p.startswith("@noble/hashes/"):
         return q + SHIM_PREFIX + "hashes_shim.mjs" + q
+    if p in HARNESS:
+        return q + SHIM_PREFIX + HARNESS[p] + q
+    if p.startswith("@noble/curves/") and p.endswith(".js"):      # the package's own name (test helpers): its src/ tree
+        return q + SHIM_PREFIX + "src/" + p[len("@noble/curves/"):-3] + ".mjs" + q
     if p.endswith(".ts"):
         p = p[:-3] + ".mjs"
     return q + p + q
+
+
+# ---- the GPU redirect: the change a maintainer of the reference would make to src/abstract/curve.ts (INTEGRATION.md shows it as
+# a diff).  Written as TypeScript and applied to the reference's text BEFORE the types are stripped, at two anchors: a backend
+# registry in front of `pippenger`, and one dispatch line after its argument checks and its empty-input return - so the
+# reference's own validation (and its error messages) always runs, inputs below `minPoints` fall through to the reference's loop.
+HOOK_REGISTRY = """/**
+ * Optional accelerator for {@link pippenger}: a backend registered for a Point constructor receives the (already validated)
+ * arguments of every call with at least `minPoints` points; smaller inputs run the loop below.
+ */
+export type MSMBackend = { minPoints: number; msm: (c: any, points: any[], scalars: bigint[]) => any };
+const msmBackends = new WeakMap<object, MSMBackend>();
+export function setMSMBackend(c: object, backend?: MSMBackend): void {
+  if (backend === undefined) msmBackends.delete(c);
+  else msmBackends.set(c, backend);
+}
+"""
+HOOK_DISPATCH = """  const backend = msmBackends.get(c);
+  if (backend !== undefined && plength >= backend.minPoints) return backend.msm(c, points, scalars) as P;
+"""
+
+
+def apply_gpu_hook(src):
+    a1 = re.search(r"^/\*\*\n(?: \*[^\n]*\n)*? \*/\nexport function pippenger<", src, flags=re.M)
+    if a1 is None:
+        a1 = re.search(r"^export function pippenger<", src, flags=re.M)
+    a2 = re.search(r"^  if \(plength === 0\) return zero as P;\n", src, flags=re.M)
+    if a1 is None or a2 is None or a2.start() < a1.start():
+        raise SyntaxError("abstract/curve.ts: pippenger anchors not found - the hook needs a look")
+    # the doc comment regex is lazy over comment lines, but may start at an EARLIER comment: take the last '/**' before the function
+    fn = src.index("export function pippenger<", a1.start())
+    doc = src.rfind("/**", 0, fn)
+    at = doc if doc >= 0 and src[doc:fn].count("*/") == 1 else fn
+    return src[:at] + HOOK_REGISTRY + src[at:a2.end()] + HOOK_DISPATCH + src[a2.end():]
 
 
 NULLISH = re.compile(r"\?\?=?")
@@ -867,8 +910,13 @@ def post(text, relname):
     """the few ES2020+ operators left (none in the arithmetic): `a ?? b` with plain operands"""
     def repl(m):
         raise SyntaxError("%s: `??` needs a hand patch" % relname)
+    # JSON modules (`import x from './a.json' with { type: 'json' }`): Node 12 has neither import attributes nor JSON modules -
+    # the packer (oracle/refjs.py) writes `a.json.mjs` (`export default <the JSON>`) beside the data file
+    text = re.sub(r"(import\s+\w+\s+from\s+'[^']*\.json)'\s*with\s*\{[^}]*\}", r"\1.mjs'", text)
     if "??" in re.sub(r"//[^\n]*|/\*.*?\*/|'[^'\n]*'|\"[^\"\n]*\"|`[^`]*`", "", text, flags=re.S):
         text = re.sub(r"([A-Za-z_$][\w$.]*)\s*\?\?\s*([A-Za-z_$][\w$.]*|'[^']*'|\d+n?)", r"(\1 != null ? \1 : \2)", text)
+        # a parenthesised left operand (what `a?.b ?? c()` has become): member reads only, so evaluating it twice is harmless
+        text = re.sub(r"(\((?:[^()]|\([^()]*\))*\))\s*\?\?\s*([A-Za-z_$][\w$]*(?:\.[\w$]+|\(\))*)", r"(\1 != null ? \1 : \2)", text)
     return text
 
 
@@ -882,8 +930,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--src", default="/root/reference/src")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(here), "_ref", "js"))
+    ap.add_argument("--gpu-hook", action="store_true", help="apply the MSM-backend patch to abstract/curve.ts (the redirect of INTEGRATION.md)")
+    ap.add_argument("--print-hook-diff", action="store_true", help="print the patch as a unified diff against the reference's file and exit")
     ap.add_argument("files", nargs="*")
     a = ap.parse_args()
+    if a.print_hook_diff:
+        import difflib
+        rel = "abstract/curve.ts" if os.path.exists(os.path.join(a.src, "abstract/curve.ts")) else "src/abstract/curve.ts"
+        old = open(os.path.join(a.src, rel)).read()
+        sys.stdout.writelines(difflib.unified_diff(old.splitlines(True), apply_gpu_hook(old).splitlines(True), "a/src/abstract/curve.ts",
+                                                   "b/src/abstract/curve.ts", n=2))
+        return
     files = a.files or DEFAULT_FILES
     ok = True
     for rel in files:
@@ -891,6 +948,8 @@ def main():
         global SHIM_PREFIX
         SHIM_PREFIX = "../" * rel.count("/") or "./"
         try:
+            if a.gpu_hook and rel.endswith("abstract/curve.ts"):
+                src = apply_gpu_hook(src)
             text = post(Stripper(src, rel).run(), rel)
         except SyntaxError as e:
             print("FAIL", e, file=sys.stderr)

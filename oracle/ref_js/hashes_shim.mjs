@@ -97,10 +97,59 @@ export const sha256 = makeHash('sha256', 32, 64);
 export const sha384 = makeHash('sha384', 48, 128);
 export const sha512 = makeHash('sha512', 64, 128);
 export const sha224 = makeHash('sha224', 28, 64);
-export const shake256 = () => {
-  throw new Error('shake256 is not part of the shim');
-};
-export const shake128 = shake256;
+// SHAKE (ed448.ts builds its hashers from shake256 while the module loads; test/point.helpers.ts imports every curve): node:crypto's XOF with
+// a fixed output length, noble's `(msg, { dkLen })` / `.create({ dkLen })` call shapes
+function makeXof(name, blockLen) {
+  const create = (opts) => {
+    const outputLen = opts && opts.dkLen !== undefined ? opts.dkLen : 32;
+    const parts = [];
+    const o = {
+      outputLen,
+      blockLen,
+      update(m) {
+        parts.push(Uint8Array.from(abytes(m)));
+        return o;
+      },
+      digest() {
+        const c = crypto.createHash(name, { outputLength: outputLen });
+        for (const p of parts) c.update(p);
+        return new Uint8Array(c.digest());
+      },
+      destroy() {},
+    };
+    return o;
+  };
+  const h = (msg, opts) => create(opts).update(msg).digest();
+  h.create = create;
+  h.outputLen = 32;
+  h.blockLen = blockLen;
+  return h;
+}
+export const shake256 = makeXof('shake256', 136);
+export const shake128 = makeXof('shake128', 168);
+// createHasher(cons) of @noble/hashes/utils.js: a hash function object from a constructor of hash instances
+export function createHasher(hashCons, info = {}) {
+  const hashC = (msg, opts) => hashCons(opts).update(msg).digest();
+  const tmp = hashCons(undefined);
+  hashC.outputLen = tmp.outputLen;
+  hashC.blockLen = tmp.blockLen;
+  hashC.create = (opts) => hashCons(opts);
+  Object.assign(hashC, info);
+  return Object.freeze(hashC);
+}
+// misc.ts (jubjub / babyjubjub, not on the hot path) names two BLAKE hashes at module load; nothing the hot-path tests run calls them
+function absentHash(name, outputLen, blockLen) {
+  const fail = () => {
+    throw new Error(name + ' is not part of the shim');
+  };
+  const h = () => fail();
+  h.create = fail;
+  h.outputLen = outputLen;
+  h.blockLen = blockLen;
+  return h;
+}
+export const blake512 = absentHash('blake512', 64, 128);
+export const blake2s = absentHash('blake2s', 32, 64);
 const nodeName = (h) => (h === sha256 ? 'sha256' : h === sha512 ? 'sha512' : h === sha384 ? 'sha384' : h === sha224 ? 'sha224' : null);
 export function hmac(hash, key, message) {
   return hmac.create(hash, key).update(message).digest();

@@ -34,8 +34,11 @@ def build(reference="/root/reference/src"):
         for f in ("hashes_shim.mjs", "polyfill.mjs", "run_ref.mjs"):
             shutil.copy(os.path.join(SRC, f), os.path.join(d, f))
         os.makedirs(os.path.dirname(BUNDLE), exist_ok=True)
-        with tarfile.open(BUNDLE + ".tmp", "w:gz") as tar:
-            tar.add(d, arcname="js")
+        with tempfile.TemporaryDirectory() as dh:
+            _build_hooked(os.path.dirname(reference.rstrip("/")), dh)
+            with tarfile.open(BUNDLE + ".tmp", "w:gz") as tar:
+                tar.add(d, arcname="js")
+                tar.add(dh, arcname="js_hooked")
         os.replace(BUNDLE + ".tmp", BUNDLE)
     old = os.path.join(HERE, "_ref", "js")
     if os.path.isdir(old):
@@ -44,8 +47,43 @@ def build(reference="/root/reference/src"):
     return available()
 
 
+# ---- the REDIRECTED copy (js_hooked/): the reference with the MSM-backend patch of INTEGRATION.md applied to src/abstract/curve.ts
+# (downlevel.py --gpu-hook), laid out like the reference's repository (src/, test/, benchmark/) together with the reference's OWN
+# test and benchmark files for the path and the data files they read, so that tests/test_node_redirect.py can run them with the GPU
+# underneath.  harness/ holds stand-ins for the test runner / property generator / benchmark loop packages that are not installed.
+HOOKED_SRC = ["utils.ts", "abstract/modular.ts", "abstract/curve.ts", "abstract/weierstrass.ts", "abstract/der.ts", "abstract/edwards.ts",
+              "abstract/hash-to-curve.ts", "abstract/tower.ts", "abstract/bls.ts", "abstract/fft.ts", "abstract/montgomery.ts",
+              "abstract/frost.ts", "abstract/oprf.ts", "secp256k1.ts", "ed25519.ts", "bls12-381.ts", "bn254.ts", "ed448.ts", "misc.ts", "nist.ts"]
+HOOKED_TESTS = ["test/point.test.ts", "test/point.helpers.ts", "test/_more-curves.helpers.ts", "test/utils.helpers.ts", "test/utils.ts",
+                "benchmark/msm_timings.ts", "benchmark/bls12-381.ts"]
+HOOKED_DATA = ["test/vectors/curves-init.json", "test/vectors/ed25519/vectors.txt", "test/vectors/bls12-381/bls12-381-g2-test-vectors.txt"]
+
+
+def _build_hooked(ref_root, out):
+    files = ["src/" + f for f in HOOKED_SRC] + HOOKED_TESTS
+    subprocess.check_call(["python3", os.path.join(SRC, "downlevel.py"), "--src", ref_root, "--out", out, "--gpu-hook"] + files,
+                          stdout=subprocess.DEVNULL)
+    for f in ("hashes_shim.mjs", "polyfill.mjs"):
+        shutil.copy(os.path.join(SRC, f), os.path.join(out, f))
+    shutil.copytree(os.path.join(SRC, "harness"), os.path.join(out, "harness"))
+    for rel in HOOKED_DATA:                      # data files the reference's tests / benchmarks read (fixtures, not source)
+        dst = os.path.join(out, rel)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.copy(os.path.join(ref_root, rel), dst)
+        os.chmod(dst, 0o644)
+        if rel.endswith(".json"):                # JSON module for Node 12 (downlevel.py rewrites the import)
+            with open(dst) as f, open(dst + ".mjs", "w") as g:
+                g.write("export default " + json.dumps(json.load(f)) + ";\n")
+
+
 def available():
     return node() is not None and os.path.exists(BUNDLE)
+
+
+def hooked_dir():
+    """the redirected copy of the bundle (js_hooked/), or None when the bundle predates it"""
+    d = os.path.join(os.path.dirname(ref_dir()), "js_hooked")
+    return d if os.path.isdir(d) else None
 
 
 def ref_dir():
