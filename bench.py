@@ -420,7 +420,7 @@ def time_pipelined(submit, collect, depth, steps, warmup, dist_on, check=None):
                 if check:
                     check(r)
             submit(i % depth, i)
-        for i in range(k, k + min(depth, k)):
+        for i in range(max(0, k - depth), k):                 # the MSMs still in flight, oldest first
             r = collect(i % depth)
             done.append(time.perf_counter())
             if check:
@@ -953,11 +953,32 @@ def main():
         out["ms_per_msm_n1"] = wall_1 / K * 1e3
         out["speedup_vs_n1"] = wall_1 / wall_w
         out["n1_note"] = "ms_per_msm_n1 = the same MSM on the same resident set by ONE GPU (ncg_msm_resident_dev), measured in this run on every rank at once, slowest rank"
+        nwin_plan = out["window_plan"]["nwin"]
+        out["world"] = world
+        # csrc/msm_shard.hpp msm_shard_window_range: contiguous ranges, sizes differ by at most one
+        out["windows_per_rank"] = [nwin_plan // world + (1 if r < nwin_plan % world else 0) for r in range(world)]
         if native_multi:
             out["rccl_ranks"] = eng.comm_count()[0]           # ncclCommCount of the communicator the all-gather ran on
+
+        def chk(r):
+            assert wire_to_affine(curve, r[0]) == exp, "pipelined window-sharded MSM mismatch"
+        if not native_multi and world > 1:
+            # the host-staged exchange with parts in flight (ranks sharing GPUs, transports other than RCCL): this rank's part of
+            # MSM i on lane i % 3 (NCG_MSM_ASYNC_PART), its slot collected just before the lane is reused, the slots all-gathered
+            # by torch.distributed, ncg_msm_shard_combine on every rank
+            from noble_curves_amd.distributed import all_gather_slots
+
+            def collect_staged(lane):
+                slot = eng.msm_async_collect_slot(lane, curve)
+                return eng.msm_shard_combine(curve, nn, all_gather_slots(slot, device), stream)
+            pwall, iv = time_pipelined(lambda lane, i: eng.msm_async_submit(lane, curve, nn, 0, dev_ptr(sc), stream, res, eng.async_part(rank, world)),
+                                       collect_staged, 3, K, W, dist_on, chk)
+            pwall = max_over_ranks(pwall, dist_on, device)
+            out["pipelined"] = {"value": nn * K / pwall, "unit": "points/s", "ms_per_msm": pwall / K * 1e3, "depth": 3, "completion_intervals_ms": iv,
+                                "speedup_vs_n1": wall_1 / pwall,
+                                "note": "3 parts in flight per rank (ncg_msm_async_submit with NCG_MSM_ASYNC_PART(rank, world) -> slot -> all-gather over "
+                                        "torch.distributed -> ncg_msm_shard_combine); every result checked"}
         if native_multi:
-            def chk(r):
-                assert wire_to_affine(curve, r[0]) == exp, "pipelined window-sharded MSM mismatch"
             pwall, iv = time_pipelined(lambda lane, i: eng.msm_async_submit(lane, curve, nn, 0, dev_ptr(sc), stream, res, eng.ASYNC_WINDOWS),
                                        lambda lane: eng.msm_async_collect(lane, curve), 3, K, W, dist_on, chk)
             pwall = max_over_ranks(pwall, dist_on, device)

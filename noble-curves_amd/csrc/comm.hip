@@ -697,6 +697,7 @@ int ncg_msm_async_submit(ncg_ctx* ctx, int lane, int curve, size_t n, const void
   rc = lane_init(ctx, ln);
   if (rc) return rc;
   ln.curve = J.curve;
+  ln.part_only = (flags & NCG_MSM_ASYNC_PART_FLAG) != 0;
   ln.state_identity = J.n_plan == 0;
   if (ln.state_identity) {
     ln.busy = true;
@@ -709,7 +710,6 @@ int ncg_msm_async_submit(ncg_ctx* ctx, int lane, int curve, size_t n, const void
   JobRes R = lane_res(ln);
   JobState S;
   const bool collective = (flags & NCG_MSM_ASYNC_WINDOWS) != 0;
-  ln.part_only = (flags & NCG_MSM_ASYNC_PART_FLAG) != 0;
   if (ln.part_only) {  // one part of a window-sharded MSM; its slot comes back through ncg_msm_async_collect_slot
     J.part = (flags >> 8) & 0xFFF;
     J.nparts = (flags >> 20) & 0x7FF;

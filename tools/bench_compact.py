@@ -69,7 +69,7 @@ def _dist3(st):
 
 
 def msm_block(e):
-    out = _pick(e, ("value", "unit", "ms_per_msm", "total_points", "points_per_gpu", "scaling", "mode", "rccl_ranks",
+    out = _pick(e, ("value", "unit", "ms_per_msm", "total_points", "points_per_gpu", "scaling", "mode", "rccl_ranks", "world",
                     "ms_per_msm_n1", "speedup_vs_n1"))
     wp = e.get("window_plan")
     if isinstance(wp, dict):
