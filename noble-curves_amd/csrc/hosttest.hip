@@ -416,7 +416,8 @@ int ht_msm_shard_combine(int curve, int n_max, int nparts, const uint8_t* slots,
 }
 // host finish of the MSM alone: variant 0 = the device templates compiled for the host, 1 = the default
 // (bls12-381: 64-bit-limb Jacobian form of bls_host64.hpp; its field product on MULX / ADX where the CPU has them),
-// 2 = the default with the portable field product forced
+// 2 = the default with the portable field product forced, 3 = the default with the helper threads of the finish woken inside the
+// call (bls_host64.hpp FinishPool: windows built by the helpers, the chain by the caller), 4 = the helper threads off
 static int ht_msm_finish_default(int curve, int c, int nwin, const uint32_t* fin, uint32_t* out, uint8_t* out_inf) {
 #define CALL(C) (msm_host_finish_any<C>(fin, c, nwin, out, out_inf), 0)
   HT_CURVE_DISPATCH(curve, CALL)
@@ -429,8 +430,10 @@ int ht_msm_finish(int curve, int c, int nwin, const uint32_t* fin, uint32_t* out
 #undef CALL
   }
   h64::adx_override() = variant == 2 ? 0 : -1;
+  h64::finish_threads_override() = variant == 3 ? 2 : variant == 4 ? 0 : 1;
   const int rc = ht_msm_finish_default(curve, c, nwin, fin, out, out_inf);
   h64::adx_override() = -1;
+  h64::finish_threads_override() = 1;
   return rc;
 }
 int ht_h64_have_adx(void) { return h64::have_adx() ? 1 : 0; }

@@ -668,6 +668,119 @@ static __global__ void __launch_bounds__(512) k_sort2_fine_place(const uint32_t*
   }
 }
 
+// ------------------------------------------------------------------ 3c. the whole sort of a SMALL plan in one launch (round 6)
+// Up to 2^15 points the six sort launches (digits, hist, totals, scan, scatter x 1-2) are 4-7 us kernels 8-10 us apart: 50-65 us of a
+// 0.45 ms device phase that does 50 us of arithmetic (profiles/r06_msm_small_timeline.txt).  Here ONE workgroup per window does all
+// of it: the window's digit of every scalar (cut from k + H' exactly as k_msm_digits does, kept as int16 in LDS), the bucket
+// histogram, its exclusive scan (= bucket_start[w][0..nb]) and the placement into bucket order, with LDS atomics throughout.
+// The same workgroup clears its window's bucket accumulators (the accumulate kernel writes non-empty buckets only) and block 0 the
+// fix-up's work-list counter, which saves the two fill launches as well.  Same outputs as the separate kernels (the order inside
+// a bucket is arbitrary there too: LDS atomics).
+constexpr int MSM_SMALL_N = 1 << 15;     // points: 64 KB of LDS digits
+constexpr int MSM_SMALL_NB = 1 << 13;    // buckets per window: 32 KB of LDS counters
+static __global__ void __launch_bounds__(1024) k_msm_sort_small(const uint32_t* __restrict__ scalars, uint32_t* __restrict__ bucket_start,
+                                                         uint32_t* __restrict__ sorted, uint32_t* __restrict__ bad_index,
+                                                         uint32_t* __restrict__ buckets, int acc_words, uint32_t* __restrict__ long_runs,
+                                                         MsmPlan pl) {
+#ifdef __HIP_DEVICE_COMPILE__
+  extern __shared__ __attribute__((aligned(16))) uint32_t small_lds[];   // nb counters, then n int16 digits
+  __shared__ uint32_t wtot[16];
+  uint32_t* hist = small_lds;
+  int16_t* dcache = reinterpret_cast<int16_t*>(small_lds + pl.nb);
+  const int w = blockIdx.x, t = threadIdx.x;
+  for (int b = t; b < pl.nb; b += 1024) hist[b] = 0;
+  if (w == 0 && t < 4) long_runs[t] = 0;
+  {  // this window's bucket accumulators: all-zero words decode as the identity
+    uint4* bz = reinterpret_cast<uint4*>(buckets + (size_t)w * pl.nb * acc_words);
+    const int quads = (pl.nb * acc_words) >> 2;
+    for (int i = t; i < quads; i += 1024) bz[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  const uint32_t mask = (1u << pl.c) - 1u;
+  const int half = 1 << (pl.c - 1);
+  const int nwt = pl.nwin_total ? pl.nwin_total : pl.nwin;
+  const int bp = (w + pl.w0) * pl.c, limb = bp >> 5, sft = bp & 31;
+  const bool top_spread = pl.top_tb && w + pl.w0 == nwt - 1;
+  for (int i0 = 0; i0 < pl.n; i0 += 1024) {   // whole waves go round together (sort2_tally)
+    const int i = i0 + t;
+    int dg = 0;
+    if (i < pl.n) {
+      uint32_t k[8];
+      const uint4* kp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+      const uint4 lo = kp[0], hi = kp[1];
+      k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w;
+      k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+      if (w == 0) {   // one workgroup checks the range of the scalars
+        uint32_t bw = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) (void)__builtin_subc(k[j], pl.order[j], bw, &bw);
+        if (bw == 0) atomicMin(bad_index, pl.index_base + (uint32_t)i);  // scalar >= order
+      }
+      uint32_t sum[11];
+      uint32_t cy = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) sum[j] = __builtin_addc(k[j], pl.hconst[j], cy, &cy);
+      sum[8] = __builtin_addc(0u, pl.hconst[8], cy, &cy);
+      sum[9] = pl.hconst[9] + cy;
+      sum[10] = 0;
+      uint32_t lo32 = 0, hi32 = 0;   // limbs `limb`, `limb + 1` without indexing the register array dynamically
+#pragma unroll
+      for (int j = 0; j < 10; j++) {
+        if (j == limb) { lo32 = sum[j]; hi32 = sum[j + 1]; }
+      }
+      const uint64_t two = ((uint64_t)hi32 << 32) | lo32;
+      const uint32_t v = (uint32_t)(two >> sft) & mask;
+      dg = (int)v - half;
+      if (top_spread && dg > 0)   // short top window: sub-bucket by the point index (MsmPlan::top_tb)
+        dg = (int)((((uint32_t)i & pl.top_submask) << pl.top_tb) + (uint32_t)min(dg, 1 << pl.top_tb));
+      dcache[i] = (int16_t)dg;
+    }
+    sort2_tally(hist, (uint32_t)((dg < 0 ? -dg : dg) - 1), dg != 0);
+  }
+  __syncthreads();
+  // exclusive scan of the nb sizes: thread t owns a run of `per` buckets
+  {
+    const int per = (pl.nb + 1023) >> 10;
+    const int b0 = min(pl.nb, t * per), b1 = min(pl.nb, b0 + per);
+    uint32_t mine = 0;
+    for (int b = b0; b < b1; b++) mine += hist[b];
+    uint32_t incl = mine;
+    const int lane = t & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= off) incl += up;
+    }
+    if (lane == 63) wtot[t >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int j = 0; j < (t >> 6); j++) base += wtot[j];
+    uint32_t run = base + incl - mine;
+    uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+    for (int b = b0; b < b1; b++) {
+      const uint32_t size = hist[b];
+      hist[b] = run;   // the bucket's cursor
+      bs[b] = run;
+      run += size;
+    }
+    if (t == 1023) bs[pl.nb] = base + incl;
+  }
+  __syncthreads();
+  uint32_t* dst = sorted + (size_t)w * pl.n;
+  for (int i0 = 0; i0 < pl.n; i0 += 1024) {
+    const int i = i0 + t;
+    const int dg = i < pl.n ? (int)dcache[i] : 0;
+    const bool valid = dg != 0;
+    const uint32_t pos = sort2_claim(hist, (uint32_t)((dg < 0 ? -dg : dg) - 1), valid);
+    if (valid) dst[pos] = (uint32_t)i | (dg < 0 ? 0x80000000u : 0u);
+  }
+#endif
+}
+static bool msm_small_sort_ok(const MsmPlan& pl) {
+  static const int on = knob("NCG_MSM_SMALL_SORT", 1);   // A/B builds: 0 = the separate kernels
+  return on && !pl.endo && !pl.shared && pl.part_flags == 3 && pl.n_layout <= pl.n && pl.n <= MSM_SMALL_N && pl.nb <= MSM_SMALL_NB;
+}
+
 // does the two-level form apply to this plan?  Fills the per-plan constants.
 static bool msm_sort2_ok(const MsmPlan& pl, int n_max, Sort2* s2) {
   static const int on = knob("NCG_MSM_SORT2", 1);   // A/B builds: 0 = the one-level kernels
@@ -1041,6 +1154,9 @@ __global__ void __launch_bounds__(256) k_msm_reduce_level_coop(const uint32_t* _
 // group of four items sharing each operation (msm_coop.hpp).  Operands and results live in memory; `lds` is the
 // unit's scratch: the exchange slots of the cooperative form, then one accumulator for the grouping chain.
 constexpr int MSM_TAIL_THREADS = 512;
+#ifndef NCG_TAIL_ROUNDS
+#define NCG_TAIL_ROUNDS 1
+#endif
 template <class C, bool COOP> struct TailOps;
 template <class C>
 struct TailOps<C, false> {
@@ -1178,6 +1294,80 @@ __global__ void __launch_bounds__(256, 2) k_msm_fixup_merge_units(const uint32_t
 #endif
 }
 
+// The fix-up merge of the SMALL plans (round 6): 2^MERGE_TREE_ULOG units per bucket (two: measured against four and against one
+// unit with the work-list threshold at 15, tools/ab_small_msm.sh -> profiles/r06_ab_small_msm.txt: four units idle through most of
+// the tree and quadruple the waves - 83 us for the 2^14-point G1 merge where two take 60).  A plan that does not fill the chip runs short lane
+// segments (msm_seg: 4-12 entries, so that the accumulate kernel's dependent chain is short), which cuts every bucket into
+// (m + 4 sqrt(m)) / seg pieces - up to 8-15 of them - and one unit adding them one after the other made the merge the longest
+// kernel of a 2^13 / 2^14-point MSM (62 us, + 35 us of work-list runs above 8 pieces).  Here unit u of the bucket's group sums the
+// pieces u, u + U, .. and a tree over the U accumulators (LDS, all in one wave) finishes: ceil(P / U) - 1 + log2 U dependent
+// additions for P pieces (two units, P = 15: 8 instead of 14).  Runs of more than run_serial heads still go to the work list.
+#ifndef NCG_MERGE_TREE_ULOG
+#define NCG_MERGE_TREE_ULOG 1
+#endif
+constexpr int MERGE_TREE_ULOG = NCG_MERGE_TREE_ULOG;
+template <class C, bool COOP>
+__global__ void __launch_bounds__(256, 2) k_msm_fixup_merge_tree(const uint32_t* __restrict__ part_pts, const int* __restrict__ part_meta,
+                                                              const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ buckets,
+                                                              MsmPlan pl, MsmSeg sg, uint32_t* __restrict__ long_runs, int run_serial) {
+#ifdef __HIP_DEVICE_COMPILE__
+  using T = TailOps<C, COOP>;
+  constexpr int XW = MsmGroup<C>::ACC_WORDS, U = 1 << MERGE_TREE_ULOG;
+  extern __shared__ __attribute__((aligned(16))) uint32_t tree_lds[];
+  const int unit = (int)(threadIdx.x >> T::UNIT_SHIFT);
+  uint32_t* lds = tree_lds + (size_t)unit * T::LDS_WORDS;
+  uint32_t* acc = lds + T::SCRATCH_WORDS;
+  const int gunit = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> T::UNIT_SHIFT);
+  const int tb = gunit >> MERGE_TREE_ULOG, sub = gunit & (U - 1), w = blockIdx.y;
+  if (tb >= pl.nb) return;
+  const uint32_t* bs = bucket_start + (size_t)w * (pl.nb + 1);
+  const uint32_t b0 = bs[tb], b1 = bs[tb + 1];
+  if (b1 == b0) return;
+  const int s = (int)(b0 / (uint32_t)sg.seg);
+  if (part_meta[((size_t)w * sg.nseg + s) * 4 + 2] != tb) return;   // the bucket is not cut
+  const int s1 = (int)((b1 - 1) / (uint32_t)sg.seg);
+  const int heads = s1 - s;
+  if (heads > run_serial) {
+    if (sub == 0 && (threadIdx.x & ((1u << T::UNIT_SHIFT) - 1u)) == 0) {
+      const uint32_t k = atomicAdd(long_runs, 1u);
+      uint32_t* e = long_runs + 4 + (size_t)k * 4;
+      e[0] = (uint32_t)w;
+      e[1] = (uint32_t)tb;
+      e[2] = (uint32_t)s;
+      e[3] = (uint32_t)s1;
+    }
+    return;
+  }
+  const uint32_t* pp = part_pts + (size_t)w * sg.nseg * 2 * XW;
+  uint32_t* dst = buckets + ((size_t)w * pl.nb + tb) * XW;
+  const int np = heads + 1;   // piece 0 = the tail slot of lane s, piece k >= 1 = the head slot of lane s + k
+  auto piece = [&](int k) { return pp + ((size_t)(s + k) * 2 + (k == 0 ? 1 : 0)) * XW; };
+  if (np == 1) {
+    if (sub == 0) T::copy(piece(0), dst);
+    return;
+  }
+  // (the units of a bucket sit in one wave: U x 4 lanes on G1, U x 8 on the lane-paired G2; T::sync orders their LDS traffic)
+  if (sub < np) {
+    T::copy(piece(sub), acc);
+    T::sync();
+    for (int k = sub + U; k < np; k += U) {
+      T::add(lds, acc, piece(k), acc);
+      T::sync();
+    }
+  }
+  const int live = np < U ? np : U;   // accumulators that hold something
+#pragma unroll
+  for (int off = U >> 1; off >= 1; off >>= 1) {
+    T::sync();
+    if (sub < off && sub + off < live) {
+      uint32_t* other = tree_lds + (size_t)(unit + off) * T::LDS_WORDS + T::SCRATCH_WORDS;
+      if (off == 1) T::add(lds, acc, other, dst);
+      else T::add(lds, acc, other, acc);
+    }
+  }
+#endif
+}
+
 // in: [narr][nwin][n_in] accumulators (read-only here: other workgroups read their windows from it);
 // s0 / s1: scratch, MSM_TAIL_REGION accumulators PER WINDOW each - a window's levels ping-pong inside its own
 // regions, laid out [array][n] (workgroups run at different levels, so they must not share a layout);
@@ -1186,9 +1376,12 @@ constexpr int MSM_TAIL_REGION = 2 * MSM_TAIL_THREADS + 64;
 template <class C, bool COOP>
 __global__ void __launch_bounds__(MSM_TAIL_THREADS) k_msm_tail(const uint32_t* __restrict__ in, uint32_t* __restrict__ s0,
                                                                uint32_t* __restrict__ s1, uint32_t* __restrict__ fin,
-                                                               int narr, int nwin, int n_in, int g, int ngroups, int top_w, int top_tb) {
+                                                               int narr, int nwin, int n_in, int g, int ngroups, int top_w, int top_tb,
+                                                               uint32_t* __restrict__ host_flag, uint32_t host_gen) {
 #ifdef __HIP_DEVICE_COMPILE__
   using T = TailOps<C, COOP>;
+  if (host_flag && blockIdx.x == 0 && threadIdx.x == 0)   // "the tail has started": the host wakes its finish helpers (msm_finish_t)
+    __hip_atomic_store(host_flag, host_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   constexpr int XW = MsmGroup<C>::ACC_WORDS;
   extern __shared__ __attribute__((aligned(16))) uint32_t tail_lds[];
   const int unit = (int)(threadIdx.x >> T::UNIT_SHIFT), units = (int)(blockDim.x >> T::UNIT_SHIFT);
@@ -1316,11 +1509,34 @@ static MsmSeg msm_seg(const MsmPlan& pl) {
     double best = 1e300;
     sg.seg = 16;
     const int n_seg = pl.n_layout > 0 ? pl.n_layout : pl.n;   // parts of one MSM share the segment of the layout plan
-    for (int seg = 16; seg <= 160; seg++) {
+    // Plans that do NOT fill the chip (round 6, tools/msm_small_sweep.py -> profiles/r06_msm_small_sweep.json): the kernel's time is
+    // then seg x the latency of one addition on a SIMD that holds k = 1, 2.. waves - max(r1, k) in units of the throughput-bound
+    // time of a wave-addition, r1 = a lone wave's latency (G1 12 us against 9.5, lane-paired G2 16 against 14.6) - and shorter
+    // segments cut every bucket of m = n / nb entries into m / seg more pieces, which its fix-up unit adds one after the other
+    // (f = one cooperative addition, 8 / 12 us; single-lane complete additions on the curves without cooperative units).  With
+    // the floor of 16 entries the G1 plans below 2^15 points ran 350-420 waves on 1024 SIMDs for 16 x 12 us; measured best
+    // segments: 4-6 up to 2^12 points, 6-8 at 2^13 / 2^14, 12 at 2^15 / 2^16 (G1 2^13 0.536 -> 0.466 ms, 2^16 0.85 -> 0.75 ms).
+    const bool bls = pl.accum_waves == 2;
+    const double r1 = pl.ls ? 1.1 : 1.25, f = bls ? 0.8 : 1.6;
+    const double m = (double)n_seg / (double)std::max(1, pl.nb);
+    for (int seg = 4; seg <= 160; seg++) {
       const long nseg = (n_seg + seg - 1) / seg;
       const long lanes = ((long)pl.nwin * nseg) << pl.ls;
       const long rounds = (lanes + cap - 1) / cap;
-      const double cost = (double)rounds * seg + 3.0 * (double)lanes / (double)cap;
+      double cost;
+      if (lanes <= cap) {
+        // waves per SIMD: the accumulate launch pins grids of up to 256 / 512 workgroups to one / two per CU (LDS reservation)
+        const long wgs = (long)pl.nwin * (((nseg << pl.ls) + 255) / 256);
+        const double k = wgs <= 256 ? 1.0 : wgs <= 512 ? 2.0 : (double)((lanes + 65535) / 65536);
+        // pieces of the fullest buckets: (m + 4 sqrt(m)) / seg + 1; the merge adds them as a tree of four units per bucket where the
+        // curve has cooperative units (k_msm_fixup_merge_tree), one after the other elsewhere
+        const double pieces = (m + 4.0 * std::sqrt(m)) / (double)seg + 1.0;
+        const double chain = bls ? std::max(0.0, std::ceil(pieces / 4.0) - 1.0) + 2.0 : pieces - 1.0;
+        cost = (double)seg * std::max(r1, k) + std::max(3.0 * (double)lanes / 65536.0, f * chain);
+      } else {
+        if (seg < 16) continue;   // full chip: the measured segments of rounds 3-5 (16..160) stand
+        cost = (double)rounds * seg * pl.accum_waves + 3.0 * (double)lanes / 65536.0;
+      }
       if (cost < best - 1e-9) {
         best = cost;
         sg.seg = seg;
@@ -1415,6 +1631,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     e = hipMemsetAsync(bad, 0xFF, 4, st);
     if (e != hipSuccess) return e;
   }
+  const bool small_sort = msm_small_sort_ok(pl);   // digits + sort + the two clears in one launch (3c)
   if (pl.endo) {  // d_pts is the expanded image set, already in storage format (msm_endo_expand)
     pts_mont = const_cast<uint32_t*>(d_pts);
     e = msm_endo_digits(pl, d_scalars, digits, bad, st);
@@ -1436,7 +1653,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       hipLaunchKernelGGL(k_points_to_mont<D>, dim3((unsigned)((((size_t)n << LS) + 255) / 256)), dim3(256), 0, st, d_pts,
                          pts_mont, n);
     }
-    hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl, bad);
+    if (!small_sort) hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, d_scalars, digits, pl, bad);
   }
   size_t lds = (size_t)pl.nb * 4;
   {  // opt in to large dynamic LDS once per process and device (c <= 16: at most 128 KB)
@@ -1457,7 +1674,18 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
   const dim3 sort_grid = pl.xcd_map ? dim3((unsigned)(pl.Q * ((pl.nwin + 7) & ~7))) : dim3(pl.Q, pl.nwin);
   uint32_t* shared_start = (uint32_t*)(base + L.shared_start);
   Sort2 s2;
-  if (msm_sort2_ok(pl, std::max(pl.n, pl.n_layout), &s2)) {   // two-level sort (3b): same bucket_start / sorted
+  if (small_sort) {
+    static bool attr_done[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+      e = hipFuncSetAttribute((const void*)k_msm_sort_small, hipFuncAttributeMaxDynamicSharedMemorySize, MSM_SMALL_NB * 4 + MSM_SMALL_N * 2);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 16) attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(k_msm_sort_small, dim3(pl.nwin), dim3(1024), (size_t)pl.nb * 4 + (size_t)((pl.n + 1) & ~1) * 2, st, d_scalars, bstart, sorted, bad,
+                       buckets, XW, (uint32_t*)(base + L.long_runs), pl);
+  } else if (msm_sort2_ok(pl, std::max(pl.n, pl.n_layout), &s2)) {   // two-level sort (3b): same bucket_start / sorted
     uint32_t* ccount = counts;
     const int R = 1 << s2.lgr;
     uint32_t* region_start = ccount + (size_t)pl.nwin * pl.Q * R;
@@ -1515,7 +1743,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     MsmSeg sg = msm_seg(av);
     uint32_t* part_pts = (uint32_t*)(base + L.part_pts);
     int* part_meta = (int*)(base + L.part_meta);
-    if (part_first) {
+    if (part_first && !small_sort) {
       e = hipMemsetAsync(buckets, 0, (size_t)av.nwin * av.nb * XW * 4, st);  // empty buckets = infinity
       if (e != hipSuccess) return e;
     }
@@ -1530,15 +1758,37 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       if (e != hipSuccess) return e;
     }
     {
+      // A grid of at most two workgroups per CU is latency-bound (every lane's chain of `seg` additions on a wave that has its SIMD
+      // to itself, or shares it with one other), and the dispatcher does not spread workgroups evenly: 238 workgroups on 256 CUs ran
+      // 18.5 us per addition where 104 ran 12.  An LDS reservation the kernel never touches makes the placement explicit: with
+      // 96 KB per workgroup a CU (160 KB) takes one, with 56 KB two.
+      static const int spread_knob = knob("NCG_MSM_ACCUM_SPREAD", 1);   // A/B builds: 0 = off
+      const size_t wgs = (size_t)grid.x * grid.y;
+      size_t reserve = 0;
+      if (spread_knob && wgs <= 256) reserve = 96 * 1024;
+      else if (spread_knob && wgs <= 512) reserve = 56 * 1024;
+      if (reserve) {
+        static bool attr_done[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+          e = hipFuncSetAttribute((const void*)k_msm_accum<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+          if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_msm_accum<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+          if (e != hipSuccess) return e;
+          if (dev >= 0 && dev < 16) attr_done[dev] = true;
+        }
+      }
       const int top_local = (pl.nwin_total ? pl.nwin_total : pl.nwin) - 1 - pl.w0;
       if (pl.top_tb && top_local >= 0 && top_local < pl.nwin)   // this launch holds a spread top window: it may be sparse
-        hipLaunchKernelGGL((k_msm_accum<D, true>), grid, dim3(256), 0, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta, av, sg);
+        hipLaunchKernelGGL((k_msm_accum<D, true>), grid, dim3(256), reserve, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta, av, sg);
       else
-        hipLaunchKernelGGL((k_msm_accum<D, false>), grid, dim3(256), 0, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta, av, sg);
+        hipLaunchKernelGGL((k_msm_accum<D, false>), grid, dim3(256), reserve, st, pts_mont, sorted, acc_start, buckets, part_pts, part_meta, av, sg);
     }
     uint32_t* long_runs = (uint32_t*)(base + L.long_runs);
-    e = hipMemsetAsync(long_runs, 0, 16, st);
-    if (e != hipSuccess) return e;
+    if (!small_sort) {
+      e = hipMemsetAsync(long_runs, 0, 16, st);
+      if (e != hipSuccess) return e;
+    }
     // How many heads the owner of a run adds itself.  A bucket of m entries cut by lanes of `seg` entries has up to
     // ceil(m / seg) heads; m is n / nb on average and rarely above m + 4 sqrt(m).  The seg that fills the chip in one
     // round can be a third of that (verified G1 set of 2^17 points: 64 entries per bucket, seg 20), and with a fixed
@@ -1554,7 +1804,10 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     // used for per-window plans on the cooperative-units kernel)
     static const int units_knob = knob("NCG_MSM_MERGE_UNITS", -1);   // A/B builds: force on (1) / off (0)
     const bool merge_units = (pl.shared || (units_knob >= 0 ? units_knob != 0 : run_serial_auto >= 3)) && CoopOK<D>::value;
-    const int run_serial_eff = rs_forced ? run_serial : std::max(run_serial, (merge_units || pl.shared) ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL);
+    static const int tree_knob = knob("NCG_MSM_MERGE_TREE", 1);   // A/B builds: 0 = one unit per bucket
+    // short segments (plans that do not fill the chip): a tree of MERGE_TREE_U units per bucket, up to 16 pieces
+    const bool merge_tree = merge_units && tree_knob && sg.seg < 16;
+    const int run_serial_eff = rs_forced ? run_serial : std::max(run_serial, merge_tree ? 15 : (merge_units || pl.shared) ? MSM_RUN_SERIAL_SHARED : MSM_RUN_SERIAL);
     if (pl.trace) {
       MsmTrace& tr = *pl.trace;
       tr.c = pl.c; tr.nwin = pl.nwin; tr.nb = pl.nb; tr.seg = sg.seg; tr.nseg = sg.nseg; tr.w0 = pl.w0;
@@ -1569,7 +1822,13 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     // entries against buckets of n / nb: the two-window ranks of a window-sharded MSM run seg = 16 against 32-entry buckets):
     // the owner's serial chain of 3-4 single-lane additions (~30 us each on a lone wave) was the longest kernel of such a share
     // after the accumulate itself (138 us of 0.88 ms); four lanes per addition shorten every link of it
-    if (merge_units) {
+    if (merge_tree) {
+      constexpr bool MCOOP = CoopOK<D>::value;
+      using K = TailOps<D, MCOOP>;
+      const dim3 mgrid((unsigned)((((size_t)av.nb << (K::UNIT_SHIFT + MERGE_TREE_ULOG)) + 255) / 256), av.nwin);
+      hipLaunchKernelGGL((k_msm_fixup_merge_tree<D, MCOOP>), mgrid, dim3(256), (size_t)(256 >> K::UNIT_SHIFT) * K::LDS_WORDS * 4, st, part_pts,
+                         part_meta, acc_start, buckets, av, sg, long_runs, run_serial_eff);
+    } else if (merge_units) {
       constexpr bool MCOOP = CoopOK<D>::value;
       using K = TailOps<D, MCOOP>;
       const dim3 mgrid((unsigned)((((size_t)av.nb << K::UNIT_SHIFT) + 255) / 256), av.nwin);
@@ -1624,7 +1883,10 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
       if (dev >= 0 && dev < 16) attr_done[dev] = true;
     }
   }
-  while (n_in > 1 && (long)(narr + 1) * (n_in >> 1) > 2L * tail_units) {
+  // a level that needs more than `tail_rounds` rounds of the tail workgroup's units is a launch of its own: chip-wide it costs
+  // 9-13 us, inside the tail 8-12 us PER ROUND (one workgroup per window)
+  static const int tail_rounds = std::max(1, knob("NCG_MSM_TAIL_ROUNDS", NCG_TAIL_ROUNDS));
+  while (n_in > 1 && (long)(narr + 1) * (n_in >> 1) > (long)tail_rounds * tail_units) {
     const long total = (long)(narr + 1) * av.nwin * (n_in >> 1);
     bool done = false;
     if constexpr (CAN_COOP) {
@@ -1653,7 +1915,7 @@ static hipError_t msm_device_t(const MsmPlan& pl, const uint32_t* d_pts, const u
     using K = TailOps<D, CAN_COOP>;
     hipLaunchKernelGGL((k_msm_tail<D, CAN_COOP>), dim3(av.nwin), dim3(MSM_TAIL_THREADS), (size_t)tail_units * K::LDS_WORDS * 4, st, cur,
                        t0, t1, fin, narr, av.nwin, n_in, MSM_GROUP, ng,
-                       pl.top_tb ? (pl.nwin_total ? pl.nwin_total : pl.nwin) - 1 - pl.w0 : -1, pl.top_tb);
+                       pl.top_tb ? (pl.nwin_total ? pl.nwin_total : pl.nwin) - 1 - pl.w0 : -1, pl.top_tb, pl.tail_flag, pl.tail_gen);
     cur = fin;
   }
   *d_fin = cur;
@@ -1666,6 +1928,9 @@ static size_t msm_fin_words_t(const MsmPlan& pl) {
   return (size_t)msm_ngroups(pl.c) * msm_acc_view(pl).nwin * MsmGroup<C>::ACC_WORDS;
 }
 
+template <class C> struct FinishHelpers { static constexpr bool value = false; };   // curves whose host finish runs over helper threads
+template <> struct FinishHelpers<CurveG1> { static constexpr bool value = true; };
+template <> struct FinishHelpers<CurveG2> { static constexpr bool value = true; };
 // Finish: the grouped window sums come to the host (one small copy), Horner, canonical affine output.
 // Synchronises `st`.
 template <class C>
@@ -1695,6 +1960,18 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
   if (d_bad && bad_host) {
     e = hipMemcpyAsync(bad_host, d_bad, 4, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return e;
+  }
+  if (pl.tail_flag && FinishHelpers<C>::value && msm_host64_enabled() && h64::finish_threads_override() == 1) {
+    // the helper threads of the host finish take 10-50 us to come out of their sleep: wake them when the tail kernel STARTS (it
+    // runs ~0.1 ms), not when the stream is done.  Polling a word of pinned memory costs what hipStreamSynchronize's own spin costs.
+    volatile uint32_t* flag = pl.tail_flag;
+    for (unsigned it = 0; *flag != pl.tail_gen; it++) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+      if ((it & 127u) == 127u && hipStreamQuery(st) != hipErrorNotReady) break;
+    }
+    h64::FinishPool::get().wake();
   }
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
@@ -1730,9 +2007,22 @@ static hipError_t msm_run_t(const MsmPlan& pl, const uint32_t* d_pts, const uint
                             uint32_t* out_affine_host, uint8_t* out_inf_host, hipStream_t st, uint32_t* bad_index,
                             const MsmSide* side) {
   const uint32_t *d_fin = nullptr, *d_bad = nullptr;
-  hipError_t e = msm_device_t<C>(pl, d_pts, d_scalars, ws, &d_fin, st, &d_bad, side);
+  MsmPlan plr = pl;
+  if (FinishHelpers<C>::value && msm_acc_view(pl).nwin >= 4) {   // one pinned word per calling thread: "the tail kernel has started"
+    static thread_local uint32_t* flag = nullptr;
+    static thread_local uint32_t gen = 0;
+    if (!flag) {
+      if (hipHostMalloc((void**)&flag, 64, hipHostMallocPortable) == hipSuccess) *flag = 0;
+      else { flag = nullptr; (void)hipGetLastError(); }
+    }
+    if (flag) {
+      plr.tail_flag = flag;
+      plr.tail_gen = ++gen ? gen : ++gen;   // never 0
+    }
+  }
+  hipError_t e = msm_device_t<C>(plr, d_pts, d_scalars, ws, &d_fin, st, &d_bad, side);
   if (e != hipSuccess) return e;
-  return msm_finish_t<C>(pl, d_fin, out_affine_host, out_inf_host, st, d_bad, bad_index);
+  return msm_finish_t<C>(plr, d_fin, out_affine_host, out_inf_host, st, d_bad, bad_index);
 }
 
 template <class C>

@@ -83,6 +83,10 @@ struct MsmPlan {
   int n_layout = 0;
   int Q_layout = 0;   // sort chunks of the layout plan (the per-chunk count arrays are sized by it)
   uint32_t index_base = 0;
+  // host side (msm_run): a word of pinned host memory that k_msm_tail sets to tail_gen when it STARTS - the caller then wakes the
+  // helper threads of the host finish (bls_host64.hpp FinishPool) while the tail still runs
+  uint32_t* tail_flag = nullptr;
+  uint32_t tail_gen = 0;
 };
 
 // what the device phase actually ran with (host memory, filled by msm_device_phase when the plan names one)

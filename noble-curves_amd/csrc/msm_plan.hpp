@@ -118,13 +118,15 @@ inline int msm_make_plan_impl(int curve, int n, int c_override, MsmPlan* pl) {
     // (measured: G1 2^17 c = 12 2.7 ms, c = 13 1.06 ms).  For bls12-381 the widths below are the measured best per
     // size on MI355X (tools/msm_csweep.py): round 3 (profiles/r03_msm_csweep.json) 8, 9, 10, 13, 15, 16; re-measured in round 5
     // with the two-level sort and the spread top windows (profiles/r05_msm_csweep.json): a short top window no longer costs long
-    // fix-up runs, so c = 10 wins up to 2^15 (G1 2^15 0.73 -> 0.61 ms, G2 2^15 1.41 -> 1.24 ms) and c = 16 from 2^19.
+    // fix-up runs, so c = 10 wins up to 2^15 (G1 2^15 0.73 -> 0.61 ms, G2 2^15 1.41 -> 1.24 ms) and c = 16 from 2^19.  Round 6
+    // (short lane segments, merge tree and one-launch sort for the plans that do not fill the chip; profiles/r06_msm_small_sweep_c.json):
+    // G1 2^10 c = 7 (0.36 against 0.41 ms at 6), 2^11 c = 8 (0.37 / 0.41), 2^16 c = 10 (0.76 / 0.87 at 13); G2 2^11 c = 8 (0.57 / 0.63).
     const int lg = ilog2((unsigned)std::max(n, 1));
     if (curve == CURVE_BLS12_381_G1) {
-      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 7, 9, 10, 10, 10, 13, 13, 15, 16, 16};
+      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 2, 3, 4, 5, 7, 8, 9, 10, 10, 10, 10, 13, 15, 16, 16};
       c = tab[std::min(lg, 20)];
     } else if (curve == CURVE_BLS12_381_G2) {
-      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 7, 7, 9, 10, 10, 10, 13, 13, 13, 15, 16};
+      static const int8_t tab[21] = {2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 10, 13, 13, 13, 15, 16};
       c = tab[std::min(lg, 20)];
     } else {
       c = lg - 4;
