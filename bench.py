@@ -46,7 +46,10 @@ CYC_MAD, CYC_PLAIN = 5.59, 2.89            # measured cycles per wave-instructio
                                            # v_mad_u64_u32 / v_add_u32; 64 lanes / 5.59 cycles x 1024 SIMDs x 2.4 GHz = the MAD_PEAK below
 MAD_PEAK = 3.08e13                         # v_mad_u64_u32 ceiling measured on MI355X (profiles/r01_ubench_instr_rates.json,
                                            # profiles/r02_valu_rates.jsonl: ~2x the issue time of a plain 32-bit VALU op)
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PLAIN_PEAK = N_SIMD * 64 * CLOCK_HZ / CYC_PLAIN   # plain 32-bit VALU ceiling, lane-ops/s (v_add_u32, same measurement)
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r06_pmc.json")
+if not os.path.exists(PMC_PROFILE):
+    PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 # FETCH_SIZE / WRITE_SIZE -> bytes, calibrated per access pattern with tools/pmc_calib on known byte counts
 # (profiles/r04_pmc.json "calibration"): item-major 64 B gathers count at face value, 16 B/lane coalesced
 # streams at half (MI355X_MICROARCH.md, HBM), writes at face value.
@@ -57,6 +60,10 @@ KERNELS = {   # workload -> (kernel-name prefix in rocprofv3 output, FETCH acces
     "msm_g2": ("ncg::k_msm_accum<ncg::CurveG2P", "gather"),
     "ed25519": ("ncg::k_ed25519_verify", "gather"),
     "ntt": ("ncg::k_ntt_pass", "stream"),
+}
+KERNEL_FAMILY = {   # workload -> (name prefix, substring, the kernel that runs once per unit): VALU counters summed over the family
+    "msm_g1": ("ncg::k_msm_", "<ncg::CurveG1", "ncg::k_msm_tail<"),
+    "msm_g2": ("ncg::k_msm_", "<ncg::CurveG2P", "ncg::k_msm_tail<"),
 }
 
 
@@ -96,7 +103,7 @@ def pmc_live(workload, log2n, budget_s=420.0):
         import pmc_summary
     except ImportError:
         return None
-    passes = [["SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]]
+    passes = [["SQ_INSTS_VALU", "SQ_INSTS_VALU_INT64", "SQ_WAVES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"]]
     out = {}
     t0 = time.perf_counter()
     tmp = tempfile.mkdtemp(prefix="ncg_pmc_", dir="/tmp")
@@ -142,7 +149,7 @@ class Pmc:
             if v:
                 return v, "live"
         v = _pmc_lookup(self.committed, prefix)
-        return (v, "profiles/r04_pmc.json") if v else (None, None)
+        return (v, os.path.relpath(PMC_PROFILE, ROOT)) if v else (None, None)
 
     def traffic(self, workload, launches_per_unit=1):
         prefix, pattern = KERNELS[workload]
@@ -152,39 +159,78 @@ class Pmc:
         b = (v["FETCH_SIZE"] * FETCH_FACTOR[pattern] + v["WRITE_SIZE"]) * 1024.0 * launches_per_unit
         return int(b), src
 
-    def valu_insts(self, workload):
+    def valu_counters(self, workload):
+        """SQ_INSTS_VALU / SQ_INSTS_VALU_INT64 per unit of the workload: per launch of the dominant kernel, or - the MSMs - summed
+        over every kernel of the MSM (accumulate, fix-up, fold levels, tail) and divided by the number of MSMs the pass ran."""
+        fam = KERNEL_FAMILY.get(workload)
+        if fam:
+            for kernels, src in ((self.live, "live"), (self.committed, os.path.relpath(PMC_PROFILE, ROOT))):
+                if not kernels:
+                    continue
+                tot, n_unit = {}, 0.0
+                for name, v in kernels.items():
+                    if not (name.startswith(fam[0]) and fam[1] in name):
+                        continue
+                    for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_INT64"):
+                        if c in v:
+                            tot[c] = tot.get(c, 0.0) + v[c] * float(v.get("launches_" + c) or v.get("_n") or 1.0)
+                    if name.startswith(fam[2]):
+                        n_unit += float(v.get("launches_SQ_INSTS_VALU") or v.get("_n") or 0.0)
+                if n_unit and "SQ_INSTS_VALU" in tot:
+                    return {c: x / n_unit for c, x in tot.items()}, src + " (all k_msm_* kernels of the curve, per MSM)"
+            return None, None
         prefix, _ = KERNELS[workload]
         v, src = self._get(prefix)
         if not v or "SQ_INSTS_VALU" not in v:
             return None, None
-        return v["SQ_INSTS_VALU"], src
+        return v, src
 
 
 BOUND_NOTE = ("bound by VALU issue (integer multiply-add chains), not by HBM or MFMA - SURVEY 8d; `achieved` / `peak` / `frac` "
               "are the contract's HBM figures (algorithmic bytes / kernel time vs 8 TB/s), the fractions that describe the "
-              "kernel are roofline.valu.mad_frac and issue_frac")
+              "kernel are roofline.valu.mad_frac and plain_frac")
+
+
+def _int64_mad_share(prefix):
+    """share of v_mad_u64_u32 among the instructions SQ_INSTS_VALU_INT64 counts (v_mad_u64_u32, v_mad_i64_i32, v_lshl_add_u64 -
+    profiles/r06_valu_calib.json), from the disassembly of the shipped kernels (tools/int64_share.py -> profiles/r06_int64_mad_share.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_int64_mad_share.json")) as f:
+            tab = json.load(f)["kernels"]
+    except (OSError, KeyError, ValueError):
+        return 1.0
+    hits = [v for k, v in tab.items() if k.startswith(prefix)]
+    return min(hits) if hits else 1.0
 
 
 def valu_block(pmc, workload, kern_s, ref_mac, exec_mads, launches=1):
-    """roofline.valu: reference-equivalent work, executed multiplier work and executed VALU instructions."""
+    """roofline.valu: reference-equivalent work, executed multiplier work (from the SQ_INSTS_VALU_INT64 counter where a counter
+    pass exists, cross-checked against the static count of the operation sequence) and the other VALU instructions, each against
+    the ceiling measured for its class.  Every *_frac is <= 1 by construction; their sum (pipe_demand_sum) is NOT a fraction."""
     blk = {"ref_equiv_mac_per_s": ref_mac / kern_s, "ref_equiv_note": "limb-MACs of the reference's op sequence (SURVEY 8d), "
-           "not executed work", "executed_mad_per_s": exec_mads / kern_s, "mad_peak_per_s": MAD_PEAK,
-           "mad_frac": exec_mads / kern_s / MAD_PEAK,
-           "executed_mad_note": "v_mad_u64_u32 per item counted from the kernel's operation sequence (DESIGN.md section 5) "
-                                "x items; peak = measured v_mad_u64_u32 ceiling"}
-    insts, src = pmc.valu_insts(workload)
+           "not executed work", "mad_peak_per_s": MAD_PEAK, "static_mad_per_s": exec_mads / kern_s,
+           "static_mad_note": "v_mad_u64_u32 per item counted from the kernel's operation sequence (DESIGN.md section 5) x items"}
+    c, src = pmc.valu_counters(workload)
+    insts = c.get("SQ_INSTS_VALU") if c else None
+    int64 = c.get("SQ_INSTS_VALU_INT64") if c else None
+    mads = exec_mads
+    blk["mad_source"] = "static count"
+    if insts and int64:
+        share = _int64_mad_share(KERNELS[workload][0])
+        mads = int64 * share * 64.0 * launches
+        blk.update({"mad_source": "SQ_INSTS_VALU_INT64 x %.4f (v_mad_u64_u32 share of the 64-bit-class VALU instructions, disassembly) x 64 lanes; %s" % (share, src),
+                    "counter_over_static": mads / exec_mads})
+    blk["executed_mad_per_s"] = mads / kern_s
+    blk["mad_frac"] = mads / kern_s / MAD_PEAK
     if insts:
-        # issue time the executed instruction mix needs at the MEASURED per-instruction issue costs (tools/valu_rates.hip,
-        # profiles/r03_valu_rates.jsonl, 8 waves per SIMD): a v_mad_u64_u32 holds a SIMD for 5.59 cycles per wave-instruction, a
-        # plain 32-bit VALU op for 2.89 - against the kernel's time on the chip's 1024 SIMDs at the nominal 2.4 GHz
-        wave_insts = insts * launches
-        wave_mads = exec_mads / 64.0
-        issue_s = (wave_mads * CYC_MAD + max(0.0, wave_insts - wave_mads) * CYC_PLAIN) / (N_SIMD * CLOCK_HZ)
-        blk.update({"issue_frac": issue_s / kern_s, "sq_insts_valu_per_launch": insts, "mad_share_of_valu_insts": wave_mads / wave_insts,
-                    "valu_source": src,
-                    "issue_note": "(v_mad_u64_u32 x 5.59 + other VALU x 2.89 cycles per wave-instruction, both measured) / (1024 SIMDs x "
-                                  "2.4 GHz) / kernel time: the share of the kernel's time its SIMDs spend issuing at the measured rates; "
-                                  "SQ_INSTS_VALU from the counter pass, multiplies counted statically"})
+        plain = max(0.0, insts * launches - mads / 64.0)           # wave-instructions that are not multiply-adds
+        blk.update({"plain_valu_per_s": plain * 64.0 / kern_s, "plain_peak_per_s": PLAIN_PEAK, "plain_frac": plain * 64.0 / kern_s / PLAIN_PEAK,
+                    "sq_insts_valu_per_launch": insts, "mad_share_of_valu_insts": mads / 64.0 / (insts * launches), "valu_source": src})
+        blk["pipe_demand_sum"] = blk["mad_frac"] + blk["plain_frac"]
+        blk["pipe_demand_note"] = ("mad_frac + plain_frac: what the two instruction classes would need if nothing overlapped, each at the rate "
+                                   "measured for it alone (tools/valu_rates.hip).  NOT a fraction of time: it passes 1 where plain instructions "
+                                   "issue in the shadow of a multiply-add of another wave; no gfx950 counter reports VALU busy CYCLES "
+                                   "(SQ_ACTIVE_INST_VALU counts one per instruction whatever its pass count, profiles/r06_valu_calib.json)")
     return blk
 
 

@@ -20,7 +20,7 @@ def _full(name):
         return json.loads(f.read().strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("name", ["r05_bench_full.json", "r04_bench_line_last_tree.json", "r04_bench_line.json", "r03_bench_line.json"])
+@pytest.mark.parametrize("name", ["r06_bench_full.json", "r05_bench_full.json", "r04_bench_line_last_tree.json", "r04_bench_line.json", "r03_bench_line.json"])
 def test_compact_line_fits_and_keeps_the_contract(name):
     full = _full(name)
     line = bench_compact.dumps(bench_compact.compact_line(full, "gpurun_out/bench_full.json"))
@@ -65,13 +65,45 @@ def test_compact_line_of_a_multi_rank_run_keeps_the_strong_blocks(name):
 
 
 def test_committed_driver_line_is_what_the_compactor_makes_of_the_committed_full_object():
-    """profiles/r05_bench_line.json is the stdout of the driver's command, profiles/r05_bench_full.json its --out file"""
-    with open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) as f:
+    """profiles/r06_bench_line.json is the stdout of the driver's command, profiles/r06_bench_full.json its --out file"""
+    with open(os.path.join(ROOT, "profiles", "r06_bench_line.json")) as f:
         text = f.read()
     assert text.count("\n") == 1 and len(text) < bench_compact.LIMIT
     line = json.loads(text)
-    again = bench_compact.compact_line(_full("r05_bench_full.json"), line.get("full"))
+    again = bench_compact.compact_line(_full("r06_bench_full.json"), line.get("full"))
     assert again == line
+
+
+def _fractions(o, path=""):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            yield from _fractions(v, path + "/" + k)
+    elif isinstance(o, list):
+        for i, v in enumerate(o):
+            yield from _fractions(v, path + "/%d" % i)
+    elif isinstance(o, (int, float)) and not isinstance(o, bool) and path.rsplit("/", 1)[-1].endswith("frac"):
+        yield path, o
+
+
+@pytest.mark.parametrize("name", ["r06_bench_full.json", "r06_bench_line.json"])
+def test_nothing_called_a_fraction_exceeds_one(name):
+    """issue_frac read 1.005 / 1.046.  From round 6 every key ending in `frac` is a rate over the ceiling
+    measured for that instruction class (mad_frac from the SQ_INSTS_VALU_INT64 counter, plain_frac from SQ_INSTS_VALU minus it),
+    and the sum of the two is reported as pipe_demand_sum - explicitly not a fraction."""
+    full = _full(name)
+    fr = list(_fractions(full))
+    assert len(fr) >= 5
+    for path, v in fr:
+        assert 0.0 <= v <= 1.0, (path, v)
+    assert "issue_frac" not in json.dumps(full)
+    valu = full["roofline"]["valu"]
+    assert "mad_frac" in valu
+    if name == "r06_bench_full.json":
+        assert valu["mad_source"].startswith("SQ_INSTS_VALU_INT64") and 0.8 < valu["counter_over_static"] < 1.1
+        assert abs(valu["pipe_demand_sum"] - valu["mad_frac"] - valu["plain_frac"]) < 1e-9
+        for key in ("msm_g1", "msm_g2", "ed25519_verify", "ntt_fr"):
+            v = full["extra"][key]["roofline"]["valu"]
+            assert v["mad_source"].startswith("SQ_INSTS_VALU_INT64"), key
 
 
 def test_compact_line_never_exceeds_the_limit_even_with_bloated_input():

@@ -38,7 +38,7 @@ def roofline_block(rf, full=True):
         out["kernel"] = _cut(rf["kernel"], 96)
     v = rf.get("valu")
     if isinstance(v, dict):
-        out["valu"] = _pick(v, ("mad_frac", "executed_mad_per_s", "mad_peak_per_s") + (("issue_frac",) if full else ()))
+        out["valu"] = _pick(v, ("mad_frac", "executed_mad_per_s", "mad_peak_per_s") + (("plain_frac", "pipe_demand_sum", "issue_frac") if full else ()))
     return out
 
 

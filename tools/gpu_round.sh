@@ -17,7 +17,7 @@ for s in $STAGES; do
     test)  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/summary.txt; tail -3 $OUT/pytest.log ;;
     bench) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --out $OUT/bench_line.json > $OUT/bench_stdout.txt 2>&1; echo "bench rc=$?" | tee -a $OUT/summary.txt ;;
     stats) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats -- python $GRAFT_REPO_ROOT/bench.py $STATS_ARGS > $GRAFT_REPO_ROOT/$OUT/stats.log 2>&1); echo "stats rc=$?" | tee -a $OUT/summary.txt ;;
-    valu)  (cd /tmp && timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_valu -- python $GRAFT_REPO_ROOT/bench.py $BENCH_ARGS > $GRAFT_REPO_ROOT/$OUT/pmc_valu.log 2>&1); echo "valu rc=$?" | tee -a $OUT/summary.txt ;;
+    valu)  (cd /tmp && timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_valu -- python $GRAFT_REPO_ROOT/bench.py $BENCH_ARGS > $GRAFT_REPO_ROOT/$OUT/pmc_valu.log 2>&1); echo "valu rc=$?" | tee -a $OUT/summary.txt ;;
     fetch) (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -- python $GRAFT_REPO_ROOT/bench.py $BENCH_ARGS > $GRAFT_REPO_ROOT/$OUT/pmc_fetch.log 2>&1); echo "fetch rc=$?" | tee -a $OUT/summary.txt ;;
     write) (cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_write -- python $GRAFT_REPO_ROOT/bench.py $BENCH_ARGS > $GRAFT_REPO_ROOT/$OUT/pmc_write.log 2>&1); echo "write rc=$?" | tee -a $OUT/summary.txt ;;
     calib) (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/calib_fetch -- $GRAFT_REPO_ROOT/tools/_build/pmc_calib > $GRAFT_REPO_ROOT/$OUT/calib.log 2>&1;

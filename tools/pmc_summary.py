@@ -5,7 +5,8 @@ the pass's kernel trace, and the derived figures DESIGN.md section 7 defines:
 
   valu_wave_insts_per_launch      SQ_INSTS_VALU (wave-level VALU instructions issued)
   valu_lane_ops_per_s             SQ_INSTS_VALU * 64 / duration
-  valu_issue_frac                 valu_lane_ops_per_s / (256 CU * 4 SIMD * 16 lanes/clk * 2.4 GHz)
+  (valu_issue_frac, the lane-op rate over 16 lanes per clock and SIMD, was dropped in round 6: gfx950 issues a plain wave64
+   instruction in under 4 cycles - 2.89 measured - so the figure could pass 1; bench.py reports mad_frac / plain_frac instead)
   valu_busy_frac                  SQ_ACTIVE_INST_VALU * 4 / (SQ_BUSY_CYCLES-normalised SIMD cycles), raw
                                   counters kept alongside so the formula can be re-derived
   hbm_bytes_per_launch            FETCH_SIZE / WRITE_SIZE (KB) scaled by the calibration factors measured
@@ -94,7 +95,6 @@ def main():
         if "SQ_INSTS_VALU" in e and e.get("avg_ms_valu_pass"):
             sec = e["avg_ms_valu_pass"] * 1e-3
             e["valu_lane_ops_per_s"] = e["SQ_INSTS_VALU"] * 64 / sec
-            e["valu_issue_frac"] = e["valu_lane_ops_per_s"] / VALU_PEAK_LANE_OPS
         if "SQ_ACTIVE_INST_VALU" in e and e.get("SQ_BUSY_CYCLES"):
             e["valu_busy_raw_ratio"] = e["SQ_ACTIVE_INST_VALU"] / e["SQ_BUSY_CYCLES"]
         if "SQ_WAVE_CYCLES" in e and e.get("SQ_ACTIVE_INST_VALU"):
