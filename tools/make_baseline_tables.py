@@ -14,26 +14,28 @@ def load(name):
 
 
 def main():
-    b = load("r05_bench_full.json")          # the FULL result object of the driver's command (bench.py --out); stdout carries the compact line
-    b1 = load("r04_bench_line_last_tree.json")
+    b = load("r06_bench_full.json")          # the FULL result object of the driver's command (bench.py --out); stdout carries the compact line
+    b1 = load("r05_bench_full.json")
     ex, ex1 = load("r05_bench_extra.json"), load("r04_bench_extra.json")
     e = b["extra"]
     host = b.get("host", {})
     out = []
-    out.append("## 5. Results table (round 5, one MI355X, the driver's command `python3 bench.py --gpus 1 --steps 20 --warmup 5` on a fresh box: `profiles/r05_bench_line.json` (the compact line the driver parses), `profiles/r05_bench_full.json` (the full object this table is made from), `profiles/r05_bench_kernel_stats.csv` + `profiles/r05_bench_line_stats_run.json` (rocprofv3 --stats around the same command, and that process's line), `profiles/r05_pmc.json`)\n")
+    out.append("## 5. Results table (round 6, one MI355X, the driver's command `python3 bench.py --gpus 1 --steps 20 --warmup 5` on a fresh box: `profiles/r06_bench_line.json` (the compact line the driver parses), `profiles/r06_bench_full.json` (the full object this table is made from), `profiles/r06_bench_kernel_stats.csv` (rocprofv3 --stats around the same command), `profiles/r06_pmc.json`)\n")
     out.append("Throughput with inputs resident in HBM, one run of the driver's command on a fresh box (per-step event / wall distributions "
                "are in the full object: `step_times`; the pool's boxes differ by up to 5 %% on these kernels, DESIGN.md section 7).  Every result is verified "
                "bit-exactly before it is printed (sample vs the CPU oracle's C restatement, full-size checksum / progression identity, "
                "ed25519 verdicts by construction + the reference's 196 zip215.json cases).  `hbm_frac` = algorithmic bytes ÷ 8 TB/s (the "
-               "contract's figure; the path is VALU-bound, §2 caveat); `mad_frac` = executed `v_mad_u64_u32` (counted from the kernel's "
-               "operation sequence) ÷ the measured multiplier ceiling 3.08×10¹³/s; `issue` = the time the executed instruction mix needs at the "
-               "measured issue costs (multiply-adds × 5.59 + other VALU × 2.89 cycles per wave-instruction; SQ_INSTS_VALU live in the bench run) ÷ "
-               "kernel time; `traffic` = HBM bytes per launch of the dominant kernel "
-               "(FETCH_SIZE/WRITE_SIZE with the per-pattern calibration of `tools/pmc_calib`, in `profiles/r05_pmc.json`).  CPU baseline = the "
+               "contract's figure; the path is VALU-bound, §2 caveat); `mad_frac` = executed `v_mad_u64_u32` FROM THE SQ_INSTS_VALU_INT64 COUNTER "
+               "(round 6, DESIGN.md section 7; the static operation-sequence counts of rounds 2-5 read 4-19 %% high) ÷ the measured multiplier ceiling "
+               "3.08×10¹³/s; `plain` = the other VALU instructions (SQ_INSTS_VALU minus the multiply-adds) ÷ the plain-instruction ceiling; `traffic` = HBM "
+               "bytes per launch of the dominant kernel "
+               "(FETCH_SIZE/WRITE_SIZE with the per-pattern calibration of `tools/pmc_calib`, in `profiles/r06_pmc.json`).  **The first time of each row is "
+               "the DRIVER's own record of the previous round (BENCH_r05.json, the driver's box), the second this round's driver-command run on whatever box the pool "
+               "handed out; the boxes differ by up to 5 %% (8.7 %% seen on the secp256k1 ladder), so the pair is not an A/B.**  CPU baseline = the "
                "REFERENCE's own TypeScript code on the GPU box's host (%s, %s logical cores; Node %s running the type-stripped sources of "
                "`oracle/_ref/refjs.bundle`, one thread), each result compared bit-exactly with the GPU's; the C port of round 1-3 beside it.\n"
                % (host.get("cpu_model"), host.get("logical_cores"), host.get("node_version")))
-    out.append("| config | N | time (r04 → r05) | throughput | hbm_frac | mad_frac | issue | traffic / algorithmic | CPU: reference (1 thread) | CPU: C port 1 thread / all threads | bit-exact |")
+    out.append("| config | N | time (BENCH_r05 → r06) | throughput | hbm_frac | mad_frac | plain | traffic / algorithmic | CPU: reference (1 thread) | CPU: C port 1 thread / all threads | bit-exact |")
     out.append("|---|---|---|---|---|---|---|---|---|---|---|")
 
     def row(name, n, t1, t2, unit, entry, alg_bytes):
@@ -47,19 +49,22 @@ def main():
         out.append("| %s | %s | %s → **%.2f ms** | **%.3g %s** | %.2f %% | %s | %s | %s | %s | %s / %s | yes |" % (
             name, n, ("%.2f ms" % t1) if t1 else "—", t2, entry["value"], unit, 100 * rf["frac"],
             ("%.0f %%" % (100 * v["mad_frac"])) if "mad_frac" in v else "—",
-            ("%.0f %%" % (100 * v["issue_frac"])) if "issue_frac" in v else "—",
+            ("%.0f %%" % (100 * v["plain_frac"])) if "plain_frac" in v else "—",
             ("%.2f GB / %.0f MB = %.0f×" % (tr / 1e9, alg_bytes / 1e6, tr / alg_bytes)) if tr else "—",
             ("**%.3g /s**" % ref["value"]) if ref else "—",
             ("%.3g /s" % cb["value"]) if cb else "—", ("%.3g /s (%d thr)" % (at["value"], at["cores"])) if at else "—"))
 
     e1 = b1["extra"]
-    row("secp256k1 `multiplyUnsafe` batch (GLV)", "2²⁰", b1["ms_per_step"], b["ms_per_step"], "scalar-mults/s", b, 160.0 * (1 << 20))
-    row("ed25519 verify batch (ZIP-215, SHA-512 on the device)", "2¹⁸", e1["ed25519_verify"]["ms_per_batch"], e["ed25519_verify"]["ms_per_batch"],
+    drv = {"secp": 9.234, "ed": 2.807, "g1": 3.491, "g2": 3.428, "ntt": 0.486}   # BENCH_r05.json (the driver's record, VERDICT r05 headline)
+    row("secp256k1 `multiplyUnsafe` batch (GLV)", "2²⁰", drv["secp"], b["ms_per_step"], "scalar-mults/s", b, 160.0 * (1 << 20))
+    row("ed25519 verify batch (ZIP-215, SHA-512 on the device)", "2¹⁸", drv["ed"], e["ed25519_verify"]["ms_per_batch"],
         "verifies/s", e["ed25519_verify"], 161.0 * (1 << 18))
-    row("bls12-381 G1 MSM", "2²⁰", e1["msm_g1"]["ms_per_msm"], e["msm_g1"]["ms_per_msm"], "points/s", e["msm_g1"], 128.0 * (1 << 20))
-    row("bls12-381 G2 MSM", "2¹⁸", e1["msm_g2"]["ms_per_msm"], e["msm_g2"]["ms_per_msm"], "points/s", e["msm_g2"], 224.0 * (1 << 18))
-    row("bls12-381 Fr NTT (natural→natural)", "2²²", e1["ntt_fr"]["ms_per_transform"], e["ntt_fr"]["ms_per_transform"], "elements/s", e["ntt_fr"],
+    row("bls12-381 G1 MSM", "2²⁰", drv["g1"], e["msm_g1"]["ms_per_msm"], "points/s", e["msm_g1"], 128.0 * (1 << 20))
+    row("bls12-381 G2 MSM", "2¹⁸", drv["g2"], e["msm_g2"]["ms_per_msm"], "points/s", e["msm_g2"], 224.0 * (1 << 18))
+    row("bls12-381 Fr NTT (natural→natural)", "2²²", drv["ntt"], e["ntt_fr"]["ms_per_transform"], "elements/s", e["ntt_fr"],
         64.0 * (1 << 22))
+    out.append("\nThe builder's own round-5 run on another box (`profiles/r05_bench_full.json`): secp256k1 %.2f ms, ed25519 %.2f, G1 MSM %.2f, G2 MSM %.2f, NTT %.3f." % (
+        b1["ms_per_step"], e1["ed25519_verify"]["ms_per_batch"], e1["msm_g1"]["ms_per_msm"], e1["msm_g2"]["ms_per_msm"], e1["ntt_fr"]["ms_per_transform"]))
     ko = e["ed25519_verify"]["kernel_only"]
     out.append("\ned25519 kernel-only (pre-hashed challenges): %.2f ms → **%.2f ms** (%.3g verifies/s); the device hash adds "
                "%.2f ms per 2¹⁸ signatures.  Multi-GPU (2/4/8): measured by the driver's scaling run - `bench.py --gpus N` reports weak "
@@ -97,7 +102,7 @@ def main():
     if p1 and p2:
         out.append("The same verified sets with `ncg_points_precompute` (interleavedMSMUnsafe's per-point tables in device form: window-"
                    "shifted copies, built once in %.0f / %.0f ms; one shared bucket set, no combine across windows): G1 2²⁰ **%.2f ms**, "
-                   "G2 2¹⁸ **%.2f ms**; per size and path: `profiles/r05_msm_timing.json`.\n"
+                   "G2 2¹⁸ **%.2f ms**; per size and path: `profiles/r06_msm_timing.json` (generic path, 2¹⁰ .. 2²⁰), `profiles/r05_msm_timing.json` (every path).\n"
                    % (p1["precompute_once_ms"], p2["precompute_once_ms"], p1["ms_per_msm"], p2["ms_per_msm"]))
     c0 = e.get("configs0_point_multiply")
     if c0:
@@ -114,6 +119,9 @@ def main():
                "meaningful (§2 caveat): its dominant kernel runs at %.0f %% of the measured multiplier ceiling in EXECUTED multiplies.\n"
                % (b["value"] / 1e7, 100 * e["msm_g1"]["roofline"]["valu"]["mad_frac"]))
     out.append("### Other entry points (one MI355X, `tools/bench_extra.py`, `profiles/r05_bench_extra.json`; r04 beside it)\n")
+    out.append("The r04 → r05 differences of this table (G2 hashToCurve +13 %, ed25519 variable-base +5 %, G1 GLV ladder +6 %, ECDSA verify +3 %; VERDICT r05 weak #7) "
+               "were the BOX, not the code: `tools/ab_trees.sh` ran `bench_extra.py` of both trees (each with its own `libncg.so` and Python side) alternately, "
+               "r04, r05, r04, r05, on ONE box - no row differs by more than its own run-to-run spread (`profiles/r06_side_table_ab.json`).\n")
     out.append("| entry point | N | r04 | r05 | throughput |")
     out.append("|---|---|---|---|---|")
     for k, v in ex.items():
