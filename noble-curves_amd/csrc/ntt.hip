@@ -26,6 +26,8 @@
 // roots(bits) (N entries); inverse(bits)[k] = roots[(N - k) mod N] is index arithmetic.
 #include <vector>
 
+#include <algorithm>
+#include "knobs.hpp"
 #include "fp.hpp"
 #include "fr29.hpp"
 #include "host_api.hpp"
@@ -413,7 +415,8 @@ NttSchedule ntt_schedule(int n, int tab_log, int flags, int t0max = 10, int tmax
 
 template <int LOGE>
 static void ntt_launch(dim3 grid, hipStream_t st, const uint32_t* in, uint32_t* out, const uint32_t* tab, const NttPass& ps) {
-  hipLaunchKernelGGL((k_ntt_pass<LOGE>), grid, dim3(ntt_threads(LOGE)), (size_t)36 << LOGE, st, in, out, tab, ps);
+  static const int lds_pct = std::max(100, knob("NCG_NTT_LDS_PCT", 100));   // A/B builds: occupancy experiment (170 = about half the workgroups per CU)
+  hipLaunchKernelGGL((k_ntt_pass<LOGE>), grid, dim3(ntt_threads(LOGE)), std::min((size_t)65536, ((size_t)36 << LOGE) * lds_pct / 100), st, in, out, tab, ps);
 }
 
 // ws: batch * N * 32 bytes (only read when the bit reversal is folded into a multi-pass transform); src may
