@@ -1961,7 +1961,7 @@ static hipError_t msm_finish_t(const MsmPlan& pl, const uint32_t* cur, uint32_t*
     e = hipMemcpyAsync(bad_host, d_bad, 4, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return e;
   }
-  if (pl.tail_flag && FinishHelpers<C>::value && msm_host64_enabled() && h64::finish_threads_override() == 1) {
+  if (pl.tail_flag && FinishHelpers<C>::value && msm_host64_enabled() && msm_finish_threads_enabled() && h64::finish_threads_override() == 1) {
     // the helper threads of the host finish take 10-50 us to come out of their sleep: wake them when the tail kernel STARTS (it
     // runs ~0.1 ms), not when the stream is done.  Polling a word of pinned memory costs what hipStreamSynchronize's own spin costs.
     volatile uint32_t* flag = pl.tail_flag;

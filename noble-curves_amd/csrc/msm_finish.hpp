@@ -35,6 +35,11 @@ inline void msm_host_finish(const uint32_t* fin, int c, int nwin, uint32_t* out_
 inline bool msm_host64_enabled() {
   return knob("NCG_MSM_HOST64", 1) != 0;
 }
+// helper threads of the bls12-381 finish (bls_host64.hpp FinishPool): on unless NCG_NO_FINISH_THREADS is set
+inline bool msm_finish_threads_enabled() {
+  static const bool off = knob_set("NCG_NO_FINISH_THREADS");
+  return !off;
+}
 
 template <class C>
 inline void msm_host_finish_any(const uint32_t* fin, int c, int nwin, uint32_t* out_affine, uint8_t* out_inf) {
@@ -42,12 +47,14 @@ inline void msm_host_finish_any(const uint32_t* fin, int c, int nwin, uint32_t* 
 }
 template <>
 inline void msm_host_finish_any<CurveG1>(const uint32_t* fin, int c, int nwin, uint32_t* out_affine, uint8_t* out_inf) {
-  if (msm_host64_enabled()) h64::msm_finish<h64::Fp>(fin, c, nwin, MSM_GROUP, msm_ngroups(c), 14, 12, out_affine, out_inf);
+  if (msm_host64_enabled() && !msm_finish_threads_enabled()) h64::msm_finish_serial<h64::Fp>(fin, c, nwin, MSM_GROUP, msm_ngroups(c), 14, 12, out_affine, out_inf);
+  else if (msm_host64_enabled()) h64::msm_finish<h64::Fp>(fin, c, nwin, MSM_GROUP, msm_ngroups(c), 14, 12, out_affine, out_inf);
   else msm_host_finish<CurveG1>(fin, c, nwin, out_affine, out_inf);
 }
 template <>
 inline void msm_host_finish_any<CurveG2>(const uint32_t* fin, int c, int nwin, uint32_t* out_affine, uint8_t* out_inf) {
-  if (msm_host64_enabled()) h64::msm_finish<h64::Fp2>(fin, c, nwin, MSM_GROUP, msm_ngroups(c), 28, 24, out_affine, out_inf);
+  if (msm_host64_enabled() && !msm_finish_threads_enabled()) h64::msm_finish_serial<h64::Fp2>(fin, c, nwin, MSM_GROUP, msm_ngroups(c), 28, 24, out_affine, out_inf);
+  else if (msm_host64_enabled()) h64::msm_finish<h64::Fp2>(fin, c, nwin, MSM_GROUP, msm_ngroups(c), 28, 24, out_affine, out_inf);
   else msm_host_finish<CurveG2>(fin, c, nwin, out_affine, out_inf);
 }
 
