@@ -24,6 +24,12 @@
 //     stages below 33 r < 2^260, far inside limb 8's 32 bits (value < 2^264).
 #pragma once
 #include "fe9.hpp"
+#include "fr29_asm_gen.hpp"
+
+// 1: the multiply-add chains of fr29_mont as one asm block per column (tools/gen_fr29_asm.py); 0: one statement per instruction
+#ifndef NCG_FR29_BLOCKS
+#define NCG_FR29_BLOCKS 1
+#endif
 
 namespace ncg {
 
@@ -96,6 +102,13 @@ NCG_DI void fr29_to_words(uint32_t (&w)[8], const Fr29& a) {
 
 // Montgomery product b * w / 2^261 (mod r).  b: limb bound <= 6; w: exact limbs.  Exact limbs out.
 NCG_DI Fr29 fr29_mont(const Fr29& b, const Fr29& w) {
+#if defined(__HIP_DEVICE_COMPILE__) && NCG_FR29_BLOCKS
+  {
+    Fr29 o;
+    NCG_FR29_MONT_BLOCKS(b, w, o)
+    return o;
+  }
+#endif
   uint32_t q[9];
   Fr29 o;
   uint64_t acc = 0;
