@@ -409,6 +409,14 @@ int ht_msm_shard_local(int curve, int n_local, int n_max, const uint32_t* pts_wi
   HT_CURVE_DISPATCH(curve, CALL)
 #undef CALL
 }
+// the lane segment msm_seg picks for a whole generic plan of n points (msm_plan.hpp): out = {c, nwin, nb, seg, nseg, lanes per window << ls, accum_waves}
+int ht_msm_seg(int curve, int n, int c_override, int* out) {
+  MsmPlan pl;
+  if (msm_make_plan_impl(curve, n, c_override, &pl) != 0) return -1;
+  const MsmSeg sg = msm_seg(pl);
+  out[0] = pl.c; out[1] = pl.nwin; out[2] = pl.nb; out[3] = sg.seg; out[4] = sg.nseg; out[5] = sg.nseg << pl.ls; out[6] = pl.accum_waves;
+  return 0;
+}
 int ht_msm_shard_combine(int curve, int n_max, int nparts, const uint8_t* slots, uint32_t* out, uint8_t* out_inf, char* err, int errlen) {
 #define CALL(C) ht_shard_combine_t<C>(curve, n_max, nparts, slots, out, out_inf, err, errlen)
   HT_CURVE_DISPATCH(curve, CALL)

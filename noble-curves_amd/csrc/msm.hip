@@ -836,10 +836,7 @@ static size_t msm_sort2_words(const MsmPlan& pl) {
 // buckets[w][b]; a bucket cut by a range boundary leaves partial sums (at most two per lane:
 // "head" = the bucket began before the range, "tail" = it continues past the range), which
 // k_msm_fixup adds up.
-struct MsmSeg {
-  int seg;    // entries per lane
-  int nseg;   // lanes per window = ceil(n / seg)
-};
+// (MsmSeg / msm_seg: msm_plan.hpp - host-side planning, shared with the CPU test twin)
 
 #ifndef NCG_ACCUM_MINW
 #define NCG_ACCUM_MINW 1
@@ -1493,59 +1490,6 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct MsmLayout {
   size_t pts_mont, digits, counts, bucket_start, sorted, sort_tmp, shared_start, buckets, part_pts, part_meta, long_runs, bad, red0, red1, tail0, tail1, fin, total;
 };
-
-static MsmSeg msm_seg(const MsmPlan& pl) {
-  MsmSeg sg;
-  const int seg_knob = pl.seg_override > 0 ? pl.seg_override : knob("NCG_MSM_SEG", 0);
-  if (seg_knob > 0) {
-    sg.seg = seg_knob;
-  } else {
-    // Every lane adds `seg` consecutive sorted entries, and the accumulate kernel keeps
-    // cap = waves/SIMD x 1024 SIMDs x 64 lanes resident, so its time goes like rounds(seg) * seg with
-    // rounds = ceil(lanes / cap), plus ~3 addition-times of fix-up per lane.  Pick the seg that minimises
-    // that (measured on MI355X: G1 2^20 seg 128 = one full round 4.29 ms, 64 = two rounds 4.46, 96 4.90,
-    // 192 5.44; G2 2^18 seg 73 = one round 4.84 ms, 32 5.08, 74 5.14).
-    const long cap = 65536L * pl.accum_waves;
-    double best = 1e300;
-    sg.seg = 16;
-    const int n_seg = pl.n_layout > 0 ? pl.n_layout : pl.n;   // parts of one MSM share the segment of the layout plan
-    // Plans that do NOT fill the chip (round 6, tools/msm_small_sweep.py -> profiles/r06_msm_small_sweep.json): the kernel's time is
-    // then seg x the latency of one addition on a SIMD that holds k = 1, 2.. waves - max(r1, k) in units of the throughput-bound
-    // time of a wave-addition, r1 = a lone wave's latency (G1 12 us against 9.5, lane-paired G2 16 against 14.6) - and shorter
-    // segments cut every bucket of m = n / nb entries into m / seg more pieces, which its fix-up unit adds one after the other
-    // (f = one cooperative addition, 8 / 12 us; single-lane complete additions on the curves without cooperative units).  With
-    // the floor of 16 entries the G1 plans below 2^15 points ran 350-420 waves on 1024 SIMDs for 16 x 12 us; measured best
-    // segments: 4-6 up to 2^12 points, 6-8 at 2^13 / 2^14, 12 at 2^15 / 2^16 (G1 2^13 0.536 -> 0.466 ms, 2^16 0.85 -> 0.75 ms).
-    const bool bls = pl.accum_waves == 2;
-    const double r1 = pl.ls ? 1.1 : 1.25, f = bls ? 0.8 : 1.6;
-    const double m = (double)n_seg / (double)std::max(1, pl.nb);
-    for (int seg = 4; seg <= 160; seg++) {
-      const long nseg = (n_seg + seg - 1) / seg;
-      const long lanes = ((long)pl.nwin * nseg) << pl.ls;
-      const long rounds = (lanes + cap - 1) / cap;
-      double cost;
-      if (lanes <= cap) {
-        // waves per SIMD: the accumulate launch pins grids of up to 256 / 512 workgroups to one / two per CU (LDS reservation)
-        const long wgs = (long)pl.nwin * (((nseg << pl.ls) + 255) / 256);
-        const double k = wgs <= 256 ? 1.0 : wgs <= 512 ? 2.0 : (double)((lanes + 65535) / 65536);
-        // pieces of the fullest buckets: (m + 4 sqrt(m)) / seg + 1; the merge adds them as a tree of four units per bucket where the
-        // curve has cooperative units (k_msm_fixup_merge_tree), one after the other elsewhere
-        const double pieces = (m + 4.0 * std::sqrt(m)) / (double)seg + 1.0;
-        const double chain = bls ? std::max(0.0, std::ceil(pieces / 4.0) - 1.0) + 2.0 : pieces - 1.0;
-        cost = (double)seg * std::max(r1, k) + std::max(3.0 * (double)lanes / 65536.0, f * chain);
-      } else {
-        if (seg < 16) continue;   // full chip: the measured segments of rounds 3-5 (16..160) stand
-        cost = (double)rounds * seg * pl.accum_waves + 3.0 * (double)lanes / 65536.0;
-      }
-      if (cost < best - 1e-9) {
-        best = cost;
-        sg.seg = seg;
-      }
-    }
-  }
-  sg.nseg = (pl.n + sg.seg - 1) / sg.seg;
-  return sg;
-}
 
 template <class C>
 static MsmLayout msm_layout(const MsmPlan& pl_in) {

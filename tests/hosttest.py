@@ -42,6 +42,7 @@ def lib():
         _lib.ht_msm_shard_windows_local.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32]
         _lib.ht_msm_finish.argtypes = [i32, i32, i32, vp, vp, vp, i32]
         _lib.ht_msm_plan.argtypes = [i32, i32, vp]
+        _lib.ht_msm_seg.argtypes = [i32, i32, i32, vp]
         _lib.ht_msm_plan_top.argtypes = [i32, i32, i32, vp]
         _lib.ht_h64_op.argtypes = [i32, vp, vp, vp, vp]
     return _lib
@@ -293,3 +294,10 @@ def msm_plan_top(curve, n, c_override=0):
     hp = sum(int(out[6 + i]) << (32 * i) for i in range(10))
     return {"c": int(out[0]), "nwin": int(out[1]), "top_tb": int(out[2]), "top_submask": int(out[3]), "vmax": int(out[4]), "nb": int(out[5]),
             "hprime": hp}
+
+
+def msm_seg(curve, n, c_override=0):
+    """{c, nwin, nb, seg, nseg, lanes, accum_waves}: the lane segment msm_seg (csrc/msm_plan.hpp) picks for a whole generic plan of n points."""
+    out = np.zeros(8, dtype=np.int32)
+    assert lib().ht_msm_seg(curve, n, c_override, out.ctypes.data) == 0
+    return dict(zip(("c", "nwin", "nb", "seg", "nseg", "lanes", "accum_waves"), [int(x) for x in out[:7]]))

@@ -692,3 +692,29 @@ def test_short_top_window_spreading_keeps_every_digit_weight():
                 assert sub + 1 >= 8
         if tb:
             assert top_max <= 1 << tb
+
+
+def test_msm_lane_segment_small_plans_are_priced_by_latency():
+    """csrc/msm_plan.hpp msm_seg (round 6): a plan that leaves SIMDs empty gets SHORT lane segments (the accumulate kernel's time is
+    then seg x the latency of one addition), a plan that fills the chip keeps the segment that makes its lanes one full round; the
+    picks measured in profiles/r06_msm_small_sweep_c*.json / r06_msm_timing.json are pinned here."""
+    import hosttest
+    from noble_curves_amd._native import BLS12_381_G1, BLS12_381_G2, ED25519, SECP256K1
+    for curve, ls in ((BLS12_381_G1, 0), (BLS12_381_G2, 1), (SECP256K1, 0), (ED25519, 0)):
+        for lg in range(6, 21):
+            p = hosttest.msm_seg(curve, 1 << lg)
+            cap = 65536 * p["accum_waves"]
+            assert 4 <= p["seg"] <= 160
+            assert p["nseg"] == -(-(1 << lg) // p["seg"]) and p["lanes"] == p["nseg"] << ls
+            total = p["nwin"] * p["lanes"]
+            if total > cap:                       # several rounds: the measured full-chip segments (16 and up) only
+                assert p["seg"] >= 16
+    g1 = {lg: hosttest.msm_seg(BLS12_381_G1, 1 << lg) for lg in (10, 13, 14, 16, 17, 20)}
+    assert [g1[lg]["seg"] for lg in (10, 13, 14)] == [4, 4, 8]
+    assert 11 <= g1[16]["seg"] <= 14 and g1[16]["c"] == 10          # 2^16: c = 10 since round 6 (0.76 against 0.87 ms at c = 13)
+    assert g1[17]["seg"] == 21 and g1[20]["seg"] == 128 and g1[20]["nwin"] * g1[20]["lanes"] == 131072   # one full round at two waves per SIMD
+    g2 = {lg: hosttest.msm_seg(BLS12_381_G2, 1 << lg) for lg in (12, 14, 18)}
+    assert g2[12]["seg"] == 4 and 12 <= g2[14]["seg"] <= 16
+    assert g2[18]["nwin"] * g2[18]["lanes"] <= 131072 < g2[18]["nwin"] * ((-(-(1 << 18) // (g2[18]["seg"] - 1))) << 1)   # the shortest segment that is one round
+    # a forced width changes the bucket size the merge chain is priced with
+    assert hosttest.msm_seg(BLS12_381_G1, 1 << 14, 12)["seg"] <= hosttest.msm_seg(BLS12_381_G1, 1 << 14, 8)["seg"]
