@@ -473,6 +473,14 @@ def time_pipelined(submit, collect, depth, steps, warmup, dist_on, check=None):
                 check(r)
         return t0, done
     run(max(warmup, depth) + (PREWARM_DIST_STEPS if dist_on else 4), False)
+    if not dist_on:
+        # the same 50 ms of untimed load every other timed loop gets (time_steps: the boost clock settles over a few tens of
+        # milliseconds after host-side set-up; a share of 0.5 ms measured over 40 jobs right after an idle gap read 0.60-0.63 ms,
+        # the same jobs 0.49-0.50 ms once the clock had settled - tools/share_stream_test.py); ranks of a distributed run keep the
+        # fixed step count above (the jobs may be collectives)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < PREWARM_S:
+            run(2 * depth, False)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
