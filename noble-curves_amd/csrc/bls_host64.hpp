@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -447,7 +448,8 @@ inline void msm_finish_serial(const uint32_t* fin, int c, int nwin, int g, int n
 // MSM's tail kernel, msm.hip msm_finish_t) makes them spin for work for at most FINISH_SPIN_US; `run()` publishes the job; windows
 // are claimed top-down from one atomic counter by the helpers AND by the caller whenever the window it needs next is not
 // there yet, so a job completes whatever the helpers do (asleep, descheduled).  If no helper is spinning when the job arrives the
-// caller runs the serial form (building every W_w itself would cost it 75 % more doublings).  One job at a time: a second
+// caller runs the serial form (building every W_w itself would cost it 75 % more doublings); helpers that have been signalled but
+// are still on their way count as present - the caller builds the top windows itself until they arrive.  One job at a time: a second
 // caller (another context's thread) finds the pool busy and runs the serial form.
 constexpr int FINISH_HELPERS = 3;
 constexpr int FINISH_SPIN_US = 600;
@@ -457,6 +459,11 @@ struct FinishPool {
   std::condition_variable cv;
   uint64_t wake_gen = 0;           // under m
   std::atomic<int> spinning{0};    // helpers looking for work right now
+  std::atomic<int> arriving{0};    // helpers that have been signalled and are not spinning yet (10-50 us from the signal to the first look)
+  std::atomic<int> alive{0};       // helper threads that exist
+  std::atomic<int> helped{0};      // windows of the current job built by helpers
+  int misses = 0, cooldown = 0;    // consecutive jobs no helper took part in; jobs left to run serially after four of those (under
+                                   // `busy`): a forked child has no helper threads, a loaded host may have them arrive too late
   std::atomic<int> next{-1};       // next window to claim (counts down); < 0: no job
   void (*fn)(void*, int) = nullptr;  // published before `next`
   void* arg = nullptr;
@@ -470,6 +477,7 @@ struct FinishPool {
       for (int i = 0; i < FINISH_HELPERS; i++) {
         try {
           std::thread([this] { helper(); }).detach();
+          alive.fetch_add(1, std::memory_order_relaxed);
         } catch (...) {   // no helpers: every job runs the serial form
         }
       }
@@ -484,11 +492,19 @@ struct FinishPool {
         seen = wake_gen;
       }
       spinning.fetch_add(1, std::memory_order_acq_rel);
+      {
+        int a = arriving.load(std::memory_order_relaxed);   // one of the signalled helpers has arrived (never below zero: wake-ups can merge)
+        while (a > 0 && !arriving.compare_exchange_weak(a, a - 1, std::memory_order_acq_rel)) {
+        }
+      }
       const auto t0 = std::chrono::steady_clock::now();
       for (unsigned it = 0;; it++) {
         if (next.load(std::memory_order_acquire) >= 0) {
           int i;
-          while ((i = next.fetch_sub(1, std::memory_order_acq_rel)) >= 0) fn(arg, i);
+          while ((i = next.fetch_sub(1, std::memory_order_acq_rel)) >= 0) {
+            fn(arg, i);
+            helped.fetch_add(1, std::memory_order_relaxed);
+          }
           break;   // one job per wake-up
         }
 #if defined(__x86_64__)
@@ -508,8 +524,11 @@ struct FinishPool {
       std::lock_guard<std::mutex> lk(m);
       wake_gen++;
     }
+    arriving.store(std::max(0, alive.load(std::memory_order_relaxed) - spinning.load(std::memory_order_relaxed)), std::memory_order_release);
     cv.notify_all();
   }
+  // helpers are looking for work, or have just been signalled and will be within tens of microseconds
+  bool expected() const { return spinning.load(std::memory_order_acquire) > 0 || arriving.load(std::memory_order_acquire) > 0; }
 };
 inline int& finish_threads_override() {  // test hook / A-B: 0 = always serial, 1 = helpers whenever they are awake (default), 2 = wake them inside run too
   static int v = 1;
@@ -555,7 +574,8 @@ inline void msm_finish(const uint32_t* fin, int c, int nwin, int g, int ngroups,
 #endif
     }
   }
-  if (P.spinning.load(std::memory_order_acquire) == 0) {
+  if (P.cooldown > 0 || !P.expected()) {
+    if (P.cooldown > 0) P.cooldown--;
     owner.unlock();
     return msm_finish_serial<F>(fin, c, nwin, g, ngroups, FW, WW, out, out_inf);
   }
@@ -565,6 +585,7 @@ inline void msm_finish(const uint32_t* fin, int c, int nwin, int g, int ngroups,
   FinishJob<F> J{fin, c, nwin, g, ngroups, FW, W, ready};
   P.fn = &FinishJob<F>::window;
   P.arg = &J;
+  P.helped.store(0, std::memory_order_relaxed);
   P.next.store(nwin - 1, std::memory_order_release);
   JacH<F> acc = jac_inf<F>();
   for (int w = nwin - 1; w >= 0; w--) {
@@ -585,6 +606,14 @@ inline void msm_finish(const uint32_t* fin, int c, int nwin, int g, int ngroups,
   }
   // every window is ready, so every claim has been served; helpers that still race for `next` find it negative
   P.next.store(-1, std::memory_order_release);
+  if (P.helped.load(std::memory_order_relaxed) == 0) {
+    if (++P.misses >= 4) {   // signalled four times, never came: run the next 64 finishes serially, then try again
+      P.misses = 0;
+      P.cooldown = 64;
+    }
+  } else {
+    P.misses = 0;
+  }
   owner.unlock();
   jac_to_wire(acc, WW, out, out_inf);
 }

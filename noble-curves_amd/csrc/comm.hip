@@ -21,6 +21,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "ctx.hpp"
@@ -116,6 +117,11 @@ struct JobState {
   int c = 0, nwin = 0;   // the WHOLE plan
   size_t stride = 0, sum_words = 0;
   bool identity = false;  // nothing to do: the result is the identity (curve.ts:878)
+  // "the tail kernel of this rank's local phase has started" (a word of the pinned landing area, set by k_msm_tail to tail_gen):
+  // the synchronous entry points poll it and wake the helper threads of the host finish while the tail, the exchange and the
+  // combine still run (wait_tail_then_wake)
+  volatile uint32_t* tail_flag = nullptr;
+  uint32_t tail_gen = 0;
   size_t slice = 0;       // SHARD_POINTS from ONE caller (ncg_msm_split_dev, ncg_msm_multi): points per part, so that a bad scalar
                           // is reported with its index in the caller's arrays ('invalid scalar at index i', curve.ts:402); 0 = the
                           // caller is one rank of several and only knows shard-relative indices
@@ -204,9 +210,21 @@ int job_local_phase(ncg_ctx* ctx, const JobRes& R, const ShardJob& J, int slot_i
   FinHeader* hstage = (FinHeader*)(*R.land) + slot_idx;  // first bytes of the landing area; overwritten by the gather's D2H later
   *hstage = h;
   NCG_HIP(ctx, hipMemcpyAsync(mine, hstage, sizeof h, hipMemcpyHostToDevice, R.st));
+  S->tail_flag = nullptr;
   if (!work) {  // an empty slice / no windows: identities (all-zero accumulators decode as such)
     if (fin_words) NCG_HIP(ctx, hipMemsetAsync(mine + sizeof h, 0, fin_words * 4, R.st));
   } else {
+    {  // the last word of the landing area (64 words of slack behind everything the copies write)
+      static std::atomic<uint32_t> gen{0};
+      uint32_t g = gen.fetch_add(1, std::memory_order_relaxed) + 1;
+      if (g == 0) g = gen.fetch_add(1, std::memory_order_relaxed) + 1;
+      uint32_t* flag = *R.land + (*R.land_words - 1);
+      *flag = 0;
+      local.tail_flag = flag;
+      local.tail_gen = g;
+      S->tail_flag = flag;
+      S->tail_gen = g;
+    }
     const uint32_t *d_fin = nullptr, *d_bad = nullptr;
     NCG_HIP(ctx, ncg::msm_device_phase(curve, local, d_pts, (const uint32_t*)J.d_sc, *R.ws, &d_fin, R.st, &d_bad,
                                        (local.pts_stored || local.endo) ? nullptr : R.side));
@@ -337,6 +355,21 @@ int job_enqueue(ncg_ctx* ctx, const JobRes& R, const ShardJob& J, bool collectiv
   return job_enqueue_combine(ctx, R, S, G);
 }
 
+// Before a synchronisation that is followed by job_finish_host: wait (polling, as hipStreamSynchronize would spin) until this
+// rank's tail kernel has started, then wake the helper threads of the host finish - the rest of the tail, the exchange and the
+// combine (0.1-0.2 ms) cover the 10-50 us a sleeping thread needs.  Without a flag (no local work on this rank) wake at once.
+static void wait_tail_then_wake(const JobState& S, hipStream_t st) {
+  if (S.tail_flag) {
+    for (unsigned it = 0; *S.tail_flag != S.tail_gen; it++) {
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+      if ((it & 127u) == 127u && hipStreamQuery(st) != hipErrorNotReady) break;
+    }
+  }
+  ncg::msm_finish_prewake(S.curve);
+}
+
 int job_run_sync(ncg_ctx* ctx, const ShardJob& J, bool collective, void* out_affine, uint8_t* out_is_inf, hipStream_t st) {
   JobRes R = ctx_res(ctx, st);
   JobState S;
@@ -345,6 +378,7 @@ int job_run_sync(ncg_ctx* ctx, const ShardJob& J, bool collective, void* out_aff
     (void)hipStreamSynchronize(st);
     return rc;
   }
+  wait_tail_then_wake(S, st);
   NCG_HIP(ctx, hipStreamSynchronize(st));
   return job_finish_host(ctx, R, S, out_affine, out_is_inf);
 }
@@ -590,6 +624,7 @@ int ncg_msm_shard_combine(ncg_ctx* ctx, int curve, size_t n_max, int nparts, con
   NCG_HIP(ctx, hipMemcpyAsync(*R.comm_buf, slots, stride * (size_t)nparts, hipMemcpyHostToDevice, st));
   rc = job_enqueue_combine(ctx, R, &S, nparts);
   if (rc) return rc;
+  ncg::msm_finish_prewake(curve);   // the upload, the packing and the copy back are tens of microseconds: the helpers of the finish start now
   NCG_HIP(ctx, hipStreamSynchronize(st));
   return job_finish_host(ctx, R, S, out_affine, out_is_inf);
 }
@@ -623,6 +658,7 @@ static int split_run(ncg_ctx* ctx, ShardJob J, int parts, size_t n, int pb, void
   }
   int rc = job_enqueue_combine(ctx, R, &S, parts);
   if (rc) return rc;
+  wait_tail_then_wake(S, st);
   NCG_HIP(ctx, hipStreamSynchronize(st));
   if (J.mode == ncg::SHARD_POINTS) S.slice = per;
   return job_finish_host(ctx, R, S, out_affine, out_is_inf);

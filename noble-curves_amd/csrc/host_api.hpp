@@ -93,6 +93,9 @@ hipError_t msm_sum_partials(int curve, uint32_t* d_gathered, int nparts, size_t 
 hipError_t msm_enqueue(int curve, const MsmPlan& pl, const uint32_t* d_pts, const uint32_t* d_scalars, void* ws, uint32_t* land,
                        hipStream_t st, const MsmSide* side = nullptr);
 void msm_finish_host(int curve, int c, int nwin, const uint32_t* fin_host, uint32_t* out_affine_host, uint8_t* out_inf_host);
+// the host finish of this curve is about to run (tens of microseconds from now): wakes its helper threads, if it has any
+// (bls12-381: bls_host64.hpp FinishPool); a no-op otherwise
+void msm_finish_prewake(int curve);
 size_t msm_fin_words(int curve, const MsmPlan& pl);
 size_t msm_acc_words(int curve);
 

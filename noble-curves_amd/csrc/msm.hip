@@ -2051,6 +2051,11 @@ hipError_t msm_enqueue(int curve, const MsmPlan& pl, const uint32_t* d_pts, cons
 #undef CALL
 }
 // Horner over [ngroups(c)][nwin] grouped window sums in HOST memory (device storage format) + canonical affine output
+void msm_finish_prewake(int curve) {
+  if ((curve == CURVE_BLS12_381_G1 || curve == CURVE_BLS12_381_G2) && msm_host64_enabled() && msm_finish_threads_enabled() &&
+      h64::finish_threads_override() == 1)
+    h64::FinishPool::get().wake();
+}
 void msm_finish_host(int curve, int c, int nwin, const uint32_t* fin_host, uint32_t* out_affine_host, uint8_t* out_inf_host) {
   switch (curve) {
     case CURVE_SECP256K1: return msm_host_finish_any<CurveSecp>(fin_host, c, nwin, out_affine_host, out_inf_host);
