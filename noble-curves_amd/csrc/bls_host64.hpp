@@ -502,8 +502,8 @@ struct FinishPool {
         if (next.load(std::memory_order_acquire) >= 0) {
           int i;
           while ((i = next.fetch_sub(1, std::memory_order_acq_rel)) >= 0) {
+            helped.fetch_add(1, std::memory_order_relaxed);   // before the window is published: the caller reads it once every window is ready
             fn(arg, i);
-            helped.fetch_add(1, std::memory_order_relaxed);
           }
           break;   // one job per wake-up
         }
