@@ -63,6 +63,15 @@ def main():
     row("bls12-381 G2 MSM", "2¹⁸", drv["g2"], e["msm_g2"]["ms_per_msm"], "points/s", e["msm_g2"], 224.0 * (1 << 18))
     row("bls12-381 Fr NTT (natural→natural)", "2²²", drv["ntt"], e["ntt_fr"]["ms_per_transform"], "elements/s", e["ntt_fr"],
         64.0 * (1 << 22))
+    try:
+        sb = load("r06_bench_full_slow_box.json")
+        se = sb["extra"]
+        out.append("\n**The same final build on a box of the slow kind** (`profiles/r06_bench_full_slow_box.json`, `r06_bench_kernel_stats_slow_box.csv`; kernel by kernel "
+                   "against the table's box: `profiles/r06_box_to_box.md` - the ladder +7 %%, the NTT passes +5-6 %%, the accumulate kernels +2-3 %%, and ≈ 0.1 ms more per MSM "
+                   "outside the kernels): secp256k1 %.2f ms, ed25519 %.2f, G1 MSM %.2f, G2 MSM %.2f, NTT %.3f - the driver's round-5 record above was taken on a box "
+                   "of this kind." % (sb["ms_per_step"], se["ed25519_verify"]["ms_per_batch"], se["msm_g1"]["ms_per_msm"], se["msm_g2"]["ms_per_msm"], se["ntt_fr"]["ms_per_transform"]))
+    except (OSError, KeyError, ValueError):
+        pass
     out.append("\nThe builder's own round-5 run on another box (`profiles/r05_bench_full.json`): secp256k1 %.2f ms, ed25519 %.2f, G1 MSM %.2f, G2 MSM %.2f, NTT %.3f." % (
         b1["ms_per_step"], e1["ed25519_verify"]["ms_per_batch"], e1["msm_g1"]["ms_per_msm"], e1["msm_g2"]["ms_per_msm"], e1["ntt_fr"]["ms_per_transform"]))
     ko = e["ed25519_verify"]["kernel_only"]
