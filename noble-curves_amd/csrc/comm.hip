@@ -706,7 +706,30 @@ int ncg_msm_split_windows_dev(ncg_ctx* ctx, int curve, size_t n, int parts, cons
 // collective: every rank submits the same sequence of lanes).
 static int lane_init(ncg_ctx* ctx, ncg_msm_lane& ln) {
   if (ln.stream) return NCG_OK;
-  hipError_t e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
+  // The lanes must not share a hardware queue with one another: HIP spreads the streams of a process over
+  // GPU_MAX_HW_QUEUES (4) queues PER PRIORITY CLASS, least-used first, so where lane 2 lands depends on every stream the
+  // host application, torch and this library created before - in bench.py lanes 0 and 2 ended up behind one another and a
+  // share of 0.50 ms read 0.59 (profiles/r06_lane_queues.txt).  The top-priority class is a pool of its own, which nothing
+  // else here uses: the (at most 4) lanes get one queue each there, whatever the process did before.
+  // NCG_LANE_QUEUES: 1 = that (default), 0 = plain streams, 2 = a full CU mask per lane stream (a queue of its own in the
+  // normal class).
+  const int qmode = ncg::knob("NCG_LANE_QUEUES", 1);
+  hipError_t e = hipSuccess;
+  if (qmode == 1) {
+    int lo = 0, hi = 0;
+    e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ln.stream, hipStreamNonBlocking, hi);
+  } else if (qmode == 2) {
+    hipDeviceProp_t pr;
+    e = hipGetDeviceProperties(&pr, ctx->device);
+    if (e == hipSuccess) {
+      std::vector<uint32_t> mask((size_t)(pr.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
+      if (pr.multiProcessorCount % 32) mask.back() = (1u << (pr.multiProcessorCount % 32)) - 1u;
+      e = hipExtStreamCreateWithCUMask(&ln.stream, (uint32_t)mask.size(), mask.data());
+    }
+  } else {
+    e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
+  }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.side.stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.side.fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.side.join, hipEventDisableTiming);

@@ -10,6 +10,8 @@
 //     NCG_MSM_C_ENDO=<c>  the same for the endomorphism plan
 //     NCG_NO_FINISH_THREADS=1   the host finish of the bls12-381 MSMs never uses its three helper threads (bls_host64.hpp FinishPool;
 //                         they are created at the first MSM that can use them, sleep between MSMs, and spin for at most 0.6 ms per MSM)
+//     NCG_LANE_QUEUES=<m> hardware queues of the asynchronous MSM lanes (comm.hip lane_init): 1 = streams of the top priority class, a
+//                         queue pool nothing else in the process uses (default); 0 = plain streams; 2 = a full CU mask per lane stream
 //   A/B builds only (-DNCG_AB_BUILD, tools/ab_*.sh, tools/msm_debug.py): ignored by the shipped library
 //     NCG_MSM_SEG, NCG_MSM_QBLOCKS, NCG_MSM_XCD     accumulate segment length, sort chunk count, XCD-aware sort grid
 //     NCG_MSM_RUN_SERIAL, NCG_MSM_COOP_LEVEL        fix-up serial threshold, cooperative level kernel on / off
@@ -27,7 +29,7 @@
 namespace ncg {
 
 inline bool knob_is_public(const char* name) {
-  static const char* const pub[] = {"NCG_TIMING", "NCG_NO_ENDO", "NCG_NO_PRECOMP", "NCG_MSM_C", "NCG_MSM_C_ENDO", "NCG_NO_FINISH_THREADS"};
+  static const char* const pub[] = {"NCG_TIMING", "NCG_NO_ENDO", "NCG_NO_PRECOMP", "NCG_MSM_C", "NCG_MSM_C_ENDO", "NCG_NO_FINISH_THREADS", "NCG_LANE_QUEUES"};
   for (const char* p : pub)
     if (std::strcmp(p, name) == 0) return true;
   return false;

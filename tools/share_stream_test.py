@@ -40,3 +40,19 @@ for rep in range(2):
     seen = {}
     pw, _ = bench.time_pipelined(sub, col, 3, 40, 5, False, lambda r: seen.__setitem__(r[0], r[1]))
     print("bench.time_pipelined", round(pw / 40 * 1e3, 4), flush=True)
+
+# ---- does the lanes' earlier use by whole generic MSMs (bench.py runs those first) change the share's in-flight time?
+def chk(r): pass
+for depth in (2, 3):
+    pw, _ = bench.time_pipelined(lambda lane, i: eng.msm_async_submit(lane, cid, n, pts.data_ptr(), sc.data_ptr(), s),
+                                 lambda lane: eng.msm_async_collect(lane, cid), depth, 20, 5, False, chk)
+    print("generic pipelined depth", depth, round(pw / 20 * 1e3, 4), flush=True)
+seen = {}
+pw, _ = bench.time_pipelined(sub, col, 3, 40, 5, False, lambda r: seen.__setitem__(r[0], r[1]))
+print("share after generic lanes: bench.time_pipelined", round(pw / 40 * 1e3, 4), flush=True)
+# the sync share calls in between, as bench.py does
+slots = [eng.msm_shard_windows_local_dev(cid, n, r, G, 0, sc.data_ptr(), s, rs) for r in range(G)]
+st_l = bench.time_steps(lambda: eng.msm_shard_windows_local_dev(cid, n, 0, G, 0, sc.data_ptr(), s, rs), 20, 5, False)
+print("local part0 sync", round(st_l[0] / 20 * 1e3, 4))
+pw, _ = bench.time_pipelined(sub, col, 3, 40, 5, False, lambda r: seen.__setitem__(r[0], r[1]))
+print("share after sync share calls: bench.time_pipelined", round(pw / 40 * 1e3, 4), flush=True)
