@@ -106,10 +106,13 @@ struct MulVarCfg {
 // and write the affine wire point.
 // ZR_IN_TAB: keep the TS Z-ratios of the table build behind the table (TS more elements per lane)
 // instead of in registers - for tables in device memory, where space is free and registers are not.
-template <class C, int W, bool JAC_OUT = false, bool ZR_IN_TAB = false, class TABPTR>
+// PF (tables in device memory, inlined multiply, GLV curves; NCG_LADDER_PREFETCH): the table entry of the NEXT window travels
+// into the wave's LDS slab (gfx950 global_load_lds_dwordx4, no register in between) while this window's doublings and
+// additions run; `pf_slab` = 2 slots x 5 chunks x 64 lanes x 16 bytes of LDS, layout [slot][chunk][lane].
+template <class C, int W, bool JAC_OUT = false, bool ZR_IN_TAB = false, bool PF = false, class TABPTR>
 NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* __restrict__ k_wire,
                          uint32_t* __restrict__ out_wire, uint8_t* __restrict__ out_inf, bool active,
-                         TABPTR tab, const int stride) {
+                         TABPTR tab, const int stride, uint32_t* pf_slab = nullptr) {
   using Cfg = MulVarCfg<C, W>;
   using F = typename C::F;
   constexpr int FW = Cfg::FW, TW = Cfg::TW, TS = Cfg::TS, M = Cfg::M, NL = Cfg::NL;
@@ -183,6 +186,68 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
 
   // ---- ladder -------------------------------------------------------------------------------
   Jac<F> R = Jac<F>::inf();
+#ifdef __HIP_DEVICE_COMPILE__
+  if constexpr (PF && NCG_MUL_INLINE && C::GLV) {
+    const int ln = threadIdx.x & 63;
+    // entry `idx` of this lane's table -> slot `slot` (80 bytes: the 72 of (x, y) and 8 of whatever follows - another entry or
+    // the Z-ratio area, both inside the lane's block)
+    auto issue = [&](int slot, int idx) {
+      const uint32_t* src = tab + idx * 2 * TW;
+#pragma unroll
+      for (int j = 0; j < 5; j++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * j),
+                                         (__attribute__((address_space(3))) void*)(pf_slab + (slot * 5 + j) * 256), 16, 0, 0);
+    };
+    // the entry in `slot` has landed (every load of this wave was issued at least one mixed addition ago); once the reads
+    // have returned the slot is free again
+    auto fetch = [&](int slot, F& qx, F& qy) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      uint32_t wv[20];
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(pf_slab + (slot * 5 + j) * 256 + ln * 4);
+        wv[4 * j] = v.x; wv[4 * j + 1] = v.y; wv[4 * j + 2] = v.z; wv[4 * j + 3] = v.w;
+      }
+#pragma unroll
+      for (int l = 0; l < 9; l++) {
+        qx.v[l] = wv[l];
+        qy.v[l] = wv[9 + l];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto entry_of = [](int d) { return ((d < 0 ? -d : d) - 1) >> 1; };
+    int d1 = w1.pop(), d2 = w2.pop();
+    issue(0, entry_of(d1));
+    issue(1, entry_of(d2));
+    for (int i = 0; i < M; i++) {
+      if (i > 0) {
+#pragma unroll 1
+        for (int d = 0; d < W; d++) R = jac_dbl(R);
+      }
+#pragma unroll 1
+      for (int e = 0; e < 2; e++) {
+        const int d = e == 0 ? d1 : d2;
+        const bool ng = e == 0 ? neg1 : neg2;
+        F qx, qy;
+        fetch(e, qx, qy);
+        // refill the slot: the next digit of this stream, or - after the last window - entry 0 for the parity fix-up below
+        int dn = 1;
+        if (i + 1 < M) dn = e == 0 ? w1.pop() : w2.pop();
+        issue(e, entry_of(dn));
+        if (e == 0) d1 = dn; else d2 = dn;
+        if (e == 1) qx = qx * beta;
+        R = jac_madd_q(R, qx, f_cneg(qy, (d < 0) != ng));
+      }
+    }
+    {
+      F qx, qy;
+      fetch(0, qx, qy);   // entry 0 (both slots hold it now; vmcnt(0) covers slot 1's load too)
+      if (w1.was_even) R = jac_madd_q(R, qx, f_cneg(qy, !neg1));
+      if (w2.was_even) R = jac_madd_q(R, qx * beta, f_cneg(qy, !neg2));
+    }
+  } else
+#endif
+  {
   for (int i = 0; i < M; i++) {
     if (i > 0) {
 #pragma unroll(NCG_MUL_INLINE ? 1 : W)
@@ -228,6 +293,7 @@ NCG_DI void mul_var_lane(const uint32_t* __restrict__ pt_wire, const uint32_t* _
     if constexpr (C::GLV) {
       if (w2.was_even) R = jac_madd_q(R, qx * beta, f_cneg(qy, !neg2));
     }
+  }
   }
   // back from the isomorphic curve, then to affine (weierstrass.ts:951-969 toAffine)
   const bool ladder_inf = R.is_inf();  // tested before the product: not every field keeps 0 * Zg literal
@@ -351,6 +417,12 @@ __global__ void __launch_bounds__(256) k_proj_batch_affine(const uint32_t* __res
   }
 }
 
+// 1: the ladder of the GLV curves with the inlined multiply (the shipped secp256k1 kernel) prefetches its table entries through LDS
+#ifndef NCG_LADDER_PREFETCH
+#define NCG_LADDER_PREFETCH 0
+#endif
+template <class C> struct LadderPrefetch { static constexpr bool value = NCG_LADDER_PREFETCH != 0 && NCG_MUL_INLINE && C::GLV; };
+
 // Variant with the per-lane table in device memory (item-major, each entry contiguous) instead of
 // LDS: no LDS footprint, so the window width is no longer tied to occupancy.
 template <class C, int W, int MINW, bool JAC_OUT>
@@ -364,8 +436,10 @@ k_mul_var_gtab(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sc
   const int idx = lane_idx >> LaneShift<C>::value;
   const bool active = idx < n;
   const int src = active ? idx : n - 1;
-  mul_var_lane<C, W, JAC_OUT, true>(pts + (size_t)src * 2 * WW, scalars + (size_t)src * 8, out + (size_t)src * OUTW,
-                                    out_inf + src, active, gtab + (size_t)lane_idx * (Cfg::TS * 3 * Cfg::TW), 1);
+  constexpr bool PF = LadderPrefetch<C>::value;
+  __shared__ __attribute__((aligned(16))) uint32_t pf_lds[PF ? 2 * 5 * 256 : 4];   // one wave per block
+  mul_var_lane<C, W, JAC_OUT, true, PF>(pts + (size_t)src * 2 * WW, scalars + (size_t)src * 8, out + (size_t)src * OUTW,
+                                        out_inf + src, active, gtab + (size_t)lane_idx * (Cfg::TS * 3 * Cfg::TW), 1, pf_lds);
 }
 
 template <class C, int W, int MINW, bool JAC_OUT>
