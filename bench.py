@@ -495,6 +495,66 @@ def time_pipelined(submit, collect, depth, steps, warmup, dist_on, check=None):
     return wall, [round((marks[i + 1] - marks[i]) * 1e3, 4) for i in range(len(done))]
 
 
+def hwmon_dir(dev_index):
+    """sysfs hwmon directory of the GPU torch calls `dev_index` (the host's sysfs lists every card; this one by its PCI address)"""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        hits = sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf))
+        if hits:
+            return hits[0]
+    except Exception:  # noqa: BLE001 - a measurement beside the result, never a failure of the bench
+        pass
+    try:   # older torch without the PCI fields: the one GPU rocm-smi lists
+        import re
+        import subprocess
+        txt = subprocess.run(["rocm-smi", "--showbus"], capture_output=True, text=True, timeout=20).stdout
+        m = re.search(r"([0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9])", txt)
+        hits = sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % m.group(1).lower())) if m and dev_index == 0 else []
+        return hits[0] if hits else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def power_state(fn, dev_index, seconds=1.2):
+    """The shader clock and package power the box holds UNDER the headline workload (untimed, after the K timed steps): `fn` runs
+    back to back for `seconds`, four steps per synchronisation, hwmon freq1_input / power1_input read in between.  The ladder is
+    power-limited on every box of the pool: ms_per_step x sclk is what the code is responsible for."""
+    h = hwmon_dir(dev_index)
+    if not h:
+        return None
+
+    def rd(name):
+        try:
+            with open(os.path.join(h, name)) as f:
+                return float(f.read().strip())
+        except Exception:  # noqa: BLE001
+            return None
+    f_hz, p_uw = [], []
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(4):
+            fn()
+        a, b = rd("freq1_input"), rd("power1_input")
+        if b is None:
+            b = rd("power1_average")
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 > 0.3:          # the readings of the first 0.3 s still see the idle gap before
+            if a:
+                f_hz.append(a / 1e6)
+            if b:
+                p_uw.append(b / 1e6)
+    if not f_hz:
+        return None
+    f_hz.sort()
+    p_uw.sort()
+    cap = rd("power1_cap")
+    return {"sclk_mhz": [f_hz[0], f_hz[len(f_hz) // 2], f_hz[-1]], "power_w": [p_uw[0], p_uw[len(p_uw) // 2], p_uw[-1]] if p_uw else None,
+            "power_cap_w": cap / 1e6 if cap else None, "samples": len(f_hz), "seconds": seconds,
+            "source": "hwmon freq1_input / power1_input of the visible GPU, [min, median, max] over the samples after 0.3 s of back-to-back steps (untimed leg)"}
+
+
 def max_over_ranks(x, dist_on, device):
     if not dist_on:
         return x
@@ -705,6 +765,7 @@ def main():
 
         st_secp = time_steps(step, K, W, dist_on)
         wall, ev_ms = st_secp
+        pstate = power_state(step, dev_index) if (rank == 0 and world == 1 and not args.quick_verify) else None
         wall = max_over_ranks(wall, dist_on, device)
         ev_ms = max_over_ranks(ev_ms, dist_on, device)
         # ---- verification (outside the timed region)
@@ -739,6 +800,9 @@ def main():
                          "kernel_ms": kern_ms,
                          "valu": valu_block(pmc, "secp256k1", kern_ms * 1e-3, 3.4e5 * n, secp_mads_per_mult() * n)},
         }
+        if pstate:
+            pstate["ms_per_step_x_sclk"] = wall / K * 1e3 * pstate["sclk_mhz"][1]
+            result["power_state"] = pstate
         if not dist_on and not args.quick_verify:   # (the PMC / kernel-stats child runs keep to the headline launches)
             # end to end through the host-pointer entry point (ncg_mul_var_batch): pinned-once host buffers, chunked H2D / kernels / D2H
             e_p, e_s = pts.cpu().numpy(), sc.cpu().numpy()

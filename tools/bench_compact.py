@@ -152,6 +152,10 @@ def compact_line(full, full_path=None):
     ee = full.get("end_to_end")
     if isinstance(ee, dict) and "ms_per_batch" in ee:
         out["end_to_end_ms"] = _r(ee["ms_per_batch"])
+    ps = full.get("power_state")
+    if isinstance(ps, dict) and isinstance(ps.get("sclk_mhz"), list):
+        out["power_state"] = {"sclk_mhz_med": _r(ps["sclk_mhz"][1], 5), "power_w_med": _r((ps.get("power_w") or [None, None])[1], 5),
+                              "ms_per_step_x_sclk": _r(ps.get("ms_per_step_x_sclk"), 5)}
     extra = full.get("extra") or {}
     for key in ("msm_g1", "msm_g1_strong", "msm_g2", "msm_g2_strong"):
         e = extra.get(key) or full.get(key)
