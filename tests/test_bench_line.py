@@ -122,3 +122,19 @@ def test_single_workload_lines_keep_what_the_ab_scripts_read():
     e.update({"n_gpus": 1, "steps": 10, "warmup": 3, "ms_per_step": None, "config": {"workload": "msm_g1"}})
     c = bench_compact.compact_line(e)
     assert c["ms_per_msm"] > 0 and c["resident_subgroup_set"]["ms_per_msm"] > 0
+
+
+def test_power_state_of_the_headline_travels_in_the_line():
+    """bench.py's untimed power_state leg (shader clock / package power the box holds under the headline workload): the compact line keeps the
+    medians and the clock-normalised time, and still fits."""
+    full = _full("r06_bench_full.json")
+    full["power_state"] = {"sclk_mhz": [2264.0, 2272.0, 2278.0], "power_w": [1272.0, 1285.0, 1297.0], "power_cap_w": 1400.0, "samples": 28,
+                           "seconds": 1.2, "source": "hwmon", "ms_per_step_x_sclk": full["ms_per_step"] * 2272.0}
+    line = bench_compact.dumps(bench_compact.compact_line(full, "gpurun_out/bench_full.json"))
+    assert len(line) < bench_compact.LIMIT
+    ps = json.loads(line)["power_state"]
+    assert ps["sclk_mhz_med"] == 2272.0 and ps["power_w_med"] == 1285.0
+    assert abs(ps["ms_per_step_x_sclk"] - full["ms_per_step"] * 2272.0) < 1.0
+    # a box without readable hwmon files: the block is simply absent
+    full.pop("power_state")
+    assert "power_state" not in json.loads(bench_compact.dumps(bench_compact.compact_line(full, None)))
