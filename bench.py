@@ -897,6 +897,7 @@ def main():
 
         st_msm = time_steps(step, K, W, dist_on)
         wall, ev_ms = st_msm
+        pstate_m = power_state(step, dev_index, 0.9) if (rank == 0 and world == 1 and not args.quick_verify) else None
         wall = max_over_ranks(wall, dist_on, device)
         expect = sum_over_ranks_bigint(local_expect, BLS_R, dist_on, device)
         got, got_inf = holder["r"]
@@ -918,6 +919,9 @@ def main():
                               "kernel": "k_msm_accum (dominant; achieved is for the whole MSM incl. the host finish, traffic for that kernel)",
                               "valu": valu_block(pmc, key, wall / K, ref_mac_pt * nn,
                                                  (g1_msm_mads_per_point(nwin, nn, 1 << (c - 1), True) * (3 if curve == BLS12_381_G2 else 1)) * nn)}}
+        if pstate_m:
+            pstate_m["ms_per_msm_x_sclk"] = wall / K * 1e3 * pstate_m["sclk_mhz"][1]
+            entry["power_state"] = pstate_m
         if not dist_on and not args.quick_verify:   # (the PMC / kernel-stats child runs keep to the headline launches)
             # end to end through the HOST-pointer entry point (the boundary the N-API addon binds: ncg_msm): inputs in pinned host
             # memory (ncg_host_register once), scalars first, the points in parts accumulated while the next part crosses PCIe
@@ -1259,6 +1263,7 @@ def main():
 
         st_ed = time_steps(step_ed, K, W, dist_on)
         wall, ev_ms = st_ed
+        pstate_e = power_state(step_ed, dev_index, 0.9) if (rank == 0 and world == 1 and not args.quick_verify) else None
         wall = max_over_ranks(wall, dist_on, device)
         got = d_ok.cpu().numpy().astype(bool)
         assert np.array_equal(got, expect), "ed25519 verdict mismatch vs construction / zip215.json"
@@ -1316,6 +1321,9 @@ def main():
                                                 "kernel": "k_ed25519_verify (+ k_ed25519_challenge in the hash-inclusive figure)",
                                                 "kernel_ms": ev_ms / K, "kernel_only_ms": ev_ms_k / K,
                                                 "valu": valu_block(pmc, "ed25519", kern_s, 4.9e5 * nv, ed25519_mads_per_verify() * nv)}}
+        if pstate_e:
+            pstate_e["ms_per_batch_x_sclk"] = wall / K * 1e3 * pstate_e["sclk_mhz"][1]
+            extra["ed25519_verify"]["power_state"] = pstate_e
         if ed_cpu:
             extra["ed25519_verify"]["cpu_baseline"] = ed_cpu
 

@@ -80,6 +80,10 @@ def msm_block(e):
     cb = cpu_block(e.get("cpu_baseline"), full=False)
     if cb:
         out["cpu_baseline"] = cb
+    ps = e.get("power_state")
+    if isinstance(ps, dict) and isinstance(ps.get("sclk_mhz"), list):
+        out["sclk_mhz_med"] = _r(ps["sclk_mhz"][1], 5)
+        out["power_w_med"] = _r((ps.get("power_w") or [None, None])[1], 5)
     ee = e.get("end_to_end")
     if isinstance(ee, dict) and "ms_per_msm" in ee:
         out["end_to_end_ms"] = _r(ee["ms_per_msm"])
@@ -120,6 +124,10 @@ def batch_block(e, ms_key):
     ko = e.get("kernel_only")
     if isinstance(ko, dict) and "ms_per_batch" in ko:
         out["kernel_only_ms"] = _r(ko["ms_per_batch"])
+    ps = e.get("power_state")
+    if isinstance(ps, dict) and isinstance(ps.get("sclk_mhz"), list):
+        out["sclk_mhz_med"] = _r(ps["sclk_mhz"][1], 5)
+        out["power_w_med"] = _r((ps.get("power_w") or [None, None])[1], 5)
     return out
 
 
