@@ -72,6 +72,29 @@ def main():
                    "of this kind." % (sb["ms_per_step"], se["ed25519_verify"]["ms_per_batch"], se["msm_g1"]["ms_per_msm"], se["msm_g2"]["ms_per_msm"], se["ntt_fr"]["ms_per_transform"]))
     except (OSError, KeyError, ValueError):
         pass
+    # runs of the final build that carry bench.py's power_state legs (third session of round 6): what clock and package power the box held
+    ps_rows = []
+    for name, label in (("r06_bench_full_with_power_state.json", "a typical box"), ("r06_bench_full_low_clock_box.json", "a low-clock box")):
+        try:
+            pb = load(name)
+            pe = pb["extra"]
+            ps = pb["power_state"]
+            g1, ed = pe["msm_g1"].get("power_state", {}), pe["ed25519_verify"].get("power_state", {})
+            ps_rows.append("| %s (`profiles/%s`) | %.3f ms at %.0f MHz, %.0f W (%.2f k cycles per step) | %.3f ms at %.0f MHz, %.0f W | %.3f ms at %.0f MHz, %.0f W | %.3f ms | %.4f ms |" % (
+                label, name, pb["ms_per_step"], ps["sclk_mhz"][1], ps["power_w"][1], ps["ms_per_step_x_sclk"] / 1e3,
+                pe["msm_g1"]["ms_per_msm"], g1.get("sclk_mhz", [0, 0])[1], (g1.get("power_w") or [0, 0])[1],
+                pe["ed25519_verify"]["ms_per_batch"], ed.get("sclk_mhz", [0, 0])[1], (ed.get("power_w") or [0, 0])[1],
+                pe["msm_g2"]["ms_per_msm"], pe["ntt_fr"]["ms_per_transform"]))
+        except (OSError, KeyError, ValueError, TypeError):
+            pass
+    if ps_rows:
+        out.append("\n**What the boxes hold under these workloads** (`bench.py` `power_state`: the visible GPU's `hwmon` shader clock and package power, medians over 0.9-1.2 s of back-to-back "
+                   "steps after the timed ones; DESIGN.md section 7, `profiles/r06_clock_probe.txt`).  The secp256k1 ladder and the ed25519 verifier run at the package power limit "
+                   "(≈ 1.3 kW of a 1.4 kW cap) on every box, and the clock a box sustains there (2.18 ... 2.34 GHz seen) is what its time is made of: ms × MHz is constant within 1 % "
+                   "across nine typical boxes.\n")
+        out.append("| run | secp256k1 2²⁰ | G1 MSM 2²⁰ | ed25519 2¹⁸ | G2 MSM 2¹⁸ | NTT 2²² |")
+        out.append("|---|---|---|---|---|---|")
+        out.extend(ps_rows)
     out.append("\nThe builder's own round-5 run on another box (`profiles/r05_bench_full.json`): secp256k1 %.2f ms, ed25519 %.2f, G1 MSM %.2f, G2 MSM %.2f, NTT %.3f." % (
         b1["ms_per_step"], e1["ed25519_verify"]["ms_per_batch"], e1["msm_g1"]["ms_per_msm"], e1["msm_g2"]["ms_per_msm"], e1["ntt_fr"]["ms_per_transform"]))
     ko = e["ed25519_verify"]["kernel_only"]
