@@ -46,11 +46,15 @@ static int run(const char* name, int waves_per_simd, uint32_t* d_sink, double se
          MIX ? ", \"plain_per_mad\": 1" : "");
   return 0;
 }
-int main(int argc, char**) {
+int main(int argc, char** argv) {
   uint32_t* d_sink;
   CK(hipMalloc(&d_sink, 64));
   int rc = 0;
-  const bool all = argc > 1;   // any argument: the whole occupancy curve
+  if (argc > 1 && (argv[1][0] == 'm')) {   // "mad8", "mad3", "mix8", "mix3": ONE point for 3 s (tools/clock_probe_cmd.sh reads the clock beside it)
+    const int w = argv[1][3] - '0';
+    return argv[1][1] == 'a' ? run<0>("v_mad_u64_u32", w, d_sink, 3.0) : run<1>("v_mad_u64_u32 + v_add_u32", w, d_sink, 3.0);
+  }
+  const bool all = argc > 1;   // any other argument: the whole occupancy curve
   for (int w : {1, 2, 3, 4, 6, 8}) {
     if (!all && w != 3 && w != 8) continue;
     rc |= run<0>("v_mad_u64_u32", w, d_sink, all ? 0.5 : 1.5);
