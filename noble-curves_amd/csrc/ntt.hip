@@ -109,12 +109,24 @@ NCG_DI Fr29 fr29_load_g(const uint32_t* __restrict__ p) {
   const Fr x = fr_load_g(p);
   return fr29_from_words(x.v);
 }
-// twiddle table entry: the 9 limbs of w 2^261 mod r in 12 words (three 16-byte loads, no conversion)
-constexpr int NTT_TW = 12;
+// twiddle table entry: the 9 limbs of w 2^261 mod r, no conversion on load.  Nine words per entry since the third session of round 6 (36 bytes at
+// 4-byte alignment; twelve words = three aligned 16-byte loads before): a 2^22 transform reads its table about twice, a quarter less of it is 1-3 % of
+// the transform (profiles/r06_ntt_tw36_ab.txt) and 50 MB less device memory per 2^22 table
+#ifndef NCG_NTT_TW_WORDS
+#define NCG_NTT_TW_WORDS 9
+#endif
+constexpr int NTT_TW = NCG_NTT_TW_WORDS;   // 12: three aligned 16-byte loads per twiddle; 9: 36-byte entries at 4-byte alignment (a quarter less table traffic)
+struct __attribute__((packed, aligned(4))) NttTw9 { uint32_t v[9]; };
 NCG_DI Fr29 ntt_load_tw(const uint32_t* __restrict__ p) {
+  Fr29 r;
+  if constexpr (NTT_TW == 9) {
+    const NttTw9 t = *reinterpret_cast<const NttTw9*>(p);
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = t.v[i];
+    return r;
+  }
   const uint4* q = reinterpret_cast<const uint4*>(p);
   const uint4 a = q[0], b = q[1], c = q[2];
-  Fr29 r;
   r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
   r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
   r.v[8] = c.x;
@@ -122,6 +134,13 @@ NCG_DI Fr29 ntt_load_tw(const uint32_t* __restrict__ p) {
 }
 NCG_DI void ntt_store_tw(uint32_t* __restrict__ p, const Fr& canonical) {
   const Fr29 l = fr29_from_words(canonical.v);
+  if constexpr (NTT_TW == 9) {
+    NttTw9 t;
+#pragma unroll
+    for (int i = 0; i < 9; i++) t.v[i] = l.v[i];
+    *reinterpret_cast<NttTw9*>(p) = t;
+    return;
+  }
   uint4* q = reinterpret_cast<uint4*>(p);
   q[0] = make_uint4(l.v[0], l.v[1], l.v[2], l.v[3]);
   q[1] = make_uint4(l.v[4], l.v[5], l.v[6], l.v[7]);
