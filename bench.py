@@ -693,6 +693,10 @@ def main():
         # fewer GPUs than ranks (a 1-GPU box): RCCL refuses two ranks on one device, so the ranks share GPUs and
         # exchange through gloo - the native per-shard phase and the native combine still run (host-staged slots)
         args.backend = "gloo"
+        # several processes on ONE GPU: each would add its own top-priority hardware queues for the asynchronous MSM lanes (comm.hip
+        # lane_init) - eight ranks x three lanes oversubscribe the queues the command processors keep resident and the in-flight legs
+        # crawl (18 -> 50 ms per MSM in the 8-rank self-launch).  Plain lane streams there: the library's knob for shared GPUs.
+        os.environ.setdefault("NCG_LANE_QUEUES", "0")
     dev_index = local_rank % torch.cuda.device_count()   # (dry runs may put several ranks on one GPU)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
